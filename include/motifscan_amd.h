@@ -1,0 +1,142 @@
+/*
+ * motifscan_amd.h -- C-ABI of the MI355X-native PWM scan path (libmotifscan_amd.so).
+ *
+ * Drop-in boundary for ONE hot path of shao-lab/MotifScan: the native scorer
+ * motifscan/motif/cscore.c (module motifscan.motif.cscore) as used by
+ * motifscan/scanner.py:125 (c_scan_motif) and motifscan/cli/motif.py:134 (c_score).
+ * Plain C, plain pointers and sizes, no Python.h, no torch types.  Every entry point
+ * returns an int status (MS_OK = 0) and never calls exit(); the message of the last
+ * failure on the calling thread is ms_last_error().  All handles are re-entrant and
+ * device-bound (no file-scope state like cscore.c:26-34).
+ *
+ * There is NO CPU fallback behind this interface: without a gfx950 device every
+ * compute entry point fails with MS_ERR_RUNTIME.
+ *
+ * Reference interface each entry point replaces (paths relative to /root/reference):
+ *
+ *   ms_pwmset_create      convert_pwm + get_max_raw_score          cscore.c:36-79
+ *                         (PWM list -> double[4][W], max_raw clamped at 0 per column,
+ *                          cutoff defaults to 1 when no cutoffs are given, cscore.c:70-74)
+ *   ms_seqset_create      convert_seq                              cscore.c:81-114
+ *                         (ASCII -> base codes: A/a C/c G/g T/t, anything else "no
+ *                          contribution"); here 2-bit codes + a 1-bit non-ACGT plane in HBM
+ *   ms_seqset_from_device same, for ASCII that is already resident in device memory
+ *   ms_scan               scan_motif / scan_motif_thread           cscore.c:317-476
+ *                         (Python name c_scan_motif; "OOOII" = pwms, cutoffs, seqs, strand,
+ *                          n_threads; n_threads has no meaning on the GPU and is not taken)
+ *   ms_result_*           the list-of-lists result building         cscore.c:443-471
+ *                         (per PWM: [seq_idx, pos, score, strand], order = seq asc, pos asc,
+ *                          '+' (1) before '-' (2)), delivered as flat arrays + offsets
+ *   ms_result_region_counts   the per-motif "number of regions with >= 1 site" that
+ *                         motifscan/stats.py:29-31 derives from the nested site lists
+ *                         (the only quantity the multi-GPU all-reduce needs)
+ *   ms_score              motif_score / motif_score_thread         cscore.c:174-302
+ *                         (Python name c_score; "OOII")
+ *   ms_dedup_hits         _deduplicate_sites / deduplicate_motif_sites  scanner.py:156-193
+ *                         (host-side, on the sparse hit arrays)
+ */
+#ifndef MOTIFSCAN_AMD_H
+#define MOTIFSCAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_OK            0
+#define MS_ERR_INVALID   1   /* bad argument / shape           -> ValueError   */
+#define MS_ERR_NOMEM     2   /* host or device allocation      -> MemoryError  */
+#define MS_ERR_RUNTIME   3   /* HIP failure, no usable device  -> RuntimeError */
+
+#define MS_STRAND_FWD    1   /* same bit mask as cscore.c:319 */
+#define MS_STRAND_REV    2
+#define MS_STRAND_BOTH   3
+
+/* ms_scan flags */
+#define MS_SCAN_DEFAULT      0u
+#define MS_SCAN_EXACT_ONLY   1u   /* skip the integer pre-filter: score every window in fp64 (validation) */
+
+typedef struct ms_pwmset ms_pwmset;
+typedef struct ms_seqset ms_seqset;
+typedef struct ms_result ms_result;
+
+/* Per-call measurements, filled by ms_scan (HIP events on the library's own stream). */
+typedef struct ms_scan_stats {
+    int64_t n_bases;            /* total bases in the sequence set                                   */
+    int64_t n_windows;          /* sum_p sum_r max(L_r - W_p + 1, 0): exact unit count               */
+    int64_t n_candidates;       /* windows x strands that passed the integer pre-filter              */
+    int64_t n_hits;
+    int32_t n_pwms;
+    int32_t n_pwms_exact;       /* PWMs routed to the all-fp64 path (W > 32, degenerate values)      */
+    int32_t n_tiles;            /* LDS tiles of pre-filter tables                                    */
+    int32_t n_passes;           /* 1, or 2 when a buffer had to grow and the scan was re-run         */
+    double  ms_prefilter;       /* device time of the pre-filter kernel (dominant kernel)            */
+    double  ms_exact;           /* fp64 kernels: N-overlapping windows + candidate re-scoring        */
+    double  ms_sort;            /* ordering of the hit list                                          */
+    double  ms_finalize;        /* coordinates, per-motif offsets, region counts                     */
+    double  ms_total;           /* first launch -> last kernel done                                  */
+    int64_t lds_bytes_read;     /* bytes the pre-filter reads from LDS (its binding on-chip stream)  */
+    int64_t hbm_bytes_algorithmic; /* codes + mask + offsets + PWMs + 16 B/hit + 8 B/PWM */
+} ms_scan_stats;
+
+const char *ms_last_error(void);
+int ms_version(void);
+
+/* Device selection is per calling thread (like hipSetDevice).  Handles remember their device. */
+int ms_device_count(int *count);
+int ms_set_device(int device);
+int ms_device_name(char *buf, int buflen);
+
+/* ---- PWM set -------------------------------------------------------------------------- */
+/* values: the P matrices concatenated, each row-major [4][width] (rows A,C,G,T).
+ * cutoffs: P doubles or NULL (then every cutoff is 1, cscore.c:70-74). */
+int ms_pwmset_create(const double *values, const int32_t *widths, const double *cutoffs,
+                     int32_t n_pwms, ms_pwmset **out);
+int ms_pwmset_set_cutoffs(ms_pwmset *pwms, const double *cutoffs);
+int ms_pwmset_size(const ms_pwmset *pwms, int32_t *n_pwms);
+int ms_pwmset_max_raw(const ms_pwmset *pwms, double *out /* [P] */);
+void ms_pwmset_free(ms_pwmset *pwms);
+
+/* ---- sequence set ---------------------------------------------------------------------- */
+/* bases: the R sequences concatenated as ASCII; offsets[R+1] (offsets[0] = 0). Copies to the
+ * device and packs there.  keep_ascii != 0 keeps the ASCII resident so ms_seqset_repack can
+ * re-run the extraction/packing kernel (bench.py times it inside the step). */
+int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, int keep_ascii,
+                     ms_seqset **out);
+/* d_bases: device pointer to the concatenated ASCII (borrowed for the call); offsets on host. */
+int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n_seqs,
+                          ms_seqset **out);
+int ms_seqset_repack(ms_seqset *seqs);
+int ms_seqset_size(const ms_seqset *seqs, int64_t *n_seqs, int64_t *n_bases);
+void ms_seqset_free(ms_seqset *seqs);
+
+/* ---- scan (c_scan_motif) ---------------------------------------------------------------- */
+int ms_scan(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags,
+            ms_result **out);
+int ms_result_num_hits(const ms_result *res, int64_t *n_hits);
+int ms_result_motif_offsets(const ms_result *res, int64_t *out /* [P+1] */);
+/* Copy the hit arrays to host buffers of length n_hits (any pointer may be NULL). */
+int ms_result_hits(const ms_result *res, int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand);
+int ms_result_region_counts(const ms_result *res, int64_t *out /* [P] */);
+/* Device pointer (int64[P]) of the same counts, for a device-side all-reduce; valid until free. */
+int ms_result_region_counts_device(const ms_result *res, void **d_counts);
+int ms_result_stats(const ms_result *res, ms_scan_stats *out);
+void ms_result_free(ms_result *res);
+
+/* ---- score (c_score) -------------------------------------------------------------------- */
+/* out: host, [P][R] row-major.  A sequence shorter than a PWM scores its missing bases as
+ * non-ACGT (the reference reads out of bounds there, cscore.c:195-196). */
+int ms_score(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, double *out);
+
+/* ---- de-duplication of overlapping sites (scanner.py:156-193), host side ---------------- */
+/* In: hits in ms_result order.  Out: keep[n_hits] (1 = kept).  Kept hits are already in the
+ * order Scanner.scan_motifs returns them (start ascending, '+' before '-' on ties). */
+int ms_dedup_hits(const int64_t *motif_offsets, int32_t n_pwms, const int32_t *widths,
+                  const int64_t *seq_idx, const int64_t *pos, const double *score,
+                  const int8_t *strand, uint8_t *keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTIFSCAN_AMD_H */

@@ -1,0 +1,30 @@
+/*
+ * motifscan_amd_debug.h -- host-only inspection of the integer pre-filter plan of
+ * libmotifscan_amd.so.  NOT part of the drop-in surface (nothing in the reference corresponds
+ * to it): it lets CPU tests prove that the quantised 2-mer tables can never drop a window the
+ * reference scorer (cscore.c:340-390) reports.  Needs no GPU.
+ */
+#ifndef MOTIFSCAN_AMD_DEBUG_H
+#define MOTIFSCAN_AMD_DEBUG_H
+
+#include "motifscan_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Build (and cache) the plan for a strand mask and an LDS budget in bytes; report its shape. */
+int ms_debug_plan_dims(const ms_pwmset *pwms, int strand_mask, int64_t lds_budget, int32_t *n_fast,
+                       int32_t *n_exact, int32_t *n_quads, int32_t *n_tiles);
+
+/* Copy the plan built by the last ms_debug_plan_dims call (any pointer may be NULL):
+ *   quad_motifs [n_quads][4] (-1 = empty slot), quad_G [n_quads],
+ *   tables [n_quads][16 groups][16 codes][4 slots] 32-bit words (lo16 forward, hi16 reverse field),
+ *   exact_motifs [n_exact], tile_first_quad [n_tiles + 1]. */
+int ms_debug_plan_tables(const ms_pwmset *pwms, int32_t *quad_motifs, int32_t *quad_G, uint32_t *tables,
+                         int32_t *exact_motifs, int32_t *tile_first_quad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

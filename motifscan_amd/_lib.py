@@ -1,0 +1,345 @@
+"""
+motifscan_amd._lib -- ctypes binding of libmotifscan_amd.so (include/motifscan_amd.h).
+
+The shared library is built in-tree by motifscan_amd/csrc/Makefile (hipcc, gfx950).  There is
+no CPU implementation behind it: if the library is missing, or no MI355X is visible when a
+compute entry point is called, the call raises -- it never falls back.
+"""
+import ctypes
+import importlib.util
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmotifscan_amd.so")
+
+MS_OK, MS_ERR_INVALID, MS_ERR_NOMEM, MS_ERR_RUNTIME = 0, 1, 2, 3
+MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY = 0, 1
+
+
+class ScanStats(ctypes.Structure):
+    _fields_ = [("n_bases", ctypes.c_int64), ("n_windows", ctypes.c_int64), ("n_candidates", ctypes.c_int64),
+                ("n_hits", ctypes.c_int64), ("n_pwms", ctypes.c_int32), ("n_pwms_exact", ctypes.c_int32),
+                ("n_tiles", ctypes.c_int32), ("n_passes", ctypes.c_int32), ("ms_prefilter", ctypes.c_double),
+                ("ms_exact", ctypes.c_double), ("ms_sort", ctypes.c_double), ("ms_finalize", ctypes.c_double),
+                ("ms_total", ctypes.c_double), ("lds_bytes_read", ctypes.c_int64),
+                ("hbm_bytes_algorithmic", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libmotifscan_amd.so in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def _preload_hip_runtime():
+    """torch wheels carry their own libamdhip64.so (same SONAME as /opt/rocm's).  If torch is
+    installed, map ITS copy first so that this library and torch share one HIP runtime in the
+    process whichever gets imported first."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C motifscan_amd/csrc`); motifscan_amd has no CPU fallback")
+    _preload_hip_runtime()
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_i32, c_i64, c_u32, vp = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p
+    pd, pi32, pi64 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)
+    pi8, pu8, pu32 = ctypes.POINTER(ctypes.c_int8), ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_u32)
+    pvp = ctypes.POINTER(vp)
+    sig = {
+        "ms_last_error": (ctypes.c_char_p, []),
+        "ms_version": (c_int, []),
+        "ms_device_count": (c_int, [ctypes.POINTER(c_int)]),
+        "ms_set_device": (c_int, [c_int]),
+        "ms_device_name": (c_int, [ctypes.c_char_p, c_int]),
+        "ms_pwmset_create": (c_int, [pd, pi32, pd, c_i32, pvp]),
+        "ms_pwmset_set_cutoffs": (c_int, [vp, pd]),
+        "ms_pwmset_size": (c_int, [vp, pi32]),
+        "ms_pwmset_max_raw": (c_int, [vp, pd]),
+        "ms_pwmset_free": (None, [vp]),
+        "ms_seqset_create": (c_int, [ctypes.c_char_p, pi64, c_i64, c_int, pvp]),
+        "ms_seqset_from_device": (c_int, [vp, pi64, c_i64, pvp]),
+        "ms_seqset_repack": (c_int, [vp]),
+        "ms_seqset_size": (c_int, [vp, pi64, pi64]),
+        "ms_seqset_free": (None, [vp]),
+        "ms_scan": (c_int, [vp, vp, c_int, c_u32, pvp]),
+        "ms_result_num_hits": (c_int, [vp, pi64]),
+        "ms_result_motif_offsets": (c_int, [vp, pi64]),
+        "ms_result_hits": (c_int, [vp, pi64, pi64, pd, pi8]),
+        "ms_result_region_counts": (c_int, [vp, pi64]),
+        "ms_result_region_counts_device": (c_int, [vp, pvp]),
+        "ms_result_stats": (c_int, [vp, ctypes.POINTER(ScanStats)]),
+        "ms_result_free": (None, [vp]),
+        "ms_score": (c_int, [vp, vp, c_int, pd]),
+        "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
+        "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
+        "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pu32, pi32, pi32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Status code -> the exception class the reference raises for that kind of failure
+    (MemoryError / RuntimeError: cscore.c:243-268, 411-430; ValueError: scanner.py:51-54)."""
+    if rc == MS_OK:
+        return
+    msg = lib().ms_last_error().decode("utf-8", "replace")
+    if rc == MS_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == MS_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = lib().ms_device_count(ctypes.byref(n))
+    return n.value if rc == MS_OK else 0
+
+
+def set_device(device):
+    check(lib().ms_set_device(int(device)))
+
+
+def device_name():
+    buf = ctypes.create_string_buffer(256)
+    check(lib().ms_device_name(buf, 256))
+    return buf.value.decode()
+
+
+# --------------------------------------------------------------------------- handles --
+
+class PwmSet:
+    """Device-side PWM set (convert_pwm + get_max_raw_score, cscore.c:36-79)."""
+
+    def __init__(self, values, widths, cutoffs=None):
+        self.values = np.ascontiguousarray(values, dtype=np.float64)
+        self.widths = np.ascontiguousarray(widths, dtype=np.int32)
+        if self.values.size != 4 * int(self.widths.sum()):
+            raise ValueError("values must hold 4*width doubles per PWM")
+        self.n = len(self.widths)
+        cut = None if cutoffs is None else np.ascontiguousarray(cutoffs, dtype=np.float64)
+        if cut is not None and cut.size != self.n:
+            raise ValueError("need one cutoff per PWM")
+        h = ctypes.c_void_p()
+        check(lib().ms_pwmset_create(ptr(self.values, ctypes.c_double), ptr(self.widths, ctypes.c_int32),
+                                     None if cut is None else ptr(cut, ctypes.c_double), self.n, ctypes.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_matrices(cls, matrices, cutoffs=None):
+        mats = []
+        for m in matrices:
+            a = np.asarray(m, dtype=np.float64)
+            if a.ndim != 2 or a.shape[0] != 4:
+                raise ValueError("each PWM must have exactly 4 rows (A, C, G, T)")
+            if a.shape[1] == 0:
+                raise ValueError("each PWM needs at least 1 position per row")
+            mats.append(np.ascontiguousarray(a))
+        widths = np.array([m.shape[1] for m in mats], dtype=np.int32)
+        values = np.concatenate([m.ravel() for m in mats]) if mats else np.zeros(0)
+        return cls(values, widths, cutoffs)
+
+    def set_cutoffs(self, cutoffs):
+        cut = np.ascontiguousarray(cutoffs, dtype=np.float64)
+        if cut.size != self.n:
+            raise ValueError("need one cutoff per PWM")
+        check(lib().ms_pwmset_set_cutoffs(self.h, ptr(cut, ctypes.c_double)))
+
+    def max_raw(self):
+        out = np.zeros(self.n, dtype=np.float64)
+        check(lib().ms_pwmset_max_raw(self.h, ptr(out, ctypes.c_double)))
+        return out
+
+    def plan(self, strand_mask=3, lds_budget=159 * 1024):
+        """Host-side view of the integer pre-filter plan (tests only)."""
+        L = lib()
+        nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
+        check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
+                                   ctypes.byref(nq), ctypes.byref(nt)))
+        qm = np.zeros((nq.value, 4), dtype=np.int32)
+        qg = np.zeros(nq.value, dtype=np.int32)
+        tb = np.zeros((nq.value, 16, 16, 4), dtype=np.uint32)
+        ex = np.zeros(max(ne.value, 1), dtype=np.int32)
+        tf = np.zeros(nt.value + 1, dtype=np.int32)
+        check(L.ms_debug_plan_tables(self.h, ptr(qm, ctypes.c_int32), ptr(qg, ctypes.c_int32),
+                                     ptr(tb, ctypes.c_uint32), ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
+        return {"n_fast": nf.value, "n_exact": ne.value, "quad_motifs": qm, "quad_G": qg, "tables": tb,
+                "exact_motifs": ex[:ne.value], "tile_first_quad": tf}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ms_pwmset_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class SeqSet:
+    """Device-side packed sequence set (convert_seq, cscore.c:81-114)."""
+
+    def __init__(self, bases, offsets, keep_ascii=False):
+        if isinstance(bases, np.ndarray):
+            bases = np.ascontiguousarray(bases, dtype=np.uint8)
+            buf = bases.ctypes.data_as(ctypes.c_char_p)
+            nbytes = bases.size
+        else:
+            bases = bytes(bases)
+            buf = bases
+            nbytes = len(bases)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if self.offsets.ndim != 1 or self.offsets.size < 1:
+            raise ValueError("offsets must have n_seqs + 1 entries")
+        if int(self.offsets[-1]) != nbytes:
+            raise ValueError("offsets[-1] must equal the number of bases")
+        self.n_seqs = self.offsets.size - 1
+        self.n_bases = nbytes
+        h = ctypes.c_void_p()
+        check(lib().ms_seqset_create(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(bool(keep_ascii)),
+                                     ctypes.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_strings(cls, seqs, keep_ascii=False):
+        bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in seqs]
+        offsets = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs])
+        return cls(b"".join(bs), offsets, keep_ascii)
+
+    @classmethod
+    def from_device(cls, device_ptr, offsets):
+        """ASCII already resident in device memory (e.g. a torch uint8 tensor's data_ptr())."""
+        self = cls.__new__(cls)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.n_seqs = self.offsets.size - 1
+        self.n_bases = int(self.offsets[-1])
+        h = ctypes.c_void_p()
+        check(lib().ms_seqset_from_device(ctypes.c_void_p(int(device_ptr)), ptr(self.offsets, ctypes.c_int64),
+                                          self.n_seqs, ctypes.byref(h)))
+        self.h = h
+        return self
+
+    def repack(self):
+        check(lib().ms_seqset_repack(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ms_seqset_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class ScanResult:
+    """Hits of one ms_scan call, in the reference's order (cscore.c:336-390, 443-471)."""
+
+    def __init__(self, handle, n_pwms):
+        self.h = handle
+        self.n_pwms = n_pwms
+        n = ctypes.c_int64()
+        check(lib().ms_result_num_hits(self.h, ctypes.byref(n)))
+        self.n_hits = n.value
+        self.motif_offsets = np.zeros(n_pwms + 1, dtype=np.int64)
+        check(lib().ms_result_motif_offsets(self.h, ptr(self.motif_offsets, ctypes.c_int64)))
+        self._hits = None
+
+    def hits(self):
+        """dict of numpy arrays: seq_idx, pos, score, strand (1 '+', 2 '-'), motif."""
+        if self._hits is None:
+            n = self.n_hits
+            seq = np.zeros(n, dtype=np.int64)
+            pos = np.zeros(n, dtype=np.int64)
+            score = np.zeros(n, dtype=np.float64)
+            strand = np.zeros(n, dtype=np.int8)
+            check(lib().ms_result_hits(self.h, ptr(seq, ctypes.c_int64), ptr(pos, ctypes.c_int64),
+                                       ptr(score, ctypes.c_double), ptr(strand, ctypes.c_int8)))
+            motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
+            self._hits = {"seq_idx": seq, "pos": pos, "score": score, "strand": strand, "motif": motif,
+                          "motif_offsets": self.motif_offsets}
+        return self._hits
+
+    def region_counts(self):
+        out = np.zeros(self.n_pwms, dtype=np.int64)
+        check(lib().ms_result_region_counts(self.h, ptr(out, ctypes.c_int64)))
+        return out
+
+    def region_counts_device_ptr(self):
+        p = ctypes.c_void_p()
+        check(lib().ms_result_region_counts_device(self.h, ctypes.byref(p)))
+        return p.value
+
+    def stats(self):
+        s = ScanStats()
+        check(lib().ms_result_stats(self.h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ms_result_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def scan(pwms, seqs, strand_mask=3, flags=MS_SCAN_DEFAULT):
+    h = ctypes.c_void_p()
+    check(lib().ms_scan(pwms.h, seqs.h, int(strand_mask), int(flags), ctypes.byref(h)))
+    return ScanResult(h, pwms.n)
+
+
+def score(pwms, seqs, strand_mask=3):
+    out = np.zeros((pwms.n, seqs.n_seqs), dtype=np.float64)
+    check(lib().ms_score(pwms.h, seqs.h, int(strand_mask), ptr(out, ctypes.c_double)))
+    return out
+
+
+def dedup_keep(motif_offsets, widths, seq_idx, pos, score_, strand):
+    motif_offsets = np.ascontiguousarray(motif_offsets, dtype=np.int64)
+    widths = np.ascontiguousarray(widths, dtype=np.int32)
+    seq_idx = np.ascontiguousarray(seq_idx, dtype=np.int64)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    score_ = np.ascontiguousarray(score_, dtype=np.float64)
+    strand = np.ascontiguousarray(strand, dtype=np.int8)
+    keep = np.ones(len(seq_idx), dtype=np.uint8)
+    check(lib().ms_dedup_hits(ptr(motif_offsets, ctypes.c_int64), len(widths), ptr(widths, ctypes.c_int32),
+                              ptr(seq_idx, ctypes.c_int64), ptr(pos, ctypes.c_int64), ptr(score_, ctypes.c_double),
+                              ptr(strand, ctypes.c_int8), ptr(keep, ctypes.c_uint8)))
+    return keep.astype(bool)

@@ -1,0 +1,860 @@
+// ms_api.hip -- the extern "C" boundary declared in include/motifscan_amd.h: handles, device
+// memory, the scan pipeline (pre-filter -> fp64 re-score -> sort -> finalize) and its
+// measurements.  One HIP stream per device owned by the library; no file-scope scan state
+// (contrast cscore.c:26-34), so handles can be used from several threads / devices.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+
+#include "ms_kernels.h"
+
+namespace ms {
+
+static thread_local std::string g_err;
+static thread_local int g_device = 0;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// ----------------------------------------------------------------- per-device state --
+
+struct Scratch {                 // grow-only work buffers of the scan pipeline
+    uint64_t *cand = nullptr;     size_t cand_cap = 0;
+    uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
+    void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
+    unsigned long long *counters = nullptr;      // [0] candidates, [1] hits
+    unsigned long long *h_counters = nullptr;    // pinned
+};
+
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    int n_cu = 0;
+    size_t lds_max = 0;
+    size_t lds_set = 0;
+    Scratch sc;
+    std::mutex mu;               // one scan at a time per device (shared scratch)
+};
+
+static std::mutex g_ctx_mu;
+static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
+
+static int get_ctx(int device, DeviceCtx **out) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) { *out = it->second.get(); MS_HIP(hipSetDevice(device)); return MS_OK; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable HIP device (%s); libmotifscan_amd has no CPU fallback", hipGetErrorString(e));
+        return MS_ERR_RUNTIME;
+    }
+    if (device < 0 || device >= n) { set_error("device %d out of range (%d devices)", device, n); return MS_ERR_INVALID; }
+    MS_HIP(hipSetDevice(device));
+    std::unique_ptr<DeviceCtx> c(new DeviceCtx());
+    c->device = device;
+    hipDeviceProp_t prop;
+    MS_HIP(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int lds_attr = 0;
+    if (hipDeviceGetAttribute(&lds_attr, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) lds_attr = 0;
+    c->lds_max = std::max<size_t>((size_t) lds_attr, prop.sharedMemPerBlock);
+    if (c->lds_max < 65536) c->lds_max = 65536;
+    if (c->lds_max > 163840) c->lds_max = 163840;
+    MS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) MS_HIP(hipEventCreate(&ev));
+    MS_HIP(hipMalloc(&c->sc.counters, 4 * sizeof(unsigned long long)));
+    MS_HIP(hipHostMalloc(&c->sc.h_counters, 4 * sizeof(unsigned long long)));
+    *out = c.get();
+    g_ctx[device] = std::move(c);
+    return MS_OK;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? MS_ERR_NOMEM : MS_ERR_RUNTIME;
+    }
+    return MS_OK;
+}
+
+template <typename T>
+static void dev_free(T *&p) {
+    if (p) (void) hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+// ------------------------------------------------------------------------- handles --
+
+struct ms_pwmset {
+    int32_t P = 0;
+    std::vector<double> values;       // concatenated [4][W] row-major, as given
+    std::vector<int64_t> val_off;     // [P+1] in doubles
+    std::vector<int32_t> widths;
+    std::vector<double> cutoffs;
+    std::vector<double> max_raw;
+    int max_width = 0;
+    uint64_t cutoff_version = 1;
+    // device copies (lazy)
+    int device = -1;
+    uint64_t dev_cutoff_version = 0;
+    double2 *d_tab2 = nullptr;
+    int64_t *d_tab_off = nullptr;
+    int32_t *d_width = nullptr;
+    double *d_max_raw = nullptr;
+    double *d_cutoff = nullptr;
+    // pre-filter plan (lazy, keyed by strand mask / cutoffs / LDS budget / exact-only)
+    PrefilterPlan plan;
+    int plan_strand = -1;
+    uint64_t plan_cutoff_version = 0;
+    size_t plan_lds = 0;
+    bool plan_exact_only = false;
+    int plan_device = -1;
+    uint4 *d_tables = nullptr;
+    TileDesc *d_tiles = nullptr;
+    int32_t *d_quad_motifs = nullptr;
+    int32_t *d_fast_motifs = nullptr;
+    int32_t *d_exact_motifs = nullptr;
+    std::mutex mu;
+};
+
+struct ms_seqset {
+    int device = 0;
+    int64_t R = 0;
+    int64_t n_bases = 0;
+    std::vector<int64_t> offsets;         // host copy [R+1]
+    std::vector<int64_t> len_sorted;      // region lengths ascending
+    std::vector<int64_t> len_suffix;      // suffix sums of len_sorted
+    uint8_t *d_ascii = nullptr;           // kept only when asked to
+    uint32_t *d_codes = nullptr;
+    uint32_t *d_nmask = nullptr;
+    int64_t *d_offsets = nullptr;
+};
+
+struct ms_result {
+    int device = 0;
+    int32_t P = 0;
+    int64_t n_hits = 0;
+    int64_t *d_seq_idx = nullptr;
+    int64_t *d_pos = nullptr;
+    double *d_score = nullptr;
+    int8_t *d_strand = nullptr;
+    unsigned long long *d_region_counts = nullptr;   // [P]
+    std::vector<int64_t> motif_offsets;               // [P+1]
+    ms_scan_stats stats;
+};
+
+// C-style max_raw: column maxima start at 0 (cscore.c:36-48)
+static double c_max_raw(const double *m, int W) {
+    double total = 0;
+    for (int c = 0; c < W; c++) {
+        double best = 0;
+        for (int b = 0; b < 4; b++)
+            if (m[(int64_t) b * W + c] > best) best = m[(int64_t) b * W + c];
+        total += best;
+    }
+    return total;
+}
+
+static void pwmset_free_device(ms_pwmset *p) {
+    if (p->device >= 0 || p->plan_device >= 0) (void) hipSetDevice(p->device >= 0 ? p->device : p->plan_device);
+    dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff);
+    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_quad_motifs); dev_free(p->d_fast_motifs);
+    dev_free(p->d_exact_motifs);
+    p->device = -1;
+    p->plan_device = -1;
+    p->dev_cutoff_version = 0;
+}
+
+static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
+    if (p->device != device) {
+        pwmset_free_device(p);
+        MS_HIP(hipSetDevice(device));
+        size_t total_w = 0;
+        for (int32_t i = 0; i < p->P; i++) total_w += (size_t) p->widths[i];
+        std::vector<double2> tab(total_w * 4);
+        std::vector<int64_t> off(p->P);
+        size_t o = 0;
+        for (int32_t i = 0; i < p->P; i++) {
+            const int W = p->widths[i];
+            const double *m = p->values.data() + p->val_off[i];
+            off[i] = (int64_t) o;
+            for (int c = 0; c < W; c++)
+                for (int b = 0; b < 4; b++) {
+                    double2 t;
+                    t.x = m[(int64_t) b * W + c];
+                    t.y = m[(int64_t) (3 - b) * W + (W - 1 - c)];       // cscore.c:351
+                    tab[o + (size_t) c * 4 + b] = t;
+                }
+            o += (size_t) W * 4;
+        }
+        int rc;
+        if ((rc = dev_alloc(&p->d_tab2, tab.size()))) return rc;
+        if ((rc = dev_alloc(&p->d_tab_off, (size_t) p->P))) return rc;
+        if ((rc = dev_alloc(&p->d_width, (size_t) p->P))) return rc;
+        if ((rc = dev_alloc(&p->d_max_raw, (size_t) p->P))) return rc;
+        if ((rc = dev_alloc(&p->d_cutoff, (size_t) p->P))) return rc;
+        if (p->P > 0) {
+            MS_HIP(hipMemcpy(p->d_tab2, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice));
+            MS_HIP(hipMemcpy(p->d_tab_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            MS_HIP(hipMemcpy(p->d_width, p->widths.data(), (size_t) p->P * sizeof(int32_t), hipMemcpyHostToDevice));
+            MS_HIP(hipMemcpy(p->d_max_raw, p->max_raw.data(), (size_t) p->P * sizeof(double), hipMemcpyHostToDevice));
+        }
+        p->device = device;
+        p->dev_cutoff_version = 0;
+    }
+    if (p->dev_cutoff_version != p->cutoff_version) {
+        if (p->P > 0)
+            MS_HIP(hipMemcpy(p->d_cutoff, p->cutoffs.data(), (size_t) p->P * sizeof(double), hipMemcpyHostToDevice));
+        p->dev_cutoff_version = p->cutoff_version;
+    }
+    (void) st;
+    return MS_OK;
+}
+
+static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
+                       int device) {
+    const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only;
+    if (stale) {
+        if (exact_only) {
+            p->plan = PrefilterPlan();
+            p->plan.strand_mask = strand_mask;
+            for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
+        } else {
+            int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
+                                p->max_raw.data(), p->P, strand_mask, lds_budget, &p->plan);
+            if (rc) return rc;
+        }
+        p->plan_strand = strand_mask;
+        p->plan_cutoff_version = p->cutoff_version;
+        p->plan_lds = lds_budget;
+        p->plan_exact_only = exact_only;
+        if (p->plan_device >= 0) {
+            (void) hipSetDevice(p->plan_device);
+            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_quad_motifs); dev_free(p->d_fast_motifs);
+            dev_free(p->d_exact_motifs);
+            p->plan_device = -1;
+        }
+    }
+    if (need_device && p->plan_device != device) {
+        MS_HIP(hipSetDevice(device));
+        const PrefilterPlan &pl = p->plan;
+        int rc;
+        if ((rc = dev_alloc(&p->d_tables, pl.tables.size() / 4))) return rc;
+        if ((rc = dev_alloc(&p->d_tiles, pl.tiles.size()))) return rc;
+        if ((rc = dev_alloc(&p->d_quad_motifs, pl.quad_motifs.size()))) return rc;
+        if ((rc = dev_alloc(&p->d_fast_motifs, pl.fast_motifs.size()))) return rc;
+        if ((rc = dev_alloc(&p->d_exact_motifs, pl.exact_motifs.size()))) return rc;
+        if (!pl.tables.empty())
+            MS_HIP(hipMemcpy(p->d_tables, pl.tables.data(), pl.tables.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!pl.tiles.empty())
+            MS_HIP(hipMemcpy(p->d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        if (!pl.quad_motifs.empty())
+            MS_HIP(hipMemcpy(p->d_quad_motifs, pl.quad_motifs.data(), pl.quad_motifs.size() * sizeof(int32_t),
+                             hipMemcpyHostToDevice));
+        if (!pl.fast_motifs.empty())
+            MS_HIP(hipMemcpy(p->d_fast_motifs, pl.fast_motifs.data(), pl.fast_motifs.size() * sizeof(int32_t),
+                             hipMemcpyHostToDevice));
+        if (!pl.exact_motifs.empty())
+            MS_HIP(hipMemcpy(p->d_exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t),
+                             hipMemcpyHostToDevice));
+        p->plan_device = device;
+    }
+    return MS_OK;
+}
+
+static DevPwm dev_pwm(const ms_pwmset *p) {
+    DevPwm d;
+    d.tab2 = p->d_tab2; d.tab_off = p->d_tab_off; d.width = p->d_width; d.max_raw = p->d_max_raw;
+    d.cutoff = p->d_cutoff; d.P = p->P;
+    return d;
+}
+
+static DevSeq dev_seq(const ms_seqset *s) {
+    DevSeq d;
+    d.codes = s->d_codes; d.nmask = s->d_nmask; d.offsets = s->d_offsets; d.R = s->R; d.n_bases = s->n_bases;
+    return d;
+}
+
+// sum_r max(L_r - W + 1, 0) from the sorted lengths
+static int64_t windows_for_width(const ms_seqset *s, int W) {
+    const auto it = std::lower_bound(s->len_sorted.begin(), s->len_sorted.end(), (int64_t) W);
+    const size_t idx = (size_t) (it - s->len_sorted.begin());
+    const int64_t cnt = (int64_t) (s->len_sorted.size() - idx);
+    return s->len_suffix[idx] - (int64_t) (W - 1) * cnt;
+}
+
+// =============================================================================== API ==
+
+extern "C" {
+
+const char *ms_last_error(void) { return g_err.c_str(); }
+
+int ms_version(void) { return 100; }
+
+int ms_device_count(int *count) {
+    if (!count) { set_error("count is NULL"); return MS_ERR_INVALID; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return MS_ERR_RUNTIME; }
+    *count = n;
+    return MS_OK;
+}
+
+int ms_set_device(int device) {
+    DeviceCtx *c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    g_device = device;
+    return MS_OK;
+}
+
+int ms_device_name(char *buf, int buflen) {
+    if (!buf || buflen <= 0) { set_error("bad buffer"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(g_device, &c);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    MS_HIP(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, (size_t) buflen, "%s (%s, %d CUs, %zu B LDS/block)", prop.name, prop.gcnArchName, c->n_cu, c->lds_max);
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------- PWM set --
+
+int ms_pwmset_create(const double *values, const int32_t *widths, const double *cutoffs, int32_t n_pwms,
+                     ms_pwmset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (n_pwms < 0 || n_pwms > kMaxMotifs) { set_error("n_pwms must be in [0, %d]", kMaxMotifs); return MS_ERR_INVALID; }
+    if (n_pwms > 0 && (!values || !widths)) { set_error("values / widths is NULL"); return MS_ERR_INVALID; }
+    std::unique_ptr<ms_pwmset> p(new (std::nothrow) ms_pwmset());
+    if (!p) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    p->P = n_pwms;
+    p->val_off.assign((size_t) n_pwms + 1, 0);
+    for (int32_t i = 0; i < n_pwms; i++) {
+        if (widths[i] < 1) { set_error("PWM %d has width %d (need >= 1 position per row)", i, widths[i]); return MS_ERR_INVALID; }
+        p->val_off[i + 1] = p->val_off[i] + 4 * (int64_t) widths[i];
+        p->max_width = std::max(p->max_width, (int) widths[i]);
+    }
+    try {
+        p->values.assign(values, values + p->val_off[n_pwms]);
+        p->widths.assign(widths, widths + n_pwms);
+        p->cutoffs.assign((size_t) n_pwms, 1.0);                       // cscore.c:70-74
+        if (cutoffs) p->cutoffs.assign(cutoffs, cutoffs + n_pwms);
+        p->max_raw.resize((size_t) n_pwms);
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    for (int32_t i = 0; i < n_pwms; i++) p->max_raw[i] = c_max_raw(p->values.data() + p->val_off[i], widths[i]);
+    *out = p.release();
+    return MS_OK;
+}
+
+int ms_pwmset_set_cutoffs(ms_pwmset *p, const double *cutoffs) {
+    if (!p || (!cutoffs && p->P > 0)) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->P > 0) p->cutoffs.assign(cutoffs, cutoffs + p->P);
+    p->cutoff_version++;
+    return MS_OK;
+}
+
+int ms_pwmset_size(const ms_pwmset *p, int32_t *n_pwms) {
+    if (!p || !n_pwms) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *n_pwms = p->P;
+    return MS_OK;
+}
+
+int ms_pwmset_max_raw(const ms_pwmset *p, double *out) {
+    if (!p || (!out && p->P > 0)) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (p->P > 0) std::memcpy(out, p->max_raw.data(), (size_t) p->P * sizeof(double));
+    return MS_OK;
+}
+
+void ms_pwmset_free(ms_pwmset *p) {
+    if (!p) return;
+    pwmset_free_device(p);
+    delete p;
+}
+
+// -------------------------------------------------------------------- sequence set --
+
+static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr<ms_seqset> &s) {
+    if (n_seqs < 0) { set_error("n_seqs < 0"); return MS_ERR_INVALID; }
+    if (!offsets) { set_error("offsets is NULL"); return MS_ERR_INVALID; }
+    if (offsets[0] != 0) { set_error("offsets[0] must be 0"); return MS_ERR_INVALID; }
+    for (int64_t r = 0; r < n_seqs; r++)
+        if (offsets[r + 1] < offsets[r]) { set_error("offsets must be non-decreasing (at %lld)", (long long) r); return MS_ERR_INVALID; }
+    s.reset(new (std::nothrow) ms_seqset());
+    if (!s) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    s->device = g_device;
+    s->R = n_seqs;
+    s->n_bases = offsets[n_seqs];
+    if (s->n_bases >= (1LL << 45)) { set_error("too many bases"); return MS_ERR_INVALID; }
+    try {
+        s->offsets.assign(offsets, offsets + n_seqs + 1);
+        s->len_sorted.resize((size_t) n_seqs);
+        for (int64_t r = 0; r < n_seqs; r++) s->len_sorted[(size_t) r] = offsets[r + 1] - offsets[r];
+        std::sort(s->len_sorted.begin(), s->len_sorted.end());
+        s->len_suffix.assign((size_t) n_seqs + 1, 0);
+        for (int64_t r = n_seqs - 1; r >= 0; r--) s->len_suffix[(size_t) r] = s->len_suffix[(size_t) r + 1] + s->len_sorted[(size_t) r];
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    return MS_OK;
+}
+
+static int seqset_alloc_packed(ms_seqset *s) {
+    const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
+    int rc;
+    if ((rc = dev_alloc(&s->d_codes, 2 * n_units + kPadWords))) return rc;
+    if ((rc = dev_alloc(&s->d_nmask, n_units + kPadWords))) return rc;
+    if ((rc = dev_alloc(&s->d_offsets, (size_t) s->R + 1))) return rc;
+    MS_HIP(hipMemset(s->d_codes, 0, (2 * n_units + kPadWords) * sizeof(uint32_t)));
+    MS_HIP(hipMemset(s->d_nmask, 0, (n_units + kPadWords) * sizeof(uint32_t)));
+    MS_HIP(hipMemcpy(s->d_offsets, s->offsets.data(), ((size_t) s->R + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    return MS_OK;
+}
+
+int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, int keep_ascii, ms_seqset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(offsets, n_seqs, s);
+    if (rc) return rc;
+    if (s->n_bases > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    if ((rc = get_ctx(s->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw))) return fail(rc);
+    if ((rc = dev_alloc(&raw->d_ascii, (size_t) raw->n_bases + 64))) return fail(rc);
+    if (raw->n_bases > 0) {
+        hipError_t e = hipMemcpy(raw->d_ascii, bases, (size_t) raw->n_bases, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    }
+    if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream))) return fail(rc);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    if (!keep_ascii) dev_free(raw->d_ascii);
+    *out = raw;
+    return MS_OK;
+}
+
+int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(offsets, n_seqs, s);
+    if (rc) return rc;
+    if (s->n_bases > 0 && !d_bases) { set_error("d_bases is NULL"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    if ((rc = get_ctx(s->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw))) return fail(rc);
+    if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, c->stream)))
+        return fail(rc);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    *out = raw;
+    return MS_OK;
+}
+
+int ms_seqset_repack(ms_seqset *s) {
+    if (!s) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (!s->d_ascii) { set_error("sequence set was created without keep_ascii"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(s->device, &c);
+    if (rc) return rc;
+    if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, c->stream))) return rc;
+    MS_HIP(hipStreamSynchronize(c->stream));
+    return MS_OK;
+}
+
+int ms_seqset_size(const ms_seqset *s, int64_t *n_seqs, int64_t *n_bases) {
+    if (!s) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (n_seqs) *n_seqs = s->R;
+    if (n_bases) *n_bases = s->n_bases;
+    return MS_OK;
+}
+
+void ms_seqset_free(ms_seqset *s) {
+    if (!s) return;
+    (void) hipSetDevice(s->device);
+    dev_free(s->d_ascii); dev_free(s->d_codes); dev_free(s->d_nmask); dev_free(s->d_offsets);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------- scan --
+
+static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap) {
+    int rc;
+    if (cand_cap > sc.cand_cap) {
+        dev_free(sc.cand);
+        sc.cand_cap = 0;
+        if ((rc = dev_alloc(&sc.cand, cand_cap))) return rc;
+        sc.cand_cap = cand_cap;
+    }
+    if (hit_cap > sc.hit_cap) {
+        dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted);
+        sc.hit_cap = 0;
+        if ((rc = dev_alloc(&sc.keys, hit_cap))) return rc;
+        if ((rc = dev_alloc(&sc.vals, hit_cap))) return rc;
+        if ((rc = dev_alloc(&sc.keys_sorted, hit_cap))) return rc;
+        sc.hit_cap = hit_cap;
+    }
+    return MS_OK;
+}
+
+int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);       // lazily cached device copies / plan
+    DeviceCtx *c;
+    int rc = get_ctx(seqs->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
+    const size_t lds_budget = c->lds_max - 1024;
+    if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
+    if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
+    const PrefilterPlan &plan = pwms->plan;
+
+    std::unique_ptr<ms_result> res(new (std::nothrow) ms_result());
+    if (!res) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    res->device = c->device;
+    res->P = pwms->P;
+    res->motif_offsets.assign((size_t) pwms->P + 1, 0);
+    ms_scan_stats &stt = res->stats;
+    std::memset(&stt, 0, sizeof(stt));
+    stt.n_bases = seqs->n_bases;
+    stt.n_pwms = pwms->P;
+    stt.n_pwms_exact = (int32_t) plan.exact_motifs.size();
+    stt.n_tiles = (int32_t) plan.tiles.size();
+    int64_t fast_windows = 0;
+    for (int32_t p = 0; p < pwms->P; p++) stt.n_windows += windows_for_width(seqs, pwms->widths[p]);
+    for (int32_t p : plan.fast_motifs) fast_windows += windows_for_width(seqs, pwms->widths[p]);
+    stt.lds_bytes_read = plan.lds_bytes_per_position * (((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads);
+
+    ms_result *raw = res.release();
+    auto fail = [&](int code) { ms_result_free(raw); return code; };
+    if ((rc = dev_alloc(&raw->d_region_counts, (size_t) pwms->P))) return fail(rc);
+    hipError_t he = hipMemsetAsync(raw->d_region_counts, 0, std::max<size_t>(1, (size_t) pwms->P) * sizeof(unsigned long long), c->stream);
+    if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+
+    int gbits = 1;
+    while ((1LL << gbits) <= seqs->n_bases) gbits++;
+    int mbits = 1;
+    while ((1 << mbits) < std::max(pwms->P, 1)) mbits++;
+
+    if (pwms->P == 0 || seqs->n_bases == 0) {                 // nothing to scan: [] / [[]...]  (cscore.c:443-445)
+        MS_HIP(hipStreamSynchronize(c->stream));
+        *out = raw;
+        return MS_OK;
+    }
+
+    Scratch &sc = c->sc;
+    // expected density at the CLI default p = 1e-4 is ~1.5e-4 candidates per window and strand; 4x head room
+    size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
+    size_t want_hits = want_cand;
+    if (!plan.exact_motifs.empty()) want_hits = std::max<size_t>(want_hits, 1 << 22);
+    want_cand = std::max(want_cand, sc.cand_cap);
+    want_hits = std::max(want_hits, sc.hit_cap);
+
+    const DevSeq S = dev_seq(seqs);
+    const DevPwm Pw = dev_pwm(pwms);
+    size_t lds_bytes = 0;
+    for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
+    if (lds_bytes > c->lds_set) {
+        if ((rc = prefilter_set_lds(lds_bytes))) return fail(rc);
+        c->lds_set = lds_bytes;
+    }
+
+    unsigned long long n_cand = 0, n_hits = 0;
+    for (int pass = 1;; pass++) {
+        if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
+        stt.n_passes = pass;
+        HitOut H;
+        H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits;
+        he = hipMemsetAsync(sc.counters, 0, 4 * sizeof(unsigned long long), c->stream);
+        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+        (void) hipEventRecord(c->ev[0], c->stream);
+        if (!plan.tiles.empty()) {
+            PfArgs A;
+            A.codes = S.codes; A.n_bases = S.n_bases; A.n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
+            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.quad_motifs = pwms->d_quad_motifs;
+            A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
+            const int n_tiles = (int) plan.tiles.size();
+            int bpt = std::max(1, c->n_cu / n_tiles);
+            bpt = (int) std::min<int64_t>(bpt, A.n_chunks);
+            if ((rc = launch_prefilter(A, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
+        }
+        (void) hipEventRecord(c->ev[1], c->stream);
+        if (!plan.fast_motifs.empty()) {
+            if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
+            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+        }
+        if (!plan.exact_motifs.empty())
+            if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
+        (void) hipEventRecord(c->ev[2], c->stream);
+        he = hipMemcpyAsync(sc.h_counters, sc.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+        n_cand = sc.h_counters[0];
+        n_hits = sc.h_counters[1];
+        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap) break;
+        if (pass >= 3) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
+        // a buffer was too small: the counters hold the exact need (a truncated candidate list
+        // under-reports hits, so leave head room there) -- grow and run the pass again
+        want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
+        const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
+        want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
+    }
+    stt.n_candidates = (int64_t) n_cand;
+    stt.n_hits = (int64_t) n_hits;
+    raw->n_hits = (int64_t) n_hits;
+
+    if ((rc = dev_alloc(&raw->d_seq_idx, (size_t) n_hits))) return fail(rc);
+    if ((rc = dev_alloc(&raw->d_pos, (size_t) n_hits))) return fail(rc);
+    if ((rc = dev_alloc(&raw->d_score, (size_t) n_hits))) return fail(rc);
+    if ((rc = dev_alloc(&raw->d_strand, (size_t) n_hits))) return fail(rc);
+    int64_t *d_motif_first = nullptr;
+    if ((rc = dev_alloc(&d_motif_first, (size_t) pwms->P + 1))) return fail(rc);
+    auto fail2 = [&](int code) { dev_free(d_motif_first); return fail(code); };
+    he = hipMemsetAsync(d_motif_first, 0xFF, ((size_t) pwms->P + 1) * sizeof(int64_t), c->stream);
+    if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+
+    (void) hipEventRecord(c->ev[3], c->stream);
+    if (n_hits > 0) {
+        size_t need = 0;
+        if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits,
+                                 gbits + 1 + mbits, c->stream))) return fail2(rc);
+        if (need > sc.sort_tmp_bytes) {
+            if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
+            sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
+            he = hipMalloc(&sc.sort_tmp, need);
+            if (he != hipSuccess) { set_error("hipMalloc of %zu bytes (sort) failed: %s", need, hipGetErrorString(he)); return fail2(MS_ERR_NOMEM); }
+            sc.sort_tmp_bytes = need;
+        }
+        size_t have = sc.sort_tmp_bytes;
+        if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits,
+                                 gbits + 1 + mbits, c->stream))) return fail2(rc);
+    }
+    (void) hipEventRecord(c->ev[4], c->stream);
+    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, S.offsets, S.R, raw->d_seq_idx, raw->d_pos,
+                              raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
+    (void) hipEventRecord(c->ev[5], c->stream);
+    std::vector<int64_t> first((size_t) pwms->P + 1);
+    he = hipMemcpyAsync(first.data(), d_motif_first, first.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    dev_free(d_motif_first);
+    raw->motif_offsets[(size_t) pwms->P] = (int64_t) n_hits;
+    for (int32_t p = pwms->P - 1; p >= 0; p--)
+        raw->motif_offsets[(size_t) p] = first[(size_t) p] >= 0 ? first[(size_t) p] : raw->motif_offsets[(size_t) p + 1];
+
+    float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
+    (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
+    (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
+    (void) hipEventElapsedTime(&ms34, c->ev[3], c->ev[4]);
+    (void) hipEventElapsedTime(&ms45, c->ev[4], c->ev[5]);
+    (void) hipEventElapsedTime(&ms05, c->ev[0], c->ev[5]);
+    stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
+    // compulsory HBM bytes of one call
+    int64_t pwm_bytes = 0;
+    for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
+    stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes +
+                                16 * (int64_t) n_hits + 8LL * pwms->P;
+    *out = raw;
+    return MS_OK;
+}
+
+int ms_result_num_hits(const ms_result *r, int64_t *n_hits) {
+    if (!r || !n_hits) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *n_hits = r->n_hits;
+    return MS_OK;
+}
+
+int ms_result_motif_offsets(const ms_result *r, int64_t *out) {
+    if (!r || !out) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    std::memcpy(out, r->motif_offsets.data(), r->motif_offsets.size() * sizeof(int64_t));
+    return MS_OK;
+}
+
+int ms_result_hits(const ms_result *r, int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand) {
+    if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (r->n_hits == 0) return MS_OK;
+    MS_HIP(hipSetDevice(r->device));
+    const size_t n = (size_t) r->n_hits;
+    if (seq_idx) MS_HIP(hipMemcpy(seq_idx, r->d_seq_idx, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (pos) MS_HIP(hipMemcpy(pos, r->d_pos, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (score) MS_HIP(hipMemcpy(score, r->d_score, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (strand) MS_HIP(hipMemcpy(strand, r->d_strand, n * sizeof(int8_t), hipMemcpyDeviceToHost));
+    return MS_OK;
+}
+
+int ms_result_region_counts(const ms_result *r, int64_t *out) {
+    if (!r || (!out && r->P > 0)) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (r->P == 0) return MS_OK;
+    MS_HIP(hipSetDevice(r->device));
+    MS_HIP(hipMemcpy(out, r->d_region_counts, (size_t) r->P * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return MS_OK;
+}
+
+int ms_result_region_counts_device(const ms_result *r, void **d_counts) {
+    if (!r || !d_counts) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *d_counts = r->d_region_counts;
+    return MS_OK;
+}
+
+int ms_result_stats(const ms_result *r, ms_scan_stats *out) {
+    if (!r || !out) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *out = r->stats;
+    return MS_OK;
+}
+
+void ms_result_free(ms_result *r) {
+    if (!r) return;
+    (void) hipSetDevice(r->device);
+    dev_free(r->d_seq_idx); dev_free(r->d_pos); dev_free(r->d_score); dev_free(r->d_strand);
+    dev_free(r->d_region_counts);
+    delete r;
+}
+
+// --------------------------------------------------------------------------- score --
+
+int ms_score(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, double *out) {
+    if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d", strand_mask); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    if (pwms->P == 0 || seqs->R == 0) return MS_OK;
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(seqs->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
+    double *d_out = nullptr;
+    const size_t n = (size_t) pwms->P * (size_t) seqs->R;
+    if ((rc = dev_alloc(&d_out, n))) return rc;
+    rc = launch_score(dev_seq(seqs), dev_pwm(pwms), strand_mask, d_out, c->stream);
+    hipError_t he = hipSuccess;
+    if (!rc) he = hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (!rc && he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    dev_free(d_out);
+    if (rc) return rc;
+    if (he != hipSuccess) { set_error("score kernel failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+    return MS_OK;
+}
+
+// --------------------------------------------------------------------------- dedup --
+
+// scanner.py:156-193 on the flat hit arrays.  Within one (motif, region) the reference splits
+// the sites by strand, runs the greedy pass on each strand, and re-merges by a stable sort on
+// start with '+' first -- which is the order the hits already have, so de-dup is a filter.
+int ms_dedup_hits(const int64_t *motif_offsets, int32_t n_pwms, const int32_t *widths, const int64_t *seq_idx,
+                  const int64_t *pos, const double *score, const int8_t *strand, uint8_t *keep) {
+    if (n_pwms < 0 || !motif_offsets) { set_error("bad arguments"); return MS_ERR_INVALID; }
+    const int64_t n = motif_offsets[n_pwms];
+    if (n > 0 && (!widths || !seq_idx || !pos || !score || !strand || !keep)) { set_error("NULL array"); return MS_ERR_INVALID; }
+    for (int64_t i = 0; i < n; i++) keep[i] = 1;
+    for (int32_t p = 0; p < n_pwms; p++) {
+        const int64_t W = widths[p];
+        int64_t a = motif_offsets[p];
+        const int64_t end = motif_offsets[p + 1];
+        while (a < end) {
+            int64_t b = a;
+            while (b < end && seq_idx[b] == seq_idx[a]) b++;
+            for (int8_t sd = 1; sd <= 2; sd++) {
+                int64_t cur = -1;                        // index of the site currently kept (scanner.py:160)
+                for (int64_t i = a; i < b; i++) {
+                    if (strand[i] != sd) continue;
+                    if (cur < 0) { cur = i; continue; }
+                    if (pos[i] - pos[cur] < W) {
+                        if (score[cur] >= score[i]) keep[i] = 0;           // tie keeps the earlier site
+                        else { keep[cur] = 0; cur = i; }
+                    } else {
+                        cur = i;
+                    }
+                }
+            }
+            a = b;
+        }
+    }
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------ test inspection --
+// Host-only views of the pre-filter plan, so CPU tests can prove the quantiser never drops a
+// window the reference reports (tests/test_prefilter_plan.py).  Not part of the drop-in surface.
+
+int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_budget, int32_t *n_fast,
+                       int32_t *n_exact, int32_t *n_quads, int32_t *n_tiles) {
+    if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    std::lock_guard<std::mutex> lk(pwms->mu);
+    int rc = pwmset_plan(pwms, strand_mask, (size_t) lds_budget, false, false, -1);
+    if (rc) return rc;
+    if (n_fast) *n_fast = (int32_t) pwms->plan.fast_motifs.size();
+    if (n_exact) *n_exact = (int32_t) pwms->plan.exact_motifs.size();
+    if (n_quads) *n_quads = (int32_t) pwms->plan.quad_G.size();
+    if (n_tiles) *n_tiles = (int32_t) pwms->plan.tiles.size();
+    return MS_OK;
+}
+
+// quad_motifs [n_quads][4], quad_G [n_quads], tables [n_quads][16 groups][16 codes][4 slots] (zero padded),
+// exact_motifs [n_exact], tile_first_quad [n_tiles+1]
+int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *quad_motifs, int32_t *quad_G, uint32_t *tables,
+                         int32_t *exact_motifs, int32_t *tile_first_quad) {
+    if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    std::lock_guard<std::mutex> lk(pwms->mu);
+    const PrefilterPlan &pl = pwms->plan;
+    if (pwms->plan_strand < 0) { set_error("call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
+    const size_t nq = pl.quad_G.size();
+    if (quad_motifs) std::memcpy(quad_motifs, pl.quad_motifs.data(), pl.quad_motifs.size() * sizeof(int32_t));
+    if (quad_G) std::memcpy(quad_G, pl.quad_G.data(), nq * sizeof(int32_t));
+    if (tables) {
+        std::memset(tables, 0, nq * 16 * 16 * 4 * sizeof(uint32_t));
+        size_t off16 = 0;
+        for (size_t q = 0; q < nq; q++) {
+            const int G = pl.quad_G[q];
+            for (int g = 0; g < G; g++)
+                for (int x = 0; x < 16; x++)
+                    for (int k = 0; k < 4; k++)
+                        tables[((q * 16 + g) * 16 + x) * 4 + k] = pl.tables[(off16 + (size_t) g * 16 + x) * 4 + k];
+            off16 += (size_t) G * 16;
+        }
+    }
+    if (exact_motifs && !pl.exact_motifs.empty())
+        std::memcpy(exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t));
+    if (tile_first_quad) {
+        for (size_t t = 0; t < pl.tiles.size(); t++) tile_first_quad[t] = pl.tiles[t].first_quad;
+        tile_first_quad[pl.tiles.size()] = (int32_t) nq;
+    }
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// ms_kernels.h -- kernel argument structs and launchers (ms_kernels.hip).
+#pragma once
+#include "ms_internal.h"
+
+namespace ms {
+
+constexpr int kPfThreads = 1024;      // pre-filter block: 16 waves, one block per CU
+constexpr int kNwMotifChunk = 64;     // motifs per nwindow_kernel thread
+
+struct DevSeq {
+    const uint32_t *codes;
+    const uint32_t *nmask;
+    const int64_t *offsets;   // [R+1]
+    int64_t R;
+    int64_t n_bases;
+};
+
+struct DevPwm {
+    const double2 *tab2;      // see ms_kernels.hip header
+    const int64_t *tab_off;   // [P] offset of motif p in tab2 (double2 units)
+    const int32_t *width;     // [P]
+    const double *max_raw;    // [P]
+    const double *cutoff;     // [P]
+    int32_t P;
+};
+
+struct HitOut {
+    uint64_t *keys;           // motif << (gbits+1) | position << 1 | strand bit
+    double *vals;             // normalised fp64 score
+    unsigned long long *n_hits;
+    uint64_t cap;
+    int gbits;                // bits needed for a base position
+};
+
+struct PfArgs {
+    const uint32_t *codes;
+    int64_t n_bases;
+    int64_t n_chunks;         // ceil(n_bases / kPfThreads)
+    const uint4 *tables;
+    const TileDesc *tiles;
+    const int32_t *quad_motifs;
+    uint64_t *cand;
+    unsigned long long *n_cand;
+    uint64_t cand_cap;
+};
+
+int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
+int prefilter_set_lds(size_t bytes);
+int launch_prefilter(const PfArgs &A, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
+int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
+                   const HitOut &H, hipStream_t st);
+int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
+                     const HitOut &H, hipStream_t st);
+int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
+                   uint64_t cand_cap, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st);
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const int64_t *offsets, int64_t R, int64_t *seq_idx,
+                    int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
+                    hipStream_t st);
+int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
+
+}  // namespace ms

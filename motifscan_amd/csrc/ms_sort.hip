@@ -1,0 +1,22 @@
+// ms_sort.hip -- ordering of the sparse hit list (keys = motif | position | strand bit,
+// values = fp64 scores).  The hit list is ~1e-4 of the scanned units, so this is not the hot
+// kernel; rocPRIM's device radix sort (AMD's own header-only primitives) is used as is.
+// Kept in its own translation unit because the rocPRIM headers dominate compile time.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ms_internal.h"
+
+namespace ms {
+
+int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
+                   const double *vals_in, double *vals_out, size_t n, int end_bit, hipStream_t stream) {
+    if (end_bit < 1) end_bit = 1;
+    if (end_bit > 64) end_bit = 64;
+    MS_HIP(rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u,
+                                     (unsigned int) end_bit, stream));
+    return MS_OK;
+}
+
+}  // namespace ms

@@ -1,0 +1,161 @@
+"""
+motifscan_amd.scanner -- host-side mirror of the reference's `motifscan.scanner`
+(/root/reference/motifscan/scanner.py) over the MI355X scan path.
+
+Same public surface and behaviour:
+    MotifSite(start, score, strand)                      scanner.py:16
+    Scanner(genome, regions, window_size=0, strand='both', p_value='1e-4',
+            remove_dup=True, n_threads=1)                scanner.py:44-69
+        .sequences / .seq_starts / .seq_ends / .window_size / .extend / .strand /
+        .p_value / .remove_dup / .n_threads
+        .scan_motifs(pwms) -> nested list [n_pwms][n_regions] of MotifSite   scanner.py:89-132
+    make_motif_sites(sites, seq_starts)                  scanner.py:135-153
+    deduplicate_motif_sites(motif_sites, lengths)        scanner.py:171-193
+plus, for inputs where n_pwms x n_regions Python lists are not an option:
+    Scanner.scan_motifs_arrays(pwms) -> flat numpy arrays in the same order.
+
+`genome` is any object with `chrom_sizes[chrom]` and `fetch_sequence(chrom, start, end)`;
+`regions` any objects with `.chrom .start .end .summit` -- i.e. the reference's own
+`Genome` / `GenomicRegion` work unchanged.  `pwms` is any iterable of objects with
+`.matrix` (4 x W), `.cutoffs[p_value]` and `.length`.
+"""
+import logging
+import os
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+MotifSite = namedtuple("MotifSite", ["start", "score", "strand"])
+
+_STRAND_FLAG = {"+": 1, "-": 2, "both": 3}
+
+
+class Scanner:
+    def __init__(self, genome, regions, window_size=0, strand="both", p_value="1e-4", remove_dup=True,
+                 n_threads=1):
+        self.window_size = window_size if window_size > 0 else 0
+        self.extend = window_size // 2
+        if strand not in _STRAND_FLAG:
+            raise ValueError(f"invalid strand option: {strand!r}")
+        self.strand = strand
+        self.p_value = p_value
+        self.remove_dup = remove_dup
+        # kept for interface parity; the GPU path has no use for host threads (scanner.py:56-65)
+        n_cpu = os.cpu_count() or 1
+        n_threads = int(n_threads)
+        if n_threads > n_cpu:
+            logger.warning(f"Threads number exceed the number of CPUs, using {n_cpu} instead")
+        self.n_threads = max(1, min(n_threads, n_cpu))
+        self.seq_starts, self.seq_ends, self.sequences = [], [], []
+        self._extract_seq(genome, regions)
+
+    def _extract_seq(self, genome, regions):
+        """Forward-strand sequence of every region (whole region, or a window of 2*(w//2) bp
+        centred on the summit and clipped to the chromosome)."""
+        logger.debug("Extracting sequences")
+        whole = self.window_size <= 0
+        for region in regions:
+            if whole:
+                lo, hi = region.start, region.end
+            else:
+                lo = max(region.summit - self.extend, 0)
+                hi = min(region.summit + self.extend, genome.chrom_sizes[region.chrom])
+            self.seq_starts.append(lo)
+            self.seq_ends.append(hi)
+            self.sequences.append(genome.fetch_sequence(region.chrom, lo, hi))
+
+    # ------------------------------------------------------------------ scanning --
+
+    def _marshal(self, pwms):
+        pwms = list(pwms)
+        cutoffs = []
+        for pwm in pwms:
+            try:
+                cutoffs.append(pwm.cutoffs[self.p_value])
+            except (TypeError, KeyError):
+                raise ValueError(f"PWM has no motif score cutoff set for P-value {self.p_value!r}")
+        matrices = [np.asarray(pwm.matrix, dtype=np.float64) for pwm in pwms]
+        lengths = [pwm.length for pwm in pwms]
+        return matrices, np.asarray(cutoffs, dtype=np.float64), lengths
+
+    def scan_motifs_arrays(self, pwms):
+        """Flat result: dict with motif, region, start (genome coordinate), score, strand (1/2),
+        motif_offsets -- ordered exactly like the nested lists scan_motifs returns."""
+        matrices, cutoffs, lengths = self._marshal(pwms)
+        logger.debug("Scanning motif PWMs")
+        pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
+        sq = _lib.SeqSet.from_strings(self.sequences)
+        res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
+        try:
+            h = res.hits()
+            region_counts = res.region_counts()
+        finally:
+            res.close()
+            sq.close()
+            pw.close()
+        keep = None
+        if self.remove_dup and len(h["pos"]):
+            keep = _lib.dedup_keep(h["motif_offsets"], lengths, h["seq_idx"], h["pos"], h["score"], h["strand"])
+        starts = np.asarray(self.seq_starts, dtype=np.int64)
+        out = {"motif": h["motif"], "region": h["seq_idx"],
+               "start": (starts[h["seq_idx"]] + h["pos"]) if len(h["pos"]) else h["pos"],
+               "score": h["score"], "strand": h["strand"]}
+        if keep is not None:
+            out = {k: v[keep] for k, v in out.items()}
+        n_pwms = len(matrices)
+        out["motif_offsets"] = np.concatenate([[0], np.cumsum(np.bincount(out["motif"], minlength=n_pwms))]).astype(
+            np.int64) if n_pwms else np.zeros(1, dtype=np.int64)
+        out["n_regions_with_site"] = region_counts        # de-dup never empties a region
+        return out
+
+    def scan_motifs(self, pwms):
+        pwms = list(pwms)
+        a = self.scan_motifs_arrays(pwms)
+        n_regions = len(self.sequences)
+        motif_sites = [[[] for _ in range(n_regions)] for _ in pwms]
+        for m, r, st, sc, sd in zip(a["motif"].tolist(), a["region"].tolist(), a["start"].tolist(),
+                                    a["score"].tolist(), a["strand"].tolist()):
+            motif_sites[m][r].append(MotifSite(st, sc, "+" if sd == 1 else "-"))
+        return motif_sites
+
+
+def make_motif_sites(sites, seq_starts):
+    """Pooled [seq_idx, pos, score, strand] hits -> [n_pwms][n_seqs] lists of MotifSite in genome coordinates."""
+    out = []
+    for per_pwm in sites:
+        buckets = [[] for _ in seq_starts]
+        for seq_idx, pos, score, strand in per_pwm:
+            buckets[seq_idx].append(MotifSite(seq_starts[seq_idx] + pos, score, "+" if strand == 1 else "-"))
+        out.append(buckets)
+    return out
+
+
+def deduplicate_motif_sites(motif_sites, lengths):
+    """Drop the lower-scoring one of two same-strand sites closer than the motif length (greedy,
+    left to right, ties keep the earlier site); strands are handled separately, the result is
+    ordered by start with '+' before '-'.  Works on the nested lists through the same C routine
+    (ms_dedup_hits) the array path uses."""
+    motif, region, start, score, strand, sizes = [], [], [], [], [], []
+    for m, per_pwm in enumerate(motif_sites):
+        for r, sites in enumerate(per_pwm):
+            sizes.append(len(sites))
+            # the C routine wants (start asc, '+' first) inside a region: stable sort by that key
+            for s in sorted(sites, key=lambda s: (s.start, 0 if s.strand == "+" else 1)):
+                motif.append(m)
+                region.append(r)
+                start.append(s.start)
+                score.append(s.score)
+                strand.append(1 if s.strand == "+" else 2)
+    n_pwms = len(motif_sites)
+    offsets = np.concatenate([[0], np.cumsum(np.bincount(np.asarray(motif, dtype=np.int64), minlength=n_pwms))]) \
+        if n_pwms else np.zeros(1)
+    keep = _lib.dedup_keep(offsets, list(lengths), region, start, np.asarray(score, dtype=np.float64), strand) \
+        if motif else np.zeros(0, dtype=bool)
+    out = [[[] for _ in per_pwm] for per_pwm in motif_sites]
+    for k in np.nonzero(keep)[0].tolist():
+        out[motif[k]][region[k]].append(MotifSite(start[k], score[k], "+" if strand[k] == 1 else "-"))
+    return out

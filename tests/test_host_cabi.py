@@ -1,0 +1,269 @@
+"""
+CPU-only checks of the host side of libmotifscan_amd.so: the library loads and exports every
+symbol the headers declare, argument validation maps to the reference's exception classes, the
+pre-filter quantiser can never drop a window the reference reports, and the host-side
+de-duplication equals the reference's.  No compute entry point is called (no GPU here).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from motifscan_amd import _lib, matrix, scanner
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = set()
+    for hdr in ("motifscan_amd.h", "motifscan_amd_debug.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+
+
+def test_scan_stats_struct_matches_header():
+    text = open(os.path.join(ROOT, "include", "motifscan_amd.h")).read()
+    body = re.search(r"typedef struct ms_scan_stats \{(.*?)\} ms_scan_stats;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int64_t|int32_t|double)\s+(\w+);", body)
+    ctmap = {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "double": ctypes.c_double}
+    assert [(n, ctmap[t]) for t, n in fields] == list(_lib.ScanStats._fields_)
+
+
+def test_validation_maps_to_reference_exceptions():
+    with pytest.raises(ValueError):
+        _lib.PwmSet.from_matrices([[[1.0], [2.0], [3.0]]])                 # 3 rows
+    with pytest.raises(ValueError):
+        _lib.PwmSet.from_matrices([[[], [], [], []]])                      # width 0
+    with pytest.raises(ValueError):
+        _lib.PwmSet(np.zeros(7), np.array([2], dtype=np.int32))            # wrong value count
+    with pytest.raises(ValueError):
+        _lib.PwmSet.from_matrices([np.zeros((4, 3))], cutoffs=[0.1, 0.2])
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        _lib.SeqSet.from_strings(["ACGT"])
+    from motifscan_amd import cscore
+    with pytest.raises(RuntimeError):
+        cscore.c_scan_motif([np.zeros((4, 3)).tolist()], [0.5], ["ACGTACGT"], 3, 1)
+
+
+def test_max_raw_is_the_c_definition(oracle, rnd):
+    pw = _lib.PwmSet.from_matrices(rnd["mats"] + [np.array([[-1, 2], [-2, 1], [-3, .5], [-4, .1]])])
+    got = pw.max_raw()
+    want = [oracle.max_raw_score(m) for m in rnd["mats"]] + [2.0]
+    assert np.array_equal(got, np.array(want))
+
+
+# ---------------------------------------------------------------- pre-filter plan --
+
+def emulate_prefilter(plan, seq_codes_2bit):
+    """numpy model of prefilter_kernel: for every window start of one N-free sequence return the
+    set of (motif, strand) whose 16-bit field reaches 0x8000."""
+    L = len(seq_codes_2bit)
+    padded = np.concatenate([seq_codes_2bit, np.zeros(40, dtype=np.int64)])
+    code = padded[:-1] | (padded[1:] << 2)                    # 2-mer code at every position
+    flagged = set()
+    for q in range(plan["quad_motifs"].shape[0]):
+        G = int(plan["quad_G"][q])
+        acc = np.zeros((L, 4), dtype=np.uint64)
+        for g in range(G):
+            acc += plan["tables"][q, g][code[2 * g:2 * g + L]]
+        for k in range(4):
+            m = int(plan["quad_motifs"][q, k])
+            if m < 0:
+                assert not (acc[:, k] & 0x80008000).any()
+                continue
+            lo, hi = acc[:, k] & 0xFFFF, acc[:, k] >> 16
+            assert (acc[:, k] < (1 << 32)).all()
+            for j in np.nonzero(lo >= 0x8000)[0]:
+                flagged.add((m, int(j), 1))
+            for j in np.nonzero(hi >= 0x8000)[0]:
+                flagged.add((m, int(j), 2))
+    return flagged
+
+
+def fields_never_overflow(plan):
+    t = plan["tables"].astype(np.uint64)
+    lo, hi = t & 0xFFFF, t >> 16
+    for part in (lo, hi):
+        worst = part.max(axis=2).sum(axis=1)                  # [quad][slot]: sum over groups of the max code entry
+        assert (worst <= 0xFFFF).all()
+
+
+@pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
+@pytest.mark.parametrize("strand", [1, 2, 3])
+def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand):
+    mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
+    pw = _lib.PwmSet.from_matrices(mats, cut)
+    plan = pw.plan(strand)
+    fields_never_overflow(plan)
+    assert plan["n_fast"] + plan["n_exact"] == len(mats)
+    fast = set(plan["quad_motifs"].ravel().tolist()) - {-1}
+    assert fast | set(plan["exact_motifs"].tolist()) == set(range(len(mats)))
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGT"), p=[.295, .205, .205, .295], size=3000)) for _ in range(3)]
+    lut = {c: i for i, c in enumerate("ACGT")}
+    n_flag = n_hit = 0
+    for s in seqs:
+        codes = np.array([lut[c] for c in s], dtype=np.int64)
+        flagged = emulate_prefilter(plan, codes)
+        sites = oracle.c_scan_motif([m.tolist() for m in mats], cut.tolist(), [s], strand, 2)
+        for m, hits in enumerate(sites):
+            if m not in fast:
+                continue
+            for _, pos, _, sd in hits:
+                assert (m, pos, sd) in flagged, (m, pos, sd)
+                n_hit += 1
+        n_flag += sum(1 for (m, j, sd) in flagged if j + mats[m].shape[1] <= len(s))
+    # the filter must stay selective: allow 2x the true hits plus slack
+    assert n_flag <= 2 * n_hit + 200, (n_flag, n_hit)
+
+
+def test_prefilter_routes_degenerate_pwms_to_exact_path():
+    wide = np.zeros((4, 40))
+    wide[0] = 1.0
+    allneg = -np.ones((4, 5))
+    nonfinite = np.ones((4, 6))
+    nonfinite[2, 3] = -np.inf
+    ok = np.array([[1.0, -2, 0.5], [-1, 1.2, -0.3], [0.2, -0.4, 0.9], [-3, 0.1, -1.0]])
+    low_cut = ok.copy()
+    pw = _lib.PwmSet.from_matrices([wide, allneg, nonfinite, ok, low_cut], [0.5, 0.5, 0.5, 0.6, -50.0])
+    plan = pw.plan(3)
+    assert sorted(plan["exact_motifs"].tolist()) == [0, 1, 2, 4]
+    assert plan["n_fast"] == 1
+
+
+def test_plan_tiles_respect_lds_budget(jaspar579):
+    pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
+    for budget in (64 * 1024, 159 * 1024):
+        plan = pw.plan(3, budget)
+        assert plan["n_exact"] == 0 and plan["n_fast"] == 579
+        tf = plan["tile_first_quad"]
+        for t in range(len(tf) - 1):
+            tile_bytes = int(plan["quad_G"][tf[t]:tf[t + 1]].sum()) * 256
+            assert 0 < tile_bytes <= budget
+        assert tf[-1] == len(plan["quad_G"]) == (579 + 3) // 4
+        assert (np.diff(plan["quad_G"]) >= 0).all()          # narrow to wide
+
+
+# --------------------------------------------------------------------------- dedup --
+
+def test_dedup_matches_reference_cases(small):
+    S = scanner.MotifSite
+    for case in small["dedup"]:
+        sites = [S(*s) for s in case["sites"]]
+        out = scanner.deduplicate_motif_sites([[sites]], [case["length"]])
+        assert [[s.start, s.score, s.strand] for s in out[0][0]] == case["out"], case["name"]
+
+
+def test_dedup_matches_oracle_on_random_hits(oracle, rnd):
+    tag = "scan_p1e-3_s3"
+    motif, seq, pos = rnd[tag + "_motif"], rnd[tag + "_seq"], rnd[tag + "_pos"]
+    score, strand = rnd[tag + "_score"], rnd[tag + "_strand"]
+    P = len(rnd["widths"])
+    offsets = np.concatenate([[0], np.cumsum(np.bincount(motif, minlength=P))])
+    keep = _lib.dedup_keep(offsets, rnd["widths"], seq, pos, score, strand)
+    sites = [[] for _ in range(P)]
+    for m, s, p_, v, d in zip(motif, seq, pos, score, strand):
+        sites[m].append([int(s), int(p_), float(v), int(d)])
+    ms = oracle.make_motif_sites(sites, [0] * len(rnd["seqs"]))
+    dd = oracle.deduplicate_motif_sites(ms, [int(w) for w in rnd["widths"]])
+    want = [(m, r, s.start, s.score, 1 if s.strand == "+" else 2)
+            for m, per in enumerate(dd) for r, ss in enumerate(per) for s in ss]
+    got = list(zip(motif[keep].tolist(), seq[keep].tolist(), pos[keep].tolist(), score[keep].tolist(),
+                   strand[keep].tolist()))
+    assert got == want
+    assert 0 < keep.sum() < len(keep)
+
+
+# -------------------------------------------------------------------------- matrix --
+
+def test_matrix_pipeline_matches_reference_values(small):
+    g = small["G7"]
+    pfm = matrix.PositionFrequencyMatrix(g["pfm"])
+    assert np.array_equal(pfm.to_ppm(normalize=False).matrix, np.array(g["pfm_to_ppm_raw"]))
+    assert np.array_equal(pfm.to_ppm(normalize=True, pseudo=0.001).matrix, np.array(g["pfm_to_ppm_norm"]))
+    ppm = matrix.PositionProbabilityMatrix(g["ppm"])
+    ppm.normalize(pseudo=0.001)
+    assert np.array_equal(ppm.matrix, np.array(g["ppm_normalized"]))
+    assert np.array_equal(ppm.to_pwm().matrix, np.array(g["ppm_to_pwm_default_bg"]))
+    assert np.array_equal(ppm.to_pwm(bg_freq=g["bg"]).matrix, np.array(g["ppm_to_pwm_bg"]))
+    pwm = matrix.PositionWeightMatrix(g["pwm"])
+    assert float(pwm.max_raw_score) == g["max_raw_score"]
+    assert float(pwm.min_raw_score) == g["min_raw_score"]
+    for s, v in g["score"].items():
+        assert float(pwm.score(s)) == v
+
+
+def test_matrix_errors_like_reference():
+    """/root/reference/tests/test_motif_matrix.py:9-60,106-112"""
+    with pytest.raises(ValueError):
+        matrix.PositionMatrix([[1], [2], [3]])
+    with pytest.raises(ValueError):
+        matrix.PositionMatrix([[], [], [], []])
+    with pytest.raises(ValueError):
+        matrix.PositionFrequencyMatrix([[1], [0.4], [7], [10]])
+    with pytest.raises(ValueError):
+        matrix.PositionFrequencyMatrix([[-1], [4], [7], [10]])
+    with pytest.raises(ValueError):
+        matrix.PositionFrequencyMatrix([[0], [0], [0], [0]])
+    with pytest.raises(ValueError):
+        matrix.PositionProbabilityMatrix([[0], [0.2], [-0.1], [0.9]])
+    with pytest.raises(ValueError):
+        matrix.PositionProbabilityMatrix([[0.3], [0.2], [0.5], [0.3]])
+    ppm = matrix.PositionProbabilityMatrix([[0.2, 0.2], [0.2, 0.2], [0.3, 0.6], [0.3, 0]])
+    with pytest.raises(ValueError):
+        ppm.normalize(pseudo=1)
+    pwm = matrix.PositionWeightMatrix([[1.35, 0.21, -5.23], [0.07, -0.21, 0.6], [2.15, 2.22, -0.84],
+                                       [-2.64, -1.89, 5.47]])
+    with pytest.raises(ValueError):
+        pwm.score("")
+    with pytest.raises(ValueError):
+        pwm.score("NNNN")
+    assert pwm.score("NNN") == 0
+
+
+def test_scanner_ctor_semantics_without_gpu(small):
+    """Window extraction is host logic (scanner.py:44-87): check it against the reference's run."""
+    g = small["G2"]
+
+    class G:
+        chrom_sizes = {k: len(v) for k, v in g["chroms"].items()}
+
+        @staticmethod
+        def fetch_sequence(chrom, start, end):
+            return g["chroms"][chrom][start:end]
+
+    class R:
+        chrom, start, end, summit = g["region"][0], g["region"][1], g["region"][2], (g["region"][1] + g["region"][2]) // 2
+
+    s0 = scanner.Scanner(G, [R], window_size=0)
+    assert [s0.sequences, s0.seq_starts, s0.seq_ends] == g["extract"]["w0"] and s0.window_size == 0
+    s4 = scanner.Scanner(G, [R], window_size=4, strand="+")
+    assert [s4.sequences, s4.seq_starts, s4.seq_ends] == g["extract"]["w4"]
+    with pytest.raises(ValueError):
+        scanner.Scanner(G, [R], window_size=0, strand="*")
+    assert scanner.Scanner(G, [R], n_threads=0).n_threads == 1
+
+    class P:
+        matrix, cutoffs, length = np.array(g["pwm"], dtype=float), {"1e-3": 0.5}, 2
+
+    with pytest.raises(ValueError):                           # missing cutoff: before any device work
+        scanner.Scanner(G, [R], window_size=4, p_value="1e-2").scan_motifs([P])
