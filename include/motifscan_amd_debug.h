@@ -24,6 +24,10 @@ int ms_debug_plan_dims(const ms_pwmset *pwms, int strand_mask, int64_t lds_budge
 int ms_debug_plan_tables(const ms_pwmset *pwms, int32_t *quad_motifs, int32_t *quad_G, uint32_t *tables,
                          int32_t *exact_motifs, int32_t *tile_first_quad);
 
+/* Free the current device's grow-only work buffers (candidate list, hit list, sort space), so a
+ * test can force the "buffer too small -> grow -> run the pass again" path.  Needs a GPU. */
+int ms_debug_release_scratch(void);
+
 #ifdef __cplusplus
 }
 #endif

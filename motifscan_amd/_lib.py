@@ -103,6 +103,7 @@ def lib():
         "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
         "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
         "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pu32, pi32, pi32]),
+        "ms_debug_release_scratch": (c_int, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -329,6 +330,10 @@ def score(pwms, seqs, strand_mask=3):
     out = np.zeros((pwms.n, seqs.n_seqs), dtype=np.float64)
     check(lib().ms_score(pwms.h, seqs.h, int(strand_mask), ptr(out, ctypes.c_double)))
     return out
+
+
+def release_scratch():
+    check(lib().ms_debug_release_scratch())
 
 
 def dedup_keep(motif_offsets, widths, seq_idx, pos, score_, strand):

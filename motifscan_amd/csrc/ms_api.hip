@@ -857,4 +857,19 @@ int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *quad_motifs, int32_t 
     return MS_OK;
 }
 
+// Free the calling thread's device work buffers (they are grow-only otherwise); lets a test
+// exercise the "buffer too small -> grow -> second pass" path deterministically.
+int ms_debug_release_scratch(void) {
+    DeviceCtx *c;
+    int rc = get_ctx(g_device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    Scratch &sc = c->sc;
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted);
+    if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
+    sc.sort_tmp = nullptr;
+    sc.cand_cap = sc.hit_cap = sc.sort_tmp_bytes = 0;
+    return MS_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,102 @@
+"""
+motifscan_amd.dist -- multi-GPU form of the scan path: one process per GPU, regions sharded,
+ONE collective.
+
+Regions are independent units (windows never cross a region, cscore.c:336-340; de-dup is per
+(motif, region, strand), scanner.py:176-193), so the path shards with no data-path exchange:
+every rank gets a contiguous block of regions (balanced by bases, not by count) and ALL PWMs.
+The only cross-rank quantity the downstream statistics need is, per motif, the number of
+regions with >= 1 site in the input set and in the control set (stats.py:29-31): a single
+all-reduce(sum) of int64[n_sets * n_pwms] (9 KB at 579 motifs; latency-bound, so ring vs tree
+and xGMI link bandwidth are irrelevant).  Hit lists stay on the rank that produced them;
+`seq_idx + shard_start` is the global region index, so concatenating the ranks' lists in rank
+order reproduces the single-GPU order within each motif.
+
+The reference has no counterpart (it has no distributed code at all); the consumer of the
+reduced counts is `motifscan.stats.motif_enrichment`, restated below only as far as needed to
+show the hand-over (Fisher exact, fold change).
+"""
+import numpy as np
+
+
+def shard_bounds(offsets, world_size):
+    """Contiguous region blocks [r0, r1) per rank, balanced by number of bases."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n_regions = len(offsets) - 1
+    total = int(offsets[-1])
+    cuts = [0]
+    for k in range(1, world_size):
+        target = total * k // world_size
+        r = int(np.searchsorted(offsets, target, side="left"))
+        cuts.append(min(max(r, cuts[-1]), n_regions))
+    cuts.append(n_regions)
+    return [(cuts[k], cuts[k + 1]) for k in range(world_size)]
+
+
+def take_shard(bases, offsets, r0, r1):
+    offsets = np.asarray(offsets, dtype=np.int64)
+    lo, hi = int(offsets[r0]), int(offsets[r1])
+    return bases[lo:hi], offsets[r0:r1 + 1] - lo
+
+
+def gpu_scan(pwm_values, widths, cutoffs, bases, offsets, strand):
+    """Local scan on this process's GPU -> (hits dict, region_counts)."""
+    from . import _lib
+    pw = _lib.PwmSet(pwm_values, widths, cutoffs)
+    sq = _lib.SeqSet(bases, offsets)
+    res = _lib.scan(pw, sq, strand)
+    try:
+        return res.hits(), res.region_counts()
+    finally:
+        res.close()
+        sq.close()
+        pw.close()
+
+
+def allreduce_counts(counts, device=None):
+    """Sum int64 counts over all ranks (RCCL when `device` is a cuda device, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(np.ascontiguousarray(counts, dtype=np.int64))
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def scan_sharded(pwm_values, widths, cutoffs, sets, rank, world_size, strand=3, scan_fn=gpu_scan, device=None):
+    """Scan this rank's shard of every region set; all-reduce the per-motif region counts.
+
+    sets: list of (bases uint8 array, offsets) -- e.g. [input, control].
+    Returns dict(hits=[per set: hits dict with GLOBAL seq_idx], counts=int64[n_sets][n_pwms] (global),
+                 shards=[per set: (r0, r1)])."""
+    n_pwms = len(widths)
+    local_counts = np.zeros((len(sets), n_pwms), dtype=np.int64)
+    all_hits, shards = [], []
+    for s, (bases, offsets) in enumerate(sets):
+        r0, r1 = shard_bounds(offsets, world_size)[rank]
+        sb, so = take_shard(bases, offsets, r0, r1)
+        hits, counts = scan_fn(pwm_values, widths, cutoffs, sb, so, strand)
+        hits = dict(hits)
+        hits["seq_idx"] = hits["seq_idx"] + r0
+        local_counts[s] = counts
+        all_hits.append(hits)
+        shards.append((r0, r1))
+    counts = allreduce_counts(local_counts.ravel(), device).reshape(len(sets), n_pwms)
+    return {"hits": all_hits, "counts": counts, "shards": shards}
+
+
+def enrichment(n_input_with_site, n_control_with_site, n_input, n_control):
+    """What stats.py:18-45 computes from the reduced counts: fold change and the two one-sided
+    Fisher exact p-values per motif (Bonferroni-corrected by the number of motifs)."""
+    from scipy.stats import fisher_exact
+    rows = []
+    n_motifs = len(n_input_with_site)
+    for a, c in zip(n_input_with_site.tolist(), n_control_with_site.tolist()):
+        table = [[a, n_input - a], [c, n_control - c]]
+        fold = a * n_control / c / n_input if c > 0 and n_input > 0 else float("nan")   # stats.py:32-35 order
+        p_enrich = fisher_exact(table, alternative="greater")[1]
+        p_deplete = fisher_exact(table, alternative="less")[1]
+        rows.append((a, c, fold, p_enrich, p_deplete, min(1.0, min(p_enrich, p_deplete) * n_motifs)))
+    return rows

@@ -1,0 +1,300 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI
+(libmotifscan_amd.so via ctypes); the oracle / golden vectors are only the checker.
+
+Bar: bit-exact positions, strands, order AND fp64 scores (north_star allows 1e-5 on scores; the
+re-scoring kernel repeats the reference's fp64 operations in the same order, so 0 is expected
+and asserted).
+"""
+import numpy as np
+import pytest
+
+from motifscan_amd import _lib, cscore, scanner, synth, matrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests need an MI355X (there is no CPU fallback)")
+    _lib.set_device(0)
+    print("device:", _lib.device_name())
+
+
+def assert_same_hits(got, want):
+    """got: dict from ScanResult.hits(); want: dict from oracle.scan_arrays()."""
+    assert np.array_equal(got["motif_offsets"], want["motif_offsets"])
+    assert np.array_equal(got["seq_idx"], want["seq_idx"])
+    assert np.array_equal(got["pos"], want["pos"])
+    assert np.array_equal(got["strand"].astype(np.int32), want["strand"].astype(np.int32))
+    assert np.array_equal(got["score"], want["score"])          # bit-exact fp64
+
+
+# ------------------------------------------------------- the reference's own known answers --
+
+def test_known_answers_of_reference_tests():
+    """/root/reference/tests/test_motif_score.py:6-32"""
+    m = [[[1.35, 0.21, -5.23], [0.07, -0.21, 0.6], [2.15, 2.22, -0.84], [-2.64, -1.89, 5.47]]]
+    seqs = ["NNN", "AGT", "ANT", "CTA"]
+    assert cscore.c_score(m, seqs, 1, 1)[0] == pytest.approx([0.0, 0.9186991869918698, 0.693089430894309, -0.7164634146341464])
+    assert cscore.c_score(m, seqs, 2, 1)[0] == pytest.approx([0.0, 0.6717479674796748, 0.693089430894309, -0.3323170731707317])
+    assert cscore.c_score(m, seqs, 3, 1)[0] == pytest.approx([0.0, 0.9186991869918698, 0.693089430894309, -0.3323170731707317])
+    sites = cscore.c_scan_motif(m, [0.2], ["NNNAG", "TANTCTA"], 3, 1)
+    assert len(sites) == 1 and len(sites[0]) == 4
+    assert sites[0][0] == pytest.approx([1, 1, 0.693089430894309, 1])
+    assert sites[0][1] == pytest.approx([1, 1, 0.693089430894309, 2])
+    assert sites[0][2] == pytest.approx([1, 2, 0.23983739837398374, 2])
+    assert sites[0][3] == pytest.approx([1, 3, 0.266260162601626, 1])
+
+
+def test_g1_and_g6_goldens_exact(small):
+    g = small["G1"]
+    for s in ("1", "2", "3"):
+        assert cscore.c_score(g["matrix"], g["score_seqs"], int(s), 1) == g["score"][s]
+        assert cscore.c_scan_motif(g["matrix"], g["scan_cutoffs"], g["scan_seqs"], int(s), 1) == g["scan"][s]
+    for case in small["G6"]:
+        if case["kind"] == "scan":
+            got = cscore.c_scan_motif(case["pwms"], case["cutoffs"], case["seqs"], case["strand"], 1)
+        else:
+            got = cscore.c_score(case["pwms"], case["seqs"], case["strand"], 1)
+        assert got == case["out"], case["name"]
+
+
+def test_g2_scanner_on_reference_toy_genome(small):
+    """/root/reference/tests/test_scanner.py:29-54 + whole-chromosome scans captured from the reference."""
+    g = small["G2"]
+
+    class G:
+        chrom_sizes = {k: len(v) for k, v in g["chroms"].items()}
+
+        @staticmethod
+        def fetch_sequence(chrom, start, end):
+            return g["chroms"][chrom][start:end]
+
+    class Reg:
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end, self.summit = c, s, e, (s + e) // 2
+
+    class P:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = np.array(m, dtype=float), c, len(m[0])
+
+    pwm = P(g["pwm"], g["cutoffs"])
+    for case in g["cases"]:
+        sc = scanner.Scanner(G, [Reg(*g["region"])], window_size=case["window_size"], p_value=case["p_value"],
+                             remove_dup=case["remove_dup"])
+        sites = sc.scan_motifs([pwm])
+        rows = [[p, r, s.start, s.score, s.strand] for p, per in enumerate(sites) for r, ss in enumerate(per) for s in ss]
+        assert rows == case["sites"]
+    sc = scanner.Scanner(G, [Reg(*g["region"])], window_size=4, p_value="1e-2")
+    with pytest.raises(ValueError):
+        sc.scan_motifs([pwm])
+    toy = [P(t["matrix"], t["cutoffs"]) for t in g["toy_pwms"]]
+    for case in g["whole"]:
+        sc = scanner.Scanner(G, [Reg(*r) for r in g["whole_regions"]], window_size=0, p_value=case["p_value"])
+        sites = sc.scan_motifs(toy)
+        rows = [[p, r, s.start, s.score, s.strand] for p, per in enumerate(sites) for r, ss in enumerate(per) for s in ss]
+        assert rows == case["sites"]
+
+
+@pytest.mark.parametrize("tag,strand", [("scan_p1e-4_s1", 1), ("scan_p1e-4_s2", 2), ("scan_p1e-4_s3", 3),
+                                        ("scan_p1e-3_s3", 3)])
+@pytest.mark.parametrize("exact_only", [False, True])
+def test_g3_random_golden_exact(rnd, tag, strand, exact_only):
+    pkey = tag.split("_")[1][1:]
+    pw = _lib.PwmSet.from_matrices(rnd["mats"], rnd["cutoff_by_key"][pkey])
+    sq = _lib.SeqSet.from_strings(rnd["seqs"])
+    res = _lib.scan(pw, sq, strand, _lib.MS_SCAN_EXACT_ONLY if exact_only else _lib.MS_SCAN_DEFAULT)
+    h = res.hits()
+    assert np.array_equal(h["motif"], rnd[tag + "_motif"])
+    assert np.array_equal(h["seq_idx"], rnd[tag + "_seq"])
+    assert np.array_equal(h["pos"], rnd[tag + "_pos"])
+    assert np.array_equal(h["strand"], rnd[tag + "_strand"])
+    assert np.array_equal(h["score"], rnd[tag + "_score"])
+    st = res.stats()
+    assert st["n_hits"] == len(h["pos"])
+    if exact_only:
+        assert st["n_pwms_exact"] == len(rnd["mats"]) and st["n_candidates"] == 0
+    else:
+        assert st["n_pwms_exact"] == 0 and st["n_candidates"] > 0
+    # regions with >= 1 site per motif (stats.py:29-31)
+    want = np.array([len(set(h["seq_idx"][h["motif"] == m].tolist())) for m in range(len(rnd["mats"]))])
+    assert np.array_equal(res.region_counts(), want)
+
+
+def test_g4_scanner_with_and_without_dedup(rnd):
+    names = [str(x) for x in rnd["g4_chrom_names"]]
+    raw = rnd["g4_chrom_bytes"].tobytes().decode()
+    n = len(raw) // len(names)
+    chroms = {nm: raw[i * n:(i + 1) * n] for i, nm in enumerate(names)}
+
+    class G:
+        chrom_sizes = {k: len(v) for k, v in chroms.items()}
+
+        @staticmethod
+        def fetch_sequence(chrom, start, end):
+            return chroms[chrom][start:end]
+
+    class Reg:
+        def __init__(self, row):
+            self.chrom, self.start, self.end, self.summit = names[int(row[0])], int(row[1]), int(row[2]), int(row[3])
+
+    class P:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = m, {"1e-3": c}, m.shape[1]
+
+    pw = [P(m, c) for m, c in zip(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])]
+    regs = [Reg(r) for r in rnd["g4_regions"]]
+    for wsize, dup, strand in ((0, True, "both"), (0, False, "both"), (200, True, "both"), (200, True, "+"),
+                               (200, False, "both"), (201, True, "both"), (201, False, "both")):
+        tag = f"g4_w{wsize}_dup{int(dup)}_{'both' if strand == 'both' else 'fwd'}"
+        sc = scanner.Scanner(G, regs, window_size=wsize, strand=strand, p_value="1e-3", remove_dup=dup)
+        assert sc.seq_starts == rnd[tag + "_seq_starts"].tolist() and sc.seq_ends == rnd[tag + "_seq_ends"].tolist()
+        a = sc.scan_motifs_arrays(pw)
+        assert np.array_equal(a["motif"], rnd[tag + "_motif"]), tag
+        assert np.array_equal(a["region"], rnd[tag + "_region"]), tag
+        assert np.array_equal(a["start"], rnd[tag + "_start"]), tag
+        assert np.array_equal(a["strand"], rnd[tag + "_strand"]), tag
+        assert np.array_equal(a["score"], rnd[tag + "_score"]), tag
+    # nested-list shape of the reference API
+    sc = scanner.Scanner(G, regs[:7], window_size=200, p_value="1e-3")
+    nested = sc.scan_motifs(pw[:5])
+    assert len(nested) == 5 and all(len(per) == 7 for per in nested)
+    assert all(isinstance(s, scanner.MotifSite) for per in nested for ss in per for s in ss)
+
+
+def test_g5_c_score_kmers_exact(rnd):
+    kmers = [row.tobytes().decode() for row in rnd["kmer_bytes"]]
+    pw = _lib.PwmSet.from_matrices(rnd["mats"])
+    sq = _lib.SeqSet.from_strings(kmers)
+    for strand in (1, 2, 3):
+        assert np.array_equal(_lib.score(pw, sq, strand), rnd[f"score_s{strand}"])
+    # the PositionWeightMatrix front end
+    m = matrix.PositionWeightMatrix(rnd["mats"][3])
+    got = m.score_batch(kmers[:50], strand=1)
+    want = np.array([m.score(k[:m.length]) for k in kmers[:50]])
+    assert np.allclose(got, want, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------- seeded inputs vs the oracle --
+
+def test_c2_config_bit_exact_vs_oracle(oracle):
+    """BASELINE.json configs[1] shape, reduced in region count so the CPU checker takes seconds:
+    2000 x 500 bp, 50 JASPAR-width PWMs, both strands, N runs + soft-masking."""
+    vals, widths, cutoffs = synth.load_motif_set(50)
+    bases, offsets = synth.make_regions(2000, 500, seed=1, frac_n=0.02)
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    pw, sq = _lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets)
+    res = _lib.scan(pw, sq, 3)
+    assert_same_hits(res.hits(), want)
+    st = res.stats()
+    assert st["n_windows"] == sum(max(500 - int(w) + 1, 0) for w in widths) * 2000
+    assert len(want["pos"]) > 1000
+
+
+@pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-5"])
+def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
+    vals, widths = jaspar579["pwm_values"], jaspar579["widths"]
+    cutoffs = jaspar579["cutoffs"][pkey]
+    bases, offsets = synth.make_regions(120, 700, seed=3, frac_n=0.05, ragged=True)
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), 3)
+    assert_same_hits(res.hits(), want)
+    assert res.stats()["n_tiles"] >= 2            # 579 motifs do not fit one LDS tile
+
+
+def test_edge_shapes_vs_oracle(oracle):
+    rng = np.random.default_rng(11)
+    mats = [np.round(rng.normal(0, 1.5, size=(4, w)), 5) for w in (1, 2, 3, 31, 32, 33, 40, 64, 7, 12)]
+    mats.append(-np.abs(mats[2]) - 0.1)                        # max_raw == 0 -> inf / nan scores, no hits
+    seqs = ["", "A", "N", "ACGTN" * 30, "acgtRYKM" * 20, "T" * 33, "G" * 64, "C" * 65]
+    seqs += ["".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=int(n))) for n in rng.integers(0, 400, size=40)]
+    ml = [m.tolist() for m in mats]
+    for cut in (-0.3, 0.1, 0.45):
+        cuts = [cut] * len(mats)
+        for strand in (1, 2, 3):
+            assert cscore.c_scan_motif(ml, cuts, seqs, strand, 1) == oracle.c_scan_motif(ml, cuts, seqs, strand, 1)
+    long_seqs = [s for s in seqs if len(s) >= 64]
+    assert cscore.c_score(ml[:10], long_seqs, 3, 1) == oracle.c_score(ml[:10], long_seqs, 3, 1)
+    assert cscore.c_scan_motif([], [], ["ACGT"], 3, 1) == []
+    assert cscore.c_scan_motif(ml[:2], [0.1, 0.1], [], 3, 1) == [[], []]
+    with pytest.raises(ValueError):
+        cscore.c_scan_motif(ml[:1], [0.1], ["ACGT"], 4, 1)
+
+
+def test_unaligned_device_resident_ascii(oracle):
+    """ms_seqset_from_device with a pointer that is not 16-byte aligned."""
+    torch = pytest.importorskip("torch")
+    vals, widths, cutoffs = synth.load_motif_set(30)
+    bases, offsets = synth.make_regions(300, 257, seed=9, frac_n=0.05)
+    t = torch.zeros(len(bases) + 16, dtype=torch.uint8, device="cuda:0")
+    t[3:3 + len(bases)] = torch.from_numpy(bases).to("cuda:0")
+    torch.cuda.synchronize()
+    sq = _lib.SeqSet.from_device(t.data_ptr() + 3, offsets)
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), sq, 3)
+    assert_same_hits(res.hits(), oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8))
+
+
+# ----------------------------------------------- full size: size-independent properties --
+
+def test_full_size_properties_c3_shape(oracle):
+    """configs[2] shape (100k x 1 kb x 579): too big for the CPU checker, so check properties:
+    (1) order and ranges, (2) pre-filter path == all-fp64 path on a slice, (3) strand 3 is the
+    union of strands 1 and 2, (4) region counts follow from the hits, (5) repeat == same,
+    (6) a 300-region sample equals the oracle bit for bit."""
+    vals, widths, cutoffs = synth.load_motif_set(579)
+    bases, offsets = synth.make_regions(100_000, 1000, seed=1)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    sq = _lib.SeqSet(bases, offsets)
+    res = _lib.scan(pw, sq, 3)
+    h = res.hits()
+    st = res.stats()
+    n = len(h["pos"])
+    assert n == st["n_hits"] and n > 1_000_000
+    assert st["n_windows"] == int(sum((1000 - int(w) + 1) for w in widths)) * 100_000
+    # (1) reference order: motif, then sequence, then position, '+' before '-'
+    key = (h["motif"].astype(np.int64) << 40) | (h["seq_idx"] << 12) | (h["pos"] << 1) | (h["strand"] == 2)
+    assert (np.diff(key) > 0).all()
+    assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= 1000).all()
+    mr = pw.max_raw()
+    assert (h["score"] - cutoffs[h["motif"]] >= -1e-10).all() and (h["score"] * mr[h["motif"]] <= mr[h["motif"]] + 1e-9).all()
+    # (4)
+    pair = np.unique((h["motif"].astype(np.int64) << 32) | h["seq_idx"])
+    assert np.array_equal(res.region_counts(), np.bincount(pair >> 32, minlength=579))
+    # (5)
+    res2 = _lib.scan(pw, sq, 3)
+    h2 = res2.hits()
+    assert all(np.array_equal(h[k], h2[k]) for k in ("seq_idx", "pos", "score", "strand", "motif_offsets"))
+    res2.close()
+    # (3)
+    h1 = _lib.scan(pw, sq, 1).hits()
+    hr = _lib.scan(pw, sq, 2).hits()
+    assert len(h1["pos"]) + len(hr["pos"]) == n
+    f = h["strand"] == 1
+    assert np.array_equal(h["pos"][f], h1["pos"]) and np.array_equal(h["score"][f], h1["score"])
+    assert np.array_equal(h["pos"][~f], hr["pos"]) and np.array_equal(h["score"][~f], hr["score"])
+    # (2) + (6) on the first 300 regions
+    sub = slice(0, int(offsets[300]))
+    sq_s = _lib.SeqSet(bases[sub], offsets[:301])
+    hs = _lib.scan(pw, sq_s, 3).hits()
+    he = _lib.scan(pw, sq_s, 3, _lib.MS_SCAN_EXACT_ONLY).hits()
+    assert all(np.array_equal(hs[k], he[k]) for k in ("seq_idx", "pos", "score", "strand", "motif_offsets"))
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases[sub].tobytes(), offsets[:301], 3, 8)
+    assert_same_hits(hs, want)
+    m = h["seq_idx"] < 300
+    assert np.array_equal(h["pos"][m], hs["pos"]) and np.array_equal(h["score"][m], hs["score"])
+
+
+def test_buffer_growth_path():
+    """A cutoff far below the p=1e-4 density forces the candidate / hit buffers to grow (second pass)."""
+    vals, widths, _ = synth.load_motif_set(40)
+    cut2, = [np.load(synth.os.path.join(synth._GOLDEN, "synth_jaspar579.npz"))["cutoffs"][:40, 0]]
+    bases, offsets = synth.make_regions(30_000, 500, seed=4)
+    _lib.release_scratch()
+    res = _lib.scan(_lib.PwmSet(vals, widths, cut2), _lib.SeqSet(bases, offsets), 3)
+    st = res.stats()
+    h = res.hits()
+    assert st["n_passes"] >= 2 and st["n_hits"] == len(h["pos"]) > 4_000_000
+    key = (h["motif"].astype(np.int64) << 40) | (h["seq_idx"] << 12) | (h["pos"] << 1) | (h["strand"] == 2)
+    assert (np.diff(key) > 0).all()
