@@ -536,7 +536,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_budget = c->lds_max - 1024;
+    const size_t lds_budget = c->lds_max - kWqBytes - 1024;      // tables; the wave queues follow them
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
     const PrefilterPlan &plan = pwms->plan;
@@ -586,6 +586,8 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     const DevPwm Pw = dev_pwm(pwms);
     size_t lds_bytes = 0;
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
+    const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
+    lds_bytes += kWqBytes;
     if (lds_bytes > c->lds_set) {
         if ((rc = prefilter_set_lds(lds_bytes))) return fail(rc);
         c->lds_set = lds_bytes;
@@ -603,7 +605,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         if (!plan.tiles.empty()) {
             PfArgs A;
             A.codes = S.codes; A.n_bases = S.n_bases; A.n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
-            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.quad_motifs = pwms->d_quad_motifs;
+            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
             int bpt = std::max(1, c->n_cu / n_tiles);
@@ -613,7 +615,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         (void) hipEventRecord(c->ev[1], c->stream);
         if (!plan.fast_motifs.empty()) {
             if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
-            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_quad_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
         }
         if (!plan.exact_motifs.empty())
             if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return fail(rc);

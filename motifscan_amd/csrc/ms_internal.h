@@ -28,9 +28,9 @@ constexpr int kMaxGroups = 16;         // 2-mer groups per motif (ceil(32 / 2))
 constexpr int kMaxMotifs = 65535;      // 16-bit motif id in candidate / hit keys
 constexpr int kPadWords = 8;           // zero words after the packed codes (window reads run past the end)
 
-// candidate record: [63:18] global base position, [17:2] motif id, [1:0] strand bits
-__host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t motif, uint32_t strands) {
-    return (g << 18) | ((uint64_t) motif << 2) | strands;
+// candidate record: [63:18] global base position, [17:2] table slot (quad * 4 + k), [1:0] strand bits
+__host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t slot, uint32_t strands) {
+    return (g << 18) | ((uint64_t) slot << 2) | strands;
 }
 
 // ------------------------------------------------------------------ pre-filter plan --

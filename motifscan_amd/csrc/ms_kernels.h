@@ -6,6 +6,8 @@ namespace ms {
 
 constexpr int kPfThreads = 1024;      // pre-filter block: 16 waves, one block per CU
 constexpr int kNwMotifChunk = 64;     // motifs per nwindow_kernel thread
+constexpr int kWqCap = 128;           // candidates per wave queue (LDS) before a spill to HBM
+constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
 
 struct DevSeq {
     const uint32_t *codes;
@@ -38,7 +40,7 @@ struct PfArgs {
     int64_t n_chunks;         // ceil(n_bases / kPfThreads)
     const uint4 *tables;
     const TileDesc *tiles;
-    const int32_t *quad_motifs;
+    uint32_t wq_off16;        // start of the wave queues in dynamic LDS (16-byte units)
     uint64_t *cand;
     unsigned long long *n_cand;
     uint64_t cand_cap;
@@ -52,7 +54,8 @@ int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
-                   uint64_t cand_cap, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st);
+                   uint64_t cand_cap, const int32_t *quad_motifs, int strand_mask, const HitOut &H, int n_blocks,
+                   hipStream_t st);
 int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const int64_t *offsets, int64_t R, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);

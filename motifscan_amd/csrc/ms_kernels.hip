@@ -149,21 +149,59 @@ __device__ __forceinline__ void add4(uint4 &a, const uint4 &b) {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
 }
 
-// Rare path: at least one lane of the wave has a flagged field in this quad.
-__device__ __noinline__ void emit_candidates(const int32_t *__restrict__ quad_motifs, uint64_t *__restrict__ cand,
-                                             unsigned long long *__restrict__ n_cand, uint64_t cand_cap, uint4 acc,
-                                             int32_t quad, int64_t g) {
+// ---- candidate hand-off --------------------------------------------------------------------
+// Candidates are ~2e-4 of the (window, motif) pairs, i.e. about one wave in ten finds one in a
+// pair of quads.  One global atomic per find would put every wave of the chip on ONE address
+// (measured: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  So each
+// wave appends to its own queue in LDS with ballot/mbcnt ranks (no atomics at all) and spills it
+// to the global list with a single atomicAdd per >= 64 entries.
+
+__device__ __forceinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
+                                      unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(n_cand, (unsigned long long) n);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < n; i += 64)
+        if (base + i < cand_cap) cand[base + i] = wbuf[i];
+}
+
+// Entered by the WHOLE wave (uniform branch) when any lane has a flagged field in this quad.
+// Returns the new queue length.
+__device__ __noinline__ uint32_t emit_candidates(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
+                                                 unsigned long long *__restrict__ n_cand, uint64_t cand_cap, uint4 acc,
+                                                 int32_t quad, int64_t g, bool live) {
     const uint32_t w[4] = {acc.x & 0x80008000u, acc.y & 0x80008000u, acc.z & 0x80008000u, acc.w & 0x80008000u};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (w[k] == 0) continue;
-        const int32_t motif = quad_motifs[quad * 4 + k];
-        if (motif < 0) continue;
-        const uint32_t strands = ((w[k] & 0x8000u) ? 1u : 0u) | ((w[k] & 0x80000000u) ? 2u : 0u);
-        const unsigned long long i = atomicAdd(n_cand, 1ULL);
-        if (i < cand_cap) cand[i] = cand_pack((uint64_t) g, (uint32_t) motif, strands);
+        const bool flagged = live && w[k] != 0;
+        const unsigned long long mask = __ballot(flagged);
+        if (mask == 0) continue;
+        const uint32_t n_new = (uint32_t) __popcll(mask);
+        if (n + n_new > (uint32_t) kWqCap) {
+            wq_flush(wbuf, n, cand, n_cand, cand_cap);
+            n = 0;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+        if (flagged) {
+            const uint32_t strands = ((w[k] & 0x8000u) ? 1u : 0u) | ((w[k] & 0x80000000u) ? 2u : 0u);
+            wbuf[n + rank] = cand_pack((uint64_t) g, (uint32_t) (quad * 4 + k), strands);
+        }
+        n += n_new;
     }
+    return n;
 }
+
+struct PfWave {
+    uint64_t *wbuf;      // this wave's queue in LDS (kWqCap entries)
+    uint32_t n;          // entries queued (wave-uniform)
+    int64_t g;           // this lane's window start
+    bool live;           // g < n_bases
+};
+
+#define MS_PF_EMIT(ACC, QUAD)                                                                               \
+    W.n = __builtin_amdgcn_readfirstlane(                                                                   \
+        emit_candidates(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap, ACC, QUAD, W.g, W.live))
 
 // All quads of one class (same group count G): per quad G LDS reads of 16 bytes (four motifs x
 // {fwd,rev} 16-bit fields) and (G-1) x 4 packed adds.  `code16[g]` is the lane's 2-mer code at
@@ -172,7 +210,7 @@ __device__ __noinline__ void emit_candidates(const int32_t *__restrict__ quad_mo
 template <int G>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
                                                 int n_quads, int32_t first_quad, const uint32_t (&code16)[kMaxGroups],
-                                                int64_t g, bool live) {
+                                                PfWave &W) {
     uint32_t a[G];
 #pragma unroll
     for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + code16[k];
@@ -186,9 +224,9 @@ __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__
             add4(acc1, lds4[a[k] + G * 16]);
         }
         const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w | acc1.x | acc1.y | acc1.z | acc1.w) & 0x80008000u;
-        if (any != 0 && live) {
-            emit_candidates(A.quad_motifs, A.cand, A.n_cand, A.cand_cap, acc0, first_quad + q, g);
-            emit_candidates(A.quad_motifs, A.cand, A.n_cand, A.cand_cap, acc1, first_quad + q + 1, g);
+        if (__any(any != 0)) {
+            MS_PF_EMIT(acc0, first_quad + q);
+            MS_PF_EMIT(acc1, first_quad + q + 1);
         }
 #pragma unroll
         for (int k = 0; k < G; k++) a[k] += 2 * G * 16;
@@ -198,17 +236,18 @@ __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__
 #pragma unroll
         for (int k = 1; k < G; k++) add4(acc0, lds4[a[k]]);
         const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w) & 0x80008000u;
-        if (any != 0 && live) emit_candidates(A.quad_motifs, A.cand, A.n_cand, A.cand_cap, acc0, first_quad + q, g);
+        if (__any(any != 0)) MS_PF_EMIT(acc0, first_quad + q);
     }
 }
 
 #define MS_PF_CASE(GG)                                                                      \
     case GG:                                                                                \
-        prefilter_class<GG>(A, lds4, base16, nq, first_quad, code16, g, live);              \
+        prefilter_class<GG>(A, lds4, base16, nq, first_quad, code16, W);                    \
         break;
 
 // grid = (blocks per tile, tiles).  One block per CU (the tile's tables fill the LDS), 16 waves,
-// each wave takes 64 consecutive window starts per iteration.
+// each wave takes 64 consecutive window starts per iteration.  Dynamic LDS = tables of the
+// largest tile, then 16 wave queues of kWqCap candidates.
 __global__ void __launch_bounds__(kPfThreads) prefilter_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -218,11 +257,14 @@ __global__ void __launch_bounds__(kPfThreads) prefilter_kernel(const PfArgs A) {
     __syncthreads();
     const int n_classes = T->n_classes;
     const int32_t tile_first_quad = T->first_quad;
+    PfWave W;
+    W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
+    W.n = 0;
 
     for (int64_t chunk = blockIdx.x; chunk < A.n_chunks; chunk += gridDim.x) {
-        const int64_t g = chunk * kPfThreads + threadIdx.x;
-        const bool live = g < A.n_bases;
-        const uint64_t cw = code_window(A.codes, live ? g : 0);
+        W.g = chunk * kPfThreads + threadIdx.x;
+        W.live = W.g < A.n_bases;
+        const uint64_t cw = code_window(A.codes, W.live ? W.g : 0);
         uint32_t code16[kMaxGroups];
 #pragma unroll
         for (int k = 0; k < kMaxGroups; k++) code16[k] = (uint32_t) (cw >> (4 * k)) & 15u;
@@ -243,6 +285,7 @@ __global__ void __launch_bounds__(kPfThreads) prefilter_kernel(const PfArgs A) {
             first_quad += nq;
         }
     }
+    if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
 }
 
 // -------------------------------------------------------------------- fp64 kernels --
@@ -288,13 +331,16 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
 
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
                                                       const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
-                                                      int strand_mask, const HitOut H) {
+                                                      const int32_t *__restrict__ quad_motifs, int strand_mask,
+                                                      const HitOut H) {
     unsigned long long n = *n_cand;
     if (n > cand_cap) n = cand_cap;
     for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long) gridDim.x * blockDim.x) {
         const uint64_t c = cand[i];
-        const uint32_t p = (uint32_t) (c >> 2) & 0xFFFFu;
+        const int32_t pm = quad_motifs[(uint32_t) (c >> 2) & 0xFFFFu];       // candidate carries its table slot
+        if (pm < 0) continue;
+        const uint32_t p = (uint32_t) pm;
         const int64_t g = (int64_t) (c >> 18);
         const int W = Pw.width[p];
         const int64_t r = find_region(S.offsets, S.R, g);
@@ -432,9 +478,10 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 }
 
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
-                   uint64_t cand_cap, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st) {
+                   uint64_t cand_cap, const int32_t *quad_motifs, int strand_mask, const HitOut &H, int n_blocks,
+                   hipStream_t st) {
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned) n_blocks), dim3(256), 0, st, S, Pw, cand, n_cand, cand_cap,
-                       strand_mask, H);
+                       quad_motifs, strand_mask, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
