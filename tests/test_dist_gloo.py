@@ -1,0 +1,100 @@
+"""
+The N > 1 path on CPU: two processes, gloo backend, world_size 2.  The GPU scan itself cannot run
+here, so the local scan function is injected (the oracle, test infrastructure); what is under test
+is the host logic of motifscan_amd.dist: shard bounds balanced by bases, global region indices,
+rank-order concatenation == single-process order, and the ONE all-reduce of the per-motif region
+counts that feeds the enrichment statistics (stats.py:29-31).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_scan(pwm_values, widths, cutoffs, bases, offsets, strand):
+    from oracle import oracle
+    r = oracle.scan_arrays(pwm_values, widths, cutoffs, bases.tobytes(), offsets, strand, 2)
+    motif = np.repeat(np.arange(len(widths), dtype=np.int32), np.diff(r["motif_offsets"]))
+    r["motif"] = motif
+    pair = np.unique((motif.astype(np.int64) << 32) | r["seq_idx"])
+    return r, np.bincount(pair >> 32, minlength=len(widths)).astype(np.int64)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from motifscan_amd import dist as msdist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vals, widths, cutoffs = synth.load_motif_set(24)
+        sets = [synth.make_regions(301, 300, seed=1, frac_n=0.05, ragged=True),
+                synth.make_regions(257, 300, seed=2, frac_n=0.05, ragged=True)]
+        out = msdist.scan_sharded(vals, widths, cutoffs, sets, rank, world, 3, scan_fn=oracle_scan)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), counts=out["counts"],
+                 shards=np.array(out["shards"]),
+                 **{f"s{s}_{k}": out["hits"][s][k] for s in range(2) for k in ("motif", "seq_idx", "pos", "score", "strand")})
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_bounds_balance_and_cover():
+    from motifscan_amd import dist as msdist
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 2000, size=1000)
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    for world in (1, 2, 3, 8):
+        b = msdist.shard_bounds(offsets, world)
+        assert b[0][0] == 0 and b[-1][1] == 1000
+        assert all(b[k][1] == b[k + 1][0] for k in range(world - 1))
+        sizes = [offsets[r1] - offsets[r0] for r0, r1 in b]
+        assert max(sizes) - min(sizes) <= 2 * 2000
+    # degenerate: fewer regions than ranks, empty set
+    assert msdist.shard_bounds(np.array([0, 5]), 4)[-1][1] == 1
+    assert msdist.shard_bounds(np.array([0]), 2) == [(0, 0), (0, 0)]
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_scan_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from motifscan_amd import synth
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
+    vals, widths, cutoffs = synth.load_motif_set(24)
+    sets = [synth.make_regions(301, 300, seed=1, frac_n=0.05, ragged=True),
+            synth.make_regions(257, 300, seed=2, frac_n=0.05, ragged=True)]
+    assert np.array_equal(r[0]["counts"], r[1]["counts"])               # every rank holds the reduced counts
+    for s, (bases, offsets) in enumerate(sets):
+        whole, counts = oracle_scan(vals, widths, cutoffs, bases, offsets, 3)
+        assert np.array_equal(r[0]["counts"][s], counts)
+        assert r[0]["shards"][s][1] == r[1]["shards"][s][0]
+        # rank-order concatenation, then a stable sort by motif, is the single-process order
+        cat = {k: np.concatenate([r[0][f"s{s}_{k}"], r[1][f"s{s}_{k}"]]) for k in ("motif", "seq_idx", "pos", "score", "strand")}
+        order = np.argsort(cat["motif"], kind="stable")
+        for k in ("seq_idx", "pos", "score", "strand"):
+            assert np.array_equal(cat[k][order], whole[k]), k
+        assert len(whole["pos"]) > 50
+
+
+def test_enrichment_consumes_reduced_counts():
+    """fold change / Fisher p-values from the reduced counts == scipy on the same 2x2 tables
+    (the reference's tests pin only counts and fold change: tests/test_stats.py:26-33)."""
+    from scipy.stats import fisher_exact
+    from motifscan_amd import dist as msdist
+    rows = msdist.enrichment(np.array([30, 0, 5]), np.array([10, 0, 5]), 100, 200)
+    assert rows[0][0] == 30 and rows[0][1] == 10 and rows[0][2] == pytest.approx(30 * 200 / 10 / 100)
+    assert np.isnan(rows[1][2])
+    assert rows[0][3] == fisher_exact([[30, 70], [10, 190]], alternative="greater")[1]
+    assert rows[2][5] == min(1.0, min(rows[2][3], rows[2][4]) * 3)
