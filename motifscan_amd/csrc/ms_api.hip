@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -33,17 +34,28 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     uint64_t *cand = nullptr;     size_t cand_cap = 0;
     uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
-    unsigned long long *counters = nullptr;      // [0] candidates, [1] hits
+    int64_t *nlist = nullptr;     size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
+    unsigned long long *counters = nullptr;      // [0] candidates, [1] hits, [2] N-window positions
     unsigned long long *h_counters = nullptr;    // pinned
+};
+
+// Free list of result blocks (ms_result keeps its arrays in HBM until freed; a scan loop would
+// otherwise pay a hipMalloc + hipFree of ~200 MB per call).
+struct BlockPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_;
+    size_t bytes = 0;
+    static constexpr size_t kMaxBytes = 8ull << 30;
 };
 
 struct DeviceCtx {
     int device = -1;
+    BlockPool pool;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
     int n_cu = 0;
     size_t lds_max = 0;
-    size_t lds_set = 0;
+    size_t lds_set[8] = {};
     Scratch sc;
     std::mutex mu;               // one scan at a time per device (shared scratch)
 };
@@ -100,6 +112,45 @@ static void dev_free(T *&p) {
     p = nullptr;
 }
 
+static int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
+    {
+        std::lock_guard<std::mutex> lk(c->pool.mu);
+        size_t best = (size_t) -1;
+        for (size_t i = 0; i < c->pool.free_.size(); i++) {
+            const size_t sz = c->pool.free_[i].second;
+            if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && (best == (size_t) -1 || sz < c->pool.free_[best].second)) best = i;
+        }
+        if (best != (size_t) -1) {
+            *out = c->pool.free_[best].first;
+            *got = c->pool.free_[best].second;
+            c->pool.bytes -= *got;
+            c->pool.free_.erase(c->pool.free_.begin() + (long) best);
+            return MS_OK;
+        }
+    }
+    char *p = nullptr;
+    int rc = dev_alloc(&p, bytes);
+    if (rc) {                                   // drop the cache and retry once
+        std::lock_guard<std::mutex> lk(c->pool.mu);
+        for (auto &b : c->pool.free_) (void) hipFree(b.first);
+        c->pool.free_.clear();
+        c->pool.bytes = 0;
+        rc = dev_alloc(&p, bytes);
+        if (rc) return rc;
+    }
+    *out = p;
+    *got = bytes;
+    return MS_OK;
+}
+
+static void pool_free(DeviceCtx *c, void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(c->pool.mu);
+    if (c->pool.bytes + bytes > BlockPool::kMaxBytes || c->pool.free_.size() >= 16) { (void) hipFree(p); return; }
+    c->pool.free_.emplace_back(p, bytes);
+    c->pool.bytes += bytes;
+}
+
 }  // namespace ms
 
 using namespace ms;
@@ -149,17 +200,21 @@ struct ms_seqset {
     uint32_t *d_codes = nullptr;
     uint32_t *d_nmask = nullptr;
     int64_t *d_offsets = nullptr;
+    int32_t *d_blk2reg = nullptr;         // region of position 64*b
 };
 
 struct ms_result {
     int device = 0;
     int32_t P = 0;
     int64_t n_hits = 0;
+    void *block = nullptr;                            // one device block holding everything below
+    size_t block_bytes = 0;
     int64_t *d_seq_idx = nullptr;
     int64_t *d_pos = nullptr;
     double *d_score = nullptr;
     int8_t *d_strand = nullptr;
     unsigned long long *d_region_counts = nullptr;   // [P]
+    int64_t *d_motif_first = nullptr;                 // [P+1]
     std::vector<int64_t> motif_offsets;               // [P+1]
     ms_scan_stats stats;
 };
@@ -293,7 +348,8 @@ static DevPwm dev_pwm(const ms_pwmset *p) {
 
 static DevSeq dev_seq(const ms_seqset *s) {
     DevSeq d;
-    d.codes = s->d_codes; d.nmask = s->d_nmask; d.offsets = s->d_offsets; d.R = s->R; d.n_bases = s->n_bases;
+    d.codes = s->d_codes; d.nmask = s->d_nmask; d.offsets = s->d_offsets; d.blk2reg = s->d_blk2reg; d.R = s->R;
+    d.n_bases = s->n_bases;
     return d;
 }
 
@@ -409,7 +465,8 @@ static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr
     s->device = g_device;
     s->R = n_seqs;
     s->n_bases = offsets[n_seqs];
-    if (s->n_bases >= (1LL << 45)) { set_error("too many bases"); return MS_ERR_INVALID; }
+    if (s->n_bases > kMaxBases) { set_error("a sequence set holds at most %lld bases; split the regions over several sets", (long long) kMaxBases); return MS_ERR_INVALID; }
+    if (n_seqs >= (1LL << 31)) { set_error("too many sequences in one set"); return MS_ERR_INVALID; }
     try {
         s->offsets.assign(offsets, offsets + n_seqs + 1);
         s->len_sorted.resize((size_t) n_seqs);
@@ -427,6 +484,7 @@ static int seqset_alloc_packed(ms_seqset *s) {
     if ((rc = dev_alloc(&s->d_codes, 2 * n_units + kPadWords))) return rc;
     if ((rc = dev_alloc(&s->d_nmask, n_units + kPadWords))) return rc;
     if ((rc = dev_alloc(&s->d_offsets, (size_t) s->R + 1))) return rc;
+    if ((rc = dev_alloc(&s->d_blk2reg, (size_t) (s->n_bases / 64 + 2)))) return rc;
     MS_HIP(hipMemset(s->d_codes, 0, (2 * n_units + kPadWords) * sizeof(uint32_t)));
     MS_HIP(hipMemset(s->d_nmask, 0, (n_units + kPadWords) * sizeof(uint32_t)));
     MS_HIP(hipMemcpy(s->d_offsets, s->offsets.data(), ((size_t) s->R + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -451,6 +509,7 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
         if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     }
     if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream))) return fail(rc);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream))) return fail(rc);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     if (!keep_ascii) dev_free(raw->d_ascii);
@@ -472,6 +531,7 @@ int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
     if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, c->stream)))
         return fail(rc);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream))) return fail(rc);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     *out = raw;
@@ -485,6 +545,7 @@ int ms_seqset_repack(ms_seqset *s) {
     int rc = get_ctx(s->device, &c);
     if (rc) return rc;
     if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, c->stream))) return rc;
+    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, c->stream))) return rc;
     MS_HIP(hipStreamSynchronize(c->stream));
     return MS_OK;
 }
@@ -499,14 +560,20 @@ int ms_seqset_size(const ms_seqset *s, int64_t *n_seqs, int64_t *n_bases) {
 void ms_seqset_free(ms_seqset *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
-    dev_free(s->d_ascii); dev_free(s->d_codes); dev_free(s->d_nmask); dev_free(s->d_offsets);
+    dev_free(s->d_ascii); dev_free(s->d_codes); dev_free(s->d_nmask); dev_free(s->d_offsets); dev_free(s->d_blk2reg);
     delete s;
 }
 
 // ---------------------------------------------------------------------------- scan --
 
-static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap) {
+static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap, size_t nlist_cap) {
     int rc;
+    if (nlist_cap > sc.nlist_cap) {
+        dev_free(sc.nlist);
+        sc.nlist_cap = 0;
+        if ((rc = dev_alloc(&sc.nlist, nlist_cap))) return rc;
+        sc.nlist_cap = nlist_cap;
+    }
     if (cand_cap > sc.cand_cap) {
         dev_free(sc.cand);
         sc.cand_cap = 0;
@@ -559,9 +626,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
 
     ms_result *raw = res.release();
     auto fail = [&](int code) { ms_result_free(raw); return code; };
-    if ((rc = dev_alloc(&raw->d_region_counts, (size_t) pwms->P))) return fail(rc);
-    hipError_t he = hipMemsetAsync(raw->d_region_counts, 0, std::max<size_t>(1, (size_t) pwms->P) * sizeof(unsigned long long), c->stream);
-    if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+    hipError_t he = hipSuccess;
 
     int gbits = 1;
     while ((1LL << gbits) <= seqs->n_bases) gbits++;
@@ -569,7 +634,15 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     while ((1 << mbits) < std::max(pwms->P, 1)) mbits++;
 
     if (pwms->P == 0 || seqs->n_bases == 0) {                 // nothing to scan: [] / [[]...]  (cscore.c:443-445)
-        MS_HIP(hipStreamSynchronize(c->stream));
+        void *blk = nullptr;
+        size_t got = 0;
+        if ((rc = pool_alloc(c, 8 * ((size_t) pwms->P + 1), &blk, &got))) return fail(rc);
+        raw->block = blk;
+        raw->block_bytes = got;
+        raw->d_region_counts = static_cast<unsigned long long *>(blk);
+        he = hipMemsetAsync(blk, 0, 8 * ((size_t) pwms->P + 1), c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         *out = raw;
         return MS_OK;
     }
@@ -579,8 +652,12 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
     size_t want_hits = want_cand;
     if (!plan.exact_motifs.empty()) want_hits = std::max<size_t>(want_hits, 1 << 22);
+    size_t want_nlist = std::max<size_t>(1 << 20, (size_t) seqs->n_bases / 64);
     want_cand = std::max(want_cand, sc.cand_cap);
     want_hits = std::max(want_hits, sc.hit_cap);
+    want_nlist = std::max(want_nlist, sc.nlist_cap);
+    int fast_max_w = 1;
+    for (int32_t p : plan.fast_motifs) fast_max_w = std::max(fast_max_w, (int) pwms->widths[p]);
 
     const DevSeq S = dev_seq(seqs);
     const DevPwm Pw = dev_pwm(pwms);
@@ -588,14 +665,18 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += kWqBytes;
-    if (lds_bytes > c->lds_set) {
-        if ((rc = prefilter_set_lds(lds_bytes))) return fail(rc);
-        c->lds_set = lds_bytes;
+    // measurement switches (not part of the interface): kernel variant, drop candidates
+    int pf_variant = 1, pf_no_emit = 0;
+    if (const char *e = getenv("MS_PF_VARIANT")) pf_variant = atoi(e) & 7;
+    if (const char *e = getenv("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
+    if (lds_bytes > c->lds_set[pf_variant]) {
+        if ((rc = prefilter_set_lds(pf_variant, lds_bytes))) return fail(rc);
+        c->lds_set[pf_variant] = lds_bytes;
     }
 
     unsigned long long n_cand = 0, n_hits = 0;
     for (int pass = 1;; pass++) {
-        if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
+        if ((rc = scratch_reserve(sc, want_cand, want_hits, want_nlist))) return fail(rc);
         stt.n_passes = pass;
         HitOut H;
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits;
@@ -604,17 +685,17 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         (void) hipEventRecord(c->ev[0], c->stream);
         if (!plan.tiles.empty()) {
             PfArgs A;
-            A.codes = S.codes; A.n_bases = S.n_bases; A.n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
+            A.codes = S.codes; A.n_bases = S.n_bases; A.no_emit = pf_no_emit;
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
-            int bpt = std::max(1, c->n_cu / n_tiles);
-            bpt = (int) std::min<int64_t>(bpt, A.n_chunks);
-            if ((rc = launch_prefilter(A, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
+            const int bpt = std::max(1, c->n_cu / n_tiles);
+            if ((rc = launch_prefilter(A, pf_variant, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
         }
         (void) hipEventRecord(c->ev[1], c->stream);
         if (!plan.fast_motifs.empty()) {
-            if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
+            if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), fast_max_w, strand_mask,
+                                     sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->stream))) return fail(rc);
             if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_quad_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
         }
         if (!plan.exact_motifs.empty())
@@ -625,27 +706,43 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         n_cand = sc.h_counters[0];
         n_hits = sc.h_counters[1];
-        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap) break;
-        if (pass >= 3) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
+        const unsigned long long n_nlist = sc.h_counters[2];
+        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap && n_nlist <= sc.nlist_cap) break;
+        if (pass >= 5) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
         // a buffer was too small: the counters hold the exact need (a truncated candidate list
         // under-reports hits, so leave head room there) -- grow and run the pass again
         want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
         const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
         want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
+        want_nlist = std::max<size_t>(sc.nlist_cap, (size_t) (n_nlist + 1024));
+        if (n_nlist > sc.nlist_cap) want_hits = std::max<size_t>(want_hits, 2 * sc.hit_cap);   // its hits were not all counted
     }
     stt.n_candidates = (int64_t) n_cand;
     stt.n_hits = (int64_t) n_hits;
     raw->n_hits = (int64_t) n_hits;
 
-    if ((rc = dev_alloc(&raw->d_seq_idx, (size_t) n_hits))) return fail(rc);
-    if ((rc = dev_alloc(&raw->d_pos, (size_t) n_hits))) return fail(rc);
-    if ((rc = dev_alloc(&raw->d_score, (size_t) n_hits))) return fail(rc);
-    if ((rc = dev_alloc(&raw->d_strand, (size_t) n_hits))) return fail(rc);
-    int64_t *d_motif_first = nullptr;
-    if ((rc = dev_alloc(&d_motif_first, (size_t) pwms->P + 1))) return fail(rc);
-    auto fail2 = [&](int code) { dev_free(d_motif_first); return fail(code); };
-    he = hipMemsetAsync(d_motif_first, 0xFF, ((size_t) pwms->P + 1) * sizeof(int64_t), c->stream);
-    if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    {   // one pooled block: [counts P][first P+1][seq_idx n][pos n][score n][strand n]
+        const size_t P1 = (size_t) pwms->P + 1, n = (size_t) n_hits;
+        const size_t n_round = (n + 65535) & ~(size_t) 65535;            // helps block reuse across calls
+        const size_t bytes = 8 * (2 * P1 + 3 * n_round) + n_round + 256;
+        void *blk = nullptr;
+        size_t got = 0;
+        if ((rc = pool_alloc(c, bytes, &blk, &got))) return fail(rc);
+        raw->block = blk;
+        raw->block_bytes = got;
+        char *b = static_cast<char *>(blk);
+        raw->d_region_counts = reinterpret_cast<unsigned long long *>(b);
+        raw->d_motif_first = reinterpret_cast<int64_t *>(b + 8 * P1);
+        raw->d_seq_idx = reinterpret_cast<int64_t *>(b + 16 * P1);
+        raw->d_pos = raw->d_seq_idx + n_round;
+        raw->d_score = reinterpret_cast<double *>(raw->d_pos + n_round);
+        raw->d_strand = reinterpret_cast<int8_t *>(raw->d_score + n_round);
+        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0xFF, 8 * P1, c->stream);
+        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+    }
+    int64_t *d_motif_first = raw->d_motif_first;
+    auto fail2 = [&](int code) { return fail(code); };
 
     (void) hipEventRecord(c->ev[3], c->stream);
     if (n_hits > 0) {
@@ -664,14 +761,13 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
                                  gbits + 1 + mbits, c->stream))) return fail2(rc);
     }
     (void) hipEventRecord(c->ev[4], c->stream);
-    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, S.offsets, S.R, raw->d_seq_idx, raw->d_pos,
+    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, S, raw->d_seq_idx, raw->d_pos,
                               raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
     (void) hipEventRecord(c->ev[5], c->stream);
     std::vector<int64_t> first((size_t) pwms->P + 1);
     he = hipMemcpyAsync(first.data(), d_motif_first, first.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
-    dev_free(d_motif_first);
     raw->motif_offsets[(size_t) pwms->P] = (int64_t) n_hits;
     for (int32_t p = pwms->P - 1; p >= 0; p--)
         raw->motif_offsets[(size_t) p] = first[(size_t) p] >= 0 ? first[(size_t) p] : raw->motif_offsets[(size_t) p + 1];
@@ -739,8 +835,11 @@ int ms_result_stats(const ms_result *r, ms_scan_stats *out) {
 void ms_result_free(ms_result *r) {
     if (!r) return;
     (void) hipSetDevice(r->device);
-    dev_free(r->d_seq_idx); dev_free(r->d_pos); dev_free(r->d_score); dev_free(r->d_strand);
-    dev_free(r->d_region_counts);
+    if (r->block) {
+        DeviceCtx *c = nullptr;
+        if (get_ctx(r->device, &c) == MS_OK) pool_free(c, r->block, r->block_bytes);
+        else (void) hipFree(r->block);
+    }
     delete r;
 }
 
@@ -867,7 +966,8 @@ int ms_debug_release_scratch(void) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     Scratch &sc = c->sc;
-    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted);
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.nlist);
+    sc.nlist_cap = 0;
     if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
     sc.sort_tmp = nullptr;
     sc.cand_cap = sc.hit_cap = sc.sort_tmp_bytes = 0;

@@ -28,9 +28,12 @@ constexpr int kMaxGroups = 16;         // 2-mer groups per motif (ceil(32 / 2))
 constexpr int kMaxMotifs = 65535;      // 16-bit motif id in candidate / hit keys
 constexpr int kPadWords = 8;           // zero words after the packed codes (window reads run past the end)
 
-// candidate record: [63:18] global base position, [17:2] table slot (quad * 4 + k), [1:0] strand bits
-__host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t slot, uint32_t strands) {
-    return (g << 18) | ((uint64_t) slot << 2) | strands;
+constexpr int64_t kMaxBases = (1LL << 34) - 64;   // 34-bit position field of a candidate record
+
+// candidate record (one per lane and pair of quads): [63:30] global base position, [29:16] first quad,
+// [15:0] flags: bit slot (0..7, over the two quads) = forward field flagged, bit 8 + slot = reverse
+__host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t quad, uint32_t flags) {
+    return (g << 30) | ((uint64_t) quad << 16) | flags;
 }
 
 // ------------------------------------------------------------------ pre-filter plan --

@@ -4,8 +4,8 @@
 
 namespace ms {
 
-constexpr int kPfThreads = 1024;      // pre-filter block: 16 waves, one block per CU
-constexpr int kNwMotifChunk = 64;     // motifs per nwindow_kernel thread
+constexpr int kPfThreads = 1024;      // largest pre-filter block: 16 waves, one block per CU
+constexpr int kNwMotifChunk = 16;     // motifs per neval_kernel thread
 constexpr int kWqCap = 128;           // candidates per wave queue (LDS) before a spill to HBM
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
 
@@ -13,6 +13,7 @@ struct DevSeq {
     const uint32_t *codes;
     const uint32_t *nmask;
     const int64_t *offsets;   // [R+1]
+    const int32_t *blk2reg;   // [n_bases/64 + 2] region of position 64*b
     int64_t R;
     int64_t n_bases;
 };
@@ -37,28 +38,30 @@ struct HitOut {
 struct PfArgs {
     const uint32_t *codes;
     int64_t n_bases;
-    int64_t n_chunks;         // ceil(n_bases / kPfThreads)
     const uint4 *tables;
     const TileDesc *tiles;
     uint32_t wq_off16;        // start of the wave queues in dynamic LDS (16-byte units)
     uint64_t *cand;
     unsigned long long *n_cand;
     uint64_t cand_cap;
+    int no_emit;              // measurement only: run the filter, drop the candidates
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int prefilter_set_lds(size_t bytes);
-int launch_prefilter(const PfArgs &A, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
-int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
-                   const HitOut &H, hipStream_t st);
+int prefilter_set_lds(int variant, size_t bytes);
+int launch_prefilter(const PfArgs &A, int variant, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
+int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
+                   int strand_mask, int64_t *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
+                   hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
                    uint64_t cand_cap, const int32_t *quad_motifs, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const int64_t *offsets, int64_t R, int64_t *seq_idx,
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);
+int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st);
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
 
 }  // namespace ms

@@ -13,7 +13,7 @@
 //   pack_kernel       ASCII -> codes + nmask                     (cscore.c:81-114)
 //   prefilter_kernel  16-bit integer upper bound of both strand scores for EVERY window, PWM
 //                     2-mer tables in LDS, one lane per window start; emits candidates
-//   nwindow_kernel    fp64 scoring of the windows that overlap a non-ACGT base
+//   nlist/neval       fp64 scoring of the windows that overlap a non-ACGT base
 //   exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take
 //   rescore_kernel    fp64 scoring of the candidates, in the reference's order of operations,
 //                     and the reference's hit test (cscore.c:356-358, 373-375)
@@ -42,9 +42,26 @@ __device__ __forceinline__ uint32_t n_window(const uint32_t *__restrict__ nmask,
 
 __device__ __forceinline__ uint32_t low_mask(int w) { return w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u); }
 
-// region r with offsets[r] <= g < offsets[r+1]  (empty regions are skipped by construction)
-__device__ __forceinline__ int64_t find_region(const int64_t *__restrict__ offsets, int64_t R, int64_t g) {
-    int64_t lo = 0, hi = R;          // invariant: offsets[lo] <= g, answer in [lo, hi)
+// region r with offsets[r] <= g < offsets[r+1]  (empty regions are skipped by construction).
+// blk2reg[g >> 6] is the region of position (g & ~63): a short forward walk finds g's region for
+// ordinary region lengths; tiny regions fall back to a binary search from there.
+__device__ __forceinline__ int64_t find_region(const DevSeq &S, int64_t g) {
+    int64_t lo = S.blk2reg[g >> 6];
+#pragma unroll 1
+    for (int step = 0; step < 4; step++) {
+        if (S.offsets[lo + 1] > g) return lo;
+        lo++;
+    }
+    int64_t hi = S.R;                 // invariant: offsets[lo] <= g, answer in [lo, hi)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (S.offsets[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int64_t find_region_bsearch(const int64_t *__restrict__ offsets, int64_t R, int64_t g) {
+    int64_t lo = 0, hi = R;
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
         if (offsets[mid] <= g) lo = mid; else hi = mid;
@@ -92,6 +109,54 @@ __device__ __forceinline__ void test_and_emit(const HitOut &H, const DevPwm &Pw,
     if (strand_mask & 2) {
         const double s = rev / max_raw;
         if (s - cutoff >= -1e-10) emit_hit(H, motif, g, 1u, s);
+    }
+}
+
+// Block-level staging of hits in LDS: one global atomicAdd per ~2000 hits instead of one per wave
+// (all hit writers of the chip share ONE counter word; it sustains only ~90 M atomics/s).
+constexpr int kHitStage = 2048;
+struct HitStage {
+    uint64_t keys[kHitStage];
+    double vals[kHitStage];
+    unsigned int n;
+    unsigned long long base;
+};
+
+__device__ __forceinline__ void stage_hit(HitStage &st, const HitOut &H, uint32_t motif, int64_t g, uint32_t sbit, double score) {
+    const unsigned int i = atomicAdd(&st.n, 1u);
+    if (i < (unsigned int) kHitStage) {
+        st.keys[i] = ((uint64_t) motif << (H.gbits + 1)) | ((uint64_t) g << 1) | sbit;
+        st.vals[i] = score;
+    } else {
+        emit_hit(H, motif, g, sbit, score);            // stage full: straight to HBM
+    }
+}
+
+// all threads of the block, at a block-uniform point
+__device__ __forceinline__ void stage_flush(HitStage &st, const HitOut &H) {
+    __syncthreads();
+    const unsigned int n = st.n < (unsigned int) kHitStage ? st.n : (unsigned int) kHitStage;
+    if (threadIdx.x == 0 && n > 0) st.base = atomicAdd(H.n_hits, (unsigned long long) n);
+    __syncthreads();
+    const unsigned long long base = st.base;
+    for (unsigned int i = threadIdx.x; i < n; i += blockDim.x)
+        if (base + i < H.cap) { H.keys[base + i] = st.keys[i]; H.vals[base + i] = st.vals[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0) st.n = 0;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void test_and_stage(HitStage &st, const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
+                                               double fwd, double rev, int strand_mask) {
+    const double max_raw = Pw.max_raw[motif];
+    const double cutoff = Pw.cutoff[motif];
+    if (strand_mask & 1) {
+        const double s = fwd / max_raw;
+        if (s - cutoff >= -1e-10) stage_hit(st, H, motif, g, 0u, s);
+    }
+    if (strand_mask & 2) {
+        const double s = rev / max_raw;
+        if (s - cutoff >= -1e-10) stage_hit(st, H, motif, g, 1u, s);
     }
 }
 
@@ -154,9 +219,11 @@ __device__ __forceinline__ void add4(uint4 &a, const uint4 &b) {
 // pair of quads.  One global atomic per find would put every wave of the chip on ONE address
 // (measured: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  So each
 // wave appends to its own queue in LDS with ballot/mbcnt ranks (no atomics at all) and spills it
-// to the global list with a single atomicAdd per >= 64 entries.
+// to the global list with a single atomicAdd per >= 64 entries.  A record is per LANE and per
+// pair of quads: position, first quad, and one flag bit per (slot, strand) -- rescore_kernel
+// expands the flags.
 
-__device__ __forceinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
+__device__ __noinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
                                       unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long base = 0;
@@ -166,30 +233,28 @@ __device__ __forceinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n
         if (base + i < cand_cap) cand[base + i] = wbuf[i];
 }
 
-// Entered by the WHOLE wave (uniform branch) when any lane has a flagged field in this quad.
-// Returns the new queue length.
-__device__ __noinline__ uint32_t emit_candidates(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
-                                                 unsigned long long *__restrict__ n_cand, uint64_t cand_cap, uint4 acc,
-                                                 int32_t quad, int64_t g, bool live) {
-    const uint32_t w[4] = {acc.x & 0x80008000u, acc.y & 0x80008000u, acc.z & 0x80008000u, acc.w & 0x80008000u};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool flagged = live && w[k] != 0;
-        const unsigned long long mask = __ballot(flagged);
-        if (mask == 0) continue;
-        const uint32_t n_new = (uint32_t) __popcll(mask);
-        if (n + n_new > (uint32_t) kWqCap) {
-            wq_flush(wbuf, n, cand, n_cand, cand_cap);
-            n = 0;
-        }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-        if (flagged) {
-            const uint32_t strands = ((w[k] & 0x8000u) ? 1u : 0u) | ((w[k] & 0x80000000u) ? 2u : 0u);
-            wbuf[n + rank] = cand_pack((uint64_t) g, (uint32_t) (quad * 4 + k), strands);
-        }
-        n += n_new;
-    }
-    return n;
+// one quad -> 8 bits: bit k = forward field of word k flagged, bit 4+k... see pair_flags
+__device__ __forceinline__ uint32_t msb_pair(uint32_t x) { return (x >> 15) & 0x00010001u; }   // bit 0: fwd, bit 16: rev
+
+// pair of quads -> 16 bits: bit s (slot 0..7 = word k of quad 0 / quad 1) forward, bit 8+s reverse
+__device__ __forceinline__ uint32_t pair_flags(const uint4 &a0, const uint4 &a1) {
+    uint32_t f = msb_pair(a0.x);
+    f |= msb_pair(a0.y) << 1;
+    f |= msb_pair(a0.z) << 2;
+    f |= msb_pair(a0.w) << 3;
+    f |= msb_pair(a1.x) << 4;
+    f |= msb_pair(a1.y) << 5;
+    f |= msb_pair(a1.z) << 6;
+    f |= msb_pair(a1.w) << 7;
+    return (f & 0xFFu) | ((f >> 8) & 0xFF00u);
+}
+
+__device__ __forceinline__ uint32_t quad_flags(const uint4 &a0) {
+    uint32_t f = msb_pair(a0.x);
+    f |= msb_pair(a0.y) << 1;
+    f |= msb_pair(a0.z) << 2;
+    f |= msb_pair(a0.w) << 3;
+    return (f & 0xFFu) | ((f >> 8) & 0xFF00u);
 }
 
 struct PfWave {
@@ -199,15 +264,41 @@ struct PfWave {
     bool live;           // g < n_bases
 };
 
-#define MS_PF_EMIT(ACC, QUAD)                                                                               \
-    W.n = __builtin_amdgcn_readfirstlane(                                                                   \
-        emit_candidates(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap, ACC, QUAD, W.g, W.live))
+// Entered by the WHOLE wave (uniform branch) when any lane flagged anything in this pair of quads.
+__device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t flags, int32_t quad) {
+    const bool flagged = W.live && flags != 0;
+    const unsigned long long mask = __ballot(flagged);
+    if (mask == 0) return;
+    const uint32_t n_new = (uint32_t) __popcll(mask);
+    if (W.n + n_new > (uint32_t) kWqCap) {
+        wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
+        W.n = 0;
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    if (flagged) W.wbuf[W.n + rank] = cand_pack((uint64_t) W.g, (uint32_t) quad, flags);
+    W.n += n_new;
+}
 
 // All quads of one class (same group count G): per quad G LDS reads of 16 bytes (four motifs x
 // {fwd,rev} 16-bit fields) and (G-1) x 4 packed adds.  `code16[g]` is the lane's 2-mer code at
 // group g (0..15); a table row of one (quad, group) is 16 codes x 16 B = 256 B = every LDS bank
 // exactly once, so the read is conflict-free whatever the codes are.
-template <int G>
+//
+// The kernel is bound by LDS bandwidth, so what matters is keeping reads in flight: variant 2
+// (default) software-pipelines across quads -- the reads of the next quad are issued before the
+// adds and the flag test of the current pair.  Variants 0/1 are kept for A/B measurements.
+
+__device__ __forceinline__ void test_pair(const PfArgs &A, PfWave &W, const uint4 &acc0, const uint4 &acc1, int32_t quad) {
+    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w | acc1.x | acc1.y | acc1.z | acc1.w) & 0x80008000u;
+    if (__any(any != 0) && !A.no_emit) emit_flags(A, W, pair_flags(acc0, acc1), quad);
+}
+
+__device__ __forceinline__ void test_one(const PfArgs &A, PfWave &W, const uint4 &acc0, int32_t quad) {
+    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w) & 0x80008000u;
+    if (__any(any != 0) && !A.no_emit) emit_flags(A, W, quad_flags(acc0), quad);
+}
+
+template <int G, int V>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
                                                 int n_quads, int32_t first_quad, const uint32_t (&code16)[kMaxGroups],
                                                 PfWave &W) {
@@ -215,19 +306,62 @@ __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__
 #pragma unroll
     for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + code16[k];
     int q = 0;
-    for (; q + 2 <= n_quads; q += 2) {
-        uint4 acc0 = lds4[a[0]];
-        uint4 acc1 = lds4[a[0] + G * 16];
+    if constexpr (V == 2 && G <= 8) {
+        // rolling prefetch: rA / rB hold the raw table rows of two quads
+        uint4 rA[G], rB[G];
 #pragma unroll
-        for (int k = 1; k < G; k++) {
-            add4(acc0, lds4[a[k]]);
-            add4(acc1, lds4[a[k] + G * 16]);
+        for (int k = 0; k < G; k++) rA[k] = lds4[a[k]];
+        for (; q + 2 <= n_quads; q += 2) {
+#pragma unroll
+            for (int k = 0; k < G; k++) rB[k] = lds4[a[k] + G * 16];
+            uint4 acc0 = rA[0];
+#pragma unroll
+            for (int k = 1; k < G; k++) add4(acc0, rA[k]);
+            // next pair's first quad (re-reads the current row at the very end: harmless)
+            const uint32_t step = (q + 2 < n_quads) ? 2u * G * 16u : 0u;
+#pragma unroll
+            for (int k = 0; k < G; k++) { a[k] += step; rA[k] = lds4[a[k]]; }
+            uint4 acc1 = rB[0];
+#pragma unroll
+            for (int k = 1; k < G; k++) add4(acc1, rB[k]);
+            test_pair(A, W, acc0, acc1, first_quad + q);
         }
-        const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w | acc1.x | acc1.y | acc1.z | acc1.w) & 0x80008000u;
-        if (__any(any != 0)) {
-            MS_PF_EMIT(acc0, first_quad + q);
-            MS_PF_EMIT(acc1, first_quad + q + 1);
+        if (q < n_quads) {
+            uint4 acc0 = rA[0];
+#pragma unroll
+            for (int k = 1; k < G; k++) add4(acc0, rA[k]);
+            test_one(A, W, acc0, first_quad + q);
         }
+        return;
+    }
+    for (; q + 2 <= n_quads; q += 2) {
+        uint4 acc0, acc1;
+        if constexpr (V >= 1) {
+            // issue the reads in batches of up to 8 groups x 2 quads, then add
+            constexpr int B = G < 8 ? G : 8;
+            uint4 r0[B], r1[B];
+#pragma unroll
+            for (int k0 = 0; k0 < G; k0 += B) {
+#pragma unroll
+                for (int k = 0; k < B; k++)
+                    if (k0 + k < G) { r0[k] = lds4[a[k0 + k]]; r1[k] = lds4[a[k0 + k] + G * 16]; }
+#pragma unroll
+                for (int k = 0; k < B; k++)
+                    if (k0 + k < G) {
+                        if (k0 + k == 0) { acc0 = r0[k]; acc1 = r1[k]; }
+                        else { add4(acc0, r0[k]); add4(acc1, r1[k]); }
+                    }
+            }
+        } else {
+            acc0 = lds4[a[0]];
+            acc1 = lds4[a[0] + G * 16];
+#pragma unroll
+            for (int k = 1; k < G; k++) {
+                add4(acc0, lds4[a[k]]);
+                add4(acc1, lds4[a[k] + G * 16]);
+            }
+        }
+        test_pair(A, W, acc0, acc1, first_quad + q);
 #pragma unroll
         for (int k = 0; k < G; k++) a[k] += 2 * G * 16;
     }
@@ -235,34 +369,35 @@ __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__
         uint4 acc0 = lds4[a[0]];
 #pragma unroll
         for (int k = 1; k < G; k++) add4(acc0, lds4[a[k]]);
-        const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w) & 0x80008000u;
-        if (__any(any != 0)) MS_PF_EMIT(acc0, first_quad + q);
+        test_one(A, W, acc0, first_quad + q);
     }
 }
 
 #define MS_PF_CASE(GG)                                                                      \
     case GG:                                                                                \
-        prefilter_class<GG>(A, lds4, base16, nq, first_quad, code16, W);                    \
+        prefilter_class<GG, V>(A, lds4, base16, nq, first_quad, code16, W);                 \
         break;
 
-// grid = (blocks per tile, tiles).  One block per CU (the tile's tables fill the LDS), 16 waves,
+// grid = (blocks per tile, tiles).  One block per CU (the tile's tables fill the LDS), NT/64 waves,
 // each wave takes 64 consecutive window starts per iteration.  Dynamic LDS = tables of the
-// largest tile, then 16 wave queues of kWqCap candidates.
-__global__ void __launch_bounds__(kPfThreads) prefilter_kernel(const PfArgs A) {
+// largest tile, then one queue of kWqCap candidates per wave.
+template <int NT, int V>
+__global__ void __launch_bounds__(NT) prefilter_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
     const uint32_t len16 = T->table_len16;
     const uint4 *__restrict__ src = A.tables + T->table_off16;
-    for (uint32_t i = threadIdx.x; i < len16; i += kPfThreads) lds4[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     __syncthreads();
     const int n_classes = T->n_classes;
     const int32_t tile_first_quad = T->first_quad;
     PfWave W;
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
     W.n = 0;
+    const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
 
-    for (int64_t chunk = blockIdx.x; chunk < A.n_chunks; chunk += gridDim.x) {
-        W.g = chunk * kPfThreads + threadIdx.x;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        W.g = chunk * NT + threadIdx.x;
         W.live = W.g < A.n_bases;
         const uint64_t cw = code_window(A.codes, W.live ? W.g : 0);
         uint32_t code16[kMaxGroups];
@@ -290,27 +425,58 @@ __global__ void __launch_bounds__(kPfThreads) prefilter_kernel(const PfArgs A) {
 
 // -------------------------------------------------------------------- fp64 kernels --
 
-// grid = (ceil(n_bases/256), ceil(n_fast/kNwMotifChunk)).  Almost every thread leaves at the
-// first test: only windows that overlap a non-ACGT base are scored here (the pre-filter packs
-// such bases as 'A', so its answer for these windows means nothing and rescore_kernel skips them).
-__global__ void __launch_bounds__(256) nwindow_kernel(const DevSeq S, const DevPwm Pw, const int32_t *__restrict__ motifs,
-                                                      int32_t n_motifs, int strand_mask, const HitOut H) {
-    const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= S.n_bases) return;
-    const uint32_t nw = n_window(S.nmask, g);
-    if (nw == 0) return;
-    const int64_t r = find_region(S.offsets, S.R, g);
-    const int64_t end = S.offsets[r + 1];
+// Windows that overlap a non-ACGT base are scored in fp64 outright: the pre-filter packs such
+// bases as 'A', so its answer for these windows means nothing (and rescore_kernel skips them).
+// Two steps so that the rare work is spread over the whole chip instead of a few waves:
+//   nlist_kernel  one thread per 32 positions: list the positions whose next max_w bases hold an N
+//   neval_kernel  one thread per (listed position, chunk of kNwMotifChunk motifs)
+__global__ void __launch_bounds__(256) nlist_kernel(const uint32_t *__restrict__ nmask, int64_t n_bases, int max_w,
+                                                    int64_t *__restrict__ list, unsigned long long *__restrict__ n_list,
+                                                    uint64_t cap) {
+    const int64_t n_words = (n_bases + 31) / 32;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const uint32_t wm = low_mask(max_w);
+    for (int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; j < n_words; j += stride) {
+        const uint32_t w0 = nmask[j], w1 = nmask[j + 1];
+        if ((w0 | w1) == 0) continue;
+        const uint64_t comb = ((uint64_t) w1 << 32) | w0;
+        uint32_t qual = 0;                                   // positions of this word whose window holds an N
+        for (int b = 0; b < 32; b++)
+            if (j * 32 + b < n_bases && ((uint32_t) (comb >> b) & wm) != 0) qual |= 1u << b;
+        if (qual == 0) continue;
+        unsigned long long i = atomicAdd(n_list, (unsigned long long) __popc(qual));
+        while (qual) {
+            const int b = __ffs((int) qual) - 1;
+            qual &= qual - 1u;
+            if (i < cap) list[i] = j * 32 + b;
+            i++;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm Pw, const int32_t *__restrict__ motifs,
+                                                    int32_t n_motifs, int strand_mask, const int64_t *__restrict__ list,
+                                                    const unsigned long long *__restrict__ n_list, uint64_t cap,
+                                                    const HitOut H) {
+    unsigned long long n = *n_list;
+    if (n > cap) n = cap;
     const int m0 = blockIdx.y * kNwMotifChunk;
     const int m1 = min(m0 + kNwMotifChunk, n_motifs);
-    for (int m = m0; m < m1; m++) {
-        const int32_t p = motifs[m];
-        const int W = Pw.width[p];
-        if ((nw & low_mask(W)) == 0) continue;
-        if (g + W > end) continue;
-        double fwd, rev;
-        score_window(S, Pw.tab2 + Pw.tab_off[p], W, g, fwd, rev);
-        test_and_emit(H, Pw, (uint32_t) p, g, fwd, rev, strand_mask);
+    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long) gridDim.x * blockDim.x) {
+        const int64_t g = list[i];
+        const uint32_t nw = n_window(S.nmask, g);
+        const int64_t r = find_region(S, g);
+        const int64_t end = S.offsets[r + 1];
+        for (int m = m0; m < m1; m++) {
+            const int32_t p = motifs[m];
+            const int W = Pw.width[p];
+            if ((nw & low_mask(W)) == 0) continue;
+            if (g + W > end) continue;
+            double fwd, rev;
+            score_window(S, Pw.tab2 + Pw.tab_off[p], W, g, fwd, rev);
+            test_and_emit(H, Pw, (uint32_t) p, g, fwd, rev, strand_mask);
+        }
     }
 }
 
@@ -322,7 +488,7 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
     if (g >= S.n_bases) return;
     const int32_t p = motifs[blockIdx.y];
     const int W = Pw.width[p];
-    const int64_t r = find_region(S.offsets, S.R, g);
+    const int64_t r = find_region(S, g);
     if (g + W > S.offsets[r + 1]) return;
     double fwd, rev;
     score_window(S, Pw.tab2 + Pw.tab_off[p], W, g, fwd, rev);
@@ -333,29 +499,47 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
                                                       const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
                                                       const int32_t *__restrict__ quad_motifs, int strand_mask,
                                                       const HitOut H) {
+    __shared__ HitStage st;
+    if (threadIdx.x == 0) st.n = 0;
+    __syncthreads();
     unsigned long long n = *n_cand;
     if (n > cand_cap) n = cand_cap;
-    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long) gridDim.x * blockDim.x) {
-        const uint64_t c = cand[i];
-        const int32_t pm = quad_motifs[(uint32_t) (c >> 2) & 0xFFFFu];       // candidate carries its table slot
-        if (pm < 0) continue;
-        const uint32_t p = (uint32_t) pm;
-        const int64_t g = (int64_t) (c >> 18);
-        const int W = Pw.width[p];
-        const int64_t r = find_region(S.offsets, S.R, g);
-        if (g + W > S.offsets[r + 1]) continue;                        // window runs past its region (cscore.c:340)
-        if (n_window(S.nmask, g) & low_mask(W)) continue;              // scored by nwindow_kernel
-        double fwd, rev;
-        score_window(S, Pw.tab2 + Pw.tab_off[p], W, g, fwd, rev);
-        test_and_emit(H, Pw, p, g, fwd, rev, strand_mask);
+    const unsigned long long per_round = (unsigned long long) gridDim.x * blockDim.x;
+    const unsigned long long rounds = (n + per_round - 1) / per_round;
+    for (unsigned long long rd = 0; rd < rounds; rd++) {
+        const unsigned long long i = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n) {
+            const uint64_t c = cand[i];
+            uint32_t flags = (uint32_t) c & 0xFFFFu;                   // bit slot: forward, bit 8+slot: reverse, slot 0..7
+            flags = (flags | (flags >> 8)) & 0xFFu;                    // both strands are re-scored anyway
+            const int32_t quad = (int32_t) ((c >> 16) & 0x3FFFu);
+            const int64_t g = (int64_t) (c >> 30);
+            const int64_t r = find_region(S, g);
+            const int64_t end = S.offsets[r + 1];
+            const uint32_t nw = n_window(S.nmask, g);
+            while (flags) {
+                const int slot = __ffs((int) flags) - 1;
+                flags &= flags - 1u;
+                const int32_t pm = quad_motifs[quad * 4 + slot];
+                if (pm < 0) continue;
+                const int W = Pw.width[pm];
+                if (g + W > end) continue;                              // window runs past its region (cscore.c:340)
+                if (nw & low_mask(W)) continue;                         // scored by neval_kernel
+                double fwd, rev;
+                score_window(S, Pw.tab2 + Pw.tab_off[pm], W, g, fwd, rev);
+                test_and_stage(st, H, Pw, (uint32_t) pm, g, fwd, rev, strand_mask);
+            }
+        }
+        __syncthreads();
+        if (st.n > (unsigned int) (kHitStage - 1024)) stage_flush(st, H);   // block-uniform
     }
+    stage_flush(st, H);
 }
 
 // ----------------------------------------------------------------------- finalize --
 
 __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, int gbits,
-                                                       const int64_t *__restrict__ offsets, int64_t R,
+                                                       const DevSeq S,
                                                        int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
                                                        int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
                                                        unsigned long long *__restrict__ region_counts) {
@@ -368,9 +552,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
         const uint64_t gmask = (1ULL << gbits) - 1ULL;
         const int64_t g = (int64_t) ((k >> 1) & gmask);
         motif = (uint32_t) (k >> (gbits + 1));
-        const int64_t r = find_region(offsets, R, g);
+        const int64_t r = find_region(S, g);
         seq_idx[i] = r;
-        pos[i] = g - offsets[r];
+        pos[i] = g - S.offsets[r];
         strand[i] = (int8_t) ((k & 1ULL) ? 2 : 1);
         bool first_of_motif = (i == 0);
         new_pair = true;
@@ -380,7 +564,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
             first_of_motif = mp != motif;
             if (!first_of_motif) {
                 const int64_t gp = (int64_t) ((kp >> 1) & gmask);
-                new_pair = gp < offsets[r];            // previous hit of this motif lies in an earlier region
+                new_pair = gp < S.offsets[r];            // previous hit of this motif lies in an earlier region
             }
         }
         if (first_of_motif) motif_first[motif] = i;
@@ -431,7 +615,26 @@ __global__ void __launch_bounds__(256) score_kernel(const DevSeq S, const DevPwm
     out[(int64_t) p * S.R + r] = s / Pw.max_raw[p];
 }
 
+// ------------------------------------------------------------------- region hints --
+
+// blk2reg[b] = region that holds position 64*b (part of the extraction stage, next to pack_kernel)
+__global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict__ offsets, int64_t R, int64_t n_blocks,
+                                                      int32_t *__restrict__ blk2reg) {
+    const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    blk2reg[b] = (int32_t) find_region_bsearch(offsets, R, b * 64);
+}
+
 // ---------------------------------------------------------------------- launchers --
+
+int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st) {
+    const int64_t n_blocks = (n_bases + 63) / 64 + 1;
+    hipLaunchKernelGGL(blk2reg_kernel, dim3((unsigned) ((n_blocks + 255) / 256)), dim3(256), 0, st, offsets, R, n_blocks,
+                       blk2reg);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st) {
     const int64_t n_units = (n_bases + 31) / 32;
@@ -443,24 +646,46 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
     return MS_OK;
 }
 
-int prefilter_set_lds(size_t bytes) {
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prefilter_kernel),
+typedef void (*PfKernel)(const PfArgs);
+
+static PfKernel pf_kernel_for(int variant, int *threads) {
+    switch (variant) {
+        case 0: *threads = 1024; return prefilter_kernel<1024, 0>;
+        case 1: *threads = 1024; return prefilter_kernel<1024, 1>;
+        case 3: *threads = 768; return prefilter_kernel<768, 2>;
+        case 4: *threads = 512; return prefilter_kernel<512, 2>;
+        case 2: *threads = 1024; return prefilter_kernel<1024, 2>;
+        default: *threads = 1024; return prefilter_kernel<1024, 1>;
+    }
+}
+
+int prefilter_set_lds(int variant, size_t bytes) {
+    int threads;
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel_for(variant, &threads)),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
-int launch_prefilter(const PfArgs &A, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL(prefilter_kernel, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads),
-                       lds_bytes, st, A);
+int launch_prefilter(const PfArgs &A, int variant, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+    int threads;
+    PfKernel k = pf_kernel_for(variant, &threads);
+    const int64_t n_chunks = (A.n_bases + threads - 1) / threads;
+    if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
+    hipLaunchKernelGGL(k, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(threads), lds_bytes, st, A);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
 
-int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
-                   const HitOut &H, hipStream_t st) {
+int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
+                   int strand_mask, int64_t *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
+                   hipStream_t st) {
     if (S.n_bases == 0 || n_motifs == 0) return MS_OK;
-    dim3 grid((unsigned) ((S.n_bases + 255) / 256), (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));
-    hipLaunchKernelGGL(nwindow_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, H);
+    const int64_t want = ((S.n_bases + 31) / 32 + 255) / 256;
+    hipLaunchKernelGGL(nlist_kernel, dim3((unsigned) (want < 4096 ? want : 4096)), dim3(256), 0, st, S.nmask, S.n_bases,
+                       max_w, list, n_list, list_cap);
+    MS_HIP(hipGetLastError());
+    dim3 grid(1024, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));
+    hipLaunchKernelGGL(neval_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, list, n_list, list_cap, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
@@ -486,12 +711,12 @@ int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, cons
     return MS_OK;
 }
 
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const int64_t *offsets, int64_t R, int64_t *seq_idx,
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st) {
     if (n == 0) return MS_OK;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, offsets,
-                       R, seq_idx, pos, strand, motif_first, region_counts);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, S,
+                       seq_idx, pos, strand, motif_first, region_counts);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
