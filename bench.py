@@ -58,16 +58,22 @@ def cpu_baseline(wl, seconds_target=12.0):
         return time.perf_counter() - t0
 
     threads = min(cores, P)                        # the reference's work unit is one whole PWM (cscore.c:181-186)
-    n0 = 40
-    t = run(n0, threads)                           # calibration
-    n = int(min(len(offsets) - 1, max(n0, n0 * seconds_target / max(t, 1e-3))))
-    n = min(n, 20000)
-    t = run(n, threads)
+    n_max = len(offsets) - 1
+    n, t = min(64, n_max), 0.0
+    for _ in range(4):                             # grow the sample until one run is a few seconds, then scale to target
+        t = run(n, threads)
+        if t >= 3.0 or n >= n_max:
+            break
+        n = int(min(n_max, max(2 * n, n * 4.0 / max(t, 1e-3))))
+    if t < 0.6 * seconds_target and n < n_max:
+        n = int(min(n_max, n * seconds_target / max(t, 1e-3)))
+        t = run(n, threads)
     units = int(offsets[n]) * P
     out = {"value": units / t, "unit": "bp*motifs/s", "cores": threads,
            "kind": "reference" if ref is not None else "port",
            "sample": f"first {n} regions x {L} bp x {P} PWMs of the same workload, both strands, {t:.1f} s wall",
            "host_cores_total": cores}
+    n0 = 16
     t1 = run(max(n // max(threads, 1), n0), 1)
     out["value_1thread"] = int(offsets[max(n // max(threads, 1), n0)]) * P / t1
     return out

@@ -78,6 +78,7 @@ typedef struct ms_scan_stats {
     double  ms_total;           /* first launch -> last kernel done                                  */
     int64_t lds_bytes_read;     /* bytes the pre-filter reads from LDS (its binding on-chip stream)  */
     int64_t hbm_bytes_algorithmic; /* codes + mask + offsets + PWMs + 16 B/hit + 8 B/PWM */
+    double  pf_clock_mhz;       /* shader clock held inside the pre-filter kernel; 0 unless MS_PF_CLOCK=1 */
 } ms_scan_stats;
 
 const char *ms_last_error(void);

@@ -603,7 +603,12 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_budget = c->lds_max - kWqBytes - 1024;      // tables; the wave queues follow them
+    size_t lds_budget = c->lds_max - kWqBytes - 1024;            // tables; the wave queues follow them
+    int pf_blocks_per_cu = 1;
+    if (const char *e = getenv("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
+        pf_blocks_per_cu = std::max(1, atoi(e));
+        lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - kWqBytes - 1024;
+    }
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
     const PrefilterPlan &plan = pwms->plan;
@@ -669,6 +674,9 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     int pf_variant = 1, pf_no_emit = 0;
     if (const char *e = getenv("MS_PF_VARIANT")) pf_variant = atoi(e) & 7;
     if (const char *e = getenv("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
+    const bool pf_clock = getenv("MS_PF_CLOCK") && atoi(getenv("MS_PF_CLOCK")) != 0;
+    unsigned long long *d_clk = nullptr;
+    int clk_blocks = 0;
     if (lds_bytes > c->lds_set[pf_variant]) {
         if ((rc = prefilter_set_lds(pf_variant, lds_bytes))) return fail(rc);
         c->lds_set[pf_variant] = lds_bytes;
@@ -689,7 +697,14 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
-            const int bpt = std::max(1, c->n_cu / n_tiles);
+            const int bpt = std::max(1, c->n_cu * pf_blocks_per_cu / n_tiles);
+            A.clk = nullptr;
+            if (pf_clock) {
+                clk_blocks = bpt * n_tiles;
+                if (!d_clk && (rc = dev_alloc(&d_clk, (size_t) 2 * clk_blocks))) return fail(rc);
+                (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * 2 * clk_blocks, c->stream);
+                A.clk = d_clk;
+            }
             if ((rc = launch_prefilter(A, pf_variant, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
         }
         (void) hipEventRecord(c->ev[1], c->stream);
@@ -719,6 +734,16 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     }
     stt.n_candidates = (int64_t) n_cand;
     stt.n_hits = (int64_t) n_hits;
+    if (d_clk) {                                             // median over blocks of cycles per 10 ns tick
+        std::vector<unsigned long long> h((size_t) 2 * clk_blocks);
+        if (hipMemcpy(h.data(), d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<double> mhz;
+            for (int b = 0; b < clk_blocks; b++)
+                if (h[2 * b + 1] > 0) mhz.push_back(100.0 * (double) h[2 * b] / (double) h[2 * b + 1]);
+            if (!mhz.empty()) { std::sort(mhz.begin(), mhz.end()); stt.pf_clock_mhz = mhz[mhz.size() / 2]; }
+        }
+        dev_free(d_clk);
+    }
     raw->n_hits = (int64_t) n_hits;
 
     {   // one pooled block: [counts P][first P+1][seq_idx n][pos n][score n][strand n]

@@ -45,6 +45,7 @@ struct PfArgs {
     unsigned long long *n_cand;
     uint64_t cand_cap;
     int no_emit;              // measurement only: run the filter, drop the candidates
+    unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);

@@ -300,11 +300,10 @@ __device__ __forceinline__ void test_one(const PfArgs &A, PfWave &W, const uint4
 
 template <int G, int V>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
-                                                int n_quads, int32_t first_quad, const uint32_t (&code16)[kMaxGroups],
-                                                PfWave &W) {
+                                                int n_quads, int32_t first_quad, const uint64_t cw, PfWave &W) {
     uint32_t a[G];
 #pragma unroll
-    for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + code16[k];
+    for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + ((uint32_t) (cw >> (4 * k)) & 15u);
     int q = 0;
     if constexpr (V == 2 && G <= 8) {
         // rolling prefetch: rA / rB hold the raw table rows of two quads
@@ -375,14 +374,14 @@ __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__
 
 #define MS_PF_CASE(GG)                                                                      \
     case GG:                                                                                \
-        prefilter_class<GG, V>(A, lds4, base16, nq, first_quad, code16, W);                 \
+        prefilter_class<GG, V>(A, lds4, base16, nq, first_quad, cw, W);                 \
         break;
 
 // grid = (blocks per tile, tiles).  One block per CU (the tile's tables fill the LDS), NT/64 waves,
 // each wave takes 64 consecutive window starts per iteration.  Dynamic LDS = tables of the
 // largest tile, then one queue of kWqCap candidates per wave.
-template <int NT, int V>
-__global__ void __launch_bounds__(NT) prefilter_kernel(const PfArgs A) {
+template <int NT, int V, int MW>
+__global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
     const uint32_t len16 = T->table_len16;
@@ -395,14 +394,25 @@ __global__ void __launch_bounds__(NT) prefilter_kernel(const PfArgs A) {
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
     W.n = 0;
     const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
+    // optional clock stamps (measurement runs only; written to a buffer nothing else reads):
+    // shader cycles (s_memtime) against the 100 MHz constant clock (s_memrealtime)
+    unsigned long long t0 = 0, r0 = 0;
+    if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
+    // the sequence words of the NEXT chunk are fetched while the current one is scanned
+    uint64_t cw_next = 0;
+    {
+        const int64_t g0 = (int64_t) blockIdx.x * NT + threadIdx.x;
+        if (blockIdx.x < n_chunks) cw_next = code_window(A.codes, g0 < A.n_bases ? g0 : 0);
+    }
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         W.g = chunk * NT + threadIdx.x;
         W.live = W.g < A.n_bases;
-        const uint64_t cw = code_window(A.codes, W.live ? W.g : 0);
-        uint32_t code16[kMaxGroups];
-#pragma unroll
-        for (int k = 0; k < kMaxGroups; k++) code16[k] = (uint32_t) (cw >> (4 * k)) & 15u;
+        const uint64_t cw = cw_next;
+        {
+            const int64_t gn = W.g + (int64_t) gridDim.x * NT;
+            if (chunk + gridDim.x < n_chunks) cw_next = code_window(A.codes, gn < A.n_bases ? gn : 0);
+        }
 
         uint32_t base16 = 0;
         int32_t first_quad = tile_first_quad;
@@ -421,6 +431,12 @@ __global__ void __launch_bounds__(NT) prefilter_kernel(const PfArgs A) {
         }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
+    if (A.clk && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        const size_t b = (size_t) blockIdx.y * gridDim.x + blockIdx.x;
+        A.clk[2 * b] = t1 - t0;
+        A.clk[2 * b + 1] = r1 - r0;
+    }
 }
 
 // -------------------------------------------------------------------- fp64 kernels --
@@ -650,12 +666,13 @@ typedef void (*PfKernel)(const PfArgs);
 
 static PfKernel pf_kernel_for(int variant, int *threads) {
     switch (variant) {
-        case 0: *threads = 1024; return prefilter_kernel<1024, 0>;
-        case 1: *threads = 1024; return prefilter_kernel<1024, 1>;
-        case 3: *threads = 768; return prefilter_kernel<768, 2>;
-        case 4: *threads = 512; return prefilter_kernel<512, 2>;
-        case 2: *threads = 1024; return prefilter_kernel<1024, 2>;
-        default: *threads = 1024; return prefilter_kernel<1024, 1>;
+        case 0: *threads = 1024; return prefilter_kernel<1024, 0, 4>;
+        case 2: *threads = 1024; return prefilter_kernel<1024, 2, 4>;
+        case 3: *threads = 768; return prefilter_kernel<768, 1, 3>;
+        case 4: *threads = 512; return prefilter_kernel<512, 1, 2>;
+        case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
+        case 6: *threads = 512; return prefilter_kernel<512, 1, 4>;       // 512 threads, two blocks per CU
+        default: *threads = 1024; return prefilter_kernel<1024, 1, 4>;
     }
 }
 

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Shader clock held inside the pre-filter kernel (s_memtime vs the 100 MHz s_memrealtime), after
+>= 2 s of back-to-back launches on the benchmark data.  Usage: python tools/pf_clock.py [workload]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from motifscan_amd import _lib, synth
+_lib.set_device(0)
+wl = synth.workload(sys.argv[1] if len(sys.argv) > 1 else "c4shard")
+pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
+sq = _lib.SeqSet(*wl["sets"][0])
+t0 = time.time()
+while time.time() - t0 < 2.5:
+    _lib.scan(pw, sq, 3).close()
+os.environ["MS_PF_CLOCK"] = "1"
+for _ in range(5):
+    r = _lib.scan(pw, sq, 3); st = r.stats(); r.close()
+    lds = st["lds_bytes_read"] / (st["ms_prefilter"] * 1e-3)
+    peak = 256 * 256 * st["pf_clock_mhz"] * 1e6
+    print(f"prefilter {st['ms_prefilter']:.3f} ms  clock {st['pf_clock_mhz']:.0f} MHz  LDS {lds/1e12:.1f} TB/s = "
+          f"{100*lds/peak:.1f}% of 256 B/clk/CU at that clock ({100*lds/(256*256*2.4e9):.1f}% at 2.4 GHz)", flush=True)

@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
 """A/B the pre-filter kernel variants in ONE process (same data, interleaved), print kernel ms.
-Usage (GPU box): python tools/pf_variants.py [workload] [variants...]"""
+Usage (GPU box): python tools/pf_variants.py workload v:b [v:b ...]   (variant : blocks per CU)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from motifscan_amd import _lib, synth
 
 wl_name = sys.argv[1] if len(sys.argv) > 1 else "c4shard"
-variants = [int(v) for v in sys.argv[2:]] or [0, 1, 2, 3, 4]
+combos = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:]] or [(1, 1), (0, 1), (5, 2), (6, 2)]
 _lib.set_device(0)
 wl = synth.workload(wl_name)
 pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
 sq = _lib.SeqSet(*wl["sets"][0])
+os.environ["MS_PF_CLOCK"] = "1"
 for rep in range(2):
     for noemit in (0, 1):
-        for v in variants:
+        for v, b in combos:
             os.environ["MS_PF_VARIANT"] = str(v)
+            os.environ["MS_PF_BLOCKS_PER_CU"] = str(b)
             os.environ["MS_PF_NOEMIT"] = str(noemit)
             ms = []
             for _ in range(4):
@@ -22,5 +24,6 @@ for rep in range(2):
                 st = r.stats()
                 ms.append(st["ms_prefilter"])
                 r.close()
-            print(f"rep {rep} variant {v} noemit {noemit}: prefilter {min(ms):.3f} ms (min of 4, all {['%.2f' % m for m in ms]}) "
-                  f"cand {st['n_candidates']} hits {st['n_hits']} exact {st['ms_exact']:.2f} ms", flush=True)
+            print(f"rep {rep} variant {v} blocks/CU {b} noemit {noemit}: prefilter {min(ms):.3f} ms "
+                  f"(all {['%.2f' % m for m in ms]}) tiles {st['n_tiles']} clock {st['pf_clock_mhz']:.0f} MHz "
+                  f"cand {st['n_candidates']} hits {st['n_hits']}", flush=True)
