@@ -15,14 +15,16 @@ extern "C" {
 
 /* Build (and cache) the plan for a strand mask and an LDS budget in bytes; report its shape. */
 int ms_debug_plan_dims(const ms_pwmset *pwms, int strand_mask, int64_t lds_budget, int32_t *n_fast,
-                       int32_t *n_exact, int32_t *n_quads, int32_t *n_tiles);
+                       int32_t *n_exact, int32_t *n_groups, int32_t *n_tiles);
 
 /* Copy the plan built by the last ms_debug_plan_dims call (any pointer may be NULL):
- *   quad_motifs [n_quads][4] (-1 = empty slot), quad_G [n_quads],
- *   tables [n_quads][16 groups][16 codes][4 slots] 32-bit words (lo16 forward, hi16 reverse field),
- *   exact_motifs [n_exact], tile_first_quad [n_tiles + 1]. */
-int ms_debug_plan_tables(const ms_pwmset *pwms, int32_t *quad_motifs, int32_t *quad_G, uint32_t *tables,
-                         int32_t *exact_motifs, int32_t *tile_first_quad);
+ *   group_motifs [n_groups][8] (-1 = empty slot), group_G [n_groups] (2-mer positions),
+ *   group_fb [n_groups] (field bits, 10 or 16),
+ *   tables [n_groups][16 positions][16 codes][4 words]: field n (motif slot n >> 1, even n forward,
+ *   odd n reverse) sits in word n & 3 at bit (n >> 2) * fb,
+ *   exact_motifs [n_exact], tile_first_group [n_tiles + 1]. */
+int ms_debug_plan_tables(const ms_pwmset *pwms, int32_t *group_motifs, int32_t *group_G, int32_t *group_fb,
+                         uint32_t *tables, int32_t *exact_motifs, int32_t *tile_first_group);
 
 /* Free the current device's grow-only work buffers (candidate list, hit list, sort space), so a
  * test can force the "buffer too small -> grow -> run the pass again" path.  Needs a GPU. */

@@ -102,7 +102,7 @@ def lib():
         "ms_score": (c_int, [vp, vp, c_int, pd]),
         "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
         "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
-        "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pu32, pi32, pi32]),
+        "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pi32, pu32, pi32, pi32]),
         "ms_debug_release_scratch": (c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -189,21 +189,22 @@ class PwmSet:
         check(lib().ms_pwmset_max_raw(self.h, ptr(out, ctypes.c_double)))
         return out
 
-    def plan(self, strand_mask=3, lds_budget=159 * 1024):
+    def plan(self, strand_mask=3, lds_budget=143 * 1024):
         """Host-side view of the integer pre-filter plan (tests only)."""
         L = lib()
         nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
         check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
                                    ctypes.byref(nq), ctypes.byref(nt)))
-        qm = np.zeros((nq.value, 4), dtype=np.int32)
-        qg = np.zeros(nq.value, dtype=np.int32)
+        gm = np.full((nq.value, 8), -1, dtype=np.int32)
+        gg = np.zeros(nq.value, dtype=np.int32)
+        gf = np.zeros(nq.value, dtype=np.int32)
         tb = np.zeros((nq.value, 16, 16, 4), dtype=np.uint32)
         ex = np.zeros(max(ne.value, 1), dtype=np.int32)
         tf = np.zeros(nt.value + 1, dtype=np.int32)
-        check(L.ms_debug_plan_tables(self.h, ptr(qm, ctypes.c_int32), ptr(qg, ctypes.c_int32),
+        check(L.ms_debug_plan_tables(self.h, ptr(gm, ctypes.c_int32), ptr(gg, ctypes.c_int32), ptr(gf, ctypes.c_int32),
                                      ptr(tb, ctypes.c_uint32), ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
-        return {"n_fast": nf.value, "n_exact": ne.value, "quad_motifs": qm, "quad_G": qg, "tables": tb,
-                "exact_motifs": ex[:ne.value], "tile_first_quad": tf}
+        return {"n_fast": nf.value, "n_exact": ne.value, "group_motifs": gm, "group_G": gg, "group_fb": gf,
+                "tables": tb, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 
     def close(self):
         if getattr(self, "h", None):

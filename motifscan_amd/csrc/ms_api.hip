@@ -180,10 +180,11 @@ struct ms_pwmset {
     uint64_t plan_cutoff_version = 0;
     size_t plan_lds = 0;
     bool plan_exact_only = false;
+    int plan_min_fb = 0;
     int plan_device = -1;
     uint4 *d_tables = nullptr;
     TileDesc *d_tiles = nullptr;
-    int32_t *d_quad_motifs = nullptr;
+    int32_t *d_group_motifs = nullptr;
     int32_t *d_fast_motifs = nullptr;
     int32_t *d_exact_motifs = nullptr;
     std::mutex mu;
@@ -234,7 +235,7 @@ static double c_max_raw(const double *m, int W) {
 static void pwmset_free_device(ms_pwmset *p) {
     if (p->device >= 0 || p->plan_device >= 0) (void) hipSetDevice(p->device >= 0 ? p->device : p->plan_device);
     dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff);
-    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_quad_motifs); dev_free(p->d_fast_motifs);
+    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
     dev_free(p->d_exact_motifs);
     p->device = -1;
     p->plan_device = -1;
@@ -289,8 +290,10 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
 
 static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
                        int device) {
+    int min_fb = 10;                                   // measurement switch: MS_PF_FIELD_BITS=16 forces 16-bit fields
+    if (const char *e = getenv("MS_PF_FIELD_BITS")) min_fb = atoi(e) >= 16 ? 16 : 10;
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
-                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only;
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_min_fb != min_fb;
     if (stale) {
         if (exact_only) {
             p->plan = PrefilterPlan();
@@ -298,16 +301,17 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
             int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
-                                p->max_raw.data(), p->P, strand_mask, lds_budget, &p->plan);
+                                p->max_raw.data(), p->P, strand_mask, lds_budget, min_fb, &p->plan);
             if (rc) return rc;
         }
         p->plan_strand = strand_mask;
         p->plan_cutoff_version = p->cutoff_version;
         p->plan_lds = lds_budget;
         p->plan_exact_only = exact_only;
+        p->plan_min_fb = min_fb;
         if (p->plan_device >= 0) {
             (void) hipSetDevice(p->plan_device);
-            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_quad_motifs); dev_free(p->d_fast_motifs);
+            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
             dev_free(p->d_exact_motifs);
             p->plan_device = -1;
         }
@@ -318,15 +322,15 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         int rc;
         if ((rc = dev_alloc(&p->d_tables, pl.tables.size() / 4))) return rc;
         if ((rc = dev_alloc(&p->d_tiles, pl.tiles.size()))) return rc;
-        if ((rc = dev_alloc(&p->d_quad_motifs, pl.quad_motifs.size()))) return rc;
+        if ((rc = dev_alloc(&p->d_group_motifs, pl.group_motifs.size()))) return rc;
         if ((rc = dev_alloc(&p->d_fast_motifs, pl.fast_motifs.size()))) return rc;
         if ((rc = dev_alloc(&p->d_exact_motifs, pl.exact_motifs.size()))) return rc;
         if (!pl.tables.empty())
             MS_HIP(hipMemcpy(p->d_tables, pl.tables.data(), pl.tables.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!pl.tiles.empty())
             MS_HIP(hipMemcpy(p->d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-        if (!pl.quad_motifs.empty())
-            MS_HIP(hipMemcpy(p->d_quad_motifs, pl.quad_motifs.data(), pl.quad_motifs.size() * sizeof(int32_t),
+        if (!pl.group_motifs.empty())
+            MS_HIP(hipMemcpy(p->d_group_motifs, pl.group_motifs.data(), pl.group_motifs.size() * sizeof(int32_t),
                              hipMemcpyHostToDevice));
         if (!pl.fast_motifs.empty())
             MS_HIP(hipMemcpy(p->d_fast_motifs, pl.fast_motifs.data(), pl.fast_motifs.size() * sizeof(int32_t),
@@ -711,7 +715,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         if (!plan.fast_motifs.empty()) {
             if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), fast_max_w, strand_mask,
                                      sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->stream))) return fail(rc);
-            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_quad_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
         }
         if (!plan.exact_motifs.empty())
             if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
@@ -937,7 +941,7 @@ int ms_dedup_hits(const int64_t *motif_offsets, int32_t n_pwms, const int32_t *w
 // window the reference reports (tests/test_prefilter_plan.py).  Not part of the drop-in surface.
 
 int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_budget, int32_t *n_fast,
-                       int32_t *n_exact, int32_t *n_quads, int32_t *n_tiles) {
+                       int32_t *n_exact, int32_t *n_groups, int32_t *n_tiles) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     std::lock_guard<std::mutex> lk(pwms->mu);
@@ -945,28 +949,29 @@ int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_bud
     if (rc) return rc;
     if (n_fast) *n_fast = (int32_t) pwms->plan.fast_motifs.size();
     if (n_exact) *n_exact = (int32_t) pwms->plan.exact_motifs.size();
-    if (n_quads) *n_quads = (int32_t) pwms->plan.quad_G.size();
+    if (n_groups) *n_groups = (int32_t) pwms->plan.group_G.size();
     if (n_tiles) *n_tiles = (int32_t) pwms->plan.tiles.size();
     return MS_OK;
 }
 
-// quad_motifs [n_quads][4], quad_G [n_quads], tables [n_quads][16 groups][16 codes][4 slots] (zero padded),
-// exact_motifs [n_exact], tile_first_quad [n_tiles+1]
-int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *quad_motifs, int32_t *quad_G, uint32_t *tables,
-                         int32_t *exact_motifs, int32_t *tile_first_quad) {
+// group_motifs [n_groups][8], group_G [n_groups], group_fb [n_groups],
+// tables [n_groups][16 positions][16 codes][4 words] (zero padded), exact_motifs [n_exact], tile_first_group [n_tiles+1]
+int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *group_motifs, int32_t *group_G, int32_t *group_fb,
+                         uint32_t *tables, int32_t *exact_motifs, int32_t *tile_first_group) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     std::lock_guard<std::mutex> lk(pwms->mu);
     const PrefilterPlan &pl = pwms->plan;
     if (pwms->plan_strand < 0) { set_error("call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
-    const size_t nq = pl.quad_G.size();
-    if (quad_motifs) std::memcpy(quad_motifs, pl.quad_motifs.data(), pl.quad_motifs.size() * sizeof(int32_t));
-    if (quad_G) std::memcpy(quad_G, pl.quad_G.data(), nq * sizeof(int32_t));
+    const size_t nq = pl.group_G.size();
+    if (group_motifs && nq) std::memcpy(group_motifs, pl.group_motifs.data(), pl.group_motifs.size() * sizeof(int32_t));
+    if (group_G && nq) std::memcpy(group_G, pl.group_G.data(), nq * sizeof(int32_t));
+    if (group_fb && nq) std::memcpy(group_fb, pl.group_fb.data(), nq * sizeof(int32_t));
     if (tables) {
         std::memset(tables, 0, nq * 16 * 16 * 4 * sizeof(uint32_t));
         size_t off16 = 0;
         for (size_t q = 0; q < nq; q++) {
-            const int G = pl.quad_G[q];
+            const int G = pl.group_G[q];
             for (int g = 0; g < G; g++)
                 for (int x = 0; x < 16; x++)
                     for (int k = 0; k < 4; k++)
@@ -976,9 +981,9 @@ int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *quad_motifs, int32_t 
     }
     if (exact_motifs && !pl.exact_motifs.empty())
         std::memcpy(exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t));
-    if (tile_first_quad) {
-        for (size_t t = 0; t < pl.tiles.size(); t++) tile_first_quad[t] = pl.tiles[t].first_quad;
-        tile_first_quad[pl.tiles.size()] = (int32_t) nq;
+    if (tile_first_group) {
+        for (size_t t = 0; t < pl.tiles.size(); t++) tile_first_group[t] = pl.tiles[t].first_group;
+        tile_first_group[pl.tiles.size()] = (int32_t) nq;
     }
     return MS_OK;
 }

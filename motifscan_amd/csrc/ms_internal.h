@@ -25,48 +25,53 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 // ------------------------------------------------------------------ limits / packing --
 constexpr int kMaxFastWidth = 32;      // one lane holds 32 bases (64 bits of 2-bit codes)
 constexpr int kMaxGroups = 16;         // 2-mer groups per motif (ceil(32 / 2))
-constexpr int kMaxMotifs = 65535;      // 16-bit motif id in candidate / hit keys
+constexpr int kMaxMotifs = 65000;      // 14-bit table-group id in a candidate record, >= 4 motifs per group
 constexpr int kPadWords = 8;           // zero words after the packed codes (window reads run past the end)
 
 constexpr int64_t kMaxBases = (1LL << 34) - 64;   // 34-bit position field of a candidate record
 
-// candidate record (one per lane and pair of quads): [63:30] global base position, [29:16] first quad,
-// [15:0] flags: bit slot (0..7, over the two quads) = forward field flagged, bit 8 + slot = reverse
-__host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t quad, uint32_t flags) {
-    return (g << 30) | ((uint64_t) quad << 16) | flags;
+// candidate record (one per lane and table group): [63:30] global base position, [29:16] table group,
+// [15:0] flags: bit n = field n flagged (motif slot n >> 1; even n forward, odd n reverse)
+__host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t group, uint32_t flags) {
+    return (g << 30) | ((uint64_t) group << 16) | flags;
 }
 
 // ------------------------------------------------------------------ pre-filter plan --
+constexpr int kGroupSlots = 8;         // motif slots per table group (4 at 16-bit fields, 6 at 10-bit)
+constexpr int kMaxClasses = 2 * kMaxGroups;
+
 struct ClassDesc {
-    int32_t G;         // 2-mer groups of every quad in the class
-    int32_t n_quads;
+    int32_t G;          // 2-mer groups of every table group in the class
+    int32_t n_groups;
+    int32_t fb;         // field bits: 16 (4 motifs per 16-byte entry) or 10 (6 motifs)
 };
 
 struct TileDesc {
     uint32_t table_off16;   // offset into the table buffer, in 16-byte units
     uint32_t table_len16;   // tile size in 16-byte units
-    int32_t first_quad;     // global index of the tile's first quad
+    int32_t first_group;    // global index of the tile's first table group
     int32_t n_classes;
-    ClassDesc cls[kMaxGroups];
+    ClassDesc cls[kMaxClasses];
 };
 
 // Host-side result of planning: which motifs take the integer pre-filter, their quantised
-// 2-mer tables grouped in quads of four motifs, and how quads are cut into LDS tiles.
+// 2-mer tables in groups that share 16-byte entries, and how groups are cut into LDS tiles.
 struct PrefilterPlan {
     int strand_mask = 0;
-    std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in quad order
+    std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in group order
     std::vector<int32_t> exact_motifs;   // motif ids scored in fp64 at every window
-    std::vector<int32_t> quad_motifs;    // [n_quads][4], -1 = empty slot
-    std::vector<int32_t> quad_G;         // [n_quads]
-    std::vector<uint32_t> tables;        // per quad: [G][16 codes][4 slots] words (lo16 fwd, hi16 rev)
+    std::vector<int32_t> group_motifs;   // [n_groups][kGroupSlots], -1 = empty slot
+    std::vector<int32_t> group_G;        // [n_groups]
+    std::vector<int32_t> group_fb;       // [n_groups]
+    std::vector<uint32_t> tables;        // per group: [G][16 codes][4 words]; field n of motif slot j: n = 2j (fwd), 2j+1 (rev)
     std::vector<TileDesc> tiles;
-    int64_t lds_bytes_per_position = 0;  // sum over quads of G * 16 bytes (per lane, per position)
+    int64_t lds_bytes_per_position = 0;  // sum over groups of G * 16 bytes (per lane, per position)
 };
 
-// Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes.
+// Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes; min_field_bits 10 or 16.
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths,
                const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
-               size_t lds_budget, PrefilterPlan *plan);
+               size_t lds_budget, int min_field_bits, PrefilterPlan *plan);
 
 // Sort (ms_sort.hip): keys ascending over bits [0, end_bit).  Query temp size with temp == nullptr.
 int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,

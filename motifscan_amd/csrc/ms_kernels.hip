@@ -11,8 +11,8 @@
 //
 // Kernels:
 //   pack_kernel       ASCII -> codes + nmask                     (cscore.c:81-114)
-//   prefilter_kernel  16-bit integer upper bound of both strand scores for EVERY window, PWM
-//                     2-mer tables in LDS, one lane per window start; emits candidates
+//   prefilter_kernel  10/16-bit fixed-point upper bound of both strand scores for EVERY window,
+//                     PWM 2-mer tables in LDS, one lane per window start; emits candidates
 //   nlist/neval       fp64 scoring of the windows that overlap a non-ACGT base
 //   exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take
 //   rescore_kernel    fp64 scoring of the candidates, in the reference's order of operations,
@@ -216,11 +216,11 @@ __device__ __forceinline__ void add4(uint4 &a, const uint4 &b) {
 
 // ---- candidate hand-off --------------------------------------------------------------------
 // Candidates are ~2e-4 of the (window, motif) pairs, i.e. about one wave in ten finds one in a
-// pair of quads.  One global atomic per find would put every wave of the chip on ONE address
+// pair of table groups.  One global atomic per find would put every wave of the chip on ONE address
 // (measured: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  So each
 // wave appends to its own queue in LDS with ballot/mbcnt ranks (no atomics at all) and spills it
 // to the global list with a single atomicAdd per >= 64 entries.  A record is per LANE and per
-// pair of quads: position, first quad, and one flag bit per (slot, strand) -- rescore_kernel
+// table group: position, group, and one flag bit per field (motif slot, strand) -- rescore_kernel
 // expands the flags.
 
 __device__ __noinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
@@ -233,28 +233,25 @@ __device__ __noinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, u
         if (base + i < cand_cap) cand[base + i] = wbuf[i];
 }
 
-// one quad -> 8 bits: bit k = forward field of word k flagged, bit 4+k... see pair_flags
-__device__ __forceinline__ uint32_t msb_pair(uint32_t x) { return (x >> 15) & 0x00010001u; }   // bit 0: fwd, bit 16: rev
+// Field geometry of a 32-bit table word at FB bits per field.
+template <int FB> struct Fields {
+    static constexpr int NF = 32 / FB;                                   // fields per word
+    static constexpr uint32_t low() { uint32_t m = 0; for (int f = 0; f < NF; f++) m |= 1u << (f * FB); return m; }
+    static constexpr uint32_t kLow = low();                              // bit 0 of every field
+    static constexpr uint32_t kTop = kLow << (FB - 1);                   // top (flag) bit of every field
+};
 
-// pair of quads -> 16 bits: bit s (slot 0..7 = word k of quad 0 / quad 1) forward, bit 8+s reverse
-__device__ __forceinline__ uint32_t pair_flags(const uint4 &a0, const uint4 &a1) {
-    uint32_t f = msb_pair(a0.x);
-    f |= msb_pair(a0.y) << 1;
-    f |= msb_pair(a0.z) << 2;
-    f |= msb_pair(a0.w) << 3;
-    f |= msb_pair(a1.x) << 4;
-    f |= msb_pair(a1.y) << 5;
-    f |= msb_pair(a1.z) << 6;
-    f |= msb_pair(a1.w) << 7;
-    return (f & 0xFFu) | ((f >> 8) & 0xFF00u);
-}
-
-__device__ __forceinline__ uint32_t quad_flags(const uint4 &a0) {
-    uint32_t f = msb_pair(a0.x);
-    f |= msb_pair(a0.y) << 1;
-    f |= msb_pair(a0.z) << 2;
-    f |= msb_pair(a0.w) << 3;
-    return (f & 0xFFu) | ((f >> 8) & 0xFF00u);
+// 16-byte entry -> flags: bit n = field n reached its top bit (field n: word n & 3, field n >> 2)
+template <int FB>
+__device__ __forceinline__ uint32_t group_flags(const uint4 &a) {
+    uint32_t f = (a.x >> (FB - 1)) & Fields<FB>::kLow;
+    f |= ((a.y >> (FB - 1)) & Fields<FB>::kLow) << 1;
+    f |= ((a.z >> (FB - 1)) & Fields<FB>::kLow) << 2;
+    f |= ((a.w >> (FB - 1)) & Fields<FB>::kLow) << 3;
+    uint32_t out = f & 0xFu;
+#pragma unroll
+    for (int k = 1; k < Fields<FB>::NF; k++) out |= ((f >> (k * FB)) & 0xFu) << (4 * k);
+    return out;
 }
 
 struct PfWave {
@@ -264,8 +261,9 @@ struct PfWave {
     bool live;           // g < n_bases
 };
 
-// Entered by the WHOLE wave (uniform branch) when any lane flagged anything in this pair of quads.
-__device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t flags, int32_t quad) {
+// Entered by the WHOLE wave (uniform branch); appends one record per lane that flagged anything in
+// this table group.
+__device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t flags, int32_t group) {
     const bool flagged = W.live && flags != 0;
     const unsigned long long mask = __ballot(flagged);
     if (mask == 0) return;
@@ -275,68 +273,44 @@ __device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t 
         W.n = 0;
     }
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    if (flagged) W.wbuf[W.n + rank] = cand_pack((uint64_t) W.g, (uint32_t) quad, flags);
+    if (flagged) W.wbuf[W.n + rank] = cand_pack((uint64_t) W.g, (uint32_t) group, flags);
     W.n += n_new;
 }
 
-// All quads of one class (same group count G): per quad G LDS reads of 16 bytes (four motifs x
-// {fwd,rev} 16-bit fields) and (G-1) x 4 packed adds.  `code16[g]` is the lane's 2-mer code at
-// group g (0..15); a table row of one (quad, group) is 16 codes x 16 B = 256 B = every LDS bank
-// exactly once, so the read is conflict-free whatever the codes are.
+// All table groups of one class (same 2-mer count G, same field width FB): per group G LDS reads
+// of 16 bytes (2 * 32/FB motifs x {fwd,rev} fields) and (G-1) x 4 packed adds.  A table row of
+// one (group, 2-mer position) is 16 codes x 16 B = 256 B = every LDS bank exactly once, so the
+// read is conflict-free whatever the codes are (SQ_LDS_BANK_CONFLICT = 0, profiles/).
 //
-// The kernel is bound by LDS bandwidth, so what matters is keeping reads in flight: variant 2
-// (default) software-pipelines across quads -- the reads of the next quad are issued before the
-// adds and the flag test of the current pair.  Variants 0/1 are kept for A/B measurements.
+// The kernel is bound by LDS bandwidth; variant 1 (default) issues the reads of two groups in
+// batches before adding, variant 0 leaves the order to the compiler (kept for A/B runs).
 
-__device__ __forceinline__ void test_pair(const PfArgs &A, PfWave &W, const uint4 &acc0, const uint4 &acc1, int32_t quad) {
-    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w | acc1.x | acc1.y | acc1.z | acc1.w) & 0x80008000u;
-    if (__any(any != 0) && !A.no_emit) emit_flags(A, W, pair_flags(acc0, acc1), quad);
+template <int FB>
+__device__ __forceinline__ void test_pair(const PfArgs &A, PfWave &W, const uint4 &acc0, const uint4 &acc1, int32_t group) {
+    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w | acc1.x | acc1.y | acc1.z | acc1.w) & Fields<FB>::kTop;
+    if (__any(any != 0) && !A.no_emit) {
+        emit_flags(A, W, group_flags<FB>(acc0), group);
+        emit_flags(A, W, group_flags<FB>(acc1), group + 1);
+    }
 }
 
-__device__ __forceinline__ void test_one(const PfArgs &A, PfWave &W, const uint4 &acc0, int32_t quad) {
-    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w) & 0x80008000u;
-    if (__any(any != 0) && !A.no_emit) emit_flags(A, W, quad_flags(acc0), quad);
+template <int FB>
+__device__ __forceinline__ void test_one(const PfArgs &A, PfWave &W, const uint4 &acc0, int32_t group) {
+    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w) & Fields<FB>::kTop;
+    if (__any(any != 0) && !A.no_emit) emit_flags(A, W, group_flags<FB>(acc0), group);
 }
 
-template <int G, int V>
+template <int G, int V, int FB>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
-                                                int n_quads, int32_t first_quad, const uint64_t cw, PfWave &W) {
+                                                int n_groups, int32_t first_group, const uint64_t cw, PfWave &W) {
     uint32_t a[G];
 #pragma unroll
     for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + ((uint32_t) (cw >> (4 * k)) & 15u);
     int q = 0;
-    if constexpr (V == 2 && G <= 8) {
-        // rolling prefetch: rA / rB hold the raw table rows of two quads
-        uint4 rA[G], rB[G];
-#pragma unroll
-        for (int k = 0; k < G; k++) rA[k] = lds4[a[k]];
-        for (; q + 2 <= n_quads; q += 2) {
-#pragma unroll
-            for (int k = 0; k < G; k++) rB[k] = lds4[a[k] + G * 16];
-            uint4 acc0 = rA[0];
-#pragma unroll
-            for (int k = 1; k < G; k++) add4(acc0, rA[k]);
-            // next pair's first quad (re-reads the current row at the very end: harmless)
-            const uint32_t step = (q + 2 < n_quads) ? 2u * G * 16u : 0u;
-#pragma unroll
-            for (int k = 0; k < G; k++) { a[k] += step; rA[k] = lds4[a[k]]; }
-            uint4 acc1 = rB[0];
-#pragma unroll
-            for (int k = 1; k < G; k++) add4(acc1, rB[k]);
-            test_pair(A, W, acc0, acc1, first_quad + q);
-        }
-        if (q < n_quads) {
-            uint4 acc0 = rA[0];
-#pragma unroll
-            for (int k = 1; k < G; k++) add4(acc0, rA[k]);
-            test_one(A, W, acc0, first_quad + q);
-        }
-        return;
-    }
-    for (; q + 2 <= n_quads; q += 2) {
+    for (; q + 2 <= n_groups; q += 2) {
         uint4 acc0, acc1;
         if constexpr (V >= 1) {
-            // issue the reads in batches of up to 8 groups x 2 quads, then add
+            // issue the reads in batches of up to 8 positions x 2 groups, then add
             constexpr int B = G < 8 ? G : 8;
             uint4 r0[B], r1[B];
 #pragma unroll
@@ -360,21 +334,22 @@ __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__
                 add4(acc1, lds4[a[k] + G * 16]);
             }
         }
-        test_pair(A, W, acc0, acc1, first_quad + q);
+        test_pair<FB>(A, W, acc0, acc1, first_group + q);
 #pragma unroll
         for (int k = 0; k < G; k++) a[k] += 2 * G * 16;
     }
-    if (q < n_quads) {
+    if (q < n_groups) {
         uint4 acc0 = lds4[a[0]];
 #pragma unroll
         for (int k = 1; k < G; k++) add4(acc0, lds4[a[k]]);
-        test_one(A, W, acc0, first_quad + q);
+        test_one<FB>(A, W, acc0, first_group + q);
     }
 }
 
-#define MS_PF_CASE(GG)                                                                      \
-    case GG:                                                                                \
-        prefilter_class<GG, V>(A, lds4, base16, nq, first_quad, cw, W);                 \
+#define MS_PF_CASE(GG)                                                                                      \
+    case GG:                                                                                                \
+        if (fb == 10) prefilter_class<GG, V, 10>(A, lds4, base16, nq, first_group, cw, W);                  \
+        else prefilter_class<GG, V, 16>(A, lds4, base16, nq, first_group, cw, W);                           \
         break;
 
 // grid = (blocks per tile, tiles).  One block per CU (the tile's tables fill the LDS), NT/64 waves,
@@ -389,7 +364,7 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     __syncthreads();
     const int n_classes = T->n_classes;
-    const int32_t tile_first_quad = T->first_quad;
+    const int32_t tile_first_group = T->first_group;
     PfWave W;
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
     W.n = 0;
@@ -415,10 +390,11 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
         }
 
         uint32_t base16 = 0;
-        int32_t first_quad = tile_first_quad;
+        int32_t first_group = tile_first_group;
         for (int c = 0; c < n_classes; c++) {
             const int G = T->cls[c].G;
-            const int nq = T->cls[c].n_quads;
+            const int nq = T->cls[c].n_groups;
+            const int fb = T->cls[c].fb;
             switch (G) {
                 MS_PF_CASE(1) MS_PF_CASE(2) MS_PF_CASE(3) MS_PF_CASE(4)
                 MS_PF_CASE(5) MS_PF_CASE(6) MS_PF_CASE(7) MS_PF_CASE(8)
@@ -427,7 +403,7 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
                 default: break;
             }
             base16 += (uint32_t) (G * 16 * nq);
-            first_quad += nq;
+            first_group += nq;
         }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
@@ -513,7 +489,7 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
 
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
                                                       const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
-                                                      const int32_t *__restrict__ quad_motifs, int strand_mask,
+                                                      const int32_t *__restrict__ group_motifs, int strand_mask,
                                                       const HitOut H) {
     __shared__ HitStage st;
     if (threadIdx.x == 0) st.n = 0;
@@ -526,17 +502,17 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
         const unsigned long long i = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
         if (i < n) {
             const uint64_t c = cand[i];
-            uint32_t flags = (uint32_t) c & 0xFFFFu;                   // bit slot: forward, bit 8+slot: reverse, slot 0..7
-            flags = (flags | (flags >> 8)) & 0xFFu;                    // both strands are re-scored anyway
-            const int32_t quad = (int32_t) ((c >> 16) & 0x3FFFu);
+            uint32_t flags = (uint32_t) c & 0xFFFFu;                   // bit n = field n; motif slot n >> 1
+            flags = (flags | (flags >> 1)) & 0x5555u;                  // both strands are re-scored anyway
+            const int32_t group = (int32_t) ((c >> 16) & 0x3FFFu);
             const int64_t g = (int64_t) (c >> 30);
             const int64_t r = find_region(S, g);
             const int64_t end = S.offsets[r + 1];
             const uint32_t nw = n_window(S.nmask, g);
             while (flags) {
-                const int slot = __ffs((int) flags) - 1;
+                const int slot = (__ffs((int) flags) - 1) >> 1;
                 flags &= flags - 1u;
-                const int32_t pm = quad_motifs[quad * 4 + slot];
+                const int32_t pm = group_motifs[group * kGroupSlots + slot];
                 if (pm < 0) continue;
                 const int W = Pw.width[pm];
                 if (g + W > end) continue;                              // window runs past its region (cscore.c:340)
@@ -667,11 +643,7 @@ typedef void (*PfKernel)(const PfArgs);
 static PfKernel pf_kernel_for(int variant, int *threads) {
     switch (variant) {
         case 0: *threads = 1024; return prefilter_kernel<1024, 0, 4>;
-        case 2: *threads = 1024; return prefilter_kernel<1024, 2, 4>;
-        case 3: *threads = 768; return prefilter_kernel<768, 1, 3>;
-        case 4: *threads = 512; return prefilter_kernel<512, 1, 2>;
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
-        case 6: *threads = 512; return prefilter_kernel<512, 1, 4>;       // 512 threads, two blocks per CU
         default: *threads = 1024; return prefilter_kernel<1024, 1, 4>;
     }
 }
@@ -720,10 +692,10 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 }
 
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
-                   uint64_t cand_cap, const int32_t *quad_motifs, int strand_mask, const HitOut &H, int n_blocks,
+                   uint64_t cand_cap, const int32_t *group_motifs, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st) {
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned) n_blocks), dim3(256), 0, st, S, Pw, cand, n_cand, cand_cap,
-                       quad_motifs, strand_mask, H);
+                       group_motifs, strand_mask, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

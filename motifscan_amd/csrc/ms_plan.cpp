@@ -1,5 +1,5 @@
-// ms_plan.cpp -- host side of the integer pre-filter: quantise every PWM into 16-bit 2-mer
-// tables that can NEVER miss a window the reference would report, and cut the tables into
+// ms_plan.cpp -- host side of the integer pre-filter: quantise every PWM into small fixed-point
+// 2-mer tables that can NEVER miss a window the reference would report, and cut the tables into
 // LDS tiles.
 //
 // Reference arithmetic being bounded (cscore.c:340-390): for a window without non-ACGT bases
@@ -14,10 +14,16 @@
 //     Q_g(code) = ceil( (max(F_g(code), lo_g) - lo_g) * s )        (an integer >= 0)
 // so that  sum_g Q_g >= (x - sum_g lo_g) * s  for every window.  lo_g = max_g - 1.25 * budget
 // clamps values so low that the window cannot reach T even with every other group at its
-// maximum (budget = best possible sum - T); the clamp only sharpens the 16-bit resolution.
-// A 16-bit field accumulates  B + sum_g Q_g  with  B = 0x8000 - floor((T - sum lo) * s);
-// hit  =>  field >= 0x8000, and the scale s is chosen so the field never exceeds 0xFFFF.
-// Forward and reverse fields of one motif share a 32-bit word (no carry can cross).
+// maximum (budget = best possible sum - T); the clamp only sharpens the resolution.
+// A field of FB bits accumulates  B + sum_g Q_g  with  B = 2^(FB-1) - floor((T - sum lo) * s);
+// hit  =>  field >= 2^(FB-1)  (its top bit), and the scale s is chosen so the field never
+// exceeds 2^FB - 1, hence no carry ever crosses into the neighbouring field of the 32-bit word.
+//
+// Field width: the pre-filter kernel is bound by LDS bytes, so narrower fields are faster:
+//   FB = 10 -> 3 fields per word, a 16-byte table entry serves 6 motifs x {fwd, rev}
+//   FB = 16 -> 2 fields per word, 4 motifs per entry
+// 10 bits are used whenever the threshold still has >= 2 quantisation levels per group of head
+// room (measured on the 579-motif set: 1.12x the true hits instead of 1.01x); otherwise 16.
 // Whatever passes is re-scored in fp64 in the reference's order, so the pre-filter decides
 // nothing by itself; it only must not lose hits.
 #include <algorithm>
@@ -33,7 +39,8 @@ namespace {
 enum QStatus { Q_DEAD = 0, Q_OK = 1, Q_NEEDS_EXACT = 2 };
 
 // e[b][c]: the strand's effective matrix (already flipped for the reverse strand).
-QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, uint16_t q[kMaxGroups][16]) {
+QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, int fb, uint16_t q[kMaxGroups][16],
+                        double *levels_per_budget) {
     const int G = (W + 1) / 2;
     double F[kMaxGroups][16], maxF[kMaxGroups], minF[kMaxGroups], lo[kMaxGroups];
     double Mx = 0;
@@ -52,6 +59,7 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, uint1
     }
     std::memset(q, 0, sizeof(uint16_t) * kMaxGroups * 16);
     const double budget = Mx - T;               // how far below the best window a hit may be
+    *levels_per_budget = 1e30;
     if (!(budget >= 0)) return Q_DEAD;          // no N-free window can reach T
     // Clamp a group's deficit (maxF - F) at D > budget: a group that alone overspends the budget
     // is as good as any other such group, but it must still sink the window.  (Clamping AT the
@@ -66,8 +74,9 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, uint1
     }
     const double thr_off = T - sum_lo;          // threshold above the clamped floor
     if (!(thr_off > 0)) return Q_NEEDS_EXACT;   // (almost) every window would pass: filter is useless
-    double s = 32768.0 / thr_off;
-    if (budget > 0) s = std::min(s, (32766.0 - G) / budget);
+    const double half = (double) (1u << (fb - 1)), top = (double) ((1u << fb) - 1u);
+    double s = half / thr_off;
+    if (budget > 0) s = std::min(s, (half - 2.0 - G) / budget);
     for (int attempt = 0; attempt < 200; attempt++, s *= 0.98) {
         uint32_t qq[kMaxGroups][16];
         uint64_t max_sum = 0;
@@ -77,7 +86,7 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, uint1
             for (int x = 0; x < 16; x++) {
                 const double v = (F[g][x] - lo[g]) * s;
                 double c = v <= 0 ? 0.0 : std::ceil(v * (1 + 1e-12) + 1e-7);
-                if (!(c <= 65535.0)) { ok = false; break; }
+                if (!(c <= top)) { ok = false; break; }
                 qq[g][x] = (uint32_t) c;
                 mq = std::max(mq, qq[g][x]);
             }
@@ -86,9 +95,10 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, uint1
         if (!ok) continue;
         double fl = std::floor(thr_off * s * (1 - 1e-12) - 1e-7);
         if (fl < 0) fl = 0;
-        if (fl > 32768.0) continue;
-        const uint32_t B = 32768u - (uint32_t) fl;
-        if ((uint64_t) B + max_sum > 65535u) continue;
+        if (fl > half) continue;
+        const uint32_t B = (uint32_t) half - (uint32_t) fl;
+        if ((double) B + (double) max_sum > top) continue;
+        *levels_per_budget = budget > 0 ? budget * s : 1e30;
         for (int g = 0; g < G; g++)
             for (int x = 0; x < 16; x++) q[g][x] = (uint16_t) (qq[g][x] + (g == 0 ? B : 0));
         return Q_OK;
@@ -99,14 +109,38 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, uint1
 struct FastMotif {
     int32_t id;
     int32_t G;
-    uint32_t words[kMaxGroups][16];   // lo16 = forward field, hi16 = reverse field
+    int32_t fb;
+    uint16_t fwd[kMaxGroups][16];
+    uint16_t rev[kMaxGroups][16];
 };
+
+// Quantise both enabled strands at a field width.  Returns false if the motif needs the fp64 path
+// at this width (or, with need_levels, if the resolution is too coarse to be a useful filter).
+bool quantize_motif(const double *m, int W, double T, int strand_mask, int fb, bool need_levels, FastMotif *fm) {
+    std::memset(fm->fwd, 0, sizeof(fm->fwd));
+    std::memset(fm->rev, 0, sizeof(fm->rev));
+    const int G = (W + 1) / 2;
+    for (int strand = 1; strand <= 2; strand <<= 1) {
+        if (!(strand_mask & strand)) continue;
+        double e[4][kMaxFastWidth];
+        for (int b = 0; b < 4; b++)
+            for (int c = 0; c < W; c++)
+                e[b][c] = strand == 1 ? m[(int64_t) b * W + c] : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
+        double levels = 0;
+        const QStatus st = quantize_strand(e, W, T, fb, strand == 1 ? fm->fwd : fm->rev, &levels);
+        if (st == Q_NEEDS_EXACT) return false;
+        if (need_levels && st == Q_OK && levels < 2.0 * G) return false;
+    }
+    fm->G = G;
+    fm->fb = fb;
+    return true;
+}
 
 }  // namespace
 
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths,
                const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
-               size_t lds_budget, PrefilterPlan *plan) {
+               size_t lds_budget, int min_field_bits, PrefilterPlan *plan) {
     *plan = PrefilterPlan();
     plan->strand_mask = strand_mask;
     std::vector<FastMotif> fast;
@@ -127,83 +161,78 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
             abs_sum += colmax;
         }
         FastMotif fm;
+        fm.id = p;
         if (ok) {
             const double E = 1e-9 * (1.0 + abs_sum);
             const double T = (cutoffs[p] - 1e-10) * max_raw[p] - E;
-            fm.id = p;
-            fm.G = (W + 1) / 2;
-            std::memset(fm.words, 0, sizeof(fm.words));
-            for (int strand = 1; strand <= 2 && ok; strand <<= 1) {
-                if (!(strand_mask & strand)) continue;
-                double e[4][kMaxFastWidth];
-                for (int b = 0; b < 4; b++)
-                    for (int c = 0; c < W; c++)
-                        e[b][c] = strand == 1 ? m[(int64_t) b * W + c]
-                                              : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
-                uint16_t q[kMaxGroups][16];
-                const QStatus st = quantize_strand(e, W, T, q);
-                if (st == Q_NEEDS_EXACT) { ok = false; break; }
-                for (int g = 0; g < fm.G; g++)
-                    for (int x = 0; x < 16; x++)
-                        fm.words[g][x] |= (uint32_t) q[g][x] << (strand == 1 ? 0 : 16);
-            }
+            ok = (min_field_bits <= 10 && quantize_motif(m, W, T, strand_mask, 10, true, &fm)) ||
+                 quantize_motif(m, W, T, strand_mask, 16, false, &fm);
         }
         if (ok) fast.push_back(fm);
         else plan->exact_motifs.push_back(p);
     }
 
-    // quads of four motifs, narrow to wide so a quad's group count wastes little
-    std::stable_sort(fast.begin(), fast.end(), [](const FastMotif &a, const FastMotif &b) { return a.G < b.G; });
-    const int32_t n_quads = (int32_t) ((fast.size() + 3) / 4);
-    plan->quad_motifs.assign((size_t) n_quads * 4, -1);
-    plan->quad_G.assign(n_quads, 0);
-    std::vector<size_t> quad_off16(n_quads + 1, 0);
-    for (int32_t q = 0; q < n_quads; q++) {
-        int G = 0;
-        for (int k = 0; k < 4; k++) {
-            const size_t i = (size_t) q * 4 + k;
-            if (i < fast.size()) {
-                plan->quad_motifs[i] = fast[i].id;
-                plan->fast_motifs.push_back(fast[i].id);
-                G = std::max(G, (int) fast[i].G);
+    // groups of 2 * (32 / FB) motifs sharing a 16-byte table entry; same field width together,
+    // narrow to wide so a group's 2-mer count wastes little
+    std::stable_sort(fast.begin(), fast.end(), [](const FastMotif &a, const FastMotif &b) {
+        return a.fb != b.fb ? a.fb < b.fb : a.G < b.G;
+    });
+    std::vector<size_t> group_off16(1, 0);
+    size_t i = 0;
+    while (i < fast.size()) {
+        const int fb = fast[i].fb;
+        const int nf = 32 / fb, nm = 2 * nf;              // fields per word, motifs per group
+        const int32_t grp = (int32_t) plan->group_G.size();
+        int G = 0, cnt = 0;
+        for (; cnt < nm && i + cnt < fast.size() && fast[i + cnt].fb == fb; cnt++) G = std::max(G, (int) fast[i + cnt].G);
+        plan->group_G.push_back(G);
+        plan->group_fb.push_back(fb);
+        plan->group_motifs.resize((size_t) (grp + 1) * kGroupSlots, -1);
+        const size_t off16 = group_off16.back();
+        plan->tables.resize((off16 + (size_t) G * 16) * 4, 0u);
+        for (int j = 0; j < cnt; j++) {
+            const FastMotif &fm = fast[i + j];
+            plan->group_motifs[(size_t) grp * kGroupSlots + j] = fm.id;
+            plan->fast_motifs.push_back(fm.id);
+            // motif j: forward field n = 2j, reverse n = 2j+1; field n lives in word n & 3 at bit (n >> 2) * FB
+            for (int sd = 0; sd < 2; sd++) {
+                const int n = 2 * j + sd, word = n & 3, shift = (n >> 2) * fb;
+                for (int g = 0; g < fm.G; g++)               // groups beyond the motif's own G stay 0
+                    for (int x = 0; x < 16; x++)
+                        plan->tables[(off16 + (size_t) g * 16 + x) * 4 + word] |=
+                            (uint32_t) (sd == 0 ? fm.fwd[g][x] : fm.rev[g][x]) << shift;
             }
         }
-        plan->quad_G[q] = G;
-        quad_off16[q + 1] = quad_off16[q] + (size_t) G * 16;
+        group_off16.push_back(off16 + (size_t) G * 16);
         plan->lds_bytes_per_position += (int64_t) G * 16;
+        i += cnt;
     }
-    plan->tables.assign(quad_off16[n_quads] * 4, 0u);
-    for (int32_t q = 0; q < n_quads; q++)
-        for (int k = 0; k < 4; k++) {
-            const size_t i = (size_t) q * 4 + k;
-            if (i >= fast.size()) continue;
-            for (int g = 0; g < fast[i].G; g++)            // groups beyond the motif's own G stay 0
-                for (int x = 0; x < 16; x++)
-                    plan->tables[(quad_off16[q] + (size_t) g * 16 + x) * 4 + k] = fast[i].words[g][x];
-        }
+    const int32_t n_groups = (int32_t) plan->group_G.size();
 
     // LDS tiles of equal work (work ~ table bytes)
-    if (n_quads > 0) {
-        const size_t total16 = quad_off16[n_quads];
+    if (n_groups > 0) {
+        const size_t total16 = group_off16[n_groups];
         const size_t budget16 = std::max<size_t>(lds_budget / 16, (size_t) kMaxGroups * 16);
         const size_t n_tiles = (total16 + budget16 - 1) / budget16;
         const size_t target16 = (total16 + n_tiles - 1) / n_tiles;
         int32_t q = 0;
-        while (q < n_quads) {
+        while (q < n_groups) {
             TileDesc t;
             std::memset(&t, 0, sizeof(t));
-            t.table_off16 = (uint32_t) quad_off16[q];
-            t.first_quad = q;
+            t.table_off16 = (uint32_t) group_off16[q];
+            t.first_group = q;
             size_t used = 0;
-            while (q < n_quads) {
-                const size_t need = (size_t) plan->quad_G[q] * 16;
+            while (q < n_groups) {
+                const size_t need = (size_t) plan->group_G[q] * 16;
                 if (used > 0 && (used + need > budget16 || used >= target16)) break;
-                if (t.n_classes == 0 || t.cls[t.n_classes - 1].G != plan->quad_G[q]) {
-                    t.cls[t.n_classes].G = plan->quad_G[q];
-                    t.cls[t.n_classes].n_quads = 0;
+                if (t.n_classes == 0 || t.cls[t.n_classes - 1].G != plan->group_G[q] ||
+                    t.cls[t.n_classes - 1].fb != plan->group_fb[q]) {
+                    t.cls[t.n_classes].G = plan->group_G[q];
+                    t.cls[t.n_classes].fb = plan->group_fb[q];
+                    t.cls[t.n_classes].n_groups = 0;
                     t.n_classes++;
                 }
-                t.cls[t.n_classes - 1].n_quads++;
+                t.cls[t.n_classes - 1].n_groups++;
                 used += need;
                 q++;
             }

@@ -75,36 +75,41 @@ def test_max_raw_is_the_c_definition(oracle, rnd):
 
 def emulate_prefilter(plan, seq_codes_2bit):
     """numpy model of prefilter_kernel: for every window start of one N-free sequence return the
-    set of (motif, strand) whose 16-bit field reaches 0x8000."""
+    set of (motif, pos, strand) whose field reaches its top bit."""
     L = len(seq_codes_2bit)
     padded = np.concatenate([seq_codes_2bit, np.zeros(40, dtype=np.int64)])
     code = padded[:-1] | (padded[1:] << 2)                    # 2-mer code at every position
     flagged = set()
-    for q in range(plan["quad_motifs"].shape[0]):
-        G = int(plan["quad_G"][q])
+    for q in range(plan["group_motifs"].shape[0]):
+        G, fb = int(plan["group_G"][q]), int(plan["group_fb"][q])
+        nf = 32 // fb
         acc = np.zeros((L, 4), dtype=np.uint64)
         for g in range(G):
             acc += plan["tables"][q, g][code[2 * g:2 * g + L]]
-        for k in range(4):
-            m = int(plan["quad_motifs"][q, k])
+        assert (acc < (1 << 32)).all()                        # the kernel adds in 32 bits
+        for n in range(4 * nf):                               # field n: word n & 3, field n >> 2
+            field = (acc[:, n & 3] >> np.uint64((n >> 2) * fb)) & np.uint64((1 << fb) - 1)
+            m = int(plan["group_motifs"][q, n >> 1])
+            hot = np.nonzero(field >= (1 << (fb - 1)))[0]
             if m < 0:
-                assert not (acc[:, k] & 0x80008000).any()
+                assert len(hot) == 0
                 continue
-            lo, hi = acc[:, k] & 0xFFFF, acc[:, k] >> 16
-            assert (acc[:, k] < (1 << 32)).all()
-            for j in np.nonzero(lo >= 0x8000)[0]:
-                flagged.add((m, int(j), 1))
-            for j in np.nonzero(hi >= 0x8000)[0]:
-                flagged.add((m, int(j), 2))
+            for j in hot:
+                flagged.add((m, int(j), 1 + (n & 1)))
+        if nf * fb < 32:                                      # unused high bits of every word stay clear
+            assert not (acc >> np.uint64(nf * fb)).any()
     return flagged
 
 
 def fields_never_overflow(plan):
+    """Worst case of every field (sum over 2-mer positions of the largest entry) fits its width, so
+    no carry can ever cross into the neighbouring field."""
     t = plan["tables"].astype(np.uint64)
-    lo, hi = t & 0xFFFF, t >> 16
-    for part in (lo, hi):
-        worst = part.max(axis=2).sum(axis=1)                  # [quad][slot]: sum over groups of the max code entry
-        assert (worst <= 0xFFFF).all()
+    for q in range(t.shape[0]):
+        fb = int(plan["group_fb"][q])
+        for n in range(4 * (32 // fb)):
+            field = (t[q, :, :, n & 3] >> np.uint64((n >> 2) * fb)) & np.uint64((1 << fb) - 1)
+            assert int(field.max(axis=1).sum()) <= (1 << fb) - 1
 
 
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
@@ -115,7 +120,7 @@ def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand):
     plan = pw.plan(strand)
     fields_never_overflow(plan)
     assert plan["n_fast"] + plan["n_exact"] == len(mats)
-    fast = set(plan["quad_motifs"].ravel().tolist()) - {-1}
+    fast = set(plan["group_motifs"].ravel().tolist()) - {-1}
     assert fast | set(plan["exact_motifs"].tolist()) == set(range(len(mats)))
     rng = np.random.default_rng(5)
     seqs = ["".join(rng.choice(list("ACGT"), p=[.295, .205, .205, .295], size=3000)) for _ in range(3)]
@@ -132,8 +137,8 @@ def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand):
                 assert (m, pos, sd) in flagged, (m, pos, sd)
                 n_hit += 1
         n_flag += sum(1 for (m, j, sd) in flagged if j + mats[m].shape[1] <= len(s))
-    # the filter must stay selective: allow 2x the true hits plus slack
-    assert n_flag <= 2 * n_hit + 200, (n_flag, n_hit)
+    # the filter must stay selective: allow 2.5x the true hits plus slack
+    assert n_flag <= 2.5 * n_hit + 200, (n_flag, n_hit)
 
 
 def test_prefilter_routes_degenerate_pwms_to_exact_path():
@@ -152,15 +157,27 @@ def test_prefilter_routes_degenerate_pwms_to_exact_path():
 
 def test_plan_tiles_respect_lds_budget(jaspar579):
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
-    for budget in (64 * 1024, 159 * 1024):
+    for budget in (64 * 1024, 143 * 1024):
         plan = pw.plan(3, budget)
         assert plan["n_exact"] == 0 and plan["n_fast"] == 579
-        tf = plan["tile_first_quad"]
+        tf = plan["tile_first_group"]
         for t in range(len(tf) - 1):
-            tile_bytes = int(plan["quad_G"][tf[t]:tf[t + 1]].sum()) * 256
+            tile_bytes = int(plan["group_G"][tf[t]:tf[t + 1]].sum()) * 256
             assert 0 < tile_bytes <= budget
-        assert tf[-1] == len(plan["quad_G"]) == (579 + 3) // 4
-        assert (np.diff(plan["quad_G"]) >= 0).all()          # narrow to wide
+        assert tf[-1] == len(plan["group_G"])
+        per_group = np.where(plan["group_fb"] == 10, 6, 4)
+        assert (plan["group_motifs"] >= 0).sum() == 579 and ((plan["group_motifs"] >= 0).sum(axis=1) <= per_group).all()
+        key = plan["group_fb"].astype(np.int64) * 100 + plan["group_G"]
+        assert (np.diff(key) >= 0).all()                      # same field width together, narrow to wide
+        assert (plan["group_fb"] == 10).sum() > 0.8 * len(key)   # JASPAR-like motifs mostly take 10-bit fields
+
+
+def test_field_width_switch(jaspar579, monkeypatch):
+    pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
+    monkeypatch.setenv("MS_PF_FIELD_BITS", "16")
+    plan = pw.plan(3)
+    assert (plan["group_fb"] == 16).all() and len(plan["group_G"]) == (579 + 3) // 4
+    fields_never_overflow(plan)
 
 
 # --------------------------------------------------------------------------- dedup --
