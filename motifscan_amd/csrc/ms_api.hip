@@ -607,11 +607,11 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    size_t lds_budget = c->lds_max - kWqBytes - 1024;            // tables; the wave queues follow them
+    size_t lds_budget = c->lds_max - kWqBytes;                   // tables; the wave queues follow them
     int pf_blocks_per_cu = 1;
     if (const char *e = getenv("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
         pf_blocks_per_cu = std::max(1, atoi(e));
-        lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - kWqBytes - 1024;
+        lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - kWqBytes;
     }
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;

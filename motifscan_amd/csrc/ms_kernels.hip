@@ -287,10 +287,12 @@ __device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t 
 
 template <int FB>
 __device__ __forceinline__ void test_pair(const PfArgs &A, PfWave &W, const uint4 &acc0, const uint4 &acc1, int32_t group) {
-    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w | acc1.x | acc1.y | acc1.z | acc1.w) & Fields<FB>::kTop;
-    if (__any(any != 0) && !A.no_emit) {
-        emit_flags(A, W, group_flags<FB>(acc0), group);
-        emit_flags(A, W, group_flags<FB>(acc1), group + 1);
+    const uint32_t any0 = (acc0.x | acc0.y | acc0.z | acc0.w) & Fields<FB>::kTop;
+    const uint32_t any1 = (acc1.x | acc1.y | acc1.z | acc1.w) & Fields<FB>::kTop;
+    if (__any((any0 | any1) != 0) && !A.no_emit) {
+        // usually only one of the two groups has a flagged lane: decode flags only for that one
+        if (__any(any0 != 0)) emit_flags(A, W, group_flags<FB>(acc0), group);
+        if (__any(any1 != 0)) emit_flags(A, W, group_flags<FB>(acc1), group + 1);
     }
 }
 

@@ -98,7 +98,7 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, int f
         if (fl > half) continue;
         const uint32_t B = (uint32_t) half - (uint32_t) fl;
         if ((double) B + (double) max_sum > top) continue;
-        *levels_per_budget = budget > 0 ? budget * s : 1e30;
+        *levels_per_budget = (D / 1.25) * s;        // resolution of the head room (incl. its absolute floor)
         for (int g = 0; g < G; g++)
             for (int x = 0; x < 16; x++) q[g][x] = (uint16_t) (qq[g][x] + (g == 0 ? B : 0));
         return Q_OK;
