@@ -30,8 +30,11 @@
  *   ms_result_region_counts   the per-motif "number of regions with >= 1 site" that
  *                         motifscan/stats.py:29-31 derives from the nested site lists
  *                         (the only quantity the multi-GPU all-reduce needs)
+ *   ms_result_dedup       _deduplicate_sites / deduplicate_motif_sites  scanner.py:156-193 (device)
+ *   ms_result_site_tables the per-(motif, region) count / max score of write_sites_table  io/__init__.py:23-33
  *   ms_score              motif_score / motif_score_thread         cscore.c:174-302
  *                         (Python name c_score; "OOII")
+ *   ms_score_ranks        c_score + the sort / rank pick of get_score_cutoffs   motif/__init__.py:378-401
  *   ms_dedup_hits         _deduplicate_sites / deduplicate_motif_sites  scanner.py:156-193
  *                         (host-side, on the sparse hit arrays)
  */
@@ -123,12 +126,26 @@ int ms_result_region_counts(const ms_result *res, int64_t *out /* [P] */);
 /* Device pointer (int64[P]) of the same counts, for a device-side all-reduce; valid until free. */
 int ms_result_region_counts_device(const ms_result *res, void **d_counts);
 int ms_result_stats(const ms_result *res, ms_scan_stats *out);
+/* De-duplicate overlapping sites on the device, in place (scanner.py:156-193: per motif, region and
+ * strand, greedy left to right, the lower-scoring of two sites closer than the motif width is
+ * dropped, a tie keeps the earlier one).  Order and per-motif region counts are unaffected. */
+int ms_result_dedup(ms_result *res, const ms_pwmset *pwms);
+/* Per (motif, region): number of sites and maximum score (NaN where there is none) -- the two
+ * aggregates the reference's site tables are made of (io/__init__.py:23-33).  Host buffers [P][R]. */
+int ms_result_site_tables(const ms_result *res, int32_t *n_sites, double *max_score);
 void ms_result_free(ms_result *res);
 
 /* ---- score (c_score) -------------------------------------------------------------------- */
 /* out: host, [P][R] row-major.  A sequence shorter than a PWM scores its missing bases as
  * non-ACGT (the reference reads out of bounds there, cscore.c:195-196). */
 int ms_score(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, double *out);
+
+/* The device half of the cutoff builder (`motifscan motif --build`: cli/motif.py:134-137 and
+ * get_score_cutoffs, motif/__init__.py:378-401): c_score of all R sequences for every PWM, each
+ * PWM's scores sorted in DESCENDING order, out[p][k] = score at 0-based rank ranks[k]
+ * (the reference reads rank int(R * 0.1**e) - 1 for e = 2 .. min(len(str(R)), 7) - 1). */
+int ms_score_ranks(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, const int64_t *ranks,
+                   int32_t n_ranks, double *out /* [P][n_ranks] */);
 
 /* ---- de-duplication of overlapping sites (scanner.py:156-193), host side ---------------- */
 /* In: hits in ms_result order.  Out: keep[n_hits] (1 = kept).  Kept hits are already in the

@@ -98,8 +98,11 @@ def lib():
         "ms_result_region_counts": (c_int, [vp, pi64]),
         "ms_result_region_counts_device": (c_int, [vp, pvp]),
         "ms_result_stats": (c_int, [vp, ctypes.POINTER(ScanStats)]),
+        "ms_result_dedup": (c_int, [vp, vp]),
+        "ms_result_site_tables": (c_int, [vp, pi32, pd]),
         "ms_result_free": (None, [vp]),
         "ms_score": (c_int, [vp, vp, c_int, pd]),
+        "ms_score_ranks": (c_int, [vp, vp, c_int, pi64, c_i32, pd]),
         "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
         "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
         "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pi32, pu32, pi32, pi32]),
@@ -298,6 +301,23 @@ class ScanResult:
                           "motif_offsets": self.motif_offsets}
         return self._hits
 
+    def dedup(self, pwms):
+        """Device-side de-duplication in place (scanner.py:156-193)."""
+        check(lib().ms_result_dedup(self.h, pwms.h))
+        n = ctypes.c_int64()
+        check(lib().ms_result_num_hits(self.h, ctypes.byref(n)))
+        self.n_hits = n.value
+        check(lib().ms_result_motif_offsets(self.h, ptr(self.motif_offsets, ctypes.c_int64)))
+        self._hits = None
+        return self
+
+    def site_tables(self, n_seqs):
+        """(n_sites int32 [P][R], max_score float64 [P][R], NaN = no site)."""
+        n_sites = np.zeros((self.n_pwms, n_seqs), dtype=np.int32)
+        max_score = np.full((self.n_pwms, n_seqs), np.nan, dtype=np.float64)
+        check(lib().ms_result_site_tables(self.h, ptr(n_sites, ctypes.c_int32), ptr(max_score, ctypes.c_double)))
+        return n_sites, max_score
+
     def region_counts(self):
         out = np.zeros(self.n_pwms, dtype=np.int64)
         check(lib().ms_result_region_counts(self.h, ptr(out, ctypes.c_int64)))
@@ -330,6 +350,15 @@ def scan(pwms, seqs, strand_mask=3, flags=MS_SCAN_DEFAULT):
 def score(pwms, seqs, strand_mask=3):
     out = np.zeros((pwms.n, seqs.n_seqs), dtype=np.float64)
     check(lib().ms_score(pwms.h, seqs.h, int(strand_mask), ptr(out, ctypes.c_double)))
+    return out
+
+
+def score_ranks(pwms, seqs, ranks, strand_mask=3):
+    """out[p][k] = the score at 0-based rank ranks[k] of PWM p's scores over all sequences, descending."""
+    ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+    out = np.zeros((pwms.n, len(ranks)), dtype=np.float64)
+    check(lib().ms_score_ranks(pwms.h, seqs.h, int(strand_mask), ptr(ranks, ctypes.c_int64), len(ranks),
+                               ptr(out, ctypes.c_double)))
     return out
 
 

@@ -207,7 +207,9 @@ struct ms_seqset {
 struct ms_result {
     int device = 0;
     int32_t P = 0;
+    int64_t R = 0;                                    // sequences of the scanned set
     int64_t n_hits = 0;
+    bool deduped = false;
     void *block = nullptr;                            // one device block holding everything below
     size_t block_bytes = 0;
     int64_t *d_seq_idx = nullptr;
@@ -215,10 +217,27 @@ struct ms_result {
     double *d_score = nullptr;
     int8_t *d_strand = nullptr;
     unsigned long long *d_region_counts = nullptr;   // [P]
-    int64_t *d_motif_first = nullptr;                 // [P+1]
+    int64_t *d_motif_first = nullptr;                 // [P+1]: after ms_scan returns, the per-motif offsets
     std::vector<int64_t> motif_offsets;               // [P+1]
     ms_scan_stats stats;
 };
+
+// Lay the result arrays out in one device block: [counts P+1][offsets P+1][seq_idx n][pos n][score n][strand n]
+static size_t result_block_bytes(int32_t P, size_t n) {
+    const size_t n_round = (n + 65535) & ~(size_t) 65535;
+    return 8 * (2 * ((size_t) P + 1) + 3 * n_round) + n_round + 256;
+}
+
+static void result_carve(ms_result *r, void *blk, size_t n) {
+    const size_t P1 = (size_t) r->P + 1, n_round = (n + 65535) & ~(size_t) 65535;
+    char *b = static_cast<char *>(blk);
+    r->d_region_counts = reinterpret_cast<unsigned long long *>(b);
+    r->d_motif_first = reinterpret_cast<int64_t *>(b + 8 * P1);
+    r->d_seq_idx = reinterpret_cast<int64_t *>(b + 16 * P1);
+    r->d_pos = r->d_seq_idx + n_round;
+    r->d_score = reinterpret_cast<double *>(r->d_pos + n_round);
+    r->d_strand = reinterpret_cast<int8_t *>(r->d_score + n_round);
+}
 
 // C-style max_raw: column maxima start at 0 (cscore.c:36-48)
 static double c_max_raw(const double *m, int W) {
@@ -621,6 +640,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     if (!res) { set_error("out of host memory"); return MS_ERR_NOMEM; }
     res->device = c->device;
     res->P = pwms->P;
+    res->R = seqs->R;
     res->motif_offsets.assign((size_t) pwms->P + 1, 0);
     ms_scan_stats &stt = res->stats;
     std::memset(&stt, 0, sizeof(stt));
@@ -645,11 +665,11 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     if (pwms->P == 0 || seqs->n_bases == 0) {                 // nothing to scan: [] / [[]...]  (cscore.c:443-445)
         void *blk = nullptr;
         size_t got = 0;
-        if ((rc = pool_alloc(c, 8 * ((size_t) pwms->P + 1), &blk, &got))) return fail(rc);
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, 0), &blk, &got))) return fail(rc);
         raw->block = blk;
         raw->block_bytes = got;
-        raw->d_region_counts = static_cast<unsigned long long *>(blk);
-        he = hipMemsetAsync(blk, 0, 8 * ((size_t) pwms->P + 1), c->stream);
+        result_carve(raw, blk, 0);
+        he = hipMemsetAsync(blk, 0, 16 * ((size_t) pwms->P + 1), c->stream);       // counts and offsets: all zero
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         *out = raw;
@@ -750,22 +770,14 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     }
     raw->n_hits = (int64_t) n_hits;
 
-    {   // one pooled block: [counts P][first P+1][seq_idx n][pos n][score n][strand n]
-        const size_t P1 = (size_t) pwms->P + 1, n = (size_t) n_hits;
-        const size_t n_round = (n + 65535) & ~(size_t) 65535;            // helps block reuse across calls
-        const size_t bytes = 8 * (2 * P1 + 3 * n_round) + n_round + 256;
+    {   // one pooled block for everything the result owns
         void *blk = nullptr;
         size_t got = 0;
-        if ((rc = pool_alloc(c, bytes, &blk, &got))) return fail(rc);
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, (size_t) n_hits), &blk, &got))) return fail(rc);
         raw->block = blk;
         raw->block_bytes = got;
-        char *b = static_cast<char *>(blk);
-        raw->d_region_counts = reinterpret_cast<unsigned long long *>(b);
-        raw->d_motif_first = reinterpret_cast<int64_t *>(b + 8 * P1);
-        raw->d_seq_idx = reinterpret_cast<int64_t *>(b + 16 * P1);
-        raw->d_pos = raw->d_seq_idx + n_round;
-        raw->d_score = reinterpret_cast<double *>(raw->d_pos + n_round);
-        raw->d_strand = reinterpret_cast<int8_t *>(raw->d_score + n_round);
+        result_carve(raw, blk, (size_t) n_hits);
+        const size_t P1 = (size_t) pwms->P + 1;
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
         if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0xFF, 8 * P1, c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
@@ -800,6 +812,8 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     raw->motif_offsets[(size_t) pwms->P] = (int64_t) n_hits;
     for (int32_t p = pwms->P - 1; p >= 0; p--)
         raw->motif_offsets[(size_t) p] = first[(size_t) p] >= 0 ? first[(size_t) p] : raw->motif_offsets[(size_t) p + 1];
+    he = hipMemcpy(raw->d_motif_first, raw->motif_offsets.data(), raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (he != hipSuccess) { set_error("offset upload failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
 
     float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
     (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
@@ -861,6 +875,91 @@ int ms_result_stats(const ms_result *r, ms_scan_stats *out) {
     return MS_OK;
 }
 
+// scanner.py:156-193 on the device, in place: afterwards the result holds only the kept sites (same
+// order), with new per-motif offsets.  The per-motif region counts do not change (a region never
+// loses its last site).
+int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
+    if (!r || !pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    if (pwms->P != r->P) { set_error("result and PWM set disagree on the number of PWMs"); return MS_ERR_INVALID; }
+    if (r->deduped || r->n_hits == 0) { r->deduped = true; return MS_OK; }
+    DeviceCtx *c;
+    int rc = get_ctx(r->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
+    const size_t n = (size_t) r->n_hits;
+    uint32_t *d_keep = nullptr, *d_dst = nullptr;
+    void *d_tmp = nullptr, *blk = nullptr;
+    size_t tmp_bytes = 0, got = 0;
+    auto cleanup = [&]() { dev_free(d_keep); dev_free(d_dst); if (d_tmp) (void) hipFree(d_tmp); };
+    if ((rc = dev_alloc(&d_keep, n)) || (rc = dev_alloc(&d_dst, n))) { cleanup(); return rc; }
+    rc = launch_dedup((int64_t) n, r->d_motif_first, r->P, pwms->d_width, r->d_seq_idx, r->d_pos, r->d_score, r->d_strand,
+                      d_keep, c->stream);
+    if (!rc) rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_keep, d_dst, n, c->stream);
+    if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
+    if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_keep, d_dst, n, c->stream);
+    uint32_t last_dst = 0, last_keep = 0;
+    if (!rc) {
+        hipError_t he = hipMemcpyAsync(&last_dst, d_dst + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(&last_keep, d_keep + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { set_error("de-dup kernels failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; }
+    }
+    if (rc) { cleanup(); return rc; }
+    const size_t n_kept = (size_t) last_dst + last_keep;
+    if ((rc = pool_alloc(c, result_block_bytes(r->P, n_kept), &blk, &got))) { cleanup(); return rc; }
+    ms_result nr;                                   // carve the new block with the same layout
+    nr.P = r->P;
+    result_carve(&nr, blk, n_kept);
+    const size_t P1 = (size_t) r->P + 1;
+    hipError_t he = hipMemcpyAsync(nr.d_region_counts, r->d_region_counts, 8 * P1, hipMemcpyDeviceToDevice, c->stream);
+    rc = launch_compact_hits((int64_t) n, d_keep, d_dst, r->d_seq_idx, r->d_pos, r->d_score, r->d_strand, nr.d_seq_idx,
+                             nr.d_pos, nr.d_score, nr.d_strand, r->d_motif_first, r->P, nr.d_motif_first, c->stream);
+    std::vector<int64_t> off(P1);
+    if (!rc && he == hipSuccess) he = hipMemcpyAsync(off.data(), nr.d_motif_first, 8 * P1, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (rc || he != hipSuccess) {
+        pool_free(c, blk, got);
+        if (!rc) { set_error("compaction failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; }
+        return rc;
+    }
+    pool_free(c, r->block, r->block_bytes);
+    r->block = blk; r->block_bytes = got;
+    result_carve(r, blk, n_kept);
+    r->n_hits = (int64_t) n_kept;
+    r->motif_offsets = off;
+    r->deduped = true;
+    return MS_OK;
+}
+
+// io/__init__.py:23-33: what the site tables need per (motif, region): number of sites, max score
+// (NaN where the writer prints 'NA').  Host buffers [P][R].
+int ms_result_site_tables(const ms_result *r, int32_t *n_sites, double *max_score) {
+    if (!r) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    const size_t cells = (size_t) r->P * (size_t) r->R;
+    if (cells == 0) return MS_OK;
+    if (!n_sites || !max_score) { set_error("NULL output"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(r->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    int32_t *d_n = nullptr;
+    double *d_m = nullptr;
+    if ((rc = dev_alloc(&d_n, cells)) || (rc = dev_alloc(&d_m, cells))) { dev_free(d_n); dev_free(d_m); return rc; }
+    rc = launch_site_tables(r->n_hits, r->d_motif_first, r->P, r->R, r->d_seq_idx, r->d_score, d_n, d_m, c->stream);
+    hipError_t he = hipSuccess;
+    if (!rc) he = hipMemcpyAsync(n_sites, d_n, cells * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (!rc && he == hipSuccess) he = hipMemcpyAsync(max_score, d_m, cells * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    dev_free(d_n); dev_free(d_m);
+    if (rc) return rc;
+    if (he != hipSuccess) { set_error("site table kernels failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+    return MS_OK;
+}
+
 void ms_result_free(ms_result *r) {
     if (!r) return;
     (void) hipSetDevice(r->device);
@@ -896,6 +995,59 @@ int ms_score(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, do
     dev_free(d_out);
     if (rc) return rc;
     if (he != hipSuccess) { set_error("score kernel failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+    return MS_OK;
+}
+
+// The cutoff builder's device half (cli/motif.py:134-137, motif/__init__.py:378-401): score R
+// sampled sequences with every PWM (c_score), sort each PWM's scores in descending order and read
+// the scores at the requested 0-based ranks (the reference takes rank int(n * 0.1**e) - 1).
+int ms_score_ranks(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, const int64_t *ranks,
+                   int32_t n_ranks, double *out) {
+    if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d", strand_mask); return MS_ERR_INVALID; }
+    if (n_ranks < 0 || (n_ranks > 0 && (!ranks || !out))) { set_error("bad ranks / out"); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    if (pwms->P == 0 || n_ranks == 0) return MS_OK;
+    if (seqs->R == 0) { set_error("no sequences to rank"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(seqs->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
+    const size_t R = (size_t) seqs->R;
+    const int32_t batch = (int32_t) std::max<size_t>(1, std::min<size_t>((size_t) pwms->P, ((size_t) 1 << 27) / R));
+    double *d_scores = nullptr, *d_sorted = nullptr, *d_out = nullptr;
+    int64_t *d_ranks = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    auto cleanup = [&]() { dev_free(d_scores); dev_free(d_sorted); dev_free(d_out); dev_free(d_ranks); if (d_tmp) (void) hipFree(d_tmp); };
+    if ((rc = dev_alloc(&d_scores, (size_t) batch * R)) || (rc = dev_alloc(&d_sorted, R)) ||
+        (rc = dev_alloc(&d_out, (size_t) pwms->P * (size_t) n_ranks)) || (rc = dev_alloc(&d_ranks, (size_t) n_ranks))) { cleanup(); return rc; }
+    hipError_t he = hipMemcpyAsync(d_ranks, ranks, (size_t) n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess && (rc = sort_doubles_desc(nullptr, &tmp_bytes, d_scores, d_sorted, R, c->stream)) == MS_OK) {
+        he = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+        if (he != hipSuccess) { set_error("hipMalloc (sort) failed: %s", hipGetErrorString(he)); rc = MS_ERR_NOMEM; }
+    }
+    const DevSeq S = dev_seq(seqs);
+    for (int32_t p0 = 0; rc == MS_OK && he == hipSuccess && p0 < pwms->P; p0 += batch) {
+        const int32_t n = std::min(batch, pwms->P - p0);
+        DevPwm sub = dev_pwm(pwms);
+        sub.tab_off += p0; sub.width += p0; sub.max_raw += p0; sub.cutoff += p0; sub.P = n;
+        rc = launch_score(S, sub, strand_mask, d_scores, c->stream);
+        for (int32_t i = 0; rc == MS_OK && i < n; i++) {
+            size_t tb = tmp_bytes;
+            rc = sort_doubles_desc(d_tmp, &tb, d_scores + (size_t) i * R, d_sorted, R, c->stream);
+            if (rc == MS_OK) rc = launch_gather_ranks(d_sorted, (int64_t) R, d_ranks, n_ranks, d_out + (size_t) (p0 + i) * n_ranks, c->stream);
+        }
+    }
+    if (rc == MS_OK && he == hipSuccess)
+        he = hipMemcpyAsync(out, d_out, (size_t) pwms->P * (size_t) n_ranks * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (rc == MS_OK && he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    else (void) hipStreamSynchronize(c->stream);
+    cleanup();
+    if (rc) return rc;
+    if (he != hipSuccess) { set_error("score/rank kernels failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
     return MS_OK;
 }
 

@@ -77,4 +77,10 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
 int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                    const double *vals_in, double *vals_out, size_t n, int end_bit, hipStream_t stream);
 
+// Descending sort of one row of fp64 scores (cutoff builder).  Query temp size with temp == nullptr.
+int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream);
+
+// Exclusive prefix sum (destination slots of the hits that survive de-duplication).
+int exclusive_sum_u32(void *temp, size_t *temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream);
+
 }  // namespace ms

@@ -64,5 +64,14 @@ int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S,
                     hipStream_t st);
 int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st);
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
+int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *seq_idx,
+                 const int64_t *pos, const double *score, const int8_t *strand, uint32_t *keep, hipStream_t st);
+int launch_compact_hits(int64_t n, const uint32_t *keep, const uint32_t *dst, const int64_t *seq_in, const int64_t *pos_in,
+                        const double *score_in, const int8_t *strand_in, int64_t *seq_out, int64_t *pos_out,
+                        double *score_out, int8_t *strand_out, const int64_t *off_in, int32_t P, int64_t *off_out,
+                        hipStream_t st);
+int launch_site_tables(int64_t n, const int64_t *motif_off, int32_t P, int64_t R, const int64_t *seq_idx,
+                       const double *score, int32_t *n_sites, double *max_score, hipStream_t st);
+int launch_gather_ranks(const double *sorted, int64_t n, const int64_t *ranks, int32_t n_ranks, double *out, hipStream_t st);
 
 }  // namespace ms

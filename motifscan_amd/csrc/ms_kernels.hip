@@ -574,6 +574,92 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
     }
 }
 
+// -------------------------------------------------------------- de-dup / site tables --
+
+__device__ __forceinline__ int32_t motif_of_hit(const int64_t *__restrict__ motif_off, int32_t P, int64_t i) {
+    int32_t lo = 0, hi = P;                       // motif_off[lo] <= i < motif_off[hi]
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (motif_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// scanner.py:156-193 on the sorted hit arrays.  The thread of the FIRST hit of a (motif, region)
+// segment walks the segment once with one "current site" per strand: a later same-strand site
+// closer than the motif width either loses (score <=: tie keeps the earlier one) or replaces it.
+// The kept hits are already in the order the reference returns (start ascending, '+' first).
+__global__ void __launch_bounds__(256) dedup_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                    const int32_t *__restrict__ width, const int64_t *__restrict__ seq_idx,
+                                                    const int64_t *__restrict__ pos, const double *__restrict__ score,
+                                                    const int8_t *__restrict__ strand, uint32_t *__restrict__ keep) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = motif_of_hit(motif_off, P, i);
+    const int64_t r = seq_idx[i];
+    if (i > motif_off[p] && seq_idx[i - 1] == r) return;            // not the head of its segment
+    const int64_t end = motif_off[p + 1];
+    const int64_t W = width[p];
+    int64_t cur[2] = {-1, -1};
+    for (int64_t j = i; j < end && seq_idx[j] == r; j++) {
+        const int s = strand[j] == 1 ? 0 : 1;
+        uint32_t kj = 1;
+        if (cur[s] >= 0 && pos[j] - pos[cur[s]] < W) {
+            if (score[cur[s]] >= score[j]) kj = 0;                   // scanner.py:163-164
+            else { keep[cur[s]] = 0; cur[s] = j; }                   // scanner.py:165-166
+        } else {
+            cur[s] = j;
+        }
+        keep[j] = kj;
+    }
+}
+
+__global__ void __launch_bounds__(256) compact_hits_kernel(int64_t n, const uint32_t *__restrict__ keep,
+                                                           const uint32_t *__restrict__ dst,
+                                                           const int64_t *__restrict__ seq_in, const int64_t *__restrict__ pos_in,
+                                                           const double *__restrict__ score_in, const int8_t *__restrict__ strand_in,
+                                                           int64_t *__restrict__ seq_out, int64_t *__restrict__ pos_out,
+                                                           double *__restrict__ score_out, int8_t *__restrict__ strand_out) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const uint32_t d = dst[i];
+    seq_out[d] = seq_in[i]; pos_out[d] = pos_in[i]; score_out[d] = score_in[i]; strand_out[d] = strand_in[i];
+}
+
+// new per-motif offsets after compaction: off_out[p] = dst[off_in[p]] (or the kept total at the end)
+__global__ void remap_offsets_kernel(const int64_t *__restrict__ off_in, int32_t P, int64_t n, const uint32_t *__restrict__ dst,
+                                     const uint32_t *__restrict__ keep, int64_t *__restrict__ off_out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > P) return;
+    const int64_t o = off_in[p];
+    off_out[p] = o < n ? (int64_t) dst[o] : (n > 0 ? (int64_t) dst[n - 1] + keep[n - 1] : 0);
+}
+
+// io/__init__.py:23-33: per (motif, region) the number of sites and the maximum score
+__global__ void __launch_bounds__(256) site_tables_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P, int64_t R,
+                                                          const int64_t *__restrict__ seq_idx, const double *__restrict__ score,
+                                                          int32_t *__restrict__ n_sites, double *__restrict__ max_score) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = motif_of_hit(motif_off, P, i);
+    const int64_t r = seq_idx[i];
+    if (i > motif_off[p] && seq_idx[i - 1] == r) return;
+    const int64_t end = motif_off[p + 1];
+    int32_t cnt = 0;
+    double best = score[i];
+    for (int64_t j = i; j < end && seq_idx[j] == r; j++) {
+        cnt++;
+        if (score[j] > best) best = score[j];
+    }
+    n_sites[(int64_t) p * R + r] = cnt;
+    max_score[(int64_t) p * R + r] = best;
+}
+
+__global__ void fill_nan_kernel(double *__restrict__ a, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = __longlong_as_double(0x7FF8000000000000LL);
+}
+
 // -------------------------------------------------------------------------- score --
 
 // c_score (cscore.c:191-224): one thread per (sequence, motif); first W bases only.
@@ -607,6 +693,15 @@ __global__ void __launch_bounds__(256) score_kernel(const DevSeq S, const DevPwm
         case 3: s = fwd > rev ? fwd : rev; break;
     }
     out[(int64_t) p * S.R + r] = s / Pw.max_raw[p];
+}
+
+// out[k] = sorted[ranks[k]]  (ranks beyond the row give NaN)
+__global__ void gather_ranks_kernel(const double *__restrict__ sorted, int64_t n, const int64_t *__restrict__ ranks,
+                                    int32_t n_ranks, double *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_ranks) return;
+    const int64_t r = ranks[k];
+    out[k] = (r >= 0 && r < n) ? sorted[r] : __longlong_as_double(0x7FF8000000000000LL);
 }
 
 // ------------------------------------------------------------------- region hints --
@@ -708,6 +803,49 @@ int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S,
     if (n == 0) return MS_OK;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, S,
                        seq_idx, pos, strand, motif_first, region_counts);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *seq_idx,
+                 const int64_t *pos, const double *score, const int8_t *strand, uint32_t *keep, hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(dedup_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, seq_idx,
+                       pos, score, strand, keep);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_compact_hits(int64_t n, const uint32_t *keep, const uint32_t *dst, const int64_t *seq_in, const int64_t *pos_in,
+                        const double *score_in, const int8_t *strand_in, int64_t *seq_out, int64_t *pos_out,
+                        double *score_out, int8_t *strand_out, const int64_t *off_in, int32_t P, int64_t *off_out,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(remap_offsets_kernel, dim3((unsigned) ((P + 1 + 255) / 256)), dim3(256), 0, st, off_in, P, n, dst, keep, off_out);
+    MS_HIP(hipGetLastError());
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(compact_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, keep, dst, seq_in, pos_in,
+                       score_in, strand_in, seq_out, pos_out, score_out, strand_out);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_site_tables(int64_t n, const int64_t *motif_off, int32_t P, int64_t R, const int64_t *seq_idx,
+                       const double *score, int32_t *n_sites, double *max_score, hipStream_t st) {
+    const int64_t cells = (int64_t) P * R;
+    if (cells == 0) return MS_OK;
+    MS_HIP(hipMemsetAsync(n_sites, 0, (size_t) cells * sizeof(int32_t), st));
+    hipLaunchKernelGGL(fill_nan_kernel, dim3((unsigned) ((cells + 255) / 256)), dim3(256), 0, st, max_score, cells);
+    MS_HIP(hipGetLastError());
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(site_tables_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, R, seq_idx,
+                       score, n_sites, max_score);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_gather_ranks(const double *sorted, int64_t n, const int64_t *ranks, int32_t n_ranks, double *out, hipStream_t st) {
+    if (n_ranks <= 0) return MS_OK;
+    hipLaunchKernelGGL(gather_ranks_kernel, dim3((unsigned) ((n_ranks + 63) / 64)), dim3(64), 0, st, sorted, n, ranks, n_ranks, out);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

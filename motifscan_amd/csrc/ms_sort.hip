@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "ms_internal.h"
 
@@ -16,6 +17,16 @@ int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint
     if (end_bit > 64) end_bit = 64;
     MS_HIP(rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u,
                                      (unsigned int) end_bit, stream));
+    return MS_OK;
+}
+
+int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream) {
+    MS_HIP(rocprim::radix_sort_keys_desc(temp, *temp_bytes, in, out, n, 0u, 64u, stream));
+    return MS_OK;
+}
+
+int exclusive_sum_u32(void *temp, size_t *temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream) {
+    MS_HIP(rocprim::exclusive_scan(temp, *temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), stream));
     return MS_OK;
 }
 

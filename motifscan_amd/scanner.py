@@ -82,34 +82,32 @@ class Scanner:
         lengths = [pwm.length for pwm in pwms]
         return matrices, np.asarray(cutoffs, dtype=np.float64), lengths
 
-    def scan_motifs_arrays(self, pwms):
+    def scan_motifs_arrays(self, pwms, with_tables=False):
         """Flat result: dict with motif, region, start (genome coordinate), score, strand (1/2),
-        motif_offsets -- ordered exactly like the nested lists scan_motifs returns."""
+        motif_offsets -- ordered exactly like the nested lists scan_motifs returns.  with_tables adds
+        the dense per-(motif, region) site count and maximum score (NaN = no site)."""
         matrices, cutoffs, lengths = self._marshal(pwms)
         logger.debug("Scanning motif PWMs")
         pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
         sq = _lib.SeqSet.from_strings(self.sequences)
         res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
         try:
+            if self.remove_dup:
+                res.dedup(pw)                      # scanner.py:156-193 on the device, order preserved
             h = res.hits()
             region_counts = res.region_counts()
+            tables = res.site_tables(len(self.sequences)) if with_tables else None
         finally:
             res.close()
             sq.close()
             pw.close()
-        keep = None
-        if self.remove_dup and len(h["pos"]):
-            keep = _lib.dedup_keep(h["motif_offsets"], lengths, h["seq_idx"], h["pos"], h["score"], h["strand"])
         starts = np.asarray(self.seq_starts, dtype=np.int64)
         out = {"motif": h["motif"], "region": h["seq_idx"],
                "start": (starts[h["seq_idx"]] + h["pos"]) if len(h["pos"]) else h["pos"],
-               "score": h["score"], "strand": h["strand"]}
-        if keep is not None:
-            out = {k: v[keep] for k, v in out.items()}
-        n_pwms = len(matrices)
-        out["motif_offsets"] = np.concatenate([[0], np.cumsum(np.bincount(out["motif"], minlength=n_pwms))]).astype(
-            np.int64) if n_pwms else np.zeros(1, dtype=np.int64)
-        out["n_regions_with_site"] = region_counts        # de-dup never empties a region
+               "score": h["score"], "strand": h["strand"], "motif_offsets": h["motif_offsets"],
+               "n_regions_with_site": region_counts}      # de-dup never empties a region
+        if tables is not None:
+            out["n_sites"], out["max_score"] = tables      # what write_sites_table prints (io/__init__.py:23-33)
         return out
 
     def scan_motifs(self, pwms):

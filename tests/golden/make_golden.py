@@ -328,6 +328,10 @@ def make_random(R):
     save["kmer_bytes"] = kmers[:2000].copy()
     for strand in (1, 2, 3):
         save[f"score_s{strand}"] = np.array(R["ext"].c_score(ml, ksub, strand, 4))
+    # ... and the reference's cutoff pick on those 2000 scores (motif/__init__.py:378-401)
+    cuts2000 = R["get_score_cutoffs"](R["ext"].c_score(ml, ksub, 3, 4))
+    save["g5_cutoff_keys"] = np.array(sorted(cuts2000[0].keys()))
+    save["g5_cutoffs"] = np.array([[c[k] for k in sorted(cuts2000[0].keys())] for c in cuts2000])
     # G4: the real Scanner (window extraction + regroup + de-dup) on a synthetic 3-chromosome genome
     chroms = {f"chr{i + 1}": random_sequences(rng, 1, 20000, 20000, bgp, frac_n=1.0, iupac=False)[0]
               for i in range(3)}

@@ -164,6 +164,38 @@ def test_g4_scanner_with_and_without_dedup(rnd):
     assert all(isinstance(s, scanner.MotifSite) for per in nested for ss in per for s in ss)
 
 
+def test_device_dedup_and_site_tables(oracle, rnd):
+    """ms_result_dedup (device) == ms_dedup_hits (host) == the oracle's restatement of scanner.py:156-193,
+    and the dense site tables equal what io/__init__.py:23-33 derives from the nested lists."""
+    mats, cut = rnd["mats"], rnd["cutoff_by_key"]["1e-3"]
+    widths = [m.shape[1] for m in mats]
+    pw = _lib.PwmSet.from_matrices(mats, cut)
+    sq = _lib.SeqSet.from_strings(rnd["seqs"])
+    res = _lib.scan(pw, sq, 3)
+    h = {k: v.copy() for k, v in res.hits().items()}
+    keep = _lib.dedup_keep(h["motif_offsets"], widths, h["seq_idx"], h["pos"], h["score"], h["strand"])
+    n0, m0 = res.site_tables(len(rnd["seqs"]))
+    res.dedup(pw)
+    d = res.hits()
+    assert 0 < keep.sum() < len(keep) and res.n_hits == keep.sum()
+    for k in ("seq_idx", "pos", "score", "strand", "motif"):
+        assert np.array_equal(d[k], h[k][keep]), k
+    assert np.array_equal(np.diff(d["motif_offsets"]), np.bincount(h["motif"][keep], minlength=len(mats)))
+    res.dedup(pw)                                               # idempotent
+    assert res.n_hits == keep.sum()
+    # oracle: nested lists -> de-dup -> the writer's aggregates
+    sites = oracle.c_scan_motif([m.tolist() for m in mats], cut.tolist(), rnd["seqs"], 3, 4)
+    ms = oracle.make_motif_sites(sites, [0] * len(rnd["seqs"]))
+    dd = oracle.deduplicate_motif_sites(ms, widths)
+    n1, m1 = res.site_tables(len(rnd["seqs"]))
+    for tabs, nested in (((n0, m0), ms), ((n1, m1), dd)):
+        want_n = np.array([[len(x) for x in per] for per in nested])
+        want_m = np.array([[max(s.score for s in x) if x else np.nan for x in per] for per in nested])
+        assert np.array_equal(tabs[0], want_n)
+        assert np.array_equal(tabs[1], want_m, equal_nan=True)
+    assert np.array_equal(res.region_counts(), (n1 > 0).sum(axis=1))
+
+
 def test_g5_c_score_kmers_exact(rnd):
     kmers = [row.tobytes().decode() for row in rnd["kmer_bytes"]]
     pw = _lib.PwmSet.from_matrices(rnd["mats"])
@@ -175,6 +207,20 @@ def test_g5_c_score_kmers_exact(rnd):
     got = m.score_batch(kmers[:50], strand=1)
     want = np.array([m.score(k[:m.length]) for k in kmers[:50]])
     assert np.allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_cutoff_builder_matches_reference(rnd):
+    """`motifscan motif --build` cutoffs: c_score + descending sort + rank pick on the device ==
+    the reference's get_score_cutoffs on the same 2000 k-mers, bit for bit."""
+    from motifscan_amd import build
+    kmers = [row.tobytes().decode() for row in rnd["kmer_bytes"]]
+    got = build.get_score_cutoffs(rnd["mats"], kmers, strand=3)
+    keys = [str(k) for k in rnd["g5_cutoff_keys"]]
+    assert np.array_equal(np.array([[d[k] for k in keys] for d in got]), rnd["g5_cutoffs"])
+    avg = build.build_cutoffs(rnd["mats"][:4], [kmers, kmers[::-1]], strand=3)
+    assert avg[0]["1e-2"] == float(np.around(rnd["g5_cutoffs"][0, 0], 8))
+    with pytest.raises(ValueError):
+        build.get_score_cutoffs(rnd["mats"][:2], kmers[:50])
 
 
 # ------------------------------------------------------------- seeded inputs vs the oracle --

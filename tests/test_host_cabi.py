@@ -210,6 +210,22 @@ def test_dedup_matches_oracle_on_random_hits(oracle, rnd):
     assert 0 < keep.sum() < len(keep)
 
 
+def test_cutoff_rank_semantics_match_reference(oracle, rnd):
+    """build.cutoff_ranks restates get_score_cutoffs' index arithmetic (motif/__init__.py:393-399):
+    picking those ranks from the oracle's scores reproduces the reference's cutoffs bit for bit."""
+    from motifscan_amd import build
+    assert build.cutoff_ranks(2000) == {"1e-2": 19, "1e-3": 1}
+    assert build.cutoff_ranks(1000000) == {"1e-2": 9999, "1e-3": 999, "1e-4": 99, "1e-5": 9, "1e-6": 0}
+    assert build.cutoff_ranks(20000) == {"1e-2": 199, "1e-3": 19, "1e-4": 1}
+    with pytest.raises(ValueError):
+        build.cutoff_ranks(99)
+    scores = -np.sort(-rnd["score_s3"], axis=1)                       # descending
+    keys = [str(k) for k in rnd["g5_cutoff_keys"]]
+    ranks = build.cutoff_ranks(scores.shape[1])
+    assert list(ranks) == keys
+    assert np.array_equal(scores[:, [ranks[k] for k in keys]], rnd["g5_cutoffs"])
+
+
 # -------------------------------------------------------------------------- matrix --
 
 def test_matrix_pipeline_matches_reference_values(small):
