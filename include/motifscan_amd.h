@@ -21,6 +21,8 @@
  *                         (ASCII -> base codes: A/a C/c G/g T/t, anything else "no
  *                          contribution"); here 2-bit codes + a 1-bit non-ACGT plane in HBM
  *   ms_seqset_from_device same, for ASCII that is already resident in device memory
+ *   ms_genome_create /    Scanner._extract_seq -> Genome.fetch_sequence (pysam)   scanner.py:71-87,
+ *   ms_seqset_from_genome   genome/__init__.py:117-135: packed genome resident in HBM, regions cut on device
  *   ms_scan               scan_motif / scan_motif_thread           cscore.c:317-476
  *                         (Python name c_scan_motif; "OOOII" = pwms, cutoffs, seqs, strand,
  *                          n_threads; n_threads has no meaning on the GPU and is not taken)
@@ -63,6 +65,7 @@ extern "C" {
 typedef struct ms_pwmset ms_pwmset;
 typedef struct ms_seqset ms_seqset;
 typedef struct ms_result ms_result;
+typedef struct ms_genome ms_genome;
 
 /* Per-call measurements, filled by ms_scan (HIP events on the library's own stream). */
 typedef struct ms_scan_stats {
@@ -114,6 +117,17 @@ int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n
 int ms_seqset_repack(ms_seqset *seqs);
 int ms_seqset_size(const ms_seqset *seqs, int64_t *n_seqs, int64_t *n_bases);
 void ms_seqset_free(ms_seqset *seqs);
+
+/* ---- resident genome + on-device region extraction ------------------------------------------ */
+/* Replaces the per-region Genome.fetch_sequence (pysam) calls of Scanner._extract_seq
+ * (scanner.py:71-87, genome/__init__.py:117-135): the genome is packed ONCE into HBM (2-bit codes +
+ * non-ACGT plane), and a region list (chromosome index, 0-based half-open [start, end) already
+ * clipped to the chromosome as scanner.py:81-83 does) is cut into a sequence set on the device. */
+int ms_genome_create(const char *bases, const int64_t *chrom_offsets, int32_t n_chroms, ms_genome **out);
+int ms_genome_size(const ms_genome *genome, int32_t *n_chroms, int64_t *n_bases);
+void ms_genome_free(ms_genome *genome);
+int ms_seqset_from_genome(const ms_genome *genome, const int32_t *chrom, const int64_t *start,
+                          const int64_t *end, int64_t n_regions, ms_seqset **out);
 
 /* ---- scan (c_scan_motif) ---------------------------------------------------------------- */
 int ms_scan(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags,

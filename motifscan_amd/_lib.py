@@ -91,6 +91,10 @@ def lib():
         "ms_seqset_repack": (c_int, [vp]),
         "ms_seqset_size": (c_int, [vp, pi64, pi64]),
         "ms_seqset_free": (None, [vp]),
+        "ms_genome_create": (c_int, [ctypes.c_char_p, pi64, c_i32, pvp]),
+        "ms_genome_size": (c_int, [vp, pi32, pi64]),
+        "ms_genome_free": (None, [vp]),
+        "ms_seqset_from_genome": (c_int, [vp, pi32, pi64, pi64, c_i64, pvp]),
         "ms_scan": (c_int, [vp, vp, c_int, c_u32, pvp]),
         "ms_result_num_hits": (c_int, [vp, pi64]),
         "ms_result_motif_offsets": (c_int, [vp, pi64]),
@@ -268,6 +272,57 @@ class SeqSet:
     def close(self):
         if getattr(self, "h", None):
             lib().ms_seqset_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class ResidentGenome:
+    """A genome packed once into HBM; regions are cut out on the device (no per-region host fetch).
+
+    Quacks like the part of `motifscan.genome.Genome` the Scanner reads: `chrom_sizes` and
+    `fetch_sequence(chrom, start, end)` (served from a host copy only if keep_host=True)."""
+
+    def __init__(self, chroms, keep_host=False):
+        """chroms: dict name -> str/bytes/uint8 array (insertion order = chromosome index)."""
+        self.names = list(chroms.keys())
+        self.index = {n: i for i, n in enumerate(self.names)}
+        raws = [v.encode() if isinstance(v, str) else (v.tobytes() if isinstance(v, np.ndarray) else bytes(v))
+                for v in chroms.values()]
+        self.chrom_sizes = {n: len(r) for n, r in zip(self.names, raws)}
+        self.offsets = np.zeros(len(raws) + 1, dtype=np.int64)
+        if raws:
+            self.offsets[1:] = np.cumsum([len(r) for r in raws])
+        self._host = dict(zip(self.names, raws)) if keep_host else None
+        h = ctypes.c_void_p()
+        check(lib().ms_genome_create(b"".join(raws), ptr(self.offsets, ctypes.c_int64), len(raws), ctypes.byref(h)))
+        self.h = h
+
+    def fetch_sequence(self, chrom, start, end):
+        if self._host is None:
+            raise RuntimeError("ResidentGenome was created without keep_host: sequences live on the device only")
+        return self._host[chrom][start:end].decode()
+
+    def extract(self, chrom_idx, starts, ends):
+        """SeqSet of the regions (chromosome indices, 0-based half-open, already clipped)."""
+        ci = np.ascontiguousarray(chrom_idx, dtype=np.int32)
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        en = np.ascontiguousarray(ends, dtype=np.int64)
+        if not (len(ci) == len(st) == len(en)):
+            raise ValueError("chrom / start / end must have the same length")
+        sq = SeqSet.__new__(SeqSet)
+        h = ctypes.c_void_p()
+        check(lib().ms_seqset_from_genome(self.h, ptr(ci, ctypes.c_int32), ptr(st, ctypes.c_int64), ptr(en, ctypes.c_int64),
+                                          len(ci), ctypes.byref(h)))
+        sq.h = h
+        sq.n_seqs = len(ci)
+        sq.offsets = np.concatenate([[0], np.cumsum(en - st)]).astype(np.int64)
+        sq.n_bases = int(sq.offsets[-1])
+        return sq
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ms_genome_free(self.h)
             self.h = None
 
     __del__ = close

@@ -587,6 +587,75 @@ void ms_seqset_free(ms_seqset *s) {
     delete s;
 }
 
+// ------------------------------------------------------------------- resident genome --
+
+// A genome is a sequence set whose "sequences" are the chromosomes, kept packed in HBM
+// (3 Gbp = 1.1 GB); regions are then cut out on the device with no ASCII traffic at all.
+int ms_genome_create(const char *bases, const int64_t *chrom_offsets, int32_t n_chroms, ms_genome **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    ms_seqset *s = nullptr;
+    int rc = ms_seqset_create(bases, chrom_offsets, n_chroms, 0, &s);
+    if (rc) return rc;
+    *out = reinterpret_cast<ms_genome *>(s);
+    return MS_OK;
+}
+
+int ms_genome_size(const ms_genome *g, int32_t *n_chroms, int64_t *n_bases) {
+    if (!g) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const ms_seqset *s = reinterpret_cast<const ms_seqset *>(g);
+    if (n_chroms) *n_chroms = (int32_t) s->R;
+    if (n_bases) *n_bases = s->n_bases;
+    return MS_OK;
+}
+
+void ms_genome_free(ms_genome *g) { ms_seqset_free(reinterpret_cast<ms_seqset *>(g)); }
+
+int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_t *start, const int64_t *end,
+                          int64_t n_regions, ms_seqset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!g) { set_error("NULL genome"); return MS_ERR_INVALID; }
+    if (n_regions < 0 || (n_regions > 0 && (!chrom || !start || !end))) { set_error("bad region arrays"); return MS_ERR_INVALID; }
+    const ms_seqset *G = reinterpret_cast<const ms_seqset *>(g);
+    std::vector<int64_t> dst((size_t) n_regions + 1, 0), src((size_t) n_regions + 1, 0);
+    for (int64_t r = 0; r < n_regions; r++) {
+        if (chrom[r] < 0 || chrom[r] >= G->R) { set_error("region %lld: chromosome index %d out of range", (long long) r, chrom[r]); return MS_ERR_INVALID; }
+        const int64_t clen = G->offsets[(size_t) chrom[r] + 1] - G->offsets[(size_t) chrom[r]];
+        if (start[r] < 0 || end[r] < start[r] || end[r] > clen) {
+            set_error("region %lld: [%lld, %lld) is outside chromosome %d of length %lld", (long long) r, (long long) start[r],
+                      (long long) end[r], chrom[r], (long long) clen);
+            return MS_ERR_INVALID;
+        }
+        src[(size_t) r] = G->offsets[(size_t) chrom[r]] + start[r];
+        dst[(size_t) r + 1] = dst[(size_t) r] + (end[r] - start[r]);
+    }
+    const int prev_dev = g_device;
+    g_device = G->device;                              // the new set lives next to its genome
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(dst.data(), n_regions, s);
+    g_device = prev_dev;
+    if (rc) return rc;
+    DeviceCtx *c;
+    if ((rc = get_ctx(G->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw))) return fail(rc);
+    int64_t *d_src = nullptr;
+    if ((rc = dev_alloc(&d_src, (size_t) n_regions + 1))) return fail(rc);
+    hipError_t he = hipMemcpy(d_src, src.data(), ((size_t) n_regions + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+        rc = launch_extract(G->d_codes, G->d_nmask, d_src, raw->d_offsets, raw->R, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream);
+        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream);
+        if (!rc) he = hipStreamSynchronize(c->stream);
+    }
+    dev_free(d_src);
+    if (rc) return fail(rc);
+    if (he != hipSuccess) { set_error("extraction failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+    *out = raw;
+    return MS_OK;
+}
+
 // ---------------------------------------------------------------------------- scan --
 
 static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap, size_t nlist_cap) {

@@ -62,6 +62,8 @@ int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, cons
 int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);
+int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,
+                   int64_t R, int64_t n_out, uint32_t *codes, uint32_t *nmask, hipStream_t st);
 int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st);
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
 int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *seq_idx,

@@ -704,6 +704,41 @@ __global__ void gather_ranks_kernel(const double *__restrict__ sorted, int64_t n
     out[k] = (r >= 0 && r < n) ? sorted[r] : __longlong_as_double(0x7FF8000000000000LL);
 }
 
+// --------------------------------------------------------------- on-device extraction --
+
+// Regions cut out of a resident packed genome (replaces Scanner._extract_seq -> Genome.fetch_sequence
+// -> pysam fetch, scanner.py:71-87 / genome/__init__.py:117-135): one thread per 32 output bases,
+// which may straddle several regions.  src_start[r] is the region's first base in the genome's
+// packed coordinates; dst_off[r] its first base in the output.
+__global__ void __launch_bounds__(256) extract_kernel(const uint32_t *__restrict__ gcodes, const uint32_t *__restrict__ gnmask,
+                                                      const int64_t *__restrict__ src_start, const int64_t *__restrict__ dst_off,
+                                                      int64_t R, int64_t n_out, uint32_t *__restrict__ codes,
+                                                      uint32_t *__restrict__ nmask) {
+    const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pos = u * 32;
+    if (pos >= n_out) return;
+    int64_t r = find_region_bsearch(dst_off, R, pos);
+    uint64_t cw = 0;
+    uint32_t nw = 0;
+    int filled = 0;
+    while (filled < 32 && pos + filled < n_out) {
+        const int64_t d = pos + filled;
+        while (dst_off[r + 1] <= d) r++;                              // skip empty regions
+        const int64_t left = dst_off[r + 1] - d;
+        const int seg = left < (int64_t) (32 - filled) ? (int) left : 32 - filled;
+        const int64_t sp = src_start[r] + (d - dst_off[r]);
+        const uint64_t scw = code_window(gcodes, sp);
+        const uint32_t snw = n_window(gnmask, sp);
+        const uint64_t m = seg >= 32 ? ~0ULL : ((1ULL << (2 * seg)) - 1ULL);
+        cw |= (scw & m) << (2 * filled);
+        nw |= (snw & low_mask(seg)) << filled;
+        filled += seg;
+    }
+    codes[2 * u] = (uint32_t) cw;
+    codes[2 * u + 1] = (uint32_t) (cw >> 32);
+    nmask[u] = nw;
+}
+
 // ------------------------------------------------------------------- region hints --
 
 // blk2reg[b] = region that holds position 64*b (part of the extraction stage, next to pack_kernel)
@@ -715,6 +750,16 @@ __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------- launchers --
+
+int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,
+                   int64_t R, int64_t n_out, uint32_t *codes, uint32_t *nmask, hipStream_t st) {
+    const int64_t n_units = (n_out + 31) / 32;
+    if (n_units == 0) return MS_OK;
+    hipLaunchKernelGGL(extract_kernel, dim3((unsigned) ((n_units + 255) / 256)), dim3(256), 0, st, gcodes, gnmask, src_start,
+                       dst_off, R, n_out, codes, nmask);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
 
 int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st) {
     const int64_t n_blocks = (n_bases + 63) / 64 + 1;

@@ -50,14 +50,29 @@ class Scanner:
         if n_threads > n_cpu:
             logger.warning(f"Threads number exceed the number of CPUs, using {n_cpu} instead")
         self.n_threads = max(1, min(n_threads, n_cpu))
-        self.seq_starts, self.seq_ends, self.sequences = [], [], []
+        self.seq_starts, self.seq_ends, self._sequences = [], [], []
+        self._resident = None                # (ResidentGenome, chromosome indices) when extraction is on the device
         self._extract_seq(genome, regions)
+
+    @property
+    def sequences(self):
+        """Region sequences as strings (scanner.py:68).  With a ResidentGenome they are only
+        materialised on demand (and only if the genome kept a host copy)."""
+        if self._sequences is None:
+            g, idx = self._resident
+            self._sequences = [g.fetch_sequence(g.names[c], lo, hi)
+                               for c, lo, hi in zip(idx, self.seq_starts, self.seq_ends)]
+        return self._sequences
 
     def _extract_seq(self, genome, regions):
         """Forward-strand sequence of every region (whole region, or a window of 2*(w//2) bp
-        centred on the summit and clipped to the chromosome)."""
+        centred on the summit and clipped to the chromosome).  A `ResidentGenome` keeps the
+        genome packed in HBM: then only coordinates are collected here and the regions are cut
+        out on the device (ms_seqset_from_genome) instead of one fetch_sequence call per region."""
         logger.debug("Extracting sequences")
         whole = self.window_size <= 0
+        resident = isinstance(genome, _lib.ResidentGenome)
+        chrom_idx = []
         for region in regions:
             if whole:
                 lo, hi = region.start, region.end
@@ -66,7 +81,19 @@ class Scanner:
                 hi = min(region.summit + self.extend, genome.chrom_sizes[region.chrom])
             self.seq_starts.append(lo)
             self.seq_ends.append(hi)
-            self.sequences.append(genome.fetch_sequence(region.chrom, lo, hi))
+            if resident:
+                chrom_idx.append(genome.index[region.chrom])
+            else:
+                self._sequences.append(genome.fetch_sequence(region.chrom, lo, hi))
+        if resident:
+            self._resident = (genome, chrom_idx)
+            self._sequences = None
+
+    def _seqset(self):
+        if self._resident is not None:
+            g, idx = self._resident
+            return g.extract(idx, self.seq_starts, self.seq_ends)
+        return _lib.SeqSet.from_strings(self._sequences)
 
     # ------------------------------------------------------------------ scanning --
 
@@ -89,14 +116,14 @@ class Scanner:
         matrices, cutoffs, lengths = self._marshal(pwms)
         logger.debug("Scanning motif PWMs")
         pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
-        sq = _lib.SeqSet.from_strings(self.sequences)
+        sq = self._seqset()
         res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
         try:
             if self.remove_dup:
                 res.dedup(pw)                      # scanner.py:156-193 on the device, order preserved
             h = res.hits()
             region_counts = res.region_counts()
-            tables = res.site_tables(len(self.sequences)) if with_tables else None
+            tables = res.site_tables(len(self.seq_starts)) if with_tables else None
         finally:
             res.close()
             sq.close()
@@ -113,7 +140,7 @@ class Scanner:
     def scan_motifs(self, pwms):
         pwms = list(pwms)
         a = self.scan_motifs_arrays(pwms)
-        n_regions = len(self.sequences)
+        n_regions = len(self.seq_starts)
         motif_sites = [[[] for _ in range(n_regions)] for _ in pwms]
         for m, r, st, sc, sd in zip(a["motif"].tolist(), a["region"].tolist(), a["start"].tolist(),
                                     a["score"].tolist(), a["strand"].tolist()):

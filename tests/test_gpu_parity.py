@@ -196,6 +196,51 @@ def test_device_dedup_and_site_tables(oracle, rnd):
     assert np.array_equal(res.region_counts(), (n1 > 0).sum(axis=1))
 
 
+def test_resident_genome_extraction_equals_host_strings(rnd):
+    """ms_genome_create + ms_seqset_from_genome (regions cut on the device from the packed genome)
+    give exactly the hits of the string path, through the same Scanner front end (G4 fixture:
+    windows, clipping at chromosome ends, N runs, soft-masking)."""
+    names = [str(x) for x in rnd["g4_chrom_names"]]
+    raw = rnd["g4_chrom_bytes"].tobytes().decode()
+    n = len(raw) // len(names)
+    chroms = {nm: raw[i * n:(i + 1) * n] for i, nm in enumerate(names)}
+    rg = _lib.ResidentGenome(chroms, keep_host=True)
+    assert rg.chrom_sizes == {k: len(v) for k, v in chroms.items()}
+
+    class Reg:
+        def __init__(self, row):
+            self.chrom, self.start, self.end, self.summit = names[int(row[0])], int(row[1]), int(row[2]), int(row[3])
+
+    class P:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = m, {"1e-3": c}, m.shape[1]
+
+    pw = [P(m, c) for m, c in zip(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])]
+    regs = [Reg(r) for r in rnd["g4_regions"]]
+    for wsize, dup in ((0, True), (200, False), (201, True)):
+        tag = f"g4_w{wsize}_dup{int(dup)}_both"
+        sc = scanner.Scanner(rg, regs, window_size=wsize, p_value="1e-3", remove_dup=dup)
+        a = sc.scan_motifs_arrays(pw)
+        for k, g in (("motif", "_motif"), ("region", "_region"), ("start", "_start"), ("strand", "_strand"), ("score", "_score")):
+            assert np.array_equal(a[k], rnd[tag + g]), (tag, k)
+        assert sc.sequences[5] == chroms[regs[5].chrom][sc.seq_starts[5]:sc.seq_ends[5]]
+    # odd alignments: many short regions, empty regions, region ends at every bit offset
+    rng = np.random.default_rng(3)
+    ci = rng.integers(0, 3, size=500)
+    st = rng.integers(0, n - 70, size=500)
+    en = st + rng.integers(0, 70, size=500)
+    sq = rg.extract(ci, st, en)
+    seqs = [chroms[names[c]][a:b] for c, a, b in zip(ci, st, en)]
+    pws = _lib.PwmSet.from_matrices(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])
+    h1 = _lib.scan(pws, sq, 3).hits()
+    h2 = _lib.scan(pws, _lib.SeqSet.from_strings(seqs), 3).hits()
+    assert len(h1["pos"]) > 100 and all(np.array_equal(h1[k], h2[k]) for k in ("seq_idx", "pos", "score", "strand", "motif_offsets"))
+    with pytest.raises(ValueError):
+        rg.extract([0], [10], [n + 1])
+    with pytest.raises(ValueError):
+        rg.extract([7], [0], [10])
+
+
 def test_g5_c_score_kmers_exact(rnd):
     kmers = [row.tobytes().decode() for row in rnd["kmer_bytes"]]
     pw = _lib.PwmSet.from_matrices(rnd["mats"])
