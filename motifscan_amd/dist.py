@@ -98,5 +98,5 @@ def enrichment(n_input_with_site, n_control_with_site, n_input, n_control):
         fold = a * n_control / c / n_input if c > 0 and n_input > 0 else float("nan")   # stats.py:32-35 order
         p_enrich = fisher_exact(table, alternative="greater")[1]
         p_deplete = fisher_exact(table, alternative="less")[1]
-        rows.append((a, c, fold, p_enrich, p_deplete, min(1.0, min(p_enrich, p_deplete) * n_motifs)))
+        rows.append((a, c, fold, p_enrich, p_deplete, min(min(p_enrich, p_deplete) * n_motifs, 1)))   # stats.py:40
     return rows

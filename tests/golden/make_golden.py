@@ -225,9 +225,73 @@ def make_small(R):
                       "out": [[s.start, s.score, s.strand] for s in res[0][0]]})
     out["dedup"] = cases
 
+    out["N4"] = make_formats(R, genome, GR, toy, chroms)
+
     with open(os.path.join(HERE, "ref_small.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote ref_small.json")
+
+
+def make_formats(R, genome, GR, toy, chroms):
+    """N4: the reference's own data files (data, not code) with what its parsers make of them, which
+    malformed files it rejects at which line, and the exact text its writers produce."""
+    import glob
+    import tempfile
+    from motifscan.motif import MotifPfms, MotifPwms
+    from motifscan import io as rio, stats as rstats
+    n4 = {"files": {}, "bad": {}}
+    droot = os.path.join(REF, "tests/data/motifs")
+    for rel in ("test/test_pfms.jaspar", "test/test_pwms.motifscan"):
+        n4["files"][rel] = open(os.path.join(droot, rel)).read()
+    pf = MotifPfms()
+    pf.read_pfms(os.path.join(droot, "test/test_pfms.jaspar"))
+    n4["pfms"] = [{"matrix_id": p.matrix_id, "name": p.name, "matrix": p.matrix.tolist()} for p in pf]
+    pw = MotifPwms()
+    pw.read_motifscan_pwms(os.path.join(droot, "test/test_pwms.motifscan"))
+    n4["pwms"] = [{"matrix_id": p.matrix_id, "name": p.name, "matrix": p.matrix.tolist(), "cutoffs": p.cutoffs} for p in pw]
+    for path in sorted(glob.glob(os.path.join(droot, "bad", "*"))):
+        rel = "bad/" + os.path.basename(path)
+        n4["files"][rel] = open(path).read()
+        try:
+            if path.endswith(".jaspar"):
+                MotifPfms().read_pfms(path)
+            else:
+                MotifPwms().read_motifscan_pwms(path)
+            n4["bad"][rel] = None
+        except Exception as e:                     # noqa: BLE001 - record what the reference says
+            n4["bad"][rel] = str(e)
+    with tempfile.TemporaryDirectory() as tmp:
+        # writer of the built-PWM format, incl. a freshly built PWM (5-decimal log-odds, %8.5f columns)
+        built = R["PFM"](n4["pfms"][1]["matrix"], name="Alx1", matrix_id="MA0854.1").to_ppm().to_pwm(
+            {"A": 0.3, "C": 0.3, "G": 0.15, "T": 0.25})
+        built.set_cutoff("1e-3", 0.20892548)
+        built.set_cutoff("1e-4", float(np.around(0.46693615340298805, 8)))
+        mp = MotifPwms(list(pw) + [built])
+        path = os.path.join(tmp, "w.motifscan")
+        mp.write_motifscan_pwms(path)
+        n4["written_pwms"] = open(path).read()
+        n4["built_matrix"] = built.matrix.tolist()
+        # result writers on the whole-chromosome scan of the toy genome at p=1e-2 (both PWMs) and on a
+        # second region set with more sites
+        whole = [GR(chrom=c, start=0, end=len(s)) for c, s in chroms.items()]
+        pwl = list(pw)
+        sites = R["scanner"].Scanner(genome=genome, regions=whole, window_size=0, p_value="1e-2").scan_motifs(pwl)
+        ctrl_regs = [GR(chrom="chr2", start=0, end=12), GR(chrom="chrX", start=2, end=16), GR(chrom="chrM", start=0, end=15)]
+        ctrl = R["scanner"].Scanner(genome=genome, regions=ctrl_regs, window_size=0, p_value="1e-2").scan_motifs(pwl)
+        rio.write_sites_table(tmp, pwl, whole, sites)
+        rio.write_sites_bed(tmp, pwl, whole, sites)
+        enr = rstats.motif_enrichment(pwl, sites, ctrl)
+        rio.write_enrich_table(tmp, enr)
+        n4["writers"] = {
+            "regions": [[r.chrom, r.start, r.end] for r in whole],
+            "control_regions": [[r.chrom, r.start, r.end] for r in ctrl_regs],
+            "p_value": "1e-2",
+            "motif_sites_number.xls": open(os.path.join(tmp, "motif_sites_number.xls")).read(),
+            "motif_sites_score.xls": open(os.path.join(tmp, "motif_sites_score.xls")).read(),
+            "motif_enrichment.xls": open(os.path.join(tmp, "motif_enrichment.xls")).read(),
+            "bed": {os.path.basename(p): open(p).read() for p in sorted(glob.glob(os.path.join(tmp, "motif_sites", "*.bed")))},
+        }
+    return n4
 
 
 # -------------------------------------------------------------------------- random --

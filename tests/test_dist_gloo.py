@@ -97,4 +97,4 @@ def test_enrichment_consumes_reduced_counts():
     assert rows[0][0] == 30 and rows[0][1] == 10 and rows[0][2] == pytest.approx(30 * 200 / 10 / 100)
     assert np.isnan(rows[1][2])
     assert rows[0][3] == fisher_exact([[30, 70], [10, 190]], alternative="greater")[1]
-    assert rows[2][5] == min(1.0, min(rows[2][3], rows[2][4]) * 3)
+    assert rows[2][5] == min(min(rows[2][3], rows[2][4]) * 3, 1)
