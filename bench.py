@@ -167,7 +167,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16 packed integer pre-filter + f64 re-scoring (decision arithmetic = reference fp64)",
+            "dtype": "u10/u16 packed fixed-point pre-filter + f64 re-scoring (decision arithmetic = reference fp64)",
             "data": "synthetic",
             "config": {"workload": {"c4shard": "BASELINE configs[3] per-GPU shard: (125k input + 125k control) regions x 500 bp x 579 PWMs "
                                                "(N=8 is the full 1M+1M config)",
