@@ -44,6 +44,8 @@ struct ClassDesc {
     int32_t G;          // 2-mer groups of every table group in the class
     int32_t n_groups;
     int32_t fb;         // field bits: 16 (4 motifs per 16-byte entry) or 10 (6 motifs)
+    uint32_t base16;    // offset of the class's tables inside the tile, 16-byte units
+    int32_t first_group;   // global index of the class's first table group
 };
 
 struct TileDesc {

@@ -366,7 +366,6 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     __syncthreads();
     const int n_classes = T->n_classes;
-    const int32_t tile_first_group = T->first_group;
     PfWave W;
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
     W.n = 0;
@@ -391,12 +390,18 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
             if (chunk + gridDim.x < n_chunks) cw_next = code_window(A.codes, gn < A.n_bases ? gn : 0);
         }
 
-        uint32_t base16 = 0;
-        int32_t first_group = tile_first_group;
-        for (int c = 0; c < n_classes; c++) {
-            const int G = T->cls[c].G;
-            const int nq = T->cls[c].n_groups;
-            const int fb = T->cls[c].fb;
+        // (walking the classes in a per-wave rotated order, so that the waves do not reach the class
+        // boundaries together, measured 5 % SLOWER: the waves then execute 11 different loops at once)
+        int c = 0;
+        ClassDesc cur = T->cls[c];
+        for (int i = 0; i < n_classes; i++) {
+            c = c + 1 < n_classes ? c + 1 : 0;
+            const ClassDesc nxt = T->cls[c];                      // scalar loads land while this class runs
+            const int G = cur.G;
+            const int nq = cur.n_groups;
+            const int fb = cur.fb;
+            const uint32_t base16 = cur.base16;
+            const int32_t first_group = cur.first_group;
             switch (G) {
                 MS_PF_CASE(1) MS_PF_CASE(2) MS_PF_CASE(3) MS_PF_CASE(4)
                 MS_PF_CASE(5) MS_PF_CASE(6) MS_PF_CASE(7) MS_PF_CASE(8)
@@ -404,8 +409,7 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
                 MS_PF_CASE(13) MS_PF_CASE(14) MS_PF_CASE(15) MS_PF_CASE(16)
                 default: break;
             }
-            base16 += (uint32_t) (G * 16 * nq);
-            first_group += nq;
+            cur = nxt;
         }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);

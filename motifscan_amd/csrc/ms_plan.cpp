@@ -230,6 +230,8 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                     t.cls[t.n_classes].G = plan->group_G[q];
                     t.cls[t.n_classes].fb = plan->group_fb[q];
                     t.cls[t.n_classes].n_groups = 0;
+                    t.cls[t.n_classes].base16 = (uint32_t) used;
+                    t.cls[t.n_classes].first_group = q;
                     t.n_classes++;
                 }
                 t.cls[t.n_classes - 1].n_groups++;
