@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c4shard", choices=["c4shard", "c3", "c2", "tiny"])
+    ap.add_argument("--workload", default="c4shard", choices=["c4shard", "c3", "c2", "c5shard", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -95,31 +95,41 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if world != a.gpus and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
     _lib.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if world != a.gpus and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     wl = synth.workload(a.workload, rank=rank)
     P = wl["n_pwms"]
     pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
-    seqsets = [_lib.SeqSet(b, o, keep_ascii=True) for b, o in wl["sets"]]
+    genome = None
+    if "genome" in wl:                             # configs[4]: windows cut from a genome that is resident in HBM
+        genome = _lib.ResidentGenome({"chr": wl["genome"]})
+        seqsets = [None]
+    else:
+        seqsets = [_lib.SeqSet(b, o, keep_ascii=True) for b, o in wl["sets"]]
     counts = torch.zeros(len(seqsets) * P, dtype=torch.int64, device=dev)
 
     def step():
         stats = []
         for s, sq in enumerate(seqsets):
-            sq.repack()                            # extraction: resident ASCII -> 2-bit codes + N mask
+            if genome is not None:                 # extraction: region list -> bit-level gather on the device
+                sq = genome.extract(*wl["windows"])
+            else:
+                sq.repack()                        # extraction: resident ASCII -> 2-bit codes + N mask
             res = _lib.scan(pw, sq, 3)
             stats.append(res.stats())
             counts[s * P:(s + 1) * P] = torch.from_numpy(res.region_counts()).to(dev, non_blocking=False)
             res.close()
+            if genome is not None:
+                sq.close()
         if world > 1:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (stats.py:29-31 input)
         return stats
@@ -173,8 +183,10 @@ def main():
                                                "(N=8 is the full 1M+1M config)",
                                     "c3": "BASELINE configs[2]: 100k x 1 kb regions x 579 PWMs",
                                     "c2": "BASELINE configs[1]: 10k x 500 bp regions x 50 PWMs",
+                                    "c5shard": "BASELINE configs[4] per-GPU shard: 375 Mbp of genome resident in HBM as 200 bp windows stride 50 "
+                                               "(7.5M windows) x 579 PWMs",
                                     "tiny": "smoke"}[a.workload],
-                       "regions_per_gpu": wl["n_regions"] * len(seqsets), "region_bp": wl["length"], "n_pwms": P,
+                       "regions_per_gpu": wl["n_regions"] * max(len(wl["sets"]), 1), "region_bp": wl["length"], "n_pwms": P,
                        "strands": "both", "p_value": "1e-4", "sharding": f"regions over {world} GPU(s), 1 all-reduce of int64[{len(seqsets) * P}]"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
@@ -188,7 +200,7 @@ def main():
             "hits_per_scan": sum(s["n_hits"] for s in all_stats) / n_launch,
             "candidates_per_scan": sum(s["n_candidates"] for s in all_stats) / n_launch,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and wl["sets"]:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
     if world > 1:

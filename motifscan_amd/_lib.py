@@ -316,8 +316,8 @@ class ResidentGenome:
                                           len(ci), ctypes.byref(h)))
         sq.h = h
         sq.n_seqs = len(ci)
-        sq.offsets = np.concatenate([[0], np.cumsum(en - st)]).astype(np.int64)
-        sq.n_bases = int(sq.offsets[-1])
+        sq.offsets = None                         # lives on the device; not needed on the host
+        sq.n_bases = int((en - st).sum())
         return sq
 
     def close(self):

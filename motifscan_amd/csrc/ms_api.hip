@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -195,8 +196,11 @@ struct ms_seqset {
     int64_t R = 0;
     int64_t n_bases = 0;
     std::vector<int64_t> offsets;         // host copy [R+1]
-    std::vector<int64_t> len_sorted;      // region lengths ascending
-    std::vector<int64_t> len_suffix;      // suffix sums of len_sorted
+    std::vector<int64_t> len_sorted;      // DISTINCT region lengths ascending
+    std::vector<int64_t> len_cnt_ge;      // [i]: number of regions with length >= len_sorted[i]   (+ trailing 0)
+    std::vector<int64_t> len_sum_ge;      // [i]: their total length                              (+ trailing 0)
+    void *block = nullptr;                // one pooled device block holding codes / nmask / offsets / blk2reg
+    size_t block_bytes = 0;
     uint8_t *d_ascii = nullptr;           // kept only when asked to
     uint32_t *d_codes = nullptr;
     uint32_t *d_nmask = nullptr;
@@ -380,8 +384,7 @@ static DevSeq dev_seq(const ms_seqset *s) {
 static int64_t windows_for_width(const ms_seqset *s, int W) {
     const auto it = std::lower_bound(s->len_sorted.begin(), s->len_sorted.end(), (int64_t) W);
     const size_t idx = (size_t) (it - s->len_sorted.begin());
-    const int64_t cnt = (int64_t) (s->len_sorted.size() - idx);
-    return s->len_suffix[idx] - (int64_t) (W - 1) * cnt;
+    return s->len_sum_ge[idx] - (int64_t) (W - 1) * s->len_cnt_ge[idx];
 }
 
 // =============================================================================== API ==
@@ -492,25 +495,64 @@ static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr
     if (n_seqs >= (1LL << 31)) { set_error("too many sequences in one set"); return MS_ERR_INVALID; }
     try {
         s->offsets.assign(offsets, offsets + n_seqs + 1);
-        s->len_sorted.resize((size_t) n_seqs);
-        for (int64_t r = 0; r < n_seqs; r++) s->len_sorted[(size_t) r] = offsets[r + 1] - offsets[r];
-        std::sort(s->len_sorted.begin(), s->len_sorted.end());
-        s->len_suffix.assign((size_t) n_seqs + 1, 0);
-        for (int64_t r = n_seqs - 1; r >= 0; r--) s->len_suffix[(size_t) r] = s->len_suffix[(size_t) r + 1] + s->len_sorted[(size_t) r];
+        // distinct lengths with counts: a direct histogram when the lengths span a small range
+        // (fixed-size windows: one bin), a sort otherwise
+        int64_t lmin = INT64_MAX, lmax = 0;
+        for (int64_t r = 0; r < n_seqs; r++) {
+            const int64_t L = offsets[r + 1] - offsets[r];
+            lmin = std::min(lmin, L);
+            lmax = std::max(lmax, L);
+        }
+        std::vector<std::pair<int64_t, int64_t>> runs;           // (length, count) ascending
+        if (n_seqs > 0 && lmax - lmin <= (1 << 20)) {
+            std::vector<int64_t> hist((size_t) (lmax - lmin + 1), 0);
+            for (int64_t r = 0; r < n_seqs; r++) hist[(size_t) (offsets[r + 1] - offsets[r] - lmin)]++;
+            for (size_t i = 0; i < hist.size(); i++)
+                if (hist[i]) runs.emplace_back(lmin + (int64_t) i, hist[i]);
+        } else if (n_seqs > 0) {
+            std::vector<int64_t> lens((size_t) n_seqs);
+            for (int64_t r = 0; r < n_seqs; r++) lens[(size_t) r] = offsets[r + 1] - offsets[r];
+            std::sort(lens.begin(), lens.end());
+            for (size_t i = 0; i < lens.size();) {
+                size_t j = i;
+                while (j < lens.size() && lens[j] == lens[i]) j++;
+                runs.emplace_back(lens[i], (int64_t) (j - i));
+                i = j;
+            }
+        }
+        const size_t nd = runs.size();
+        s->len_sorted.resize(nd);
+        s->len_cnt_ge.assign(nd + 1, 0);
+        s->len_sum_ge.assign(nd + 1, 0);
+        for (size_t i = nd; i-- > 0;) {
+            s->len_sorted[i] = runs[i].first;
+            s->len_cnt_ge[i] = s->len_cnt_ge[i + 1] + runs[i].second;
+            s->len_sum_ge[i] = s->len_sum_ge[i + 1] + runs[i].first * runs[i].second;
+        }
     } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
     return MS_OK;
 }
 
 static int seqset_alloc_packed(ms_seqset *s) {
     const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
-    int rc;
-    if ((rc = dev_alloc(&s->d_codes, 2 * n_units + kPadWords))) return rc;
-    if ((rc = dev_alloc(&s->d_nmask, n_units + kPadWords))) return rc;
-    if ((rc = dev_alloc(&s->d_offsets, (size_t) s->R + 1))) return rc;
-    if ((rc = dev_alloc(&s->d_blk2reg, (size_t) (s->n_bases / 64 + 2)))) return rc;
-    MS_HIP(hipMemset(s->d_codes, 0, (2 * n_units + kPadWords) * sizeof(uint32_t)));
-    MS_HIP(hipMemset(s->d_nmask, 0, (n_units + kPadWords) * sizeof(uint32_t)));
-    MS_HIP(hipMemcpy(s->d_offsets, s->offsets.data(), ((size_t) s->R + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    const size_t b_codes = (2 * n_units + kPadWords) * sizeof(uint32_t);
+    const size_t b_nmask = (n_units + kPadWords) * sizeof(uint32_t);
+    const size_t b_off = ((size_t) s->R + 1) * sizeof(int64_t);
+    const size_t b_blk = ((size_t) (s->n_bases / 64) + 2) * sizeof(int32_t);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+    DeviceCtx *c;
+    int rc = get_ctx(s->device, &c);
+    if (rc) return rc;
+    if ((rc = pool_alloc(c, up(b_codes) + up(b_nmask) + up(b_off) + up(b_blk), &s->block, &s->block_bytes))) return rc;
+    char *b = static_cast<char *>(s->block);
+    s->d_codes = reinterpret_cast<uint32_t *>(b);
+    s->d_nmask = reinterpret_cast<uint32_t *>(b + up(b_codes));
+    s->d_offsets = reinterpret_cast<int64_t *>(b + up(b_codes) + up(b_nmask));
+    s->d_blk2reg = reinterpret_cast<int32_t *>(b + up(b_codes) + up(b_nmask) + up(b_off));
+    // only the pad words behind the packed data need clearing: the kernels write everything else
+    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), c->stream));
+    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), c->stream));
+    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, c->stream));
     return MS_OK;
 }
 
@@ -583,7 +625,12 @@ int ms_seqset_size(const ms_seqset *s, int64_t *n_seqs, int64_t *n_bases) {
 void ms_seqset_free(ms_seqset *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
-    dev_free(s->d_ascii); dev_free(s->d_codes); dev_free(s->d_nmask); dev_free(s->d_offsets); dev_free(s->d_blk2reg);
+    dev_free(s->d_ascii);
+    if (s->block) {
+        DeviceCtx *c = nullptr;
+        if (get_ctx(s->device, &c) == MS_OK) pool_free(c, s->block, s->block_bytes);
+        else (void) hipFree(s->block);
+    }
     delete s;
 }
 

@@ -819,7 +819,7 @@ int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int
     hipLaunchKernelGGL(nlist_kernel, dim3((unsigned) (want < 4096 ? want : 4096)), dim3(256), 0, st, S.nmask, S.n_bases,
                        max_w, list, n_list, list_cap);
     MS_HIP(hipGetLastError());
-    dim3 grid(1024, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));
+    dim3 grid(256, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));
     hipLaunchKernelGGL(neval_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, list, n_list, list_cap, H);
     MS_HIP(hipGetLastError());
     return MS_OK;

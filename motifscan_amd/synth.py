@@ -27,6 +27,9 @@ WORKLOADS = {
     "tiny": (512, 300, 24, 2),           # smoke / CPU-side tests
 }
 
+# configs[4] (whole-genome sweep, 3 Gbp as 200 bp windows stride 50 over 8 GPUs): one GPU's share
+C5_SHARD = {"genome_bp": 375_000_000, "window": 200, "stride": 50, "n_pwms": 579}
+
 
 def load_motif_set(n_pwms=579, p_value="1e-4"):
     """(pwm_values, widths, cutoffs) of the first n_pwms synthetic JASPAR-like motifs."""
@@ -80,9 +83,28 @@ def make_regions(n_regions, length, seed, frac_n=0.01, frac_lower=0.30, ragged=F
     return bases, offsets
 
 
+def sweep_windows(genome_len, window, stride):
+    """(chrom index, start, end) of the windows of a single-chromosome sweep."""
+    starts = np.arange(0, genome_len - window + 1, stride, dtype=np.int64)
+    return np.zeros(len(starts), dtype=np.int32), starts, starts + window
+
+
 def workload(name, rank=0):
     """Returns dict(pwm_values, widths, cutoffs, sets=[(bases, offsets), ...], units) for a named
     workload; rank shifts the sequence seeds so every GPU scans different regions."""
+    if name == "c5shard":
+        c = C5_SHARD
+        vals, widths, cutoffs = load_motif_set(c["n_pwms"])
+        genome, _ = make_regions(1, c["genome_bp"], seed=5000 + rank, frac_n=0.0)
+        rng = np.random.default_rng(6000 + rank)
+        for _ in range(c["genome_bp"] // 2_000_000):               # assembly gaps: runs of N
+            st = int(rng.integers(0, c["genome_bp"] - 5000))
+            genome[st:st + int(rng.integers(50, 5000))] = ord("N")
+        win = sweep_windows(c["genome_bp"], c["window"], c["stride"])
+        n_win = len(win[0])
+        return {"name": name, "pwm_values": vals, "widths": widths, "cutoffs": cutoffs, "sets": [], "genome": genome,
+                "windows": win, "units": n_win * c["window"] * c["n_pwms"], "n_regions": n_win, "length": c["window"],
+                "n_pwms": c["n_pwms"]}
     n_regions, length, n_pwms, n_sets = WORKLOADS[name]
     vals, widths, cutoffs = load_motif_set(n_pwms)
     sets = [make_regions(n_regions, length, seed=1000 * rank + s + 1) for s in range(n_sets)]
