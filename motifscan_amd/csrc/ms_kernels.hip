@@ -285,67 +285,72 @@ __device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t 
 // The kernel is bound by LDS bandwidth; variant 1 (default) issues the reads of two groups in
 // batches before adding, variant 0 leaves the order to the compiler (kept for A/B runs).
 
-template <int FB>
-__device__ __forceinline__ void test_pair(const PfArgs &A, PfWave &W, const uint4 &acc0, const uint4 &acc1, int32_t group) {
-    const uint32_t any0 = (acc0.x | acc0.y | acc0.z | acc0.w) & Fields<FB>::kTop;
-    const uint32_t any1 = (acc1.x | acc1.y | acc1.z | acc1.w) & Fields<FB>::kTop;
-    if (__any((any0 | any1) != 0) && !A.no_emit) {
-        // usually only one of the two groups has a flagged lane: decode flags only for that one
-        if (__any(any0 != 0)) emit_flags(A, W, group_flags<FB>(acc0), group);
-        if (__any(any1 != 0)) emit_flags(A, W, group_flags<FB>(acc1), group + 1);
+// One loop trip: NG consecutive table groups of a class for the lane's window start.  All NG*G
+// reads are issued as one batch (at most 8 rows at a time when that is more than 16 reads), then
+// added, then ONE test decides whether any of the 64 lanes flagged any field of the NG groups.
+template <int G, int NG, int FB>
+__device__ __forceinline__ void prefilter_trip(const PfArgs &A, PfWave &W, const uint4 *__restrict__ lds4,
+                                               const uint32_t (&a)[G], int32_t group) {
+    uint4 acc[NG];
+    constexpr int B = (NG * G <= 16) ? G : (16 / NG < 1 ? 1 : 16 / NG);      // rows per batch
+#pragma unroll
+    for (int k0 = 0; k0 < G; k0 += B) {
+        uint4 r[NG][B];
+#pragma unroll
+        for (int k = 0; k < B; k++)
+            if (k0 + k < G) {
+#pragma unroll
+                for (int u = 0; u < NG; u++) r[u][k] = lds4[a[k0 + k] + u * G * 16];
+            }
+#pragma unroll
+        for (int k = 0; k < B; k++)
+            if (k0 + k < G) {
+#pragma unroll
+                for (int u = 0; u < NG; u++) {
+                    if (k0 + k == 0) acc[u] = r[u][k];
+                    else add4(acc[u], r[u][k]);
+                }
+            }
+    }
+    uint32_t any[NG], all = 0;
+#pragma unroll
+    for (int u = 0; u < NG; u++) {
+        any[u] = (acc[u].x | acc[u].y | acc[u].z | acc[u].w) & Fields<FB>::kTop;
+        all |= any[u];
+    }
+    if (__any(all != 0) && !A.no_emit) {
+        // usually only one of the groups has a flagged lane: decode flags only for that one
+#pragma unroll
+        for (int u = 0; u < NG; u++)
+            if (NG == 1 || __any(any[u] != 0)) emit_flags(A, W, group_flags<FB>(acc[u]), group + u);
     }
 }
 
-template <int FB>
-__device__ __forceinline__ void test_one(const PfArgs &A, PfWave &W, const uint4 &acc0, int32_t group) {
-    const uint32_t any = (acc0.x | acc0.y | acc0.z | acc0.w) & Fields<FB>::kTop;
-    if (__any(any != 0) && !A.no_emit) emit_flags(A, W, group_flags<FB>(acc0), group);
-}
-
+// All table groups of one class (same 2-mer count G, same field width FB): per group G LDS reads
+// of 16 bytes (2 * 32/FB motifs x {fwd,rev} fields) and (G-1) x 4 packed adds.  A table row of
+// one (group, 2-mer position) is 16 codes x 16 B = 256 B = every LDS bank exactly once, so the
+// read is conflict-free whatever the codes are (SQ_LDS_BANK_CONFLICT = 0, profiles/).
+//
+// The kernel is bound by LDS bandwidth, so a trip covers as many groups as give 12-16 reads in
+// flight per wave (4 groups of narrow motifs, 2 of wide ones); the few groups left over at the
+// end of a class take one smaller trip.  V = 0 keeps the plain two-groups-per-trip form for A/B.
 template <int G, int V, int FB>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
                                                 int n_groups, int32_t first_group, const uint64_t cw, PfWave &W) {
     uint32_t a[G];
 #pragma unroll
     for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + ((uint32_t) (cw >> (4 * k)) & 15u);
+    constexpr int NG = V == 0 ? 2 : (G <= 4 ? 4 : (G == 5 ? 3 : 2));
     int q = 0;
-    for (; q + 2 <= n_groups; q += 2) {
-        uint4 acc0, acc1;
-        if constexpr (V >= 1) {
-            // issue the reads in batches of up to 8 positions x 2 groups, then add
-            constexpr int B = G < 8 ? G : 8;
-            uint4 r0[B], r1[B];
+    for (; q + NG <= n_groups; q += NG) {
+        prefilter_trip<G, NG, FB>(A, W, lds4, a, first_group + q);
 #pragma unroll
-            for (int k0 = 0; k0 < G; k0 += B) {
-#pragma unroll
-                for (int k = 0; k < B; k++)
-                    if (k0 + k < G) { r0[k] = lds4[a[k0 + k]]; r1[k] = lds4[a[k0 + k] + G * 16]; }
-#pragma unroll
-                for (int k = 0; k < B; k++)
-                    if (k0 + k < G) {
-                        if (k0 + k == 0) { acc0 = r0[k]; acc1 = r1[k]; }
-                        else { add4(acc0, r0[k]); add4(acc1, r1[k]); }
-                    }
-            }
-        } else {
-            acc0 = lds4[a[0]];
-            acc1 = lds4[a[0] + G * 16];
-#pragma unroll
-            for (int k = 1; k < G; k++) {
-                add4(acc0, lds4[a[k]]);
-                add4(acc1, lds4[a[k] + G * 16]);
-            }
-        }
-        test_pair<FB>(A, W, acc0, acc1, first_group + q);
-#pragma unroll
-        for (int k = 0; k < G; k++) a[k] += 2 * G * 16;
+        for (int k = 0; k < G; k++) a[k] += NG * G * 16;
     }
-    if (q < n_groups) {
-        uint4 acc0 = lds4[a[0]];
-#pragma unroll
-        for (int k = 1; k < G; k++) add4(acc0, lds4[a[k]]);
-        test_one<FB>(A, W, acc0, first_group + q);
-    }
+    const int rem = n_groups - q;                       // wave-uniform
+    if (NG > 3 && rem == 3) prefilter_trip<G, 3, FB>(A, W, lds4, a, first_group + q);
+    else if (NG > 2 && rem == 2) prefilter_trip<G, 2, FB>(A, W, lds4, a, first_group + q);
+    else if (rem == 1) prefilter_trip<G, 1, FB>(A, W, lds4, a, first_group + q);
 }
 
 #define MS_PF_CASE(GG)                                                                                      \
