@@ -136,6 +136,10 @@ int ms_result_num_hits(const ms_result *res, int64_t *n_hits);
 int ms_result_motif_offsets(const ms_result *res, int64_t *out /* [P+1] */);
 /* Copy the hit arrays to host buffers of length n_hits (any pointer may be NULL). */
 int ms_result_hits(const ms_result *res, int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand);
+/* The same arrays in library-owned pinned host memory (one device-to-host copy at PCIe rate); the
+ * pointers stay valid until the result is freed or de-duplicated. */
+int ms_result_hits_host(ms_result *res, const int64_t **seq_idx, const int64_t **pos, const double **score,
+                        const int8_t **strand);
 int ms_result_region_counts(const ms_result *res, int64_t *out /* [P] */);
 /* Device pointer (int64[P]) of the same counts, for a device-side all-reduce; valid until free. */
 int ms_result_region_counts_device(const ms_result *res, void **d_counts);

@@ -99,6 +99,7 @@ def lib():
         "ms_result_num_hits": (c_int, [vp, pi64]),
         "ms_result_motif_offsets": (c_int, [vp, pi64]),
         "ms_result_hits": (c_int, [vp, pi64, pi64, pd, pi8]),
+        "ms_result_hits_host": (c_int, [vp, ctypes.POINTER(pi64), ctypes.POINTER(pi64), ctypes.POINTER(pd), ctypes.POINTER(pi8)]),
         "ms_result_region_counts": (c_int, [vp, pi64]),
         "ms_result_region_counts_device": (c_int, [vp, pvp]),
         "ms_result_stats": (c_int, [vp, ctypes.POINTER(ScanStats)]),
@@ -340,20 +341,26 @@ class ScanResult:
         self.motif_offsets = np.zeros(n_pwms + 1, dtype=np.int64)
         check(lib().ms_result_motif_offsets(self.h, ptr(self.motif_offsets, ctypes.c_int64)))
         self._hits = None
+        self._hits_owned = True
 
-    def hits(self):
-        """dict of numpy arrays: seq_idx, pos, score, strand (1 '+', 2 '-'), motif."""
-        if self._hits is None:
+    def hits(self, copy=True):
+        """dict of numpy arrays: seq_idx, pos, score, strand (1 '+', 2 '-'), motif.
+        copy=False returns views of the library's pinned host buffers (valid until close())."""
+        if self._hits is None or (copy and not self._hits_owned):
             n = self.n_hits
-            seq = np.zeros(n, dtype=np.int64)
-            pos = np.zeros(n, dtype=np.int64)
-            score = np.zeros(n, dtype=np.float64)
-            strand = np.zeros(n, dtype=np.int8)
-            check(lib().ms_result_hits(self.h, ptr(seq, ctypes.c_int64), ptr(pos, ctypes.c_int64),
-                                       ptr(score, ctypes.c_double), ptr(strand, ctypes.c_int8)))
+            ps, pp = ctypes.POINTER(ctypes.c_int64)(), ctypes.POINTER(ctypes.c_int64)()
+            pv, pd_ = ctypes.POINTER(ctypes.c_double)(), ctypes.POINTER(ctypes.c_int8)()
+            check(lib().ms_result_hits_host(self.h, ctypes.byref(ps), ctypes.byref(pp), ctypes.byref(pv), ctypes.byref(pd_)))
+            if n:
+                arrs = [np.ctypeslib.as_array(q, shape=(n,)) for q in (ps, pp, pv, pd_)]
+                if copy:
+                    arrs = [a.copy() for a in arrs]
+            else:
+                arrs = [np.zeros(0, dtype=t) for t in (np.int64, np.int64, np.float64, np.int8)]
             motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
-            self._hits = {"seq_idx": seq, "pos": pos, "score": score, "strand": strand, "motif": motif,
+            self._hits = {"seq_idx": arrs[0], "pos": arrs[1], "score": arrs[2], "strand": arrs[3], "motif": motif,
                           "motif_offsets": self.motif_offsets}
+            self._hits_owned = copy or n == 0
         return self._hits
 
     def dedup(self, pwms):

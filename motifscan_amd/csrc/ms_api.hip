@@ -144,6 +144,40 @@ static int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
     return MS_OK;
 }
 
+// Pinned host blocks are even dearer to create than device blocks; keep a few for reuse.
+static std::mutex g_pin_mu;
+static std::vector<std::pair<void *, size_t>> g_pin_free;
+
+static void *pinned_alloc(size_t bytes, size_t *got) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        size_t best = (size_t) -1;
+        for (size_t i = 0; i < g_pin_free.size(); i++) {
+            const size_t sz = g_pin_free[i].second;
+            if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && (best == (size_t) -1 || sz < g_pin_free[best].second)) best = i;
+        }
+        if (best != (size_t) -1) {
+            void *p = g_pin_free[best].first;
+            *got = g_pin_free[best].second;
+            g_pin_free.erase(g_pin_free.begin() + (long) best);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+    *got = bytes;
+    return p;
+}
+
+static void pinned_free(void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    size_t total = bytes;
+    for (auto &b : g_pin_free) total += b.second;
+    if (g_pin_free.size() >= 4 || total > (4ull << 30)) { (void) hipHostFree(p); return; }
+    g_pin_free.emplace_back(p, bytes);
+}
+
 static void pool_free(DeviceCtx *c, void *p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(c->pool.mu);
@@ -223,6 +257,9 @@ struct ms_result {
     unsigned long long *d_region_counts = nullptr;   // [P]
     int64_t *d_motif_first = nullptr;                 // [P+1]: after ms_scan returns, the per-motif offsets
     std::vector<int64_t> motif_offsets;               // [P+1]
+    void *h_pinned = nullptr;                         // host copy of the hit arrays (pinned), made on demand
+    size_t h_pinned_bytes = 0;
+    int64_t h_pinned_hits = -1;
     ms_scan_stats stats;
 };
 
@@ -971,6 +1008,35 @@ int ms_result_hits(const ms_result *r, int64_t *seq_idx, int64_t *pos, double *s
     return MS_OK;
 }
 
+// Hit arrays in library-owned PINNED host memory (one D2H copy at PCIe rate instead of four copies
+// into pageable buffers).  The pointers stay valid until the result is freed or de-duplicated.
+int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **pos, const double **score,
+                        const int8_t **strand) {
+    if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const size_t n = (size_t) r->n_hits;
+    const size_t n_round = (n + 65535) & ~(size_t) 65535;
+    const size_t bytes = 25 * n_round + 64;
+    if (r->h_pinned_hits != r->n_hits || !r->h_pinned) {
+        if (r->h_pinned && r->h_pinned_bytes < bytes) { pinned_free(r->h_pinned, r->h_pinned_bytes); r->h_pinned = nullptr; }
+        if (!r->h_pinned) {
+            r->h_pinned = pinned_alloc(bytes, &r->h_pinned_bytes);
+            if (!r->h_pinned) { set_error("pinned host allocation of %zu bytes failed", bytes); return MS_ERR_NOMEM; }
+        }
+        if (n > 0) {
+            MS_HIP(hipSetDevice(r->device));
+            // seq_idx | pos | score | strand are consecutive in the device block (n_round elements apart)
+            MS_HIP(hipMemcpy(r->h_pinned, r->d_seq_idx, 24 * n_round + n, hipMemcpyDeviceToHost));
+        }
+        r->h_pinned_hits = r->n_hits;
+    }
+    char *b = static_cast<char *>(r->h_pinned);
+    if (seq_idx) *seq_idx = reinterpret_cast<const int64_t *>(b);
+    if (pos) *pos = reinterpret_cast<const int64_t *>(b + 8 * n_round);
+    if (score) *score = reinterpret_cast<const double *>(b + 16 * n_round);
+    if (strand) *strand = reinterpret_cast<const int8_t *>(b + 24 * n_round);
+    return MS_OK;
+}
+
 int ms_result_region_counts(const ms_result *r, int64_t *out) {
     if (!r || (!out && r->P > 0)) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->P == 0) return MS_OK;
@@ -1048,6 +1114,7 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     r->n_hits = (int64_t) n_kept;
     r->motif_offsets = off;
     r->deduped = true;
+    r->h_pinned_hits = -1;                            // host copy (if any) is stale
     return MS_OK;
 }
 
@@ -1079,6 +1146,7 @@ int ms_result_site_tables(const ms_result *r, int32_t *n_sites, double *max_scor
 void ms_result_free(ms_result *r) {
     if (!r) return;
     (void) hipSetDevice(r->device);
+    if (r->h_pinned) pinned_free(r->h_pinned, r->h_pinned_bytes);
     if (r->block) {
         DeviceCtx *c = nullptr;
         if (get_ctx(r->device, &c) == MS_OK) pool_free(c, r->block, r->block_bytes);

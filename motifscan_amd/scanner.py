@@ -121,18 +121,21 @@ class Scanner:
         try:
             if self.remove_dup:
                 res.dedup(pw)                      # scanner.py:156-193 on the device, order preserved
-            h = res.hits()
+            h = res.hits(copy=False)               # views of the library's pinned host buffers (kept alive below)
             region_counts = res.region_counts()
             tables = res.site_tables(len(self.seq_starts)) if with_tables else None
-        finally:
+        except BaseException:
             res.close()
+            raise
+        finally:
             sq.close()
             pw.close()
         starts = np.asarray(self.seq_starts, dtype=np.int64)
         out = {"motif": h["motif"], "region": h["seq_idx"],
                "start": (starts[h["seq_idx"]] + h["pos"]) if len(h["pos"]) else h["pos"],
                "score": h["score"], "strand": h["strand"], "motif_offsets": h["motif_offsets"],
-               "n_regions_with_site": region_counts}      # de-dup never empties a region
+               "n_regions_with_site": region_counts,      # de-dup never empties a region
+               "_result": res}                            # owns the memory behind region / score / strand
         if tables is not None:
             out["n_sites"], out["max_score"] = tables      # what write_sites_table prints (io/__init__.py:23-33)
         return out
