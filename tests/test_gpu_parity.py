@@ -329,6 +329,62 @@ def test_edge_shapes_vs_oracle(oracle):
         cscore.c_scan_motif(ml[:1], [0.1], ["ACGT"], 4, 1)
 
 
+def test_low_complexity_sequences_flood_the_candidate_path(oracle):
+    """Homopolymers and short tandem repeats: whole waves flag the same motif at every position, so the
+    per-wave candidate queues spill on every append and the hit stager overflows to direct emission."""
+    rng = np.random.default_rng(2)
+    vals, widths, cutoffs = synth.load_motif_set(120, p_value="1e-3")
+    mats = [m.copy() for m in synth.matrices_of(vals, widths)]
+    # motifs that match a homopolymer / a dinucleotide repeat at EVERY position (on one strand each)
+    for w, pattern in ((8, "A"), (13, "A"), (10, "AC"), (32, "GGC")):
+        m = np.full((4, w), -3.0)
+        for c in range(w):
+            m["ACGT".index(pattern[c % len(pattern)]), c] = 1.25
+        mats.append(m)
+        cutoffs = np.append(cutoffs, 0.95)
+    vals = np.concatenate([m.ravel() for m in mats])
+    widths = np.array([m.shape[1] for m in mats], dtype=np.int32)
+    # make sure some motifs really match the repeats: consensus of three motifs, repeated
+    cons = ["".join("ACGT"[int(np.argmax(m[:, c]))] for c in range(m.shape[1])) for m in mats[:3]]
+    seqs = ["A" * 3000, "T" * 2500, "AC" * 1500, "GGC" * 900, "acgt" * 700, (cons[0] * 400)[:3000], (cons[1] * 300)[:3000],
+            (cons[2] + "N") * 150, "N" * 500 + cons[0] * 50]
+    seqs += ["".join(rng.choice(list("ACGT"), size=800)) for _ in range(10)]
+    raw = "".join(seqs).encode()
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+    want = oracle.scan_arrays(vals, widths, cutoffs, raw, offsets, 3, 8)
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(raw, offsets), 3)
+    assert_same_hits(res.hits(), want)
+    assert len(want["pos"]) > 15000
+
+
+def test_concurrent_scans_from_threads(oracle):
+    """Handles are re-entrant (no file-scope state, cscore.c:26-34 had it): scans issued from several
+    host threads on the same device give the same results as serial ones."""
+    import threading
+    vals, widths, cutoffs = synth.load_motif_set(60)
+    jobs = []
+    for seed in range(4):
+        bases, offsets = synth.make_regions(300, 400, seed=20 + seed, frac_n=0.03)
+        jobs.append((bases, offsets, oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 4)))
+    pw = _lib.PwmSet(vals, widths, cutoffs)                       # one PWM set shared by all threads
+    out, errs = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                sq = _lib.SeqSet(jobs[i][0], jobs[i][1])
+                out[i] = {k: v.copy() for k, v in _lib.scan(pw, sq, 3).hits().items()}
+        except Exception as e:                                    # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs
+    for i, (_, _, want) in enumerate(jobs):
+        assert_same_hits(out[i], want)
+
+
 def test_unaligned_device_resident_ascii(oracle):
     """ms_seqset_from_device with a pointer that is not 16-byte aligned."""
     torch = pytest.importorskip("torch")
