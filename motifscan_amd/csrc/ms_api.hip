@@ -53,6 +53,8 @@ struct DeviceCtx {
     int device = -1;
     BlockPool pool;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // side stream: the N-window kernels run beside the candidate re-scoring
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev[6] = {};
     int n_cu = 0;
     size_t lds_max = 0;
@@ -87,6 +89,9 @@ static int get_ctx(int device, DeviceCtx **out) {
     if (c->lds_max < 65536) c->lds_max = 65536;
     if (c->lds_max > 163840) c->lds_max = 163840;
     MS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    MS_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    MS_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (auto &ev : c->ev) MS_HIP(hipEventCreate(&ev));
     MS_HIP(hipMalloc(&c->sc.counters, 4 * sizeof(unsigned long long)));
     MS_HIP(hipHostMalloc(&c->sc.h_counters, 4 * sizeof(unsigned long long)));
@@ -886,9 +891,15 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         }
         (void) hipEventRecord(c->ev[1], c->stream);
         if (!plan.fast_motifs.empty()) {
+            // two independent latency-bound jobs, both appending hits: run them side by side
+            // (forked AFTER the pre-filter, whose blocks need whole CUs to themselves)
+            (void) hipEventRecord(c->ev_fork, c->stream);
+            (void) hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
             if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), fast_max_w, strand_mask,
-                                     sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->stream))) return fail(rc);
+                                     sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->stream2))) return fail(rc);
+            (void) hipEventRecord(c->ev_join, c->stream2);
             if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+            (void) hipStreamWaitEvent(c->stream, c->ev_join, 0);
         }
         if (!plan.exact_motifs.empty())
             if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return fail(rc);

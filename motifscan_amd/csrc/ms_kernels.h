@@ -5,7 +5,7 @@
 namespace ms {
 
 constexpr int kPfThreads = 1024;      // largest pre-filter block: 16 waves, one block per CU
-constexpr int kNwMotifChunk = 4;      // motifs per neval_kernel thread
+constexpr int kNwMotifChunk = 8;      // motifs per neval_kernel thread
 constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spilled to HBM when the next append would not fit
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
 

@@ -70,7 +70,8 @@ __device__ __forceinline__ int64_t find_region_bsearch(const int64_t *__restrict
 }
 
 // fp64 scores of one window in the reference's order: c = 0..W-1, forward adds M[row][c],
-// reverse adds M[3-row][W-1-c], non-ACGT adds nothing (cscore.c:345-354).
+// reverse adds M[3-row][W-1-c], non-ACGT adds nothing (cscore.c:345-354).  The table entries of
+// eight columns are fetched together (independent loads), then added strictly in column order.
 __device__ __forceinline__ void score_window(const DevSeq &S, const double2 *__restrict__ tab, int W,
                                              int64_t g, double &fwd, double &rev) {
     fwd = 0.0;
@@ -79,12 +80,22 @@ __device__ __forceinline__ void score_window(const DevSeq &S, const double2 *__r
         const uint64_t cw = code_window(S.codes, g + c0);
         const uint32_t nw = n_window(S.nmask, g + c0);
         const int n = (W - c0) < 32 ? (W - c0) : 32;
-        for (int c = 0; c < n; c++) {
-            if ((nw >> c) & 1u) continue;
-            const uint32_t b = (uint32_t) (cw >> (2 * c)) & 3u;
-            const double2 t = tab[(c0 + c) * 4 + b];
-            fwd += t.x;
-            rev += t.y;
+        for (int c1 = 0; c1 < n; c1 += 8) {
+            double2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = c1 + k;
+                const uint32_t b = (uint32_t) (cw >> (2 * (c & 31))) & 3u;
+                t[k] = tab[(c0 + (c < n ? c : n - 1)) * 4 + b];               // clamped: always a valid entry
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = c1 + k;
+                if (c < n && !((nw >> c) & 1u)) {
+                    fwd += t[k].x;
+                    rev += t[k].y;
+                }
+            }
         }
     }
 }
@@ -824,7 +835,7 @@ int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int
     hipLaunchKernelGGL(nlist_kernel, dim3((unsigned) (want < 4096 ? want : 4096)), dim3(256), 0, st, S.nmask, S.n_bases,
                        max_w, list, n_list, list_cap);
     MS_HIP(hipGetLastError());
-    dim3 grid(256, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));
+    dim3 grid(64, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));      // few, fat blocks: block dispatch, not work, bounds this kernel
     hipLaunchKernelGGL(neval_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, list, n_list, list_cap, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
