@@ -853,7 +853,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += kWqBytes;
     // measurement switches (not part of the interface): kernel variant, drop candidates
-    int pf_variant = 1, pf_no_emit = 0;
+    int pf_variant = 4, pf_no_emit = 0;
     if (const char *e = getenv("MS_PF_VARIANT")) pf_variant = atoi(e) & 7;
     if (const char *e = getenv("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
     const bool pf_clock = getenv("MS_PF_CLOCK") && atoi(getenv("MS_PF_CLOCK")) != 0;

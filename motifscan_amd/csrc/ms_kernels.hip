@@ -299,29 +299,103 @@ __device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t 
 // One loop trip: NG consecutive table groups of a class for the lane's window start.  All NG*G
 // reads are issued as one batch (at most 8 rows at a time when that is more than 16 reads), then
 // added, then ONE test decides whether any of the 64 lanes flagged any field of the NG groups.
-template <int G, int NG, int FB>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ds_read_b128 issued by hand: hipcc's scheduler otherwise splits a trip's reads into per-group
+// batches of G with a full lgkmcnt(0) drain between them (kernel .s), i.e. keeps only ~6 reads in
+// flight per wave.  The loads below are issued back to back; ONE s_waitcnt lgkmcnt(0) +
+// sched_barrier follows (hipcc tracks neither inline-asm loads nor their waits).  lgkmcnt(0) also
+// covers any scalar load in flight, so no counted wait has to reason about SMEM's out-of-order
+// returns.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128_asm(uint32_t byte_addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(byte_addr), "n"(OFF));
+    return r;
+}
+
+// s_waitcnt lgkmcnt(rows_left * NG), as an immediate
+template <int NG>
+__device__ __forceinline__ void wait_lgkm(int rows_left) {
+    switch (rows_left * NG) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
+        default: break;                                   // >= 15 outstanding: nothing to wait for yet
+    }
+}
+
+template <int G, int NG, int FB, bool ASM, bool PROG>
 __device__ __forceinline__ void prefilter_trip(const PfArgs &A, PfWave &W, const uint4 *__restrict__ lds4,
                                                const uint32_t (&a)[G], int32_t group) {
     uint4 acc[NG];
     constexpr int B = (NG * G <= 16) ? G : (16 / NG < 1 ? 1 : 16 / NG);      // rows per batch
+    if constexpr (ASM) {
+        // a[] holds BYTE addresses here
 #pragma unroll
-    for (int k0 = 0; k0 < G; k0 += B) {
-        uint4 r[NG][B];
+        for (int k0 = 0; k0 < G; k0 += B) {
+            u32x4 r[NG][B];
 #pragma unroll
-        for (int k = 0; k < B; k++)
-            if (k0 + k < G) {
-#pragma unroll
-                for (int u = 0; u < NG; u++) r[u][k] = lds4[a[k0 + k] + u * G * 16];
-            }
-#pragma unroll
-        for (int k = 0; k < B; k++)
-            if (k0 + k < G) {
-#pragma unroll
-                for (int u = 0; u < NG; u++) {
-                    if (k0 + k == 0) acc[u] = r[u][k];
-                    else add4(acc[u], r[u][k]);
+            for (int k = 0; k < B; k++)
+                if (k0 + k < G) {
+                    if constexpr (NG >= 1) r[0][k] = lds_read128_asm<0>(a[k0 + k]);
+                    if constexpr (NG >= 2) r[1][k] = lds_read128_asm<1 * G * 256>(a[k0 + k]);
+                    if constexpr (NG >= 3) r[2][k] = lds_read128_asm<2 * G * 256>(a[k0 + k]);
+                    if constexpr (NG >= 4) r[3][k] = lds_read128_asm<3 * G * 256>(a[k0 + k]);
                 }
+            if constexpr (!PROG) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int k = 0; k < B; k++)
+                if (k0 + k < G) {
+                    if constexpr (PROG) {
+                        // LDS returns in order and nothing else is on lgkmcnt inside the trip loop: row k of
+                        // all NG groups is back once at most (rows still behind it) x NG reads are outstanding
+                        const int rows_in_batch = (G - k0) < B ? (G - k0) : B;       // folds after unrolling
+                        wait_lgkm<NG>(rows_in_batch - 1 - k);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NG; u++) {
+                        if (k0 + k == 0) { acc[u].x = r[u][k].x; acc[u].y = r[u][k].y; acc[u].z = r[u][k].z; acc[u].w = r[u][k].w; }
+                        else { acc[u].x += r[u][k].x; acc[u].y += r[u][k].y; acc[u].z += r[u][k].z; acc[u].w += r[u][k].w; }
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int k0 = 0; k0 < G; k0 += B) {
+            uint4 r[NG][B];
+#pragma unroll
+            for (int k = 0; k < B; k++)
+                if (k0 + k < G) {
+#pragma unroll
+                    for (int u = 0; u < NG; u++) r[u][k] = lds4[a[k0 + k] + u * G * 16];
+                }
+#pragma unroll
+            for (int k = 0; k < B; k++)
+                if (k0 + k < G) {
+#pragma unroll
+                    for (int u = 0; u < NG; u++) {
+                        if (k0 + k == 0) acc[u] = r[u][k];
+                        else add4(acc[u], r[u][k]);
+                    }
+                }
+        }
     }
     uint32_t any[NG], all = 0;
 #pragma unroll
@@ -344,24 +418,29 @@ __device__ __forceinline__ void prefilter_trip(const PfArgs &A, PfWave &W, const
 //
 // The kernel is bound by LDS bandwidth, so a trip covers as many groups as give 12-16 reads in
 // flight per wave (4 groups of narrow motifs, 2 of wide ones); the few groups left over at the
-// end of a class take one smaller trip.  V = 0 keeps the plain two-groups-per-trip form for A/B.
+// end of a class take one smaller trip.  Variants (A/B runs, tools/pf_variants.py): V = 0 two groups
+// per trip; V = 1 trips sized by width, reads left to hipcc; V = 3 reads issued by hand, one wait;
+// V = 4 (default) reads issued by hand, counted waits so the adds start as rows arrive.
 template <int G, int V, int FB>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
                                                 int n_groups, int32_t first_group, const uint64_t cw, PfWave &W) {
+    constexpr bool ASM = V == 3 || V == 4;
+    constexpr bool PROG = V == 4;
+    constexpr uint32_t unit = ASM ? 16u : 1u;          // a[] in bytes (hand-issued reads) or in 16-byte entries
     uint32_t a[G];
 #pragma unroll
-    for (int k = 0; k < G; k++) a[k] = base16 + (uint32_t) k * 16u + ((uint32_t) (cw >> (4 * k)) & 15u);
+    for (int k = 0; k < G; k++) a[k] = (base16 + (uint32_t) k * 16u + ((uint32_t) (cw >> (4 * k)) & 15u)) * unit;
     constexpr int NG = V == 0 ? 2 : (G <= 4 ? 4 : (G == 5 ? 3 : 2));
     int q = 0;
     for (; q + NG <= n_groups; q += NG) {
-        prefilter_trip<G, NG, FB>(A, W, lds4, a, first_group + q);
+        prefilter_trip<G, NG, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
 #pragma unroll
-        for (int k = 0; k < G; k++) a[k] += NG * G * 16;
+        for (int k = 0; k < G; k++) a[k] += NG * G * 16 * unit;
     }
     const int rem = n_groups - q;                       // wave-uniform
-    if (NG > 3 && rem == 3) prefilter_trip<G, 3, FB>(A, W, lds4, a, first_group + q);
-    else if (NG > 2 && rem == 2) prefilter_trip<G, 2, FB>(A, W, lds4, a, first_group + q);
-    else if (rem == 1) prefilter_trip<G, 1, FB>(A, W, lds4, a, first_group + q);
+    if (NG > 3 && rem == 3) prefilter_trip<G, 3, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
+    else if (NG > 2 && rem == 2) prefilter_trip<G, 2, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
+    else if (rem == 1) prefilter_trip<G, 1, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
 }
 
 #define MS_PF_CASE(GG)                                                                                      \
@@ -803,10 +882,12 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 typedef void (*PfKernel)(const PfArgs);
 
 static PfKernel pf_kernel_for(int variant, int *threads) {
-    switch (variant) {
-        case 0: *threads = 1024; return prefilter_kernel<1024, 0, 4>;
+    switch (variant) {                                                    // measurement switch MS_PF_VARIANT
+        case 0: *threads = 1024; return prefilter_kernel<1024, 0, 4>;     // two groups per trip, compiler-ordered reads
+        case 1: *threads = 1024; return prefilter_kernel<1024, 1, 4>;     // 2-4 groups per trip, compiler-ordered reads
+        case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
-        default: *threads = 1024; return prefilter_kernel<1024, 1, 4>;
+        default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }
 
