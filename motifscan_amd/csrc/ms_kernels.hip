@@ -288,14 +288,6 @@ __device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t 
     W.n += n_new;
 }
 
-// All table groups of one class (same 2-mer count G, same field width FB): per group G LDS reads
-// of 16 bytes (2 * 32/FB motifs x {fwd,rev} fields) and (G-1) x 4 packed adds.  A table row of
-// one (group, 2-mer position) is 16 codes x 16 B = 256 B = every LDS bank exactly once, so the
-// read is conflict-free whatever the codes are (SQ_LDS_BANK_CONFLICT = 0, profiles/).
-//
-// The kernel is bound by LDS bandwidth; variant 1 (default) issues the reads of two groups in
-// batches before adding, variant 0 leaves the order to the compiler (kept for A/B runs).
-
 // One loop trip: NG consecutive table groups of a class for the lane's window start.  All NG*G
 // reads are issued as one batch (at most 8 rows at a time when that is more than 16 reads), then
 // added, then ONE test decides whether any of the 64 lanes flagged any field of the NG groups.
@@ -420,7 +412,9 @@ __device__ __forceinline__ void prefilter_trip(const PfArgs &A, PfWave &W, const
 // flight per wave (4 groups of narrow motifs, 2 of wide ones); the few groups left over at the
 // end of a class take one smaller trip.  Variants (A/B runs, tools/pf_variants.py): V = 0 two groups
 // per trip; V = 1 trips sized by width, reads left to hipcc; V = 3 reads issued by hand, one wait;
-// V = 4 (default) reads issued by hand, counted waits so the adds start as rows arrive.
+// V = 4 (default) reads issued by hand, counted waits so the adds start as rows arrive.  (A fully
+// double-buffered form -- next trip's reads queued behind the current one's -- measured 6 % slower:
+// one group per trip costs more test instructions than the shorter LDS queue gaps win.)
 template <int G, int V, int FB>
 __device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
                                                 int n_groups, int32_t first_group, const uint64_t cw, PfWave &W) {
