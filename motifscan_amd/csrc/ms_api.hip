@@ -214,6 +214,7 @@ struct ms_pwmset {
     int32_t *d_width = nullptr;
     double *d_max_raw = nullptr;
     double *d_cutoff = nullptr;
+    double *d_raw_floor = nullptr;
     // pre-filter plan (lazy, keyed by strand mask / cutoffs / LDS budget / exact-only)
     PrefilterPlan plan;
     int plan_strand = -1;
@@ -299,7 +300,7 @@ static double c_max_raw(const double *m, int W) {
 
 static void pwmset_free_device(ms_pwmset *p) {
     if (p->device >= 0 || p->plan_device >= 0) (void) hipSetDevice(p->device >= 0 ? p->device : p->plan_device);
-    dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff);
+    dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff); dev_free(p->d_raw_floor);
     dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
     dev_free(p->d_exact_motifs);
     p->device = -1;
@@ -335,6 +336,7 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
         if ((rc = dev_alloc(&p->d_width, (size_t) p->P))) return rc;
         if ((rc = dev_alloc(&p->d_max_raw, (size_t) p->P))) return rc;
         if ((rc = dev_alloc(&p->d_cutoff, (size_t) p->P))) return rc;
+        if ((rc = dev_alloc(&p->d_raw_floor, (size_t) p->P))) return rc;
         if (p->P > 0) {
             MS_HIP(hipMemcpy(p->d_tab2, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice));
             MS_HIP(hipMemcpy(p->d_tab_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -345,8 +347,29 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
         p->dev_cutoff_version = 0;
     }
     if (p->dev_cutoff_version != p->cutoff_version) {
-        if (p->P > 0)
+        if (p->P > 0) {
             MS_HIP(hipMemcpy(p->d_cutoff, p->cutoffs.data(), (size_t) p->P * sizeof(double), hipMemcpyHostToDevice));
+            // raw-sum floor of the hit test (same bound as ms_plan.cpp's T, with twice its slack): a window whose
+            // fp64 column sum is below it fails `sum / max_raw - cutoff >= -1e-10` for sure
+            std::vector<double> fl((size_t) p->P);
+            for (int32_t i = 0; i < p->P; i++) {
+                const int W = p->widths[i];
+                const double *m = p->values.data() + p->val_off[i];
+                double abs_sum = 0;
+                bool finite = std::isfinite(p->max_raw[i]) && p->max_raw[i] > 0 && std::isfinite(p->cutoffs[i]);
+                for (int c = 0; c < W && finite; c++) {
+                    double colmax = 0;
+                    for (int b = 0; b < 4; b++) {
+                        const double v = m[(int64_t) b * W + c];
+                        if (!std::isfinite(v)) { finite = false; break; }
+                        colmax = std::max(colmax, std::fabs(v));
+                    }
+                    abs_sum += colmax;
+                }
+                fl[(size_t) i] = finite ? (p->cutoffs[i] - 1e-10) * p->max_raw[i] - 2e-9 * (1.0 + abs_sum) : -INFINITY;
+            }
+            MS_HIP(hipMemcpy(p->d_raw_floor, fl.data(), (size_t) p->P * sizeof(double), hipMemcpyHostToDevice));
+        }
         p->dev_cutoff_version = p->cutoff_version;
     }
     (void) st;
@@ -411,7 +434,7 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
 static DevPwm dev_pwm(const ms_pwmset *p) {
     DevPwm d;
     d.tab2 = p->d_tab2; d.tab_off = p->d_tab_off; d.width = p->d_width; d.max_raw = p->d_max_raw;
-    d.cutoff = p->d_cutoff; d.P = p->P;
+    d.cutoff = p->d_cutoff; d.raw_floor = p->d_raw_floor; d.P = p->P;
     return d;
 }
 
@@ -1228,7 +1251,7 @@ int ms_score_ranks(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_ma
     for (int32_t p0 = 0; rc == MS_OK && he == hipSuccess && p0 < pwms->P; p0 += batch) {
         const int32_t n = std::min(batch, pwms->P - p0);
         DevPwm sub = dev_pwm(pwms);
-        sub.tab_off += p0; sub.width += p0; sub.max_raw += p0; sub.cutoff += p0; sub.P = n;
+        sub.tab_off += p0; sub.width += p0; sub.max_raw += p0; sub.cutoff += p0; sub.raw_floor += p0; sub.P = n;
         rc = launch_score(S, sub, strand_mask, d_scores, c->stream);
         for (int32_t i = 0; rc == MS_OK && i < n; i++) {
             size_t tb = tmp_bytes;

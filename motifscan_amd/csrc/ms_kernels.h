@@ -24,6 +24,7 @@ struct DevPwm {
     const int32_t *width;     // [P]
     const double *max_raw;    // [P]
     const double *cutoff;     // [P]
+    const double *raw_floor;  // [P] a raw (un-normalised) sum below this can never pass the hit test (-inf if unknown)
     int32_t P;
 };
 

@@ -100,6 +100,30 @@ __device__ __forceinline__ void score_window(const DevSeq &S, const double2 *__r
     }
 }
 
+// The same for W <= 32 with the lane's code / mask windows already in registers
+__device__ __forceinline__ void score_window32(const double2 *__restrict__ tab, int W, uint64_t cw, uint32_t nw,
+                                               double &fwd, double &rev) {
+    fwd = 0.0;
+    rev = 0.0;
+    for (int c1 = 0; c1 < W; c1 += 8) {
+        double2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = c1 + k;
+            const uint32_t b = (uint32_t) (cw >> (2 * (c & 31))) & 3u;
+            t[k] = tab[(c < W ? c : W - 1) * 4 + b];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = c1 + k;
+            if (c < W && !((nw >> c) & 1u)) {
+                fwd += t[k].x;
+                rev += t[k].y;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void emit_hit(const HitOut &H, uint32_t motif, int64_t g, uint32_t sbit, double score) {
     const unsigned long long i = atomicAdd(H.n_hits, 1ULL);
     if (i < H.cap) {
@@ -111,13 +135,20 @@ __device__ __forceinline__ void emit_hit(const HitOut &H, uint32_t motif, int64_
 // the reference's normalisation and threshold test, verbatim (cscore.c:356-358 / 373-375)
 __device__ __forceinline__ void test_and_emit(const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
                                               double fwd, double rev, int strand_mask) {
+    // raw_floor: (cutoff - 1e-10) * max_raw minus 2000x the worst fp64 rounding of the sum, the divide and
+    // the subtract (ms_api.hip): below it the reference's test is false whatever the roundings do, so the
+    // two IEEE divides are only paid by windows that can actually be hits
+    const double floor_ = Pw.raw_floor[motif];
+    const bool try_f = (strand_mask & 1) && !(fwd < floor_);
+    const bool try_r = (strand_mask & 2) && !(rev < floor_);
+    if (!try_f && !try_r) return;
     const double max_raw = Pw.max_raw[motif];
     const double cutoff = Pw.cutoff[motif];
-    if (strand_mask & 1) {
+    if (try_f) {
         const double s = fwd / max_raw;
         if (s - cutoff >= -1e-10) emit_hit(H, motif, g, 0u, s);
     }
-    if (strand_mask & 2) {
+    if (try_r) {
         const double s = rev / max_raw;
         if (s - cutoff >= -1e-10) emit_hit(H, motif, g, 1u, s);
     }
@@ -159,13 +190,17 @@ __device__ __forceinline__ void stage_flush(HitStage &st, const HitOut &H) {
 
 __device__ __forceinline__ void test_and_stage(HitStage &st, const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
                                                double fwd, double rev, int strand_mask) {
+    const double floor_ = Pw.raw_floor[motif];               // see test_and_emit
+    const bool try_f = (strand_mask & 1) && !(fwd < floor_);
+    const bool try_r = (strand_mask & 2) && !(rev < floor_);
+    if (!try_f && !try_r) return;
     const double max_raw = Pw.max_raw[motif];
     const double cutoff = Pw.cutoff[motif];
-    if (strand_mask & 1) {
+    if (try_f) {
         const double s = fwd / max_raw;
         if (s - cutoff >= -1e-10) stage_hit(st, H, motif, g, 0u, s);
     }
-    if (strand_mask & 2) {
+    if (try_r) {
         const double s = rev / max_raw;
         if (s - cutoff >= -1e-10) stage_hit(st, H, motif, g, 1u, s);
     }
@@ -553,15 +588,16 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
          i += (unsigned long long) gridDim.x * blockDim.x) {
         const int64_t g = list[i];
         const uint32_t nw = n_window(S.nmask, g);
+        const uint64_t cw = code_window(S.codes, g);
         const int64_t r = find_region(S, g);
         const int64_t end = S.offsets[r + 1];
         for (int m = m0; m < m1; m++) {
             const int32_t p = motifs[m];
-            const int W = Pw.width[p];
+            const int W = Pw.width[p];                          // <= 32: only pre-filter motifs come here
             if ((nw & low_mask(W)) == 0) continue;
             if (g + W > end) continue;
             double fwd, rev;
-            score_window(S, Pw.tab2 + Pw.tab_off[p], W, g, fwd, rev);
+            score_window32(Pw.tab2 + Pw.tab_off[p], W, cw, nw, fwd, rev);
             test_and_emit(H, Pw, (uint32_t) p, g, fwd, rev, strand_mask);
         }
     }
@@ -604,6 +640,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             const int64_t r = find_region(S, g);
             const int64_t end = S.offsets[r + 1];
             const uint32_t nw = n_window(S.nmask, g);
+            const uint64_t cw = code_window(S.codes, g);
             while (flags) {
                 const int slot = (__ffs((int) flags) - 1) >> 1;
                 flags &= flags - 1u;
@@ -613,7 +650,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
                 if (g + W > end) continue;                              // window runs past its region (cscore.c:340)
                 if (nw & low_mask(W)) continue;                         // scored by neval_kernel
                 double fwd, rev;
-                score_window(S, Pw.tab2 + Pw.tab_off[pm], W, g, fwd, rev);
+                score_window32(Pw.tab2 + Pw.tab_off[pm], W, cw, 0u, fwd, rev);      // no N in the window (checked above)
                 test_and_stage(st, H, Pw, (uint32_t) pm, g, fwd, rev, strand_mask);
             }
         }
@@ -995,7 +1032,7 @@ int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out
     for (int32_t p0 = 0; p0 < Pw.P; p0 += 32768) {
         const int32_t n = Pw.P - p0 < 32768 ? Pw.P - p0 : 32768;
         DevPwm sub = Pw;
-        sub.tab_off += p0; sub.width += p0; sub.max_raw += p0; sub.cutoff += p0; sub.P = n;
+        sub.tab_off += p0; sub.width += p0; sub.max_raw += p0; sub.cutoff += p0; sub.raw_floor += p0; sub.P = n;
         dim3 grid((unsigned) ((S.R + 255) / 256), (unsigned) n);
         hipLaunchKernelGGL(score_kernel, grid, dim3(256), 0, st, S, sub, strand_mask, out + (int64_t) p0 * S.R);
         MS_HIP(hipGetLastError());
