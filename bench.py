@@ -177,7 +177,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u10/u16 packed fixed-point pre-filter + f64 re-scoring (decision arithmetic = reference fp64)",
+            "dtype": "f64 (every hit decision and score, as in the reference) behind a u32 pre-filter of three packed 10-bit fixed-point fields",
             "data": "synthetic",
             "config": {"workload": {"c4shard": "BASELINE configs[3] per-GPU shard: (125k input + 125k control) regions x 500 bp x 579 PWMs "
                                                "(N=8 is the full 1M+1M config)",

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurements for the SURVEY.md 8(f) rows built on top of the scan path (N1-N3), with the CPU
 reference beside them where the reference has a counterpart.  Prints one JSON object.
-Usage (GPU box): python tools/next_rows_bench.py"""
+Usage (GPU box): python tests/perf_next_rows.py   (lives under tests/ because it times the oracle / the real reference beside the GPU rows)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
