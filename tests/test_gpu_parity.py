@@ -448,6 +448,47 @@ def test_full_size_properties_c3_shape(oracle):
     assert np.array_equal(h["pos"][m], hs["pos"]) and np.array_equal(h["score"][m], hs["score"])
 
 
+def test_many_motifs_several_tiles_by_default(oracle, jaspar579):
+    """1737 motifs (the set three times over, the copies with shifted cutoffs): ~290 table groups that no
+    longer fit one LDS tile, group ids beyond 8 bits -- default settings, no measurement switches."""
+    vals = np.tile(jaspar579["pwm_values"], 3)
+    widths = np.tile(jaspar579["widths"], 3)
+    c = jaspar579["cutoffs"]
+    cutoffs = np.concatenate([c["1e-4"], c["1e-3"], c["1e-5"]])
+    bases, offsets = synth.make_regions(60, 400, seed=8, frac_n=0.05, ragged=True)
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), 3)
+    assert_same_hits(res.hits(), want)
+    assert res.stats()["n_tiles"] >= 2 and res.stats()["n_pwms_exact"] == 0
+
+
+def test_positions_beyond_2_to_the_31(oracle):
+    """A sequence set of 2.4e9 bases (windows cut from a resident genome): every position / index on
+    the device must be 64-bit.  The tail of the set (beyond 2^31) is compared with the oracle."""
+    vals, widths, cutoffs = synth.load_motif_set(24)
+    glen, window, stride = 600_000_000, 200, 50
+    genome, _ = synth.make_regions(1, glen, seed=11, frac_n=0.0)
+    genome[glen - 5000:glen - 4900] = ord("N")
+    rg = _lib.ResidentGenome({"chr": genome})
+    ci, st, en = synth.sweep_windows(glen, window, stride)
+    sq = rg.extract(ci, st, en)
+    assert sq.n_bases > 2 ** 31
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), sq, 3)
+    h = res.hits(copy=False)
+    n_tail = 400                                                   # the last windows, compared in full
+    r0 = len(ci) - n_tail
+    tail_bases = np.concatenate([genome[a:b] for a, b in zip(st[r0:], en[r0:])])
+    tail_off = np.arange(n_tail + 1, dtype=np.int64) * window
+    want = oracle.scan_arrays(vals, widths, cutoffs, tail_bases.tobytes(), tail_off, 3, 4)
+    m = h["seq_idx"] >= r0
+    assert m.sum() == len(want["pos"]) > 0
+    assert np.array_equal(h["seq_idx"][m] - r0, want["seq_idx"]) and np.array_equal(h["pos"][m], want["pos"])
+    assert np.array_equal(h["score"][m], want["score"]) and np.array_equal(h["strand"][m].astype(np.int32), want["strand"])
+    key = (h["motif"].astype(np.int64) << 40) | (h["seq_idx"] << 9) | (h["pos"] << 1) | (h["strand"] == 2)
+    assert (np.diff(key) > 0).all()
+    res.close(); sq.close(); rg.close()
+
+
 def test_buffer_growth_path():
     """A cutoff far below the p=1e-4 density forces the candidate / hit buffers to grow (second pass)."""
     vals, widths, _ = synth.load_motif_set(40)
