@@ -318,7 +318,9 @@ class ResidentGenome:
         sq.h = h
         sq.n_seqs = len(ci)
         sq.offsets = None                         # lives on the device; not needed on the host
-        sq.n_bases = int((en - st).sum())
+        nb = ctypes.c_int64()
+        check(lib().ms_seqset_size(sq.h, None, ctypes.byref(nb)))
+        sq.n_bases = nb.value
         return sq
 
     def close(self):

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "ms_kernels.h"
 
@@ -286,6 +287,22 @@ static void result_carve(ms_result *r, void *blk, size_t n) {
     r->d_strand = reinterpret_cast<int8_t *>(r->d_score + n_round);
 }
 
+// Host loops over tens of millions of regions (whole-genome window sweeps) are split over a few threads.
+template <typename F>
+static void parallel_chunks(int64_t n, F fn) {                 // fn(chunk index, begin, end)
+    int T = 1;
+    if (n >= (1 << 20)) T = (int) std::min<int64_t>(16, std::max<int64_t>(1, (int64_t) std::thread::hardware_concurrency()));
+    if (T <= 1) { fn(0, (int64_t) 0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t step = (n + T - 1) / T;
+    for (int t = 0; t < T; t++) {
+        const int64_t b = std::min<int64_t>(n, t * step), e = std::min<int64_t>(n, (t + 1) * step);
+        th.emplace_back([=]() { fn(t, b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+static constexpr int kMaxChunks = 16;
+
 // C-style max_raw: column maxima start at 0 (cscore.c:36-48)
 static double c_max_raw(const double *m, int W) {
     double total = 0;
@@ -545,12 +562,30 @@ void ms_pwmset_free(ms_pwmset *p) {
 
 // -------------------------------------------------------------------- sequence set --
 
-static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr<ms_seqset> &s) {
+static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr<ms_seqset> &s,
+                         std::vector<int64_t> *adopt = nullptr) {
     if (n_seqs < 0) { set_error("n_seqs < 0"); return MS_ERR_INVALID; }
     if (!offsets) { set_error("offsets is NULL"); return MS_ERR_INVALID; }
     if (offsets[0] != 0) { set_error("offsets[0] must be 0"); return MS_ERR_INVALID; }
-    for (int64_t r = 0; r < n_seqs; r++)
-        if (offsets[r + 1] < offsets[r]) { set_error("offsets must be non-decreasing (at %lld)", (long long) r); return MS_ERR_INVALID; }
+    // one pass: monotonicity, shortest and longest sequence
+    int64_t cmin[kMaxChunks], cmax[kMaxChunks], cbad[kMaxChunks];
+    for (int t = 0; t < kMaxChunks; t++) { cmin[t] = INT64_MAX; cmax[t] = 0; cbad[t] = -1; }
+    parallel_chunks(n_seqs, [&](int t, int64_t b, int64_t e) {
+        int64_t mn = INT64_MAX, mx = 0, bad = -1;
+        for (int64_t r = b; r < e; r++) {
+            const int64_t L = offsets[r + 1] - offsets[r];
+            if (L < 0 && bad < 0) bad = r;
+            mn = std::min(mn, L);
+            mx = std::max(mx, L);
+        }
+        cmin[t] = mn; cmax[t] = mx; cbad[t] = bad;
+    });
+    int64_t lmin = INT64_MAX, lmax = 0;
+    for (int t = 0; t < kMaxChunks; t++) {
+        if (cbad[t] >= 0) { set_error("offsets must be non-decreasing (at %lld)", (long long) cbad[t]); return MS_ERR_INVALID; }
+        lmin = std::min(lmin, cmin[t]);
+        lmax = std::max(lmax, cmax[t]);
+    }
     s.reset(new (std::nothrow) ms_seqset());
     if (!s) { set_error("out of host memory"); return MS_ERR_NOMEM; }
     s->device = g_device;
@@ -559,21 +594,24 @@ static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr
     if (s->n_bases > kMaxBases) { set_error("a sequence set holds at most %lld bases; split the regions over several sets", (long long) kMaxBases); return MS_ERR_INVALID; }
     if (n_seqs >= (1LL << 31)) { set_error("too many sequences in one set"); return MS_ERR_INVALID; }
     try {
-        s->offsets.assign(offsets, offsets + n_seqs + 1);
-        // distinct lengths with counts: a direct histogram when the lengths span a small range
+        if (adopt) s->offsets.swap(*adopt);
+        else s->offsets.assign(offsets, offsets + n_seqs + 1);
+        offsets = s->offsets.data();
+        // distinct lengths with counts: direct histograms when the lengths span a small range
         // (fixed-size windows: one bin), a sort otherwise
-        int64_t lmin = INT64_MAX, lmax = 0;
-        for (int64_t r = 0; r < n_seqs; r++) {
-            const int64_t L = offsets[r + 1] - offsets[r];
-            lmin = std::min(lmin, L);
-            lmax = std::max(lmax, L);
-        }
         std::vector<std::pair<int64_t, int64_t>> runs;           // (length, count) ascending
-        if (n_seqs > 0 && lmax - lmin <= (1 << 20)) {
-            std::vector<int64_t> hist((size_t) (lmax - lmin + 1), 0);
-            for (int64_t r = 0; r < n_seqs; r++) hist[(size_t) (offsets[r + 1] - offsets[r] - lmin)]++;
-            for (size_t i = 0; i < hist.size(); i++)
-                if (hist[i]) runs.emplace_back(lmin + (int64_t) i, hist[i]);
+        if (n_seqs > 0 && lmax - lmin <= (1 << 16)) {
+            const size_t bins = (size_t) (lmax - lmin + 1);
+            std::vector<std::vector<int64_t>> hist(kMaxChunks);
+            parallel_chunks(n_seqs, [&](int t, int64_t b, int64_t e) {
+                hist[(size_t) t].assign(bins, 0);
+                for (int64_t r = b; r < e; r++) hist[(size_t) t][(size_t) (offsets[r + 1] - offsets[r] - lmin)]++;
+            });
+            for (size_t i = 0; i < bins; i++) {
+                int64_t cnt = 0;
+                for (int t = 0; t < kMaxChunks; t++) if (!hist[(size_t) t].empty()) cnt += hist[(size_t) t][i];
+                if (cnt) runs.emplace_back(lmin + (int64_t) i, cnt);
+            }
         } else if (n_seqs > 0) {
             std::vector<int64_t> lens((size_t) n_seqs);
             for (int64_t r = 0; r < n_seqs; r++) lens[(size_t) r] = offsets[r + 1] - offsets[r];
@@ -730,22 +768,52 @@ int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_
     if (!g) { set_error("NULL genome"); return MS_ERR_INVALID; }
     if (n_regions < 0 || (n_regions > 0 && (!chrom || !start || !end))) { set_error("bad region arrays"); return MS_ERR_INVALID; }
     const ms_seqset *G = reinterpret_cast<const ms_seqset *>(g);
-    std::vector<int64_t> dst((size_t) n_regions + 1, 0), src((size_t) n_regions + 1, 0);
-    for (int64_t r = 0; r < n_regions; r++) {
-        if (chrom[r] < 0 || chrom[r] >= G->R) { set_error("region %lld: chromosome index %d out of range", (long long) r, chrom[r]); return MS_ERR_INVALID; }
-        const int64_t clen = G->offsets[(size_t) chrom[r] + 1] - G->offsets[(size_t) chrom[r]];
-        if (start[r] < 0 || end[r] < start[r] || end[r] > clen) {
-            set_error("region %lld: [%lld, %lld) is outside chromosome %d of length %lld", (long long) r, (long long) start[r],
-                      (long long) end[r], chrom[r], (long long) clen);
+    std::vector<int64_t> dst, src;
+    try { dst.resize((size_t) n_regions + 1); src.resize((size_t) n_regions + 1); }
+    catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    // pass 1 (threads): validate, source position and length of every region, per-chunk totals
+    int64_t csum[kMaxChunks], cbad[kMaxChunks];
+    for (int t = 0; t < kMaxChunks; t++) { csum[t] = 0; cbad[t] = -1; }
+    const int64_t n_chroms = G->R;
+    const int64_t *goff = G->offsets.data();
+    parallel_chunks(n_regions, [&](int t, int64_t b, int64_t e) {
+        int64_t sum = 0, bad = -1;
+        for (int64_t r = b; r < e; r++) {
+            const int64_t ch = chrom[r];
+            bool ok = ch >= 0 && ch < n_chroms;
+            if (ok) {
+                const int64_t clen = goff[ch + 1] - goff[ch];
+                ok = start[r] >= 0 && end[r] >= start[r] && end[r] <= clen;
+            }
+            if (!ok) { if (bad < 0) bad = r; continue; }
+            src[(size_t) r] = goff[ch] + start[r];
+            dst[(size_t) r + 1] = end[r] - start[r];          // length for now
+            sum += end[r] - start[r];
+        }
+        csum[t] = sum; cbad[t] = bad;
+    });
+    for (int t = 0; t < kMaxChunks; t++)
+        if (cbad[t] >= 0) {
+            const int64_t r = cbad[t];
+            if (chrom[r] < 0 || chrom[r] >= n_chroms) set_error("region %lld: chromosome index %d out of range", (long long) r, chrom[r]);
+            else set_error("region %lld: [%lld, %lld) is outside chromosome %d of length %lld", (long long) r, (long long) start[r],
+                           (long long) end[r], chrom[r], (long long) (goff[chrom[r] + 1] - goff[chrom[r]]));
             return MS_ERR_INVALID;
         }
-        src[(size_t) r] = G->offsets[(size_t) chrom[r]] + start[r];
-        dst[(size_t) r + 1] = dst[(size_t) r] + (end[r] - start[r]);
-    }
+    // pass 2 (threads): lengths -> offsets, every chunk starting at the sum of the chunks before it
+    int64_t cbase[kMaxChunks + 1];
+    cbase[0] = 0;
+    for (int t = 0; t < kMaxChunks; t++) cbase[t + 1] = cbase[t] + csum[t];
+    dst[0] = 0;
+    parallel_chunks(n_regions, [&](int t, int64_t b, int64_t e) {
+        int64_t run = cbase[t];
+        for (int64_t r = b; r < e; r++) { run += dst[(size_t) r + 1]; dst[(size_t) r + 1] = run; }
+    });
+    src[(size_t) n_regions] = 0;
     const int prev_dev = g_device;
     g_device = G->device;                              // the new set lives next to its genome
     std::unique_ptr<ms_seqset> s;
-    int rc = seqset_common(dst.data(), n_regions, s);
+    int rc = seqset_common(dst.data(), n_regions, s, &dst);
     g_device = prev_dev;
     if (rc) return rc;
     DeviceCtx *c;
