@@ -360,7 +360,7 @@ __device__ __forceinline__ void wait_lgkm(int rows_left) {
         case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
         case 13: asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory"); break;
         case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
-        default: break;                                   // >= 15 outstanding: nothing to wait for yet
+        default: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;   // 15 cannot be relied on (4-bit counter): a stricter wait is never wrong
     }
 }
 
