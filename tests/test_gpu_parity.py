@@ -404,7 +404,7 @@ def test_full_size_properties_c3_shape(oracle):
     """configs[2] shape (100k x 1 kb x 579): too big for the CPU checker, so check properties:
     (1) order and ranges, (2) pre-filter path == all-fp64 path on a slice, (3) strand 3 is the
     union of strands 1 and 2, (4) region counts follow from the hits, (5) repeat == same,
-    (6) a 300-region sample equals the oracle bit for bit."""
+    (6) a 300-region sample equals the oracle bit for bit, (7) a 6000-region slice equals the all-fp64 kernel."""
     vals, widths, cutoffs = synth.load_motif_set(579)
     bases, offsets = synth.make_regions(100_000, 1000, seed=1)
     pw = _lib.PwmSet(vals, widths, cutoffs)
@@ -446,6 +446,13 @@ def test_full_size_properties_c3_shape(oracle):
     assert_same_hits(hs, want)
     m = h["seq_idx"] < 300
     assert np.array_equal(h["pos"][m], hs["pos"]) and np.array_equal(h["score"][m], hs["score"])
+    # (7) a larger slice against the all-fp64 kernel (no pre-filter, no hand-issued LDS reads involved)
+    n_big = 6000
+    sq_b = _lib.SeqSet(bases[:int(offsets[n_big])], offsets[:n_big + 1])
+    hb = _lib.scan(pw, sq_b, 3, _lib.MS_SCAN_EXACT_ONLY).hits()
+    mb = h["seq_idx"] < n_big
+    for k in ("seq_idx", "pos", "score", "strand"):
+        assert np.array_equal(h[k][mb], hb[k]), k
 
 
 def test_many_motifs_several_tiles_by_default(oracle, jaspar579):
