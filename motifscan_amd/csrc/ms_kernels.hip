@@ -19,6 +19,10 @@
 //                     and the reference's hit test (cscore.c:356-358, 373-375)
 //   finalize_kernel   sorted keys -> (seq_idx, pos, strand), per-motif offsets, region counts
 //   score_kernel      c_score: first W bases of every sequence    (cscore.c:191-224)
+//   gather_ranks_kernel   the rank pick of the cutoff builder    (motif/__init__.py:393-399)
+//   dedup / compact / site_tables kernels   scanner.py:156-193 and io/__init__.py:23-33 on the sorted hits
+//   extract_kernel    regions cut out of a genome that is resident as 2-bit codes (scanner.py:71-87)
+//   blk2reg_kernel    region of every 64th position, so later position -> region lookups are O(1)
 #include "ms_kernels.h"
 
 namespace ms {
