@@ -922,6 +922,7 @@ static PfKernel pf_kernel_for(int variant, int *threads) {
         case 1: *threads = 1024; return prefilter_kernel<1024, 1, 4>;     // 2-4 groups per trip, compiler-ordered reads
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
+        case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }

@@ -508,3 +508,16 @@ def test_buffer_growth_path():
     assert st["n_passes"] >= 2 and st["n_hits"] == len(h["pos"]) > 4_000_000
     key = (h["motif"].astype(np.int64) << 40) | (h["seq_idx"] << 12) | (h["pos"] << 1) | (h["strand"] == 2)
     assert (np.diff(key) > 0).all()
+
+
+def test_fuzz_decision_boundary(oracle):
+    """tests/fuzz_parity.py: ties, cutoffs exactly on attainable scores (+- 1 ulp, +- 1e-10), max_raw == 0,
+    huge / tiny magnitudes, widths either side of the 32-column fast path.  The integer pre-filter must
+    never drop a window the fp64 rule accepts."""
+    import fuzz_parity
+    n_hits = 0
+    for seed in range(1000, 1040):
+        ok, info, _ = fuzz_parity.run_case(seed, oracle, _lib)
+        assert ok, info
+        n_hits += info
+    assert n_hits > 5000

@@ -138,3 +138,20 @@ def test_live_reference_agrees_when_present(oracle, rnd):
         assert oracle.c_scan_motif(ml, cut, seqs, strand, 3) == ref.c_scan_motif(ml, cut, seqs, strand, 3)
     long_seqs = [s for s in seqs if len(s) >= 34]
     assert oracle.c_score(ml, long_seqs, 3, 2) == ref.c_score(ml, long_seqs, 3, 2)
+
+
+def test_live_reference_agrees_on_decision_boundary_fuzz(oracle):
+    """tests/fuzz_parity.py's cases (ties, cutoffs on attainable scores +- 1 ulp / 1e-10, max_raw == 0,
+    huge and tiny magnitudes) through the oracle and through the real extension."""
+    ref = oracle.load_reference_ext()
+    if ref is None:
+        pytest.skip("oracle/_ref not built on this box")
+    import fuzz_parity
+    n_hits = 0
+    for seed in range(60):
+        mats, cutoffs, seqs, strand = fuzz_parity.make_case(seed)
+        ml = [m.tolist() for m in mats]
+        got = oracle.c_scan_motif(ml, cutoffs.tolist(), seqs, strand, 2)
+        assert got == ref.c_scan_motif(ml, cutoffs.tolist(), seqs, strand, 2), seed
+        n_hits += sum(len(g) for g in got)
+    assert n_hits > 10000
