@@ -118,6 +118,42 @@ def make_case(seed):
     return mats, cutoffs, seqs, strand
 
 
+def check_dedup_and_score(seed, oracle, _lib, mats, widths, seqs, strand, want, pw, res):
+    """Device de-dup (ms_result_dedup) vs the oracle's restatement of scanner.py:156-193 on the nested
+    lists (cases small enough for Python lists), and ms_score vs oracle_score on the regions long
+    enough for every motif (shorter ones read out of bounds in the reference, cscore.c:196-204)."""
+    if len(want["pos"]) <= 150_000:
+        off = want["motif_offsets"]
+        cols = [want[k].tolist() for k in ("seq_idx", "pos", "score", "strand")]
+        nested = [[[cols[0][k], cols[1][k], cols[2][k], cols[3][k]] for k in range(off[p], off[p + 1])]
+                  for p in range(len(widths))]
+        dd = oracle.deduplicate_motif_sites(oracle.make_motif_sites(nested, [0] * len(seqs)), widths.tolist())
+        flat = [(p, r, s.start, s.score, 1 if s.strand == "+" else 2)
+                for p, per in enumerate(dd) for r, sites in enumerate(per) for s in sites]
+        res.dedup(pw)
+        d = res.hits()
+        motif = np.repeat(np.arange(len(widths)), np.diff(d["motif_offsets"]))
+        mine = list(zip(motif.tolist(), d["seq_idx"].tolist(), d["pos"].tolist(), d["score"].tolist(),
+                        d["strand"].astype(np.int32).tolist()))
+        if mine != flat:
+            return f"seed {seed}: de-duplicated sites differ ({len(mine)} vs {len(flat)})"
+    wmax = int(widths.max())
+    long_seqs = [s for s in seqs if len(s) >= wmax]
+    if long_seqs:
+        raw = "".join(long_seqs).encode()
+        offsets = np.concatenate([[0], np.cumsum([len(s) for s in long_seqs])]).astype(np.int64)
+        vals = np.concatenate([m.ravel() for m in mats])
+        sq = _lib.SeqSet(raw, offsets)
+        try:
+            got = _lib.score(pw, sq, strand)
+        finally:
+            sq.close()
+        ref = oracle.score_arrays(vals, widths, raw, offsets, strand, 4)
+        if not np.array_equal(got, ref, equal_nan=True):
+            return f"seed {seed}: c_score differs"
+    return None
+
+
 def run_case(seed, oracle, _lib):
     mats, cutoffs, seqs, strand = make_case(seed)
     vals = np.concatenate([m.ravel() for m in mats])
@@ -128,12 +164,15 @@ def run_case(seed, oracle, _lib):
     pw, sq = _lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(raw, offsets)
     res = _lib.scan(pw, sq, strand)
     try:
-        got = res.hits()
+        got = {k: v.copy() for k, v in res.hits().items()}
         st = res.stats()
+        extra = check_dedup_and_score(seed, oracle, _lib, mats, widths, seqs, strand, want, pw, res)
     finally:
         res.close()
         sq.close()
         pw.close()
+    if extra:
+        return False, extra, st
     for k in ("motif_offsets", "seq_idx", "pos"):
         if not np.array_equal(got[k], want[k]):
             return False, f"seed {seed}: {k} differs ({len(got['pos'])} vs {len(want['pos'])} hits)", st
