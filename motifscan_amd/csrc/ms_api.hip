@@ -59,7 +59,7 @@ struct DeviceCtx {
     hipEvent_t ev[6] = {};
     int n_cu = 0;
     size_t lds_max = 0;
-    size_t lds_set[8] = {};
+    size_t lds_set[32] = {};
     Scratch sc;
     std::mutex mu;               // one scan at a time per device (shared scratch)
 };
@@ -223,6 +223,7 @@ struct ms_pwmset {
     size_t plan_lds = 0;
     bool plan_exact_only = false;
     int plan_min_fb = 0;
+    int plan_engine = -1;
     int plan_device = -1;
     uint4 *d_tables = nullptr;
     TileDesc *d_tiles = nullptr;
@@ -393,20 +394,31 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
     return MS_OK;
 }
 
+// Pre-filter engine: 0 = packed 2-mer tables read per lane from LDS, 1 = int8 one-hot product on the matrix cores.
+static int pf_engine() {
+    if (const char *e = getenv("MS_PF_ENGINE")) return atoi(e) == 1 ? 1 : 0;
+    return 0;
+}
+
 static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
                        int device) {
+    const int engine = pf_engine();
     int min_fb = 10;                                   // measurement switch: MS_PF_FIELD_BITS=16 forces 16-bit fields
     if (const char *e = getenv("MS_PF_FIELD_BITS")) min_fb = atoi(e) >= 16 ? 16 : 10;
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
-                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_min_fb != min_fb;
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_min_fb != min_fb ||
+                       p->plan_engine != engine;
     if (stale) {
         if (exact_only) {
             p->plan = PrefilterPlan();
             p->plan.strand_mask = strand_mask;
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
-            int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
-                                p->max_raw.data(), p->P, strand_mask, lds_budget, min_fb, &p->plan);
+            int rc = engine == 1
+                         ? build_plan_mfma(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
+                                           p->max_raw.data(), p->P, strand_mask, lds_budget, &p->plan)
+                         : build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
+                                      p->max_raw.data(), p->P, strand_mask, lds_budget, min_fb, &p->plan);
             if (rc) return rc;
         }
         p->plan_strand = strand_mask;
@@ -414,6 +426,7 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         p->plan_lds = lds_budget;
         p->plan_exact_only = exact_only;
         p->plan_min_fb = min_fb;
+        p->plan_engine = engine;
         if (p->plan_device >= 0) {
             (void) hipSetDevice(p->plan_device);
             dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
@@ -944,8 +957,11 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += kWqBytes;
     // measurement switches (not part of the interface): kernel variant, drop candidates
-    int pf_variant = 4, pf_no_emit = 0;
-    if (const char *e = getenv("MS_PF_VARIANT")) pf_variant = atoi(e) & 7;
+    int pf_variant = plan.engine == 1 ? 16 : 4, pf_no_emit = 0;
+    if (const char *e = getenv("MS_PF_VARIANT")) {
+        const int v = atoi(e) & 31;
+        if ((v >= 16) == (plan.engine == 1)) pf_variant = v;          // a variant of the other engine cannot read this plan
+    }
     if (const char *e = getenv("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
     const bool pf_clock = getenv("MS_PF_CLOCK") && atoi(getenv("MS_PF_CLOCK")) != 0;
     unsigned long long *d_clk = nullptr;
@@ -1422,6 +1438,31 @@ int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *group_motifs, int32_t
     if (tile_first_group) {
         for (size_t t = 0; t < pl.tiles.size(); t++) tile_first_group[t] = pl.tiles[t].first_group;
         tile_first_group[pl.tiles.size()] = (int32_t) nq;
+    }
+    return MS_OK;
+}
+
+// Engine 1 plan (MS_PF_ENGINE=1 at ms_debug_plan_dims time), decoded from the PHYSICAL operand image the
+// kernel reads: rows [n_groups][16 fields][32 columns][4 bases] int8, group_kb [n_groups] k-blocks.
+int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int8_t *rows, int32_t *group_kb) {
+    if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    std::lock_guard<std::mutex> lk(pwms->mu);
+    const PrefilterPlan &pl = pwms->plan;
+    if (pwms->plan_strand < 0 || pl.engine != 1) { set_error("no engine-1 plan: set MS_PF_ENGINE=1 and call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
+    const size_t nq = pl.group_G.size();
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(pl.tables.data());
+    size_t off = 0;
+    for (size_t q = 0; q < nq; q++) {
+        const int kb_n = pl.group_G[q];
+        const int h = (int) (q & 1);
+        if (group_kb) group_kb[q] = kb_n;
+        for (int f = 0; f < 16; f++)
+            for (int c = 0; c < 32; c++)
+                for (int b = 0; b < 4; b++)
+                    rows[((q * 16 + f) * 32 + c) * 4 + b] =
+                        c < 8 * kb_n ? (int8_t) bytes[off + mfma_byte_index(c >> 3, mfma_row_of(h, f), c & 7, b)] : (int8_t) 0;
+        if (h == 1) off += (size_t) kb_n * kMfmaRowTileBytesPerKb;
     }
     return MS_OK;
 }

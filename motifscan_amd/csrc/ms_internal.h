@@ -60,6 +60,7 @@ struct TileDesc {
 // 2-mer tables in groups that share 16-byte entries, and how groups are cut into LDS tiles.
 struct PrefilterPlan {
     int strand_mask = 0;
+    int engine = 0;                      // 0: packed 2-mer tables read per lane from LDS; 1: int8 one-hot MFMA (below)
     std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in group order
     std::vector<int32_t> exact_motifs;   // motif ids scored in fp64 at every window
     std::vector<int32_t> group_motifs;   // [n_groups][kGroupSlots], -1 = empty slot
@@ -70,7 +71,35 @@ struct PrefilterPlan {
     int64_t lds_bytes_per_position = 0;  // sum over groups of G * 16 bytes (per lane, per position)
 };
 
+// ---- engine 1: the pre-filter as an int8 matrix product on the matrix cores -------------------
+// v_mfma_i32_32x32x32_i8: D[row][col] += sum_k A[row][k] * B[k][col].  Rows are (motif, strand)
+// fields, columns are 32 consecutive window starts, and k runs over (column of the motif, base):
+// B is the one-hot image of the sequence (1 where the base at window start + column is that base),
+// A holds the quantised PWM entries.  One instruction covers 8 motif columns ("k-block"); a row
+// tile (32 rows = 2 table groups of 8 motifs x {fwd, rev}) needs ceil(W_max / 8) of them.
+//
+// Operand bytes: lane l = 32 * khalf + r holds 16 bytes; byte i of k-block kb is motif column
+// 8 * kb + 4 * khalf + (i >> 2), base i & 3 -- for A (r = row) and for B (r = window) alike, so the
+// hardware's own k order never matters.  A row tile is stored as [kb][lane][16 bytes]: a wave reads
+// its A operand with one conflict-free ds_read_b128 at lane * 16.
+//
+// Result register j of lane (r, khalf = h) is row (j & 3) + 8 * (j >> 2) + 4 * h.  Lane half h of
+// row tile t therefore owns table group 2t + h, and register j is that group's field 15 - j
+// (field n: motif slot n >> 1, even n forward, odd n reverse), so that shifting the 16 sign bits
+// together in register order yields the flag word of a candidate record directly.
+constexpr int kMfmaRowTileBytesPerKb = 1024;
+inline int mfma_row_of(int h, int field) { const int j = 15 - field; return (j & 3) + 8 * (j >> 2) + 4 * h; }
+inline size_t mfma_byte_index(int kb, int row, int col_in_kb, int base) {     // inside a row tile
+    const int khalf = col_in_kb >> 2;
+    return (size_t) kb * kMfmaRowTileBytesPerKb + (size_t) (khalf * 32 + row) * 16 + (size_t) (col_in_kb & 3) * 4 + base;
+}
+
 // Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes; min_field_bits 10 or 16.
+// engine 1 (build_plan_mfma): ClassDesc.G = k-blocks per row tile, .n_groups = ROW TILES in the class,
+// .first_group = table group of its first row tile; group_G = k-blocks, group_fb = 8.
+int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t *widths,
+                    const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
+                    size_t lds_budget, PrefilterPlan *plan);
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths,
                const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
                size_t lds_budget, int min_field_bits, PrefilterPlan *plan);

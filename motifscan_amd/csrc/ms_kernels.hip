@@ -549,6 +549,143 @@ __global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
     }
 }
 
+// ------------------------------------------------------- pre-filter on the matrix cores --
+//
+// Engine 1 (ms_internal.h, "engine 1"): the same rigorous upper-bound test as above, evaluated as an
+// int8 matrix product.  Per wave and iteration: 64 consecutive window starts = two 32-column
+// B operands per k-block (the one-hot image of the lane's bases, built once in registers and reused
+// by every row tile), and per row tile of 16 motifs x {fwd, rev} one ds_read_b128 per k-block for the
+// A operand.  acc >= 0 (sign bit clear) in any of the 16 result registers of a lane marks a candidate.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// 4 bases (8 bits of 2-bit codes) -> 4 words, byte `code` of each word = 1
+__device__ __forceinline__ i32x4 onehot4(uint32_t codes8) {
+    i32x4 r;
+    r.x = (int) (1u << ((codes8 & 3u) << 3));
+    r.y = (int) (1u << (((codes8 >> 2) & 3u) << 3));
+    r.z = (int) (1u << (((codes8 >> 4) & 3u) << 3));
+    r.w = (int) (1u << (((codes8 >> 6) & 3u) << 3));
+    return r;
+}
+
+__device__ __forceinline__ int max16(const i32x16 &c) {
+    int a = max(max(c[0], c[1]), c[2]);             // v_max3_i32
+    int b = max(max(c[3], c[4]), c[5]);
+    int d = max(max(c[6], c[7]), c[8]);
+    int e = max(max(c[9], c[10]), c[11]);
+    int f = max(max(c[12], c[13]), c[14]);
+    a = max(max(a, b), d);
+    e = max(max(e, f), c[15]);
+    return max(a, e);
+}
+
+// bit n of the result = result register 15 - n is non-negative (field n of the lane's table group)
+__device__ __forceinline__ uint32_t nonneg_flags(const i32x16 &c) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) m = __builtin_amdgcn_alignbit(m, (uint32_t) c[j], 31);   // (m << 1) | sign
+    return ~m & 0xFFFFu;
+}
+
+struct MfWave {
+    uint64_t *wbuf;
+    uint32_t n;
+};
+
+__device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, int64_t g, uint32_t flags, int32_t group) {
+    const bool flagged = live && flags != 0;
+    const unsigned long long mask = __ballot(flagged);
+    if (mask == 0) return;
+    const uint32_t n_new = (uint32_t) __popcll(mask);
+    if (W.n + n_new > (uint32_t) kWqCap) {
+        wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
+        W.n = 0;
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    if (flagged) W.wbuf[W.n + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
+    W.n += n_new;
+}
+
+// All row tiles of one class (NK k-blocks each).
+template <int NK>
+__device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off,
+                                           int n_row_tiles, int32_t first_group, const i32x4 (&b0)[4], const i32x4 (&b1)[4],
+                                           int64_t g0, bool live0, bool live1) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const char *p = lds + byte_off + lane * 16u;
+    const int32_t my_group = first_group + (int32_t) (lane >> 5);
+    for (int t = 0; t < n_row_tiles; t++, p += NK * kMfmaRowTileBytesPerKb) {
+        i32x4 a[NK];
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) a[kb] = *reinterpret_cast<const i32x4 *>(p + kb * kMfmaRowTileBytesPerKb);
+        i32x16 c0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        i32x16 c1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b0[kb], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b1[kb], c1, 0, 0, 0);
+        }
+        const int m0 = max16(c0), m1 = max16(c1);
+        if (__any((m0 & m1) >= 0) && !A.no_emit) {                 // sign(m0 & m1) clear: one of them is >= 0
+            if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), my_group + 2 * t);
+            if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), my_group + 2 * t);
+        }
+    }
+}
+
+// grid = (blocks per tile, tiles); NT / 64 waves per block, each takes 64 consecutive window starts
+// per iteration (lanes l and l + 32 share window l & 31 and hold the two halves of every k-block).
+template <int NT>
+__global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
+    extern __shared__ uint4 lds4[];
+    const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
+    const uint32_t len16 = T->table_len16;
+    const uint4 *__restrict__ src = A.tables + T->table_off16;
+    for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
+    __syncthreads();
+    const char *lds = reinterpret_cast<const char *>(lds4);
+    const int n_classes = T->n_classes;
+    MfWave W;
+    W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
+    W.n = 0;
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
+    const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
+    unsigned long long t0 = 0, r0 = 0;
+    if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t g0 = chunk * NT + (threadIdx.x & ~63u) + r;          // window start of N-tile 0; N-tile 1: + 32
+        const bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
+        const uint64_t cw0 = code_window(A.codes, live0 ? g0 : 0);
+        const uint64_t cw1 = code_window(A.codes, live1 ? g0 + 32 : 0);
+        i32x4 b0[4], b1[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            b0[kb] = onehot4((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu);
+            b1[kb] = onehot4((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu);
+        }
+        for (int i = 0; i < n_classes; i++) {
+            const ClassDesc cd = T->cls[i];
+            const uint32_t off = cd.base16 * 16u;
+            switch (cd.G) {
+                case 1: mfma_class<1>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
+                case 2: mfma_class<2>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
+                case 3: mfma_class<3>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
+                case 4: mfma_class<4>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
+                default: break;
+            }
+        }
+    }
+    if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
+    if (A.clk && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        const size_t b = (size_t) blockIdx.y * gridDim.x + blockIdx.x;
+        A.clk[2 * b] = t1 - t0;
+        A.clk[2 * b + 1] = r1 - r0;
+    }
+}
+
 // -------------------------------------------------------------------- fp64 kernels --
 
 // Windows that overlap a non-ACGT base are scored in fp64 outright: the pre-filter packs such
@@ -923,6 +1060,8 @@ static PfKernel pf_kernel_for(int variant, int *threads) {
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
         case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
+        case 16: *threads = 1024; return prefilter_mfma_kernel<1024>;     // engine 1 (int8 MFMA), 16 waves per CU
+        case 17: *threads = 512; return prefilter_mfma_kernel<512>;       // engine 1, 8 waves per block
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }

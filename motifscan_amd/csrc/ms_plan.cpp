@@ -106,6 +106,26 @@ QStatus quantize_strand(const double e[4][kMaxFastWidth], int W, double T, int f
     return Q_NEEDS_EXACT;
 }
 
+// Can the motif take an integer pre-filter at all, and at which threshold T on the exact real sum
+// (header comment: a reported hit implies x >= T)?
+bool filter_threshold(const double *m, int W, double cutoff, double max_raw, double *T) {
+    bool ok = W >= 1 && W <= kMaxFastWidth && std::isfinite(max_raw) && max_raw > 0 && std::isfinite(cutoff);
+    double abs_sum = 0;
+    for (int c = 0; ok && c < W; c++) {
+        double colmax = 0;
+        for (int b = 0; b < 4; b++) {
+            const double v = m[(int64_t) b * W + c];
+            if (!std::isfinite(v) || std::fabs(v) > 1e9) { ok = false; break; }
+            colmax = std::max(colmax, std::fabs(v));
+        }
+        abs_sum += colmax;
+    }
+    if (!ok) return false;
+    const double E = 1e-9 * (1.0 + abs_sum);
+    *T = (cutoff - 1e-10) * max_raw - E;
+    return true;
+}
+
 struct FastMotif {
     int32_t id;
     int32_t G;
@@ -148,23 +168,11 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
     for (int32_t p = 0; p < n_pwms; p++) {
         const int W = widths[p];
         const double *m = values + val_off[p];
-        bool ok = W >= 1 && W <= kMaxFastWidth && std::isfinite(max_raw[p]) && max_raw[p] > 0 &&
-                  std::isfinite(cutoffs[p]);
-        double abs_sum = 0;
-        for (int c = 0; ok && c < W; c++) {
-            double colmax = 0;
-            for (int b = 0; b < 4; b++) {
-                const double v = m[(int64_t) b * W + c];
-                if (!std::isfinite(v) || std::fabs(v) > 1e9) { ok = false; break; }
-                colmax = std::max(colmax, std::fabs(v));
-            }
-            abs_sum += colmax;
-        }
+        double T = 0;
+        bool ok = filter_threshold(m, W, cutoffs[p], max_raw[p], &T);
         FastMotif fm;
         fm.id = p;
         if (ok) {
-            const double E = 1e-9 * (1.0 + abs_sum);
-            const double T = (cutoffs[p] - 1e-10) * max_raw[p] - E;
             ok = (min_field_bits <= 10 && quantize_motif(m, W, T, strand_mask, 10, true, &fm)) ||
                  quantize_motif(m, W, T, strand_mask, 16, false, &fm);
         }
@@ -239,6 +247,194 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                 q++;
             }
             t.table_len16 = (uint32_t) used;
+            plan->tiles.push_back(t);
+        }
+    }
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------ engine 1: int8 / MFMA --
+//
+// Per strand, with e[b][c] the effective matrix, hi_c = max_b e[b][c] and the deficit
+// d_c(b) = hi_c - e[b][c] >= 0:   x = sum hi_c - sum_c d_c(code_c), so
+//     hit  =>  sum_c d_c(code_c) <= budget := sum hi_c - T.
+// Deficits are quantised DOWN, dq_c(b) = min(floor(d_c(b) * s), Bq + 1) with Bq = floor(budget * s)
+// (both with a hair of slack against the fp64 rounding of the products), so a hit implies
+// sum dq <= Bq; a clamped column alone already exceeds Bq, so clamping changes no decision that
+// matters.  The table stores v_c(b) = t_c - dq_c(b) with sum_c t_c = Bq:
+//     acc = sum_c v_c(code_c) = Bq - sum dq >= 0   <=>   candidate  (sign bit of the i32 result).
+// int8 range: v_c in [t_c - cap_c, t_c] with cap_c the largest dq of the column, so any
+// t_c in [cap_c - 128, 127] works; the largest Bq <= 254 for which such t_c can sum to Bq is taken
+// (>= 127 always: one column carries Bq, the others 0).  Columns past the motif's width hold 0.
+namespace {
+
+struct I8Strand {
+    int8_t v[kMaxFastWidth][4];
+    int levels;                     // Bq: quantisation levels of the budget (0: strand can never hit)
+};
+
+// Returns false if the strand needs the fp64 path (threshold so low that filtering is pointless).
+bool quantize_strand_i8(const double e[4][kMaxFastWidth], int W, double T, I8Strand *out) {
+    std::memset(out->v, 0, sizeof(out->v));
+    out->levels = 0;
+    double hi[kMaxFastWidth], Mx = 0, lowest = 0;
+    for (int c = 0; c < W; c++) {
+        hi[c] = std::max(std::max(e[0][c], e[1][c]), std::max(e[2][c], e[3][c]));
+        Mx += hi[c];
+        lowest += std::min(std::min(e[0][c], e[1][c]), std::min(e[2][c], e[3][c]));
+    }
+    const double budget = Mx - T;
+    if (!(budget >= 0)) {                       // dead: no N-free window reaches T -> acc = -1 everywhere
+        for (int b = 0; b < 4; b++) out->v[0][b] = -1;
+        return true;
+    }
+    if (!(T > lowest)) return false;            // every window passes
+    for (int Bq = 254; Bq >= 1; Bq--) {
+        const double s = budget > 0 ? ((double) Bq + 0.5) / budget : 1e300;
+        int dq[kMaxFastWidth][4], cap[kMaxFastWidth];
+        long lo_sum = 0;
+        for (int c = 0; c < W; c++) {
+            cap[c] = 0;
+            for (int b = 0; b < 4; b++) {
+                const double d = hi[c] - e[b][c];
+                double q = d <= 0 ? 0.0 : std::floor(std::min(d * s * (1 - 1e-12) - 1e-7, 1e6));
+                if (!(q >= 0)) q = 0;
+                dq[c][b] = (int) std::min<double>(q, Bq + 1);
+                cap[c] = std::max(cap[c], dq[c][b]);
+            }
+            lo_sum += cap[c] - 128;
+        }
+        if (lo_sum > Bq) continue;              // the offsets t_c cannot sum to Bq inside int8
+        long rest = Bq - lo_sum;                // >= 0; hand it out over the columns
+        for (int c = 0; c < W; c++) {
+            const int lo_t = cap[c] - 128;
+            const int add = (int) std::min<long>(rest, 127 - lo_t);
+            const int t = lo_t + add;
+            rest -= add;
+            for (int b = 0; b < 4; b++) out->v[c][b] = (int8_t) (t - dq[c][b]);
+        }
+        if (rest != 0) continue;                // (cannot happen: sum of 127 >= Bq)
+        out->levels = Bq;
+        return true;
+    }
+    return false;
+}
+
+struct FastMotifI8 {
+    int32_t id;
+    int32_t W;
+    I8Strand strand[2];
+};
+
+}  // namespace
+
+int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t *widths,
+                    const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
+                    size_t lds_budget, PrefilterPlan *plan) {
+    *plan = PrefilterPlan();
+    plan->strand_mask = strand_mask;
+    plan->engine = 1;
+    std::vector<FastMotifI8> fast;
+    fast.reserve(n_pwms);
+    for (int32_t p = 0; p < n_pwms; p++) {
+        const int W = widths[p];
+        const double *m = values + val_off[p];
+        double T = 0;
+        bool ok = filter_threshold(m, W, cutoffs[p], max_raw[p], &T);
+        FastMotifI8 fm;
+        fm.id = p;
+        fm.W = W;
+        for (int sd = 0; ok && sd < 2; sd++) {
+            if (!(strand_mask & (1 << sd))) {                    // strand not asked for: never a candidate
+                std::memset(&fm.strand[sd], 0, sizeof(I8Strand));
+                for (int b = 0; b < 4; b++) fm.strand[sd].v[0][b] = -1;
+                continue;
+            }
+            double e[4][kMaxFastWidth];
+            for (int b = 0; b < 4; b++)
+                for (int c = 0; c < W; c++)
+                    e[b][c] = sd == 0 ? m[(int64_t) b * W + c] : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
+            ok = quantize_strand_i8(e, W, T, &fm.strand[sd]);
+        }
+        if (ok) fast.push_back(fm);
+        else plan->exact_motifs.push_back(p);
+    }
+    std::stable_sort(fast.begin(), fast.end(), [](const FastMotifI8 &a, const FastMotifI8 &b) {
+        return (a.W + 7) / 8 != (b.W + 7) / 8 ? (a.W + 7) / 8 < (b.W + 7) / 8 : a.W < b.W;
+    });
+
+    // row tiles of 16 motifs (2 table groups), narrow to wide
+    const size_t n_rt = (fast.size() + 15) / 16;
+    std::vector<int> rt_kb(n_rt, 0);
+    std::vector<size_t> rt_off(n_rt + 1, 0);
+    for (size_t t = 0; t < n_rt; t++) {
+        for (size_t j = 16 * t; j < std::min(fast.size(), 16 * (t + 1)); j++) rt_kb[t] = std::max(rt_kb[t], (fast[j].W + 7) / 8);
+        rt_off[t + 1] = rt_off[t] + (size_t) rt_kb[t] * kMfmaRowTileBytesPerKb;
+    }
+    std::vector<uint8_t> bytes(rt_off[n_rt], 0);
+    plan->group_motifs.assign(2 * n_rt * kGroupSlots, -1);
+    plan->group_G.assign(2 * n_rt, 0);
+    plan->group_fb.assign(2 * n_rt, 8);
+    for (size_t t = 0; t < n_rt; t++) {
+        uint8_t *tab = bytes.data() + rt_off[t];
+        for (int h = 0; h < 2; h++) {
+            const size_t grp = 2 * t + h;
+            plan->group_G[grp] = rt_kb[t];
+            for (int slot = 0; slot < kGroupSlots; slot++) {
+                const size_t j = 16 * t + 8 * h + slot;
+                for (int sd = 0; sd < 2; sd++) {
+                    const int row = mfma_row_of(h, 2 * slot + sd);
+                    if (j >= fast.size()) {                      // empty slot: never a candidate
+                        for (int b = 0; b < 4; b++) tab[mfma_byte_index(0, row, 0, b)] = (uint8_t) (int8_t) -1;
+                        continue;
+                    }
+                    const FastMotifI8 &fm = fast[j];
+                    // an all-zero row would flag every window (acc = 0): a quantised strand never is one
+                    // (dead strands carry -1), and columns past W stay 0
+                    for (int c = 0; c < 8 * rt_kb[t] && c < kMaxFastWidth; c++)
+                        for (int b = 0; b < 4; b++)
+                            tab[mfma_byte_index(c >> 3, row, c & 7, b)] = (uint8_t) (c < fm.W ? fm.strand[sd].v[c][b] : 0);
+                }
+                if (j < fast.size()) {
+                    plan->group_motifs[grp * kGroupSlots + slot] = fast[j].id;
+                }
+            }
+        }
+        plan->lds_bytes_per_position += (int64_t) rt_kb[t] * kMfmaRowTileBytesPerKb / 64;     // A-operand bytes per window start (2 x 32 windows share a read)
+    }
+    for (const FastMotifI8 &fm : fast) plan->fast_motifs.push_back(fm.id);
+    plan->tables.resize(bytes.size() / 4);
+    if (!bytes.empty()) std::memcpy(plan->tables.data(), bytes.data(), bytes.size());
+
+    // LDS tiles (whole row tiles; work ~ bytes), classes = runs of equal k-block count
+    if (n_rt > 0) {
+        const size_t total = rt_off[n_rt];
+        const size_t budget = std::max<size_t>(lds_budget, (size_t) 4 * kMfmaRowTileBytesPerKb);
+        const size_t n_tiles = (total + budget - 1) / budget;
+        const size_t target = (total + n_tiles - 1) / n_tiles;
+        size_t q = 0;
+        while (q < n_rt) {
+            TileDesc t;
+            std::memset(&t, 0, sizeof(t));
+            t.table_off16 = (uint32_t) (rt_off[q] / 16);
+            t.first_group = (int32_t) (2 * q);
+            size_t used = 0;
+            while (q < n_rt) {
+                const size_t need = (size_t) rt_kb[q] * kMfmaRowTileBytesPerKb;
+                if (used > 0 && (used + need > budget || used >= target)) break;
+                if (t.n_classes == 0 || t.cls[t.n_classes - 1].G != rt_kb[q]) {
+                    ClassDesc &cd = t.cls[t.n_classes++];
+                    cd.G = rt_kb[q];
+                    cd.fb = 8;
+                    cd.n_groups = 0;
+                    cd.base16 = (uint32_t) (used / 16);
+                    cd.first_group = (int32_t) (2 * q);
+                }
+                t.cls[t.n_classes - 1].n_groups++;
+                used += need;
+                q++;
+            }
+            t.table_len16 = (uint32_t) (used / 16);
             plan->tiles.push_back(t);
         }
     }

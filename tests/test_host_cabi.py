@@ -141,6 +141,86 @@ def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand):
     assert n_flag <= 2.5 * n_hit + 200, (n_flag, n_hit)
 
 
+def emulate_mfma_prefilter(plan, seq_codes_2bit):
+    """numpy model of prefilter_mfma_kernel: i32 sums of int8 rows over the one-hot sequence image;
+    a (field, window) is a candidate iff the sum is >= 0."""
+    L = len(seq_codes_2bit)
+    padded = np.concatenate([seq_codes_2bit, np.zeros(40, dtype=np.int64)])
+    flagged = set()
+    rows = plan["rows"].astype(np.int64)
+    for q in range(rows.shape[0]):
+        ncol = 8 * int(plan["group_kb"][q])
+        assert not rows[q, :, ncol:, :].any()
+        for n in range(16):
+            m = int(plan["group_motifs"][q, n >> 1])
+            acc = np.zeros(L, dtype=np.int64)
+            for c in range(ncol):
+                acc += rows[q, n, c][padded[c:c + L]]
+            hot = np.nonzero(acc >= 0)[0]
+            if m < 0:
+                assert len(hot) == 0                          # empty slots never flag
+                continue
+            for j in hot:
+                flagged.add((m, int(j), 1 + (n & 1)))
+    return flagged
+
+
+@pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
+@pytest.mark.parametrize("strand", [1, 2, 3])
+def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch):
+    monkeypatch.setenv("MS_PF_ENGINE", "1")
+    mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
+    pw = _lib.PwmSet.from_matrices(mats, cut)
+    plan = pw.plan_mfma(strand)
+    assert plan["n_fast"] + plan["n_exact"] == len(mats)
+    fast = set(plan["group_motifs"].ravel().tolist()) - {-1}
+    assert fast | set(plan["exact_motifs"].tolist()) == set(range(len(mats)))
+    assert plan["rows"].shape[0] % 2 == 0                     # two table groups per 32-row operand tile
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGT"), p=[.295, .205, .205, .295], size=3000)) for _ in range(3)]
+    lut = {c: i for i, c in enumerate("ACGT")}
+    n_flag = n_hit = 0
+    for s in seqs:
+        codes = np.array([lut[c] for c in s], dtype=np.int64)
+        flagged = emulate_mfma_prefilter(plan, codes)
+        assert all((strand >> (sd - 1)) & 1 for (_, _, sd) in flagged)      # a strand not asked for never flags
+        sites = oracle.c_scan_motif([m.tolist() for m in mats], cut.tolist(), [s], strand, 2)
+        for m, hits in enumerate(sites):
+            if m not in fast:
+                continue
+            for _, pos, _, sd in hits:
+                assert (m, pos, sd) in flagged, (m, pos, sd)
+                n_hit += 1
+        n_flag += sum(1 for (m, j, sd) in flagged if j + mats[m].shape[1] <= len(s))
+    assert n_flag <= 2.0 * n_hit + 200, (n_flag, n_hit)
+
+
+def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch):
+    """The fuzzer's tie-heavy cases (cutoffs exactly on attainable scores): the int8 plan keeps every hit."""
+    import fuzz_parity
+    monkeypatch.setenv("MS_PF_ENGINE", "1")
+    lut = {c: i for i, c in enumerate("ACGT")}
+    checked = 0
+    for seed in range(40):
+        mats, cutoffs, seqs, strand = fuzz_parity.make_case(seed)
+        if len(mats) > 40:
+            continue
+        seqs = [s.upper() for s in seqs if len(s) >= 8 and set(s.upper()) <= set("ACGT")][:6]
+        if not seqs:
+            continue
+        pw = _lib.PwmSet.from_matrices(mats, cutoffs)
+        plan = pw.plan_mfma(strand)
+        fast = set(plan["group_motifs"].ravel().tolist()) - {-1}
+        sites = oracle.c_scan_motif([m.tolist() for m in mats], cutoffs.tolist(), seqs, strand, 2)
+        flagged = [emulate_mfma_prefilter(plan, np.array([lut[c] for c in s], dtype=np.int64)) for s in seqs]
+        for m, hits in enumerate(sites):
+            if m in fast:
+                for si, pos, _, sd in hits:
+                    assert (m, pos, sd) in flagged[si], (seed, m, pos, sd)
+                    checked += 1
+    assert checked > 2000
+
+
 def test_prefilter_routes_degenerate_pwms_to_exact_path():
     wide = np.zeros((4, 40))
     wide[0] = 1.0
