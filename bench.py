@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 LDS_PEAK = 256 * 256 * 2.4e9      # B/s: 256 B/clk/CU (ds_read_b128) x 256 CUs x 2.4 GHz
+I8_MFMA_PEAK = 256 * 4 * 2048 * 2.4e9   # op/s: v_mfma_i32_32x32x32_i8 = 65536 ops per 32 cycles per SIMD (measured, tools/ubench),
+                                        # 1024 SIMDs, 2.4 GHz = 5.03e15 = 2 x the dense bf16 peak of MI355X_MICROARCH.md
 
 
 def cpu_baseline(wl, seconds_target=12.0):
@@ -170,6 +172,28 @@ def main():
                 traffic = json.load(open(tfile)).get(a.workload, {}).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
+        engine = all_stats[0]["pf_engine"]
+        hbm = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+               "traffic": traffic, "kernel": "prefilter_kernel", "kernel_ms": pf_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        if engine == 1:
+            # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe: algorithmic ops =
+            # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the
+            # kernel ISSUES is 4x that (one-hot: 4 k-slots per base) plus padding of widths to 8 columns
+            alg_ops = sum(s["mfma_ops_algorithmic"] for s in all_stats) / n_launch
+            issued = sum(s["mfma_ops"] for s in all_stats) / n_launch
+            roofline = {"bound": "mfma", "achieved": alg_ops / (pf_ms * 1e-3) / 1e12, "peak": I8_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                        "frac": alg_ops / (pf_ms * 1e-3) / I8_MFMA_PEAK, "traffic": traffic, "kernel": "prefilter_mfma_kernel",
+                        "kernel_ms": pf_ms, "algorithmic_ops_per_launch": alg_ops, "dtype": "int8 x int8 -> int32"}
+            on_chip = {"bound": "matrix pipe (issued int8 ops incl. one-hot zeros and width padding)",
+                       "achieved": issued / (pf_ms * 1e-3) / 1e12, "peak": I8_MFMA_PEAK / 1e12, "unit": "TOP/s",
+                       "frac": issued / (pf_ms * 1e-3) / I8_MFMA_PEAK, "issued_ops_per_launch": issued,
+                       "lds_TBps": lds_bytes / (pf_ms * 1e-3) / 1e12, "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
+        else:
+            roofline = hbm
+            # the stream that actually binds the engine-0 kernel: PWM 2-mer tables read from LDS
+            on_chip = {"bound": "lds", "achieved": lds_bytes / (pf_ms * 1e-3) / 1e12, "peak": LDS_PEAK / 1e12,
+                       "unit": "TB/s", "frac": lds_bytes / (pf_ms * 1e-3) / LDS_PEAK,
+                       "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
         line = {
             "metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
             "value": total_units * a.steps / elapsed,
@@ -177,7 +201,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 (every hit decision and score, as in the reference) behind a u32 pre-filter of three packed 10-bit fixed-point fields",
+            "dtype": ("f64 (every hit decision and score, as in the reference) behind an int8 one-hot matrix-core pre-filter (i32 accumulate)"
+                      if engine == 1 else
+                      "f64 (every hit decision and score, as in the reference) behind a u32 pre-filter of three packed 10-bit fixed-point fields"),
             "data": "synthetic",
             "config": {"workload": {"c4shard": "BASELINE configs[3] per-GPU shard: (125k input + 125k control) regions x 500 bp x 579 PWMs "
                                                "(N=8 is the full 1M+1M config)",
@@ -188,13 +214,10 @@ def main():
                                     "tiny": "smoke"}[a.workload],
                        "regions_per_gpu": wl["n_regions"] * max(len(wl["sets"]), 1), "region_bp": wl["length"], "n_pwms": P,
                        "strands": "both", "p_value": "1e-4", "sharding": f"regions over {world} GPU(s), 1 all-reduce of int64[{len(seqsets) * P}]"},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "prefilter_kernel", "kernel_ms": pf_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            # the stream that actually binds this kernel: PWM 2-mer tables read from LDS
-            "roofline_on_chip": {"bound": "lds", "achieved": lds_bytes / (pf_ms * 1e-3) / 1e12, "peak": LDS_PEAK / 1e12,
-                                 "unit": "TB/s", "frac": lds_bytes / (pf_ms * 1e-3) / LDS_PEAK,
-                                 "windows_per_s_kernel": windows / (pf_ms * 1e-3)},
+            "roofline": roofline,
+            "roofline_hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline_on_chip": on_chip,
             "stage_ms_per_scan": {k: sum(s[k] for s in all_stats) / n_launch
                                   for k in ("ms_prefilter", "ms_exact", "ms_sort", "ms_finalize", "ms_total")},
             "hits_per_scan": sum(s["n_hits"] for s in all_stats) / n_launch,

@@ -25,7 +25,9 @@ class ScanStats(ctypes.Structure):
                 ("n_tiles", ctypes.c_int32), ("n_passes", ctypes.c_int32), ("ms_prefilter", ctypes.c_double),
                 ("ms_exact", ctypes.c_double), ("ms_sort", ctypes.c_double), ("ms_finalize", ctypes.c_double),
                 ("ms_total", ctypes.c_double), ("lds_bytes_read", ctypes.c_int64),
-                ("hbm_bytes_algorithmic", ctypes.c_int64), ("pf_clock_mhz", ctypes.c_double)]
+                ("hbm_bytes_algorithmic", ctypes.c_int64), ("pf_clock_mhz", ctypes.c_double),
+                ("mfma_ops", ctypes.c_int64), ("mfma_ops_algorithmic", ctypes.c_int64), ("pf_engine", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

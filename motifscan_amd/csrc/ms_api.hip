@@ -396,8 +396,8 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
 
 // Pre-filter engine: 0 = packed 2-mer tables read per lane from LDS, 1 = int8 one-hot product on the matrix cores.
 static int pf_engine() {
-    if (const char *e = getenv("MS_PF_ENGINE")) return atoi(e) == 1 ? 1 : 0;
-    return 0;
+    if (const char *e = getenv("MS_PF_ENGINE")) return atoi(e) == 0 ? 0 : 1;     // measurement / A-B switch
+    return 1;
 }
 
 static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
@@ -914,6 +914,18 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     for (int32_t p = 0; p < pwms->P; p++) stt.n_windows += windows_for_width(seqs, pwms->widths[p]);
     for (int32_t p : plan.fast_motifs) fast_windows += windows_for_width(seqs, pwms->widths[p]);
     stt.lds_bytes_read = plan.lds_bytes_per_position * (((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads);
+    stt.pf_engine = plan.engine;
+    {
+        int64_t cells = 0;                                                          // (window, column) pairs of one strand
+        for (int32_t p : plan.fast_motifs) cells += windows_for_width(seqs, pwms->widths[p]) * pwms->widths[p];
+        stt.mfma_ops_algorithmic = 2 * (strand_mask == 3 ? 2 : 1) * cells;           // one multiply-add per cell and strand
+        if (plan.engine == 1) {
+            int64_t kb_sum = 0;                                                     // k-blocks over all row tiles (2 groups each)
+            for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_sum += plan.group_G[q];
+            const int64_t padded = ((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads;
+            stt.mfma_ops = padded / 32 * kb_sum * (2LL * 32 * 32 * 32);               // one 32x32x32 instruction per (32 windows, row tile, k-block)
+        }
+    }
 
     ms_result *raw = res.release();
     auto fail = [&](int code) { ms_result_free(raw); return code; };

@@ -607,36 +607,78 @@ __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, 
     W.n += n_new;
 }
 
-// All row tiles of one class (NK k-blocks each).
+// One row tile: NK k-blocks x two 32-window operands.
 template <int NK>
+__device__ __forceinline__ void mfma_tile(const char *__restrict__ p, const i32x4 (&b0)[NK], const i32x4 (&b1)[NK],
+                                          i32x16 &c0, i32x16 &c1) {
+    i32x4 a[NK];
+#pragma unroll
+    for (int kb = 0; kb < NK; kb++) a[kb] = *reinterpret_cast<const i32x4 *>(p + kb * kMfmaRowTileBytesPerKb);
+    const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b0[0], z, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b1[0], z, 0, 0, 0);
+#pragma unroll
+    for (int kb = 1; kb < NK; kb++) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b0[kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b1[kb], c1, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void mfma_test(const PfArgs &A, MfWave &W, const i32x16 &c0, const i32x16 &c1, int32_t group,
+                                          int64_t g0, bool live0, bool live1) {
+    const int m0 = max16(c0), m1 = max16(c1);
+    if (__any((m0 & m1) >= 0) && !A.no_emit) {                     // sign(m0 & m1) clear: one of them is >= 0
+        if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
+        if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
+    }
+}
+
+// All row tiles of one class (NK k-blocks each).  PIPE: the matrix products of tile t + 1 are issued
+// before the 16 + 16 result registers of tile t are reduced (two accumulator sets, tiles taken in
+// pairs so no register is ever copied).
+template <int NK, bool PIPE>
 __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off,
-                                           int n_row_tiles, int32_t first_group, const i32x4 (&b0)[4], const i32x4 (&b1)[4],
+                                           int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
                                            int64_t g0, bool live0, bool live1) {
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     const char *p = lds + byte_off + lane * 16u;
-    const int32_t my_group = first_group + (int32_t) (lane >> 5);
-    for (int t = 0; t < n_row_tiles; t++, p += NK * kMfmaRowTileBytesPerKb) {
-        i32x4 a[NK];
+    const int32_t grp = first_group + (int32_t) h;
+    constexpr int kStep = NK * kMfmaRowTileBytesPerKb;
+    i32x4 b0[NK], b1[NK];
 #pragma unroll
-        for (int kb = 0; kb < NK; kb++) a[kb] = *reinterpret_cast<const i32x4 *>(p + kb * kMfmaRowTileBytesPerKb);
-        i32x16 c0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        i32x16 c1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b0[kb], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b1[kb], c1, 0, 0, 0);
+    for (int kb = 0; kb < NK; kb++) {
+        b0[kb] = onehot4((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu);
+        b1[kb] = onehot4((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu);
+    }
+    if constexpr (!PIPE) {
+        for (int t = 0; t < n_row_tiles; t++, p += kStep) {
+            i32x16 c0, c1;
+            mfma_tile<NK>(p, b0, b1, c0, c1);
+            mfma_test(A, W, c0, c1, grp + 2 * t, g0, live0, live1);
         }
-        const int m0 = max16(c0), m1 = max16(c1);
-        if (__any((m0 & m1) >= 0) && !A.no_emit) {                 // sign(m0 & m1) clear: one of them is >= 0
-            if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), my_group + 2 * t);
-            if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), my_group + 2 * t);
+    } else {
+        i32x16 xa0, xa1, xb0, xb1;
+        mfma_tile<NK>(p, b0, b1, xa0, xa1);                      // tile 0
+        int t = 1;
+        for (; t + 1 < n_row_tiles; t += 2) {
+            mfma_tile<NK>(p + (size_t) t * kStep, b0, b1, xb0, xb1);
+            mfma_test(A, W, xa0, xa1, grp + 2 * (t - 1), g0, live0, live1);
+            mfma_tile<NK>(p + (size_t) (t + 1) * kStep, b0, b1, xa0, xa1);
+            mfma_test(A, W, xb0, xb1, grp + 2 * t, g0, live0, live1);
+        }
+        if (t < n_row_tiles) {                                      // xa holds tile t - 1; one tile left
+            mfma_tile<NK>(p + (size_t) t * kStep, b0, b1, xb0, xb1);
+            mfma_test(A, W, xa0, xa1, grp + 2 * (t - 1), g0, live0, live1);
+            mfma_test(A, W, xb0, xb1, grp + 2 * t, g0, live0, live1);
+        } else {
+            mfma_test(A, W, xa0, xa1, grp + 2 * (t - 1), g0, live0, live1);
         }
     }
 }
 
 // grid = (blocks per tile, tiles); NT / 64 waves per block, each takes 64 consecutive window starts
 // per iteration (lanes l and l + 32 share window l & 31 and hold the two halves of every k-block).
-template <int NT>
+template <int NT, bool PIPE>
 __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -649,7 +691,7 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     MfWave W;
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
     W.n = 0;
-    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
     unsigned long long t0 = 0, r0 = 0;
     if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -659,20 +701,14 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
         const bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
         const uint64_t cw0 = code_window(A.codes, live0 ? g0 : 0);
         const uint64_t cw1 = code_window(A.codes, live1 ? g0 + 32 : 0);
-        i32x4 b0[4], b1[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++) {
-            b0[kb] = onehot4((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu);
-            b1[kb] = onehot4((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu);
-        }
         for (int i = 0; i < n_classes; i++) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
             switch (cd.G) {
-                case 1: mfma_class<1>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
-                case 2: mfma_class<2>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
-                case 3: mfma_class<3>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
-                case 4: mfma_class<4>(A, W, lds, off, cd.n_groups, cd.first_group, b0, b1, g0, live0, live1); break;
+                case 1: mfma_class<1, PIPE>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 2: mfma_class<2, PIPE>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 3: mfma_class<3, false>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 4: mfma_class<4, false>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 default: break;
             }
         }
@@ -1060,8 +1096,12 @@ static PfKernel pf_kernel_for(int variant, int *threads) {
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
         case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
-        case 16: *threads = 1024; return prefilter_mfma_kernel<1024>;     // engine 1 (int8 MFMA), 16 waves per CU
-        case 17: *threads = 512; return prefilter_mfma_kernel<512>;       // engine 1, 8 waves per block
+        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, false>;   // engine 1 (int8 MFMA), 16 waves per CU
+        case 17: *threads = 1024; return prefilter_mfma_kernel<1024, true>;    // engine 1, tiles software-pipelined in pairs
+        case 18: *threads = 512; return prefilter_mfma_kernel<512, false>;     // engine 1, 8 waves per block
+        case 19: *threads = 512; return prefilter_mfma_kernel<512, true>;
+        case 20: *threads = 256; return prefilter_mfma_kernel<256, true>;
+        case 21: *threads = 256; return prefilter_mfma_kernel<256, false>;
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }

@@ -294,20 +294,32 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
     assert_same_hits(res.hits(), want)
 
 
-@pytest.mark.parametrize("env", [{"MS_PF_FIELD_BITS": "16"}, {"MS_PF_BLOCKS_PER_CU": "3"},
-                                 {"MS_PF_FIELD_BITS": "16", "MS_PF_BLOCKS_PER_CU": "2", "MS_PF_VARIANT": "0"}])
+@pytest.mark.parametrize("env", [{"MS_PF_ENGINE": "0"},
+                                 {"MS_PF_ENGINE": "0", "MS_PF_FIELD_BITS": "16"},
+                                 {"MS_PF_ENGINE": "0", "MS_PF_BLOCKS_PER_CU": "3"},
+                                 {"MS_PF_ENGINE": "0", "MS_PF_FIELD_BITS": "16", "MS_PF_BLOCKS_PER_CU": "2", "MS_PF_VARIANT": "0"},
+                                 {"MS_PF_ENGINE": "1", "MS_PF_VARIANT": "17"},
+                                 {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4"},
+                                 {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "17"}])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
-    """Field width, number of LDS tiles and kernel variant are tuning knobs: every setting must
-    give the same (bit-exact) hits.  Small LDS budgets force several tiles."""
+    """Pre-filter engine (matrix-core product / packed LDS lookups), field width, number of LDS tiles
+    and kernel variant are tuning knobs: every setting must give the same (bit-exact) hits.  Small
+    LDS budgets force several tiles."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     vals, widths = jaspar579["pwm_values"], jaspar579["widths"]
     cutoffs = jaspar579["cutoffs"]["1e-4"]
     bases, offsets = synth.make_regions(150, 600, seed=5, frac_n=0.05, ragged=True)
     want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
-    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), 3)
-    assert_same_hits(res.hits(), want)
-    assert res.stats()["n_tiles"] >= 2
+    for strand in (3, 1, 2):
+        if strand != 3:
+            want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, strand, 8)
+        res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), strand)
+        assert_same_hits(res.hits(), want)
+        st = res.stats()
+        assert st["pf_engine"] == int(env["MS_PF_ENGINE"])
+        if len(env) > 1 and "MS_PF_BLOCKS_PER_CU" in env or "MS_PF_FIELD_BITS" in env:
+            assert st["n_tiles"] >= 2
 
 
 def test_edge_shapes_vs_oracle(oracle):

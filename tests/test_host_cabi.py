@@ -114,7 +114,8 @@ def fields_never_overflow(plan):
 
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
 @pytest.mark.parametrize("strand", [1, 2, 3])
-def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand):
+def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch):
+    monkeypatch.setenv("MS_PF_ENGINE", "0")
     mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
     pw = _lib.PwmSet.from_matrices(mats, cut)
     plan = pw.plan(strand)
@@ -221,7 +222,9 @@ def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch):
     assert checked > 2000
 
 
-def test_prefilter_routes_degenerate_pwms_to_exact_path():
+@pytest.mark.parametrize("engine", ["0", "1"])
+def test_prefilter_routes_degenerate_pwms_to_exact_path(monkeypatch, engine):
+    monkeypatch.setenv("MS_PF_ENGINE", engine)
     wide = np.zeros((4, 40))
     wide[0] = 1.0
     allneg = -np.ones((4, 5))
@@ -230,12 +233,13 @@ def test_prefilter_routes_degenerate_pwms_to_exact_path():
     ok = np.array([[1.0, -2, 0.5], [-1, 1.2, -0.3], [0.2, -0.4, 0.9], [-3, 0.1, -1.0]])
     low_cut = ok.copy()
     pw = _lib.PwmSet.from_matrices([wide, allneg, nonfinite, ok, low_cut], [0.5, 0.5, 0.5, 0.6, -50.0])
-    plan = pw.plan(3)
+    plan = pw.plan(3) if engine == "0" else pw.plan_mfma(3)
     assert sorted(plan["exact_motifs"].tolist()) == [0, 1, 2, 4]
     assert plan["n_fast"] == 1
 
 
-def test_plan_tiles_respect_lds_budget(jaspar579):
+def test_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
+    monkeypatch.setenv("MS_PF_ENGINE", "0")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     for budget in (64 * 1024, 143 * 1024):
         plan = pw.plan(3, budget)
@@ -252,7 +256,31 @@ def test_plan_tiles_respect_lds_budget(jaspar579):
         assert (plan["group_fb"] == 10).sum() > 0.8 * len(key)   # JASPAR-like motifs mostly take 10-bit fields
 
 
+def test_mfma_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
+    """Engine 1: 16 motifs x {fwd, rev} per 32-row operand tile, ceil(W_max / 8) KiB each, narrow to wide;
+    LDS tiles hold whole row tiles and stay inside the budget."""
+    monkeypatch.setenv("MS_PF_ENGINE", "1")
+    pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
+    widths = jaspar579["widths"]
+    for budget in (32 * 1024, 143 * 1024):
+        plan = pw.plan_mfma(3, budget)
+        assert plan["n_exact"] == 0 and plan["n_fast"] == 579
+        gm, kb, tf = plan["group_motifs"], plan["group_kb"], plan["tile_first_group"]
+        assert len(kb) == 2 * ((579 + 15) // 16) and (kb[0::2] == kb[1::2]).all()
+        assert (np.diff(kb) >= 0).all()
+        for q in range(len(kb)):
+            ws = widths[gm[q][gm[q] >= 0]]
+            assert len(ws) == 0 or (ws <= 8 * kb[q]).all()
+        assert sorted(gm[gm >= 0].tolist()) == list(range(579))
+        assert plan["n_tiles"] == len(tf) - 1 and tf[-1] == len(kb) and (np.array(tf) % 2 == 0).all()
+        for t in range(len(tf) - 1):
+            tile_bytes = int(kb[tf[t]:tf[t + 1]:2].sum()) * 1024
+            assert 0 < tile_bytes <= budget
+        assert (plan["n_tiles"] == 1) == (budget > 100 * 1024)
+
+
 def test_field_width_switch(jaspar579, monkeypatch):
+    monkeypatch.setenv("MS_PF_ENGINE", "0")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     monkeypatch.setenv("MS_PF_FIELD_BITS", "16")
     plan = pw.plan(3)
