@@ -888,11 +888,12 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    size_t lds_budget = c->lds_max - kWqBytes;                   // tables; the wave queues follow them
+    const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : 0);      // wave queues (+ one-hot table) follow the tables
+    size_t lds_budget = c->lds_max - lds_fixed;
     int pf_blocks_per_cu = 1;
     if (const char *e = getenv("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
         pf_blocks_per_cu = std::max(1, atoi(e));
-        lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - kWqBytes;
+        lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - lds_fixed;
     }
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
@@ -967,7 +968,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     size_t lds_bytes = 0;
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
-    lds_bytes += kWqBytes;
+    lds_bytes += lds_fixed;
     // measurement switches (not part of the interface): kernel variant, drop candidates
     int pf_variant = plan.engine == 1 ? 16 : 4, pf_no_emit = 0;
     if (const char *e = getenv("MS_PF_VARIANT")) {

@@ -607,86 +607,100 @@ __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, 
     W.n += n_new;
 }
 
-// One row tile: NK k-blocks x two 32-window operands.
-template <int NK>
-__device__ __forceinline__ void mfma_tile(const char *__restrict__ p, const i32x4 (&b0)[NK], const i32x4 (&b1)[NK],
-                                          i32x16 &c0, i32x16 &c1) {
-    i32x4 a[NK];
+// any of the 32 result registers of the two 32-window operands non-negative?  (16 x v_max3_i32)
+__device__ __forceinline__ int max32(const i32x16 &c, const i32x16 &d) {
+    int m[11];
 #pragma unroll
-    for (int kb = 0; kb < NK; kb++) a[kb] = *reinterpret_cast<const i32x4 *>(p + kb * kMfmaRowTileBytesPerKb);
-    const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b0[0], z, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b1[0], z, 0, 0, 0);
-#pragma unroll
-    for (int kb = 1; kb < NK; kb++) {
-        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b0[kb], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b1[kb], c1, 0, 0, 0);
+    for (int i = 0; i < 5; i++) {
+        m[i] = max(max(c[3 * i], c[3 * i + 1]), c[3 * i + 2]);
+        m[5 + i] = max(max(d[3 * i], d[3 * i + 1]), d[3 * i + 2]);
     }
+    m[10] = max(max(c[15], d[15]), m[0]);
+    const int x = max(max(m[1], m[2]), m[3]), y = max(max(m[4], m[5]), m[6]), z = max(max(m[7], m[8]), m[9]);
+    return max(max(x, y), max(z, m[10]));
 }
 
-__device__ __forceinline__ void mfma_test(const PfArgs &A, MfWave &W, const i32x16 &c0, const i32x16 &c1, int32_t group,
+// Rare path (about one tile in five has a candidate in some lane): which of the two 32-window operands, which
+// fields; queue the records.  (Inlined: a real call would pass the 32 result registers and the argument block
+// through scratch memory.)
+__device__ __forceinline__ void mfma_emit(const PfArgs &A, MfWave &W, const i32x16 &c0, const i32x16 &c1, int32_t group,
                                           int64_t g0, bool live0, bool live1) {
-    const int m0 = max16(c0), m1 = max16(c1);
-    if (__any((m0 & m1) >= 0) && !A.no_emit) {                     // sign(m0 & m1) clear: one of them is >= 0
-        if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
-        if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
-    }
+    if (__any(max16(c0) >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
+    if (__any(max16(c1) >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
 }
 
-// All row tiles of one class (NK k-blocks each).  PIPE: the matrix products of tile t + 1 are issued
-// before the 16 + 16 result registers of tile t are reduced (two accumulator sets, tiles taken in
-// pairs so no register is ever copied).
-template <int NK, bool PIPE>
-__device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off,
-                                           int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
+// All row tiles of one class (NK k-blocks each): per tile NK ds_read_b128 (A operand), 2 * NK matrix
+// instructions, 16 v_max3 and one compare.  The B operands (one-hot image of the lane's bases) come from a
+// 256-entry table in LDS: 4 bases (one byte of 2-bit codes) -> 16 operand bytes.
+template <int NK, int V>
+__device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
+                                           uint32_t byte_off, int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
                                            int64_t g0, bool live0, bool live1) {
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     const char *p = lds + byte_off + lane * 16u;
-    const int32_t grp = first_group + (int32_t) h;
     constexpr int kStep = NK * kMfmaRowTileBytesPerKb;
     i32x4 b0[NK], b1[NK];
 #pragma unroll
     for (int kb = 0; kb < NK; kb++) {
-        b0[kb] = onehot4((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu);
-        b1[kb] = onehot4((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu);
+        b0[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
+        b1[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
     }
-    if constexpr (!PIPE) {
-        for (int t = 0; t < n_row_tiles; t++, p += kStep) {
-            i32x16 c0, c1;
-            mfma_tile<NK>(p, b0, b1, c0, c1);
-            mfma_test(A, W, c0, c1, grp + 2 * t, g0, live0, live1);
+    const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto product = [&](const char *q, i32x16 &c0, i32x16 &c1) {
+        i32x4 a[NK];
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) a[kb] = *reinterpret_cast<const i32x4 *>(q + kb * kMfmaRowTileBytesPerKb);
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b0[0], z, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b1[0], z, 0, 0, 0);
+#pragma unroll
+        for (int kb = 1; kb < NK; kb++) {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b0[kb], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b1[kb], c1, 0, 0, 0);
         }
-    } else {
-        i32x16 xa0, xa1, xb0, xb1;
-        mfma_tile<NK>(p, b0, b1, xa0, xa1);                      // tile 0
-        int t = 1;
-        for (; t + 1 < n_row_tiles; t += 2) {
-            mfma_tile<NK>(p + (size_t) t * kStep, b0, b1, xb0, xb1);
-            mfma_test(A, W, xa0, xa1, grp + 2 * (t - 1), g0, live0, live1);
-            mfma_tile<NK>(p + (size_t) (t + 1) * kStep, b0, b1, xa0, xa1);
-            mfma_test(A, W, xb0, xb1, grp + 2 * t, g0, live0, live1);
-        }
-        if (t < n_row_tiles) {                                      // xa holds tile t - 1; one tile left
-            mfma_tile<NK>(p + (size_t) t * kStep, b0, b1, xb0, xb1);
-            mfma_test(A, W, xa0, xa1, grp + 2 * (t - 1), g0, live0, live1);
-            mfma_test(A, W, xb0, xb1, grp + 2 * t, g0, live0, live1);
-        } else {
-            mfma_test(A, W, xa0, xa1, grp + 2 * (t - 1), g0, live0, live1);
-        }
+    };
+    auto test = [&](const i32x16 &c0, const i32x16 &c1, int t) {
+        if (__builtin_expect(__any(max32(c0, c1) >= 0) && !A.no_emit, 0))
+            mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
+    };
+    // ILP tiles' products are issued back to back (independent accumulators), then reduced: a wave that
+    // spends more of its time issuing matrix instructions leaves the pipe idle less often (4 waves per SIMD)
+    constexpr int ILP = (V & 1) && NK <= 2 ? 2 : 1;
+    int t = 0;
+    for (; t + ILP <= n_row_tiles; t += ILP, p += ILP * kStep) {
+        i32x16 c0[ILP], c1[ILP];
+#pragma unroll
+        for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
+#pragma unroll
+        for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
+    }
+    for (; t < n_row_tiles; t++, p += kStep) {
+        i32x16 c0, c1;
+        product(p, c0, c1);
+        test(c0, c1, t);
     }
 }
 
 // grid = (blocks per tile, tiles); NT / 64 waves per block, each takes 64 consecutive window starts
 // per iteration (lanes l and l + 32 share window l & 31 and hold the two halves of every k-block).
-template <int NT, bool PIPE>
+// Dynamic LDS: operand tables of the tile | wave queues | one-hot table (kMfmaLutBytes).
+// V (A/B measurement): 1 = two row tiles' products in flight per wave in the narrow classes.
+// (Measured and dropped, tools/pf_variants.py: fetching the next chunk's sequence words early, class descriptors
+// in registers, waves walking the classes in rotated order, tiles software-pipelined in pairs -- each within noise.)
+template <int NT, int V>
 __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
     const uint32_t len16 = T->table_len16;
     const uint4 *__restrict__ src = A.tables + T->table_off16;
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
+    uint4 *lut4 = lds4 + A.wq_off16 + kWqBytes / 16;
+    for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
+        const i32x4 v = onehot4(i);
+        lut4[i] = make_uint4((uint32_t) v.x, (uint32_t) v.y, (uint32_t) v.z, (uint32_t) v.w);
+    }
     __syncthreads();
     const char *lds = reinterpret_cast<const char *>(lds4);
+    const char *lut = reinterpret_cast<const char *>(lut4);
     const int n_classes = T->n_classes;
     MfWave W;
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
@@ -705,10 +719,10 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
             switch (cd.G) {
-                case 1: mfma_class<1, PIPE>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 2: mfma_class<2, PIPE>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 3: mfma_class<3, false>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 4: mfma_class<4, false>(A, W, lds, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 1: mfma_class<1, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 2: mfma_class<2, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 3: mfma_class<3, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 4: mfma_class<4, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 default: break;
             }
         }
@@ -1096,12 +1110,9 @@ static PfKernel pf_kernel_for(int variant, int *threads) {
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
         case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
-        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, false>;   // engine 1 (int8 MFMA), 16 waves per CU
-        case 17: *threads = 1024; return prefilter_mfma_kernel<1024, true>;    // engine 1, tiles software-pipelined in pairs
-        case 18: *threads = 512; return prefilter_mfma_kernel<512, false>;     // engine 1, 8 waves per block
-        case 19: *threads = 512; return prefilter_mfma_kernel<512, true>;
-        case 20: *threads = 256; return prefilter_mfma_kernel<256, true>;
-        case 21: *threads = 256; return prefilter_mfma_kernel<256, false>;
+        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, 0>;  // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU
+        case 17: *threads = 512; return prefilter_mfma_kernel<512, 0>;    // engine 1, 8 waves per block
+        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 1>;  // A/B: two tiles in flight
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }

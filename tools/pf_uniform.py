@@ -21,11 +21,15 @@ def run(tag, pw):
             if best is None or st["ms_prefilter"] < best["ms_prefilter"]:
                 best = st
         lds = best["lds_bytes_read"] / (best["ms_prefilter"] * 1e-3)
-        print(f"{tag:28s} noemit {noemit}: {best['ms_prefilter']:.3f} ms, tiles {best['n_tiles']}, cand {best['n_candidates']}, "
-              f"LDS {lds/1e12:.1f} TB/s = {100*lds/(256*256*best['pf_clock_mhz']*1e6):.1f}% at {best['pf_clock_mhz']:.0f} MHz", flush=True)
+        line = (f"{tag:28s} noemit {noemit}: {best['ms_prefilter']:.3f} ms, tiles {best['n_tiles']}, cand {best['n_candidates']}, "
+                f"LDS {lds/1e12:.1f} TB/s = {100*lds/(256*256*best['pf_clock_mhz']*1e6):.1f}% at {best['pf_clock_mhz']:.0f} MHz")
+        if best["pf_engine"] == 1:                                   # matrix-core engine: cycles per instruction per SIMD
+            n_mfma = best["mfma_ops"] / 65536 / 1024
+            line += f", {best['ms_prefilter'] * 1e-3 * best['pf_clock_mhz'] * 1e6 / n_mfma:.1f} cycles per MFMA per SIMD"
+        print(line, flush=True)
 
 run("benchmark set (11 classes)", _lib.PwmSet(vals, widths, cutoffs))
-for W in (8, 12, 16):
+for W in (8, 12, 16, 21):
     sel = [i for i in range(579) if widths[i] == W]
     reps = (579 + len(sel) - 1) // len(sel)
     idx = (sel * reps)[:579]
