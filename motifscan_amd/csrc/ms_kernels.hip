@@ -1110,9 +1110,9 @@ static PfKernel pf_kernel_for(int variant, int *threads) {
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
         case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
-        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, 0>;  // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU
-        case 17: *threads = 512; return prefilter_mfma_kernel<512, 0>;    // engine 1, 8 waves per block
-        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 1>;  // A/B: two tiles in flight
+        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, 1>;  // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU (default)
+        case 17: *threads = 512; return prefilter_mfma_kernel<512, 1>;    // engine 1, 8 waves per block
+        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0>;  // A/B: one row tile in flight per wave
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }

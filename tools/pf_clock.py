@@ -16,5 +16,10 @@ for _ in range(5):
     r = _lib.scan(pw, sq, 3); st = r.stats(); r.close()
     lds = st["lds_bytes_read"] / (st["ms_prefilter"] * 1e-3)
     peak = 256 * 256 * st["pf_clock_mhz"] * 1e6
-    print(f"prefilter {st['ms_prefilter']:.3f} ms  clock {st['pf_clock_mhz']:.0f} MHz  LDS {lds/1e12:.1f} TB/s = "
-          f"{100*lds/peak:.1f}% of 256 B/clk/CU at that clock ({100*lds/(256*256*2.4e9):.1f}% at 2.4 GHz)", flush=True)
+    line = (f"prefilter {st['ms_prefilter']:.3f} ms  clock {st['pf_clock_mhz']:.0f} MHz  LDS {lds/1e12:.1f} TB/s = "
+            f"{100*lds/peak:.1f}% of 256 B/clk/CU at that clock ({100*lds/(256*256*2.4e9):.1f}% at 2.4 GHz)")
+    if st["pf_engine"] == 1:                        # matrix pipe: 32 cycles per v_mfma_i32_32x32x32_i8 per SIMD (tools/ubench)
+        cycles = st["ms_prefilter"] * 1e-3 * st["pf_clock_mhz"] * 1e6
+        n_mfma = st["mfma_ops"] / 65536 / 1024
+        line += f"  matrix pipe busy {100 * 32 * n_mfma / cycles:.1f}% ({cycles / n_mfma:.1f} cycles per instruction per SIMD)"
+    print(line, flush=True)
