@@ -11,8 +11,10 @@
 //
 // Kernels:
 //   pack_kernel       ASCII -> codes + nmask                     (cscore.c:81-114)
-//   prefilter_kernel  10/16-bit fixed-point upper bound of both strand scores for EVERY window,
-//                     PWM 2-mer tables in LDS, one lane per window start; emits candidates
+//   prefilter_mfma_kernel  rigorous integer upper bound of both strand scores for EVERY window as an int8
+//                     one-hot product on the matrix cores (v_mfma_i32_32x32x32_i8); emits candidates
+//   prefilter_kernel  the same bound from packed 10/16-bit 2-mer fields read per lane from LDS
+//                     (engine 0, MS_PF_ENGINE=0: A/B reference)
 //   nlist/neval       fp64 scoring of the windows that overlap a non-ACGT base
 //   exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take
 //   rescore_kernel    fp64 scoring of the candidates, in the reference's order of operations,
