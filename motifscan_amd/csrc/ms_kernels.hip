@@ -687,7 +687,8 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
 // Dynamic LDS: operand tables of the tile | wave queues | one-hot table (kMfmaLutBytes).
 // V (A/B measurement): 1 = two row tiles' products in flight per wave in the narrow classes.
 // (Measured and dropped, tools/pf_variants.py: fetching the next chunk's sequence words early, class descriptors
-// in registers, waves walking the classes in rotated order, tiles software-pipelined in pairs -- each within noise.)
+// in registers, waves walking the classes in rotated order, tiles software-pipelined in pairs -- each within noise;
+// 5 waves per SIMD (two 640-thread blocks per CU at <= 96 VGPRs) spills and is 35 % slower.)
 template <int NT, int V>
 __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];

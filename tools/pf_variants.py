@@ -9,7 +9,8 @@ wl_name = sys.argv[1] if len(sys.argv) > 1 else "c4shard"
 combos = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:]] or [(1, 1), (0, 1), (5, 2), (6, 2)]
 _lib.set_device(0)
 wl = synth.workload(wl_name)
-pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
+n_pw = int(os.environ.get("N_PWMS", "0")) or len(wl["widths"])       # optional: first N motifs only
+pw = _lib.PwmSet(wl["pwm_values"][:4 * int(wl["widths"][:n_pw].sum())], wl["widths"][:n_pw], wl["cutoffs"][:n_pw])
 sq = _lib.SeqSet(*wl["sets"][0])
 os.environ["MS_PF_CLOCK"] = "1"
 for rep in range(2):
