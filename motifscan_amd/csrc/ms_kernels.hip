@@ -774,10 +774,31 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
                                                     int32_t n_motifs, int strand_mask, const int64_t *__restrict__ list,
                                                     const unsigned long long *__restrict__ n_list, uint64_t cap,
                                                     const HitOut H) {
+    // the block's motifs never change: their fp64 tables are read from LDS, not through L1/L2
+    __shared__ double2 s_tab[kNwMotifChunk * kMaxFastWidth * 4];
+    __shared__ int32_t s_motif[kNwMotifChunk], s_width[kNwMotifChunk], s_off[kNwMotifChunk];
     unsigned long long n = *n_list;
     if (n > cap) n = cap;
     const int m0 = blockIdx.y * kNwMotifChunk;
-    const int m1 = min(m0 + kNwMotifChunk, n_motifs);
+    const int cnt = min(kNwMotifChunk, n_motifs - m0);
+    __shared__ int64_t s_src[kNwMotifChunk];
+    if ((int) threadIdx.x < cnt) {
+        const int32_t p = motifs[m0 + threadIdx.x];
+        s_motif[threadIdx.x] = p;
+        s_width[threadIdx.x] = Pw.width[p];
+        s_src[threadIdx.x] = Pw.tab_off[p];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int m = 0; m < cnt; m++) { s_off[m] = off; off += s_width[m] * 4; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt * kMaxFastWidth * 4; j += blockDim.x) {       // all motifs' loads in flight together
+        const int m = j / (kMaxFastWidth * 4), i = j % (kMaxFastWidth * 4);
+        if (i < s_width[m] * 4) s_tab[s_off[m] + i] = Pw.tab2[s_src[m] + i];
+    }
+    __syncthreads();
     for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long) gridDim.x * blockDim.x) {
         const int64_t g = list[i];
@@ -785,14 +806,13 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
         const uint64_t cw = code_window(S.codes, g);
         const int64_t r = find_region(S, g);
         const int64_t end = S.offsets[r + 1];
-        for (int m = m0; m < m1; m++) {
-            const int32_t p = motifs[m];
-            const int W = Pw.width[p];                          // <= 32: only pre-filter motifs come here
+        for (int m = 0; m < cnt; m++) {
+            const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
             if ((nw & low_mask(W)) == 0) continue;
             if (g + W > end) continue;
             double fwd, rev;
-            score_window32(Pw.tab2 + Pw.tab_off[p], W, cw, nw, fwd, rev);
-            test_and_emit(H, Pw, (uint32_t) p, g, fwd, rev, strand_mask);
+            score_window32(s_tab + s_off[m], W, cw, nw, fwd, rev);
+            test_and_emit(H, Pw, (uint32_t) s_motif[m], g, fwd, rev, strand_mask);
         }
     }
 }
