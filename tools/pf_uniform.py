@@ -28,8 +28,11 @@ def run(tag, pw):
             line += f", {best['ms_prefilter'] * 1e-3 * best['pf_clock_mhz'] * 1e6 / n_mfma:.1f} cycles per MFMA per SIMD"
         print(line, flush=True)
 
-run("benchmark set (11 classes)", _lib.PwmSet(vals, widths, cutoffs))
-for W in (8, 12, 16, 21):
+if os.environ.get("MS_PF_VARIANT"):
+    print("MS_PF_VARIANT", os.environ["MS_PF_VARIANT"])
+only = [int(x) for x in os.environ.get("PF_WIDTHS", "8,12,16,21").split(",")]
+run("benchmark set", _lib.PwmSet(vals, widths, cutoffs))
+for W in only:
     sel = [i for i in range(579) if widths[i] == W]
     reps = (579 + len(sel) - 1) // len(sel)
     idx = (sel * reps)[:579]
