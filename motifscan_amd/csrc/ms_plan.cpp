@@ -1,6 +1,8 @@
-// ms_plan.cpp -- host side of the integer pre-filter: quantise every PWM into small fixed-point
-// 2-mer tables that can NEVER miss a window the reference would report, and cut the tables into
-// LDS tiles.
+// ms_plan.cpp -- host side of the integer pre-filter: quantise every PWM into small integer tables
+// that can NEVER miss a window the reference would report, and cut the tables into LDS tiles.
+// Two table forms share the threshold derivation below:
+//   engine 1 (default)  int8 rows of a matrix product on the matrix cores -- second half of this file
+//   engine 0            packed 10/16-bit fixed-point 2-mer fields read per lane from LDS -- first half
 //
 // Reference arithmetic being bounded (cscore.c:340-390): for a window without non-ACGT bases
 //     s   = fl64( sum_c M[code_c][c] )            (column order)
@@ -9,7 +11,7 @@
 //     x >= T := (cutoff - 1e-10) * max_raw - E,   E = 1e-9 * (1 + sum_c max_b |M[b][c]|)
 // (E is ~10^3 times the worst-case fp64 rounding of the W adds, the divide and the subtract).
 //
-// Pre-filter: columns are taken in pairs ("2-mer groups", g = 0..G-1, G = ceil(W/2)); for
+// Engine 0: columns are taken in pairs ("2-mer groups", g = 0..G-1, G = ceil(W/2)); for
 // the pair value F_g(code) = M[b0][2g] + M[b1][2g+1] the table stores
 //     Q_g(code) = ceil( (max(F_g(code), lo_g) - lo_g) * s )        (an integer >= 0)
 // so that  sum_g Q_g >= (x - sum_g lo_g) * s  for every window.  lo_g = max_g - 1.25 * budget

@@ -75,7 +75,33 @@ __global__ void __launch_bounds__(1024) kt(int iters, int *out, unsigned long lo
         const int m0 = max16(c0), m1 = MODE == 5 ? c1[3] : max16(c1);
         if (__any((m0 & m1) >= 0)) { sink += t; out[threadIdx.x] = t; }
     };
-    if (MODE == 4) {
+    if (MODE == 6) {
+        // software pipeline with the A operands fetched one tile ahead: per iteration  read(t+2) | product(t+1) | reduce(t)
+        auto rd = [&](int t, i32x4 &a0, i32x4 &a1) {
+            const char *q = p + (t & 31) * 2048;
+            a0 = *reinterpret_cast<const i32x4 *>(q); a1 = *reinterpret_cast<const i32x4 *>(q + 1024);
+        };
+        auto prod = [&](const i32x4 &a0, const i32x4 &a1, i32x16 &c0, i32x16 &c1) {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, z, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, z, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b3, c1, 0, 0, 0);
+        };
+        i32x4 pa0, pa1, qa0, qa1;
+        i32x16 xa0, xa1, xb0, xb1;
+        rd(0, pa0, pa1);
+        prod(pa0, pa1, xa0, xa1);
+        rd(1, qa0, qa1);
+        for (int t = 1; t + 1 < iters; t += 2) {
+            rd(t + 1, pa0, pa1);
+            prod(qa0, qa1, xb0, xb1);
+            test(xa0, xa1, t - 1);
+            rd(t + 2, qa0, qa1);
+            prod(pa0, pa1, xa0, xa1);
+            test(xb0, xb1, t);
+        }
+        test(xa0, xa1, iters);
+    } else if (MODE == 4) {
         i32x16 xa0, xa1, xb0, xb1;
         tile(0, xa0, xa1);
         for (int t = 1; t + 1 < iters; t += 2) {
@@ -127,6 +153,7 @@ int main() {
             run<3>("production tile (2 reads, 4 MFMA, 2 max16)", threads, blocks);
             run<4>("production tile, pipelined in pairs", threads, blocks);
             run<5>("production tile, one max16 only", threads, blocks);
+            run<6>("production tile, pipelined + operand prefetch", threads, blocks);
         }
     }
     return 0;
