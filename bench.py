@@ -99,12 +99,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
-    _lib.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MS_BENCH_BACKEND=gloo (test aid only): lets the N > 1 code path run on a box with fewer GPUs than ranks
+    # (ranks then share devices; RCCL itself refuses two ranks on one GPU)
+    backend = os.environ.get("MS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % _lib.device_count()
+    torch.cuda.set_device(dev_index)               # before the process group: RCCL binds to the current device
+    _lib.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
