@@ -23,6 +23,8 @@
  *   ms_seqset_from_device same, for ASCII that is already resident in device memory
  *   ms_genome_create /    Scanner._extract_seq -> Genome.fetch_sequence (pysam)   scanner.py:71-87,
  *   ms_seqset_from_genome   genome/__init__.py:117-135: packed genome resident in HBM, regions cut on device
+ *   ms_scan_sweep         the same extraction + scan for the windows of a fixed-stride sweep of one chromosome
+ *                         (BASELINE configs[4]); every base is scored once instead of window / stride times
  *   ms_scan               scan_motif / scan_motif_thread           cscore.c:317-476
  *                         (Python name c_scan_motif; "OOOII" = pwms, cutoffs, seqs, strand,
  *                          n_threads; n_threads has no meaning on the GPU and is not taken)
@@ -136,6 +138,13 @@ int ms_seqset_from_genome(const ms_genome *genome, const int32_t *chrom, const i
 /* ---- scan (c_scan_motif) ---------------------------------------------------------------- */
 int ms_scan(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags,
             ms_result **out);
+/* Window sweep: windows k = 0 .. n-1 = [begin + k*stride, begin + k*stride + window) of chromosome `chrom`, all inside
+ * [begin, end) (n = (end - begin - window) / stride + 1).  The result is what ms_scan gives for those n windows as n
+ * regions (seq_idx = k, pos relative to the window start, same order, same fp64 scores, region counts = windows with
+ * a site) -- scanner.py:71-87 + cscore.c:336-390 per window -- but the span is scanned ONCE and every hit is handed to
+ * the windows that contain all of its bases. */
+int ms_scan_sweep(const ms_pwmset *pwms, const ms_genome *genome, int32_t chrom, int64_t begin, int64_t end,
+                  int32_t window, int32_t stride, int strand_mask, uint32_t flags, ms_result **out);
 int ms_result_num_hits(const ms_result *res, int64_t *n_hits);
 int ms_result_motif_offsets(const ms_result *res, int64_t *out /* [P+1] */);
 /* Copy the hit arrays to host buffers of length n_hits (any pointer may be NULL). */

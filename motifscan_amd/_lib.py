@@ -98,6 +98,7 @@ def lib():
         "ms_genome_free": (None, [vp]),
         "ms_seqset_from_genome": (c_int, [vp, pi32, pi64, pi64, c_i64, pvp]),
         "ms_scan": (c_int, [vp, vp, c_int, c_u32, pvp]),
+        "ms_scan_sweep": (c_int, [vp, vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_int, c_u32, pvp]),
         "ms_result_num_hits": (c_int, [vp, pi64]),
         "ms_result_motif_offsets": (c_int, [vp, pi64]),
         "ms_result_hits": (c_int, [vp, pi64, pi64, pd, pi8]),
@@ -428,6 +429,16 @@ class ScanResult:
 def scan(pwms, seqs, strand_mask=3, flags=MS_SCAN_DEFAULT):
     h = ctypes.c_void_p()
     check(lib().ms_scan(pwms.h, seqs.h, int(strand_mask), int(flags), ctypes.byref(h)))
+    return ScanResult(h, pwms.n)
+
+
+def scan_sweep(pwms, genome, chrom, begin, end, window, stride, strand_mask=3, flags=MS_SCAN_DEFAULT):
+    """Scan the windows [begin + k*stride, begin + k*stride + window) of one chromosome of a ResidentGenome.  Same
+    result as scan() over those windows as separate regions (seq_idx = k), with every base scored once."""
+    ci = genome.index[chrom] if isinstance(chrom, str) else int(chrom)
+    h = ctypes.c_void_p()
+    check(lib().ms_scan_sweep(pwms.h, genome.h, ci, int(begin), int(end), int(window), int(stride), int(strand_mask),
+                              int(flags), ctypes.byref(h)))
     return ScanResult(h, pwms.n)
 
 

@@ -1286,6 +1286,148 @@ void ms_result_free(ms_result *r) {
     delete r;
 }
 
+// --------------------------------------------------------------------- window sweep --
+//
+// configs[4]-style sweep (N3): the windows [begin + k*stride, begin + k*stride + window), k = 0..n_windows-1, of one
+// chromosome, with the result the reference gives when every window is a region of its own (scanner.py:71-87 cuts them,
+// cscore.c:336-390 scans each) -- but every base is scored ONCE: the span is scanned as one region and each hit is
+// handed to all windows that contain it whole (window / stride of them), then ordered (motif, window, position, strand).
+int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, int64_t begin, int64_t end, int32_t window,
+                  int32_t stride, int strand_mask, uint32_t flags, ms_result **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!pwms_c || !g) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (window < 1 || stride < 1) { set_error("window and stride must be positive"); return MS_ERR_INVALID; }
+    if (begin < 0 || end < begin) { set_error("bad span [%lld, %lld)", (long long) begin, (long long) end); return MS_ERR_INVALID; }
+    const int64_t n_windows = end - begin >= window ? (end - begin - window) / stride + 1 : 0;
+    const int64_t span_end = n_windows > 0 ? begin + (n_windows - 1) * stride + window : begin;
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    ms_seqset *span = nullptr;
+    int rc = ms_seqset_from_genome(g, &chrom, &begin, &span_end, 1, &span);       // validates chrom / coordinates
+    if (rc) return rc;
+    ms_result *r1 = nullptr;
+    rc = ms_scan(pwms_c, span, strand_mask, flags, &r1);
+    const int64_t span_bases = span->n_bases;
+    ms_seqset_free(span);
+    if (rc) return rc;
+    auto fail = [&](int code) { ms_result_free(r1); return code; };
+
+    DeviceCtx *c;
+    if ((rc = get_ctx(r1->device, &c))) return fail(rc);
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    const size_t n1 = (size_t) r1->n_hits;
+    int wbits = 1, pbits = 1, mbits = 1;
+    while ((1LL << wbits) < std::max<int64_t>(n_windows, 1)) wbits++;
+    while ((1LL << pbits) < window) pbits++;
+    while ((1 << mbits) < std::max(pwms->P, 1)) mbits++;
+    if (wbits + pbits + mbits + 1 > 64) { set_error("sweep too large for a 64-bit ordering key"); return fail(MS_ERR_INVALID); }
+
+    std::unique_ptr<ms_result> res(new (std::nothrow) ms_result());
+    if (!res) { set_error("out of host memory"); return fail(MS_ERR_NOMEM); }
+    res->device = r1->device;
+    res->P = pwms->P;
+    res->R = n_windows;
+    res->stats = r1->stats;
+    res->motif_offsets.assign((size_t) pwms->P + 1, 0);
+    ms_result *raw = res.release();
+    auto fail2 = [&](int code) { ms_result_free(raw); return fail(code); };
+
+    uint32_t *d_cnt = nullptr, *d_dst = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { dev_free(d_cnt); dev_free(d_dst); if (d_tmp) (void) hipFree(d_tmp); };
+    uint64_t total = 0;
+    hipError_t he = hipSuccess;
+    (void) hipEventRecord(c->ev[0], c->stream);
+    if (n1 > 0) {
+        size_t tmp_bytes = 0;
+        if ((rc = dev_alloc(&d_cnt, n1)) || (rc = dev_alloc(&d_dst, n1))) { cleanup(); return fail2(rc); }
+        rc = launch_sweep_count((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, window, stride, n_windows,
+                                d_cnt, c->stream);
+        if (!rc) rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
+        if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
+        if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
+        uint32_t last[2] = {0, 0};
+        if (!rc) {
+            he = hipMemcpyAsync(&last[0], d_cnt + (n1 - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(&last[1], d_dst + (n1 - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            if (he != hipSuccess) { set_error("sweep count failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; }
+        }
+        if (rc) { cleanup(); return fail2(rc); }
+        total = (uint64_t) last[0] + last[1];
+        // the 32-bit prefix sum wraps silently: bound it by the largest possible expansion
+        if ((double) n1 * (double) (window / stride + 1) >= 4.0e9) { cleanup(); set_error("sweep yields more than 2^32 sites: split the span"); return fail2(MS_ERR_INVALID); }
+    }
+    raw->n_hits = (int64_t) total;
+    {
+        void *blk = nullptr;
+        size_t got = 0;
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, (size_t) total), &blk, &got))) { cleanup(); return fail2(rc); }
+        raw->block = blk;
+        raw->block_bytes = got;
+        result_carve(raw, blk, (size_t) total);
+        const size_t P1 = (size_t) pwms->P + 1;
+        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0xFF, 8 * P1, c->stream);
+        if (he != hipSuccess) { cleanup(); set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    }
+    Scratch &sc = c->sc;
+    if (total > 0) {
+        if ((rc = scratch_reserve(sc, sc.cand_cap, std::max<size_t>(sc.hit_cap, (size_t) total), sc.nlist_cap))) { cleanup(); return fail2(rc); }
+        rc = launch_sweep_expand((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, r1->d_score, r1->d_strand,
+                                 d_dst, window, stride, n_windows, wbits, pbits, sc.keys, sc.vals, c->stream);
+        (void) hipEventRecord(c->ev[1], c->stream);
+        size_t need = 0;
+        const int end_bit = wbits + pbits + mbits + 1;
+        if (!rc) rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) total, end_bit, c->stream);
+        if (!rc && need > sc.sort_tmp_bytes) {
+            if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
+            sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
+            if (hipMalloc(&sc.sort_tmp, need) != hipSuccess) { set_error("hipMalloc of %zu bytes (sort) failed", need); rc = MS_ERR_NOMEM; }
+            else sc.sort_tmp_bytes = need;
+        }
+        size_t have = sc.sort_tmp_bytes;
+        if (!rc) rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) total, end_bit, c->stream);
+        (void) hipEventRecord(c->ev[2], c->stream);
+        if (!rc) rc = launch_sweep_finalize(sc.keys_sorted, (int64_t) total, wbits, pbits, raw->d_seq_idx, raw->d_pos, raw->d_strand,
+                                            raw->d_motif_first, raw->d_region_counts, c->stream);
+        if (rc) { cleanup(); return fail2(rc); }
+    } else {
+        (void) hipEventRecord(c->ev[1], c->stream);
+        (void) hipEventRecord(c->ev[2], c->stream);
+    }
+    (void) hipEventRecord(c->ev[3], c->stream);
+    std::vector<int64_t> first((size_t) pwms->P + 1);
+    he = hipMemcpyAsync(first.data(), raw->d_motif_first, first.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (he != hipSuccess) { set_error("sweep finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    raw->motif_offsets[(size_t) pwms->P] = (int64_t) total;
+    for (int32_t p = pwms->P - 1; p >= 0; p--)
+        raw->motif_offsets[(size_t) p] = first[(size_t) p] >= 0 ? first[(size_t) p] : raw->motif_offsets[(size_t) p + 1];
+    he = hipMemcpy(raw->d_motif_first, raw->motif_offsets.data(), raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (he != hipSuccess) { set_error("offset upload failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+
+    // statistics: the span scan's stage times plus the hand-out (expansion under ms_sort, the last kernel under ms_finalize)
+    float ms01 = 0, ms12 = 0, ms23 = 0;
+    (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
+    (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
+    (void) hipEventElapsedTime(&ms23, c->ev[2], c->ev[3]);
+    ms_scan_stats &stt = raw->stats;
+    stt.ms_sort += ms01 + ms12;
+    stt.ms_finalize += ms23;
+    stt.ms_total += ms01 + ms12 + ms23;
+    stt.n_hits = (int64_t) total;
+    stt.n_bases = span_bases;                                   // bases scanned (each once)
+    stt.n_windows = 0;                                          // unit count of the sweep as the reference sees it
+    for (int32_t p = 0; p < pwms->P; p++) stt.n_windows += n_windows * std::max<int64_t>(window - pwms->widths[p] + 1, 0);
+    stt.hbm_bytes_algorithmic += 16 * ((int64_t) total - (int64_t) n1);
+    ms_result_free(r1);
+    *out = raw;
+    return MS_OK;
+}
+
 // --------------------------------------------------------------------------- score --
 
 int ms_score(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, double *out) {

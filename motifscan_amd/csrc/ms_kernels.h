@@ -68,6 +68,13 @@ int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t
                    int64_t R, int64_t n_out, uint32_t *codes, uint32_t *nmask, hipStream_t st);
 int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st);
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
+int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                       int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st);
+int launch_sweep_expand(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                        const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
+                        int64_t n_windows, int wbits, int pbits, uint64_t *keys, double *vals, hipStream_t st);
+int launch_sweep_finalize(const uint64_t *keys, int64_t n, int wbits, int pbits, int64_t *seq_idx, int64_t *pos,
+                          int8_t *strand, int64_t *motif_first, unsigned long long *region_counts, hipStream_t st);
 int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *seq_idx,
                  const int64_t *pos, const double *score, const int8_t *strand, uint32_t *keep, hipStream_t st);
 int launch_compact_hits(int64_t n, const uint32_t *keep, const uint32_t *dst, const int64_t *seq_in, const int64_t *pos_in,

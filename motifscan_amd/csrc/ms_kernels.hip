@@ -1000,6 +1000,82 @@ __global__ void __launch_bounds__(256) site_tables_kernel(int64_t n, const int64
     max_score[(int64_t) p * R + r] = best;
 }
 
+// ---------------------------------------------------------------- window sweep (N3) --
+// A sweep scans one chromosome span as ONE region and hands every hit to each window that holds it whole:
+// window k = [k * stride, k * stride + window) of the span; a hit of a width-W motif at span position g lies in
+// windows ceil((g + W - window) / stride) .. floor(g / stride)  (cscore.c:340: the window must contain all W bases).
+__device__ __forceinline__ void sweep_window_range(int64_t g, int W, int32_t window, int32_t stride, int64_t n_windows,
+                                                   int64_t &lo, int64_t &hi) {
+    hi = g / stride;
+    if (hi > n_windows - 1) hi = n_windows - 1;
+    const int64_t need = g + W - window;                       // smallest window start that still holds the site
+    lo = need <= 0 ? 0 : (need + stride - 1) / stride;
+}
+
+__global__ void __launch_bounds__(256) sweep_count_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                          const int32_t *__restrict__ width, const int64_t *__restrict__ pos,
+                                                          int32_t window, int32_t stride, int64_t n_windows,
+                                                          uint32_t *__restrict__ cnt) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = motif_of_hit(motif_off, P, i);
+    int64_t lo, hi;
+    sweep_window_range(pos[i], width[m], window, stride, n_windows, lo, hi);
+    cnt[i] = hi >= lo ? (uint32_t) (hi - lo + 1) : 0u;
+}
+
+// key = motif | window index (wbits) | position inside the window (pbits) | strand bit: the reference's order for
+// per-window regions (motif, region, position, '+' before '-')
+__global__ void __launch_bounds__(256) sweep_expand_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                           const int32_t *__restrict__ width, const int64_t *__restrict__ pos,
+                                                           const double *__restrict__ score, const int8_t *__restrict__ strand,
+                                                           const uint32_t *__restrict__ dst, int32_t window, int32_t stride,
+                                                           int64_t n_windows, int wbits, int pbits,
+                                                           uint64_t *__restrict__ keys, double *__restrict__ vals) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = motif_of_hit(motif_off, P, i);
+    const int64_t g = pos[i];
+    int64_t lo, hi;
+    sweep_window_range(g, width[m], window, stride, n_windows, lo, hi);
+    const double sc = score[i];
+    const uint64_t sbit = strand[i] == 2 ? 1u : 0u;
+    uint64_t o = dst[i];
+    for (int64_t w = lo; w <= hi; w++, o++) {
+        keys[o] = ((uint64_t) m << (wbits + pbits + 1)) | ((uint64_t) w << (pbits + 1)) | ((uint64_t) (g - w * stride) << 1) | sbit;
+        vals[o] = sc;
+    }
+}
+
+__global__ void __launch_bounds__(256) sweep_finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, int wbits, int pbits,
+                                                             int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
+                                                             int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
+                                                             unsigned long long *__restrict__ region_counts) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    uint32_t motif = 0xFFFFFFFFu;
+    bool new_pair = false;
+    if (live) {
+        const uint64_t k = keys[i];
+        const uint64_t pair = k >> (pbits + 1);                 // (motif, window)
+        motif = (uint32_t) (pair >> wbits);
+        seq_idx[i] = (int64_t) (pair & ((1ULL << wbits) - 1ULL));
+        pos[i] = (int64_t) ((k >> 1) & ((1ULL << pbits) - 1ULL));
+        strand[i] = (int8_t) ((k & 1ULL) ? 2 : 1);
+        const uint64_t prev = i > 0 ? keys[i - 1] >> (pbits + 1) : ~0ULL;
+        new_pair = prev != pair;
+        if (i == 0 || (uint32_t) (prev >> wbits) != motif) motif_first[motif] = i;
+    }
+    unsigned long long todo = __ballot(live && new_pair);       // windows with >= 1 hit per motif: one atomic per (wave, motif)
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const uint32_t m = __shfl(motif, leader);
+        const unsigned long long same = __ballot(live && new_pair && motif == m);
+        if ((int) (threadIdx.x & 63) == leader) atomicAdd(&region_counts[m], (unsigned long long) __popcll(same));
+        todo &= ~same;
+    }
+}
+
 __global__ void fill_nan_kernel(double *__restrict__ a, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = __longlong_as_double(0x7FF8000000000000LL);
@@ -1198,6 +1274,34 @@ int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S,
                     hipStream_t st) {
     if (n == 0) return MS_OK;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, S,
+                       seq_idx, pos, strand, motif_first, region_counts);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                       int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(sweep_count_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, pos,
+                       window, stride, n_windows, cnt);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_sweep_expand(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                        const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
+                        int64_t n_windows, int wbits, int pbits, uint64_t *keys, double *vals, hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(sweep_expand_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, pos,
+                       score, strand, dst, window, stride, n_windows, wbits, pbits, keys, vals);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_sweep_finalize(const uint64_t *keys, int64_t n, int wbits, int pbits, int64_t *seq_idx, int64_t *pos,
+                          int8_t *strand, int64_t *motif_first, unsigned long long *region_counts, hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(sweep_finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, wbits, pbits,
                        seq_idx, pos, strand, motif_first, region_counts);
     MS_HIP(hipGetLastError());
     return MS_OK;

@@ -533,3 +533,48 @@ def test_fuzz_decision_boundary(oracle):
         assert ok, info
         n_hits += info
     assert n_hits > 5000
+
+
+@pytest.mark.parametrize("window,stride,strand", [(200, 50, 3), (37, 10, 3), (64, 64, 1), (30, 7, 2), (12, 5, 3)])
+def test_window_sweep_equals_per_window_regions(oracle, jaspar579, window, stride, strand):
+    """ms_scan_sweep (span scanned once, hits handed to every window that holds them whole) == the reference's result
+    for the same windows as separate regions (scanner.py:71-87 cuts them, cscore.c:336-390 scans each): positions,
+    order, strands, fp64 scores, per-motif window counts.  Windows narrower than a motif get no site of it."""
+    rng = np.random.default_rng(window * 1000 + stride)
+    vals, widths = jaspar579["pwm_values"], jaspar579["widths"]
+    n_pw = 120
+    vals, widths = vals[:4 * int(widths[:n_pw].sum())], widths[:n_pw]
+    cutoffs = jaspar579["cutoffs"]["1e-3"][:n_pw]
+    chroms = {}
+    for name, L in (("chrA", 3000), ("chrB", 9137)):
+        s = rng.choice(list("ACGTacgt"), size=L)
+        for _ in range(6):                                         # assembly gaps / soft-masked stretches
+            a = int(rng.integers(0, L - 60))
+            s[a:a + int(rng.integers(1, 60))] = "N"
+        chroms[name] = "".join(s)
+    genome = _lib.ResidentGenome(chroms)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    for chrom, begin, end in (("chrB", 0, 9137), ("chrB", 123, 8001), ("chrA", 2950, 3000), ("chrA", 10, 10 + window - 1)):
+        n_win = (end - begin - window) // stride + 1 if end - begin >= window else 0
+        seqs = [chroms[chrom][begin + k * stride: begin + k * stride + window] for k in range(n_win)]
+        raw = "".join(seqs).encode()
+        offsets = np.arange(n_win + 1, dtype=np.int64) * window
+        want = oracle.scan_arrays(vals, widths, cutoffs, raw, offsets, strand, 8)
+        res = _lib.scan_sweep(pw, genome, chrom, begin, end, window, stride, strand)
+        assert_same_hits(res.hits(), want)
+        pair = np.unique((np.repeat(np.arange(n_pw), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
+        assert np.array_equal(res.region_counts(), np.bincount(pair >> 32, minlength=n_pw))
+        st = res.stats()
+        assert st["n_windows"] == sum(max(window - int(w) + 1, 0) for w in widths) * n_win
+        if n_win > 20 and window >= 30:
+            assert len(want["pos"]) > 50
+        # device de-dup works on the handed-out sites like on any other result
+        h = {k: v.copy() for k, v in res.hits().items()}
+        keep = _lib.dedup_keep(h["motif_offsets"], widths, h["seq_idx"], h["pos"], h["score"], h["strand"])
+        res.dedup(pw)
+        assert res.n_hits == int(keep.sum())
+        res.close()
+    with pytest.raises(ValueError):
+        _lib.scan_sweep(pw, genome, "chrA", 0, 4000, window, stride, strand)       # past the chromosome end
+    with pytest.raises(ValueError):
+        _lib.scan_sweep(pw, genome, "chrA", 0, 3000, window, 0, strand)
