@@ -1291,7 +1291,8 @@ void ms_result_free(ms_result *r) {
 // configs[4]-style sweep (N3): the windows [begin + k*stride, begin + k*stride + window), k = 0..n_windows-1, of one
 // chromosome, with the result the reference gives when every window is a region of its own (scanner.py:71-87 cuts them,
 // cscore.c:336-390 scans each) -- but every base is scored ONCE: the span is scanned as one region and each hit is
-// handed to all windows that contain it whole (window / stride of them), then ordered (motif, window, position, strand).
+// handed to all windows that contain it whole (window / stride of them), written straight to its place in the
+// reference's order (motif, window, position, strand) -- sweep_scatter_kernel, no second sort.
 int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, int64_t begin, int64_t end, int32_t window,
                   int32_t stride, int strand_mask, uint32_t flags, ms_result **out) {
     if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
@@ -1317,11 +1318,6 @@ int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, in
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     const size_t n1 = (size_t) r1->n_hits;
-    int wbits = 1, pbits = 1, mbits = 1;
-    while ((1LL << wbits) < std::max<int64_t>(n_windows, 1)) wbits++;
-    while ((1LL << pbits) < window) pbits++;
-    while ((1 << mbits) < std::max(pwms->P, 1)) mbits++;
-    if (wbits + pbits + mbits + 1 > 64) { set_error("sweep too large for a 64-bit ordering key"); return fail(MS_ERR_INVALID); }
 
     std::unique_ptr<ms_result> res(new (std::nothrow) ms_result());
     if (!res) { set_error("out of host memory"); return fail(MS_ERR_NOMEM); }
@@ -1372,52 +1368,25 @@ int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, in
         if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0xFF, 8 * P1, c->stream);
         if (he != hipSuccess) { cleanup(); set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
     }
-    Scratch &sc = c->sc;
-    if (total > 0) {
-        if ((rc = scratch_reserve(sc, sc.cand_cap, std::max<size_t>(sc.hit_cap, (size_t) total), sc.nlist_cap))) { cleanup(); return fail2(rc); }
-        rc = launch_sweep_expand((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, r1->d_score, r1->d_strand,
-                                 d_dst, window, stride, n_windows, wbits, pbits, sc.keys, sc.vals, c->stream);
-        (void) hipEventRecord(c->ev[1], c->stream);
-        size_t need = 0;
-        const int end_bit = wbits + pbits + mbits + 1;
-        if (!rc) rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) total, end_bit, c->stream);
-        if (!rc && need > sc.sort_tmp_bytes) {
-            if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
-            sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
-            if (hipMalloc(&sc.sort_tmp, need) != hipSuccess) { set_error("hipMalloc of %zu bytes (sort) failed", need); rc = MS_ERR_NOMEM; }
-            else sc.sort_tmp_bytes = need;
-        }
-        size_t have = sc.sort_tmp_bytes;
-        if (!rc) rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) total, end_bit, c->stream);
-        (void) hipEventRecord(c->ev[2], c->stream);
-        if (!rc) rc = launch_sweep_finalize(sc.keys_sorted, (int64_t) total, wbits, pbits, raw->d_seq_idx, raw->d_pos, raw->d_strand,
-                                            raw->d_motif_first, raw->d_region_counts, c->stream);
-        if (rc) { cleanup(); return fail2(rc); }
-    } else {
-        (void) hipEventRecord(c->ev[1], c->stream);
-        (void) hipEventRecord(c->ev[2], c->stream);
-    }
-    (void) hipEventRecord(c->ev[3], c->stream);
-    std::vector<int64_t> first((size_t) pwms->P + 1);
-    he = hipMemcpyAsync(first.data(), raw->d_motif_first, first.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    (void) hipEventRecord(c->ev[1], c->stream);
+    rc = launch_sweep_scatter((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, r1->d_score, r1->d_strand, d_dst,
+                              window, stride, n_windows, (int64_t) total, raw->d_seq_idx, raw->d_pos, raw->d_score, raw->d_strand,
+                              raw->d_motif_first, raw->d_region_counts, c->stream);
+    if (rc) { cleanup(); return fail2(rc); }
+    (void) hipEventRecord(c->ev[2], c->stream);
+    he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t),
+                        hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     cleanup();
-    if (he != hipSuccess) { set_error("sweep finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
-    raw->motif_offsets[(size_t) pwms->P] = (int64_t) total;
-    for (int32_t p = pwms->P - 1; p >= 0; p--)
-        raw->motif_offsets[(size_t) p] = first[(size_t) p] >= 0 ? first[(size_t) p] : raw->motif_offsets[(size_t) p + 1];
-    he = hipMemcpy(raw->d_motif_first, raw->motif_offsets.data(), raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice);
-    if (he != hipSuccess) { set_error("offset upload failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    if (he != hipSuccess) { set_error("sweep hand-out failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
 
-    // statistics: the span scan's stage times plus the hand-out (expansion under ms_sort, the last kernel under ms_finalize)
-    float ms01 = 0, ms12 = 0, ms23 = 0;
+    // statistics: the span scan's stage times plus the hand-out (counts + prefix sum + scatter, booked under ms_finalize)
+    float ms01 = 0, ms12 = 0;
     (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
     (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
-    (void) hipEventElapsedTime(&ms23, c->ev[2], c->ev[3]);
     ms_scan_stats &stt = raw->stats;
-    stt.ms_sort += ms01 + ms12;
-    stt.ms_finalize += ms23;
-    stt.ms_total += ms01 + ms12 + ms23;
+    stt.ms_finalize += ms01 + ms12;
+    stt.ms_total += ms01 + ms12;
     stt.n_hits = (int64_t) total;
     stt.n_bases = span_bases;                                   // bases scanned (each once)
     stt.n_windows = 0;                                          // unit count of the sweep as the reference sees it

@@ -70,11 +70,10 @@ int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
 int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                        int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st);
-int launch_sweep_expand(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
-                        const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
-                        int64_t n_windows, int wbits, int pbits, uint64_t *keys, double *vals, hipStream_t st);
-int launch_sweep_finalize(const uint64_t *keys, int64_t n, int wbits, int pbits, int64_t *seq_idx, int64_t *pos,
-                          int8_t *strand, int64_t *motif_first, unsigned long long *region_counts, hipStream_t st);
+int launch_sweep_scatter(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                         const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
+                         int64_t n_windows, int64_t total, int64_t *seq_idx_out, int64_t *pos_out, double *score_out,
+                         int8_t *strand_out, int64_t *motif_off_out, unsigned long long *region_counts, hipStream_t st);
 int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *seq_idx,
                  const int64_t *pos, const double *score, const int8_t *strand, uint32_t *keep, hipStream_t st);
 int launch_compact_hits(int64_t n, const uint32_t *keep, const uint32_t *dst, const int64_t *seq_in, const int64_t *pos_in,

@@ -1024,56 +1024,84 @@ __global__ void __launch_bounds__(256) sweep_count_kernel(int64_t n, const int64
     cnt[i] = hi >= lo ? (uint32_t) (hi - lo + 1) : 0u;
 }
 
-// key = motif | window index (wbits) | position inside the window (pbits) | strand bit: the reference's order for
-// per-window regions (motif, region, position, '+' before '-')
-__global__ void __launch_bounds__(256) sweep_expand_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
-                                                           const int32_t *__restrict__ width, const int64_t *__restrict__ pos,
-                                                           const double *__restrict__ score, const int8_t *__restrict__ strand,
-                                                           const uint32_t *__restrict__ dst, int32_t window, int32_t stride,
-                                                           int64_t n_windows, int wbits, int pbits,
-                                                           uint64_t *__restrict__ keys, double *__restrict__ vals) {
+// Hand-out without a sort.  Within a motif the hits are ordered by span position g (then strand), and both ends of
+// a hit's window range are non-decreasing in g, so the number of sites that precede site (hit i, window w) in the
+// reference's order (motif, window, position, strand) is
+//     dst[i]                                   all windows of all earlier hits (exclusive prefix sum of the counts)
+//   + (w - lo_i)                               the hit's own earlier windows
+//   - sum_{i' < i} max(0, hi_i' - w)           earlier hits' windows that come AFTER w
+//   + sum_{i' > i} max(0, min(w, hi_i' + 1) - lo_i')   later hits' windows that come BEFORE w
+// where only hits of the same motif within one window length of g contribute to the two sums (a few at most, except
+// in low-complexity floods where the walk is bounded by window * 2 strands).  A site is the first of its
+// (motif, window) iff the previous hit of the motif does not reach window w.
+__global__ void __launch_bounds__(256) sweep_scatter_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                            const int32_t *__restrict__ width, const int64_t *__restrict__ pos,
+                                                            const double *__restrict__ score, const int8_t *__restrict__ strand,
+                                                            const uint32_t *__restrict__ dst, int32_t window, int32_t stride,
+                                                            int64_t n_windows, int64_t *__restrict__ seq_idx_out,
+                                                            int64_t *__restrict__ pos_out, double *__restrict__ score_out,
+                                                            int8_t *__restrict__ strand_out,
+                                                            unsigned long long *__restrict__ region_counts) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t m = motif_of_hit(motif_off, P, i);
-    const int64_t g = pos[i];
-    int64_t lo, hi;
-    sweep_window_range(g, width[m], window, stride, n_windows, lo, hi);
-    const double sc = score[i];
-    const uint64_t sbit = strand[i] == 2 ? 1u : 0u;
-    uint64_t o = dst[i];
-    for (int64_t w = lo; w <= hi; w++, o++) {
-        keys[o] = ((uint64_t) m << (wbits + pbits + 1)) | ((uint64_t) w << (pbits + 1)) | ((uint64_t) (g - w * stride) << 1) | sbit;
-        vals[o] = sc;
+    const bool live = i < n;
+    int32_t m = -1;
+    int n_first = 0;
+    if (live) {
+        m = motif_of_hit(motif_off, P, i);
+        const int W = width[m];
+        const int64_t first = motif_off[m], last = motif_off[m + 1];
+        const int64_t g = pos[i];
+        int64_t lo, hi;
+        sweep_window_range(g, W, window, stride, n_windows, lo, hi);
+        if (hi >= lo) {
+            const double sc = score[i];
+            const int8_t sd = strand[i];
+            const int64_t base = (int64_t) dst[i];
+            int64_t prev_hi = -1;                                    // window range end of the previous hit of this motif
+            if (i > first) { int64_t l2; sweep_window_range(pos[i - 1], W, window, stride, n_windows, l2, prev_hi); if (prev_hi < l2) prev_hi = -1; }
+            for (int64_t w = lo; w <= hi; w++) {
+                int64_t idx = base + (w - lo);
+                for (int64_t j = i - 1; j >= first; j--) {           // earlier hits still reaching past w
+                    int64_t l2, h2;
+                    sweep_window_range(pos[j], W, window, stride, n_windows, l2, h2);
+                    if (h2 <= lo) break;                             // monotone: nothing further back reaches past lo <= w
+                    if (h2 >= l2 && h2 > w) idx -= h2 - w;
+                }
+                for (int64_t j = i + 1; j < last; j++) {             // later hits that already started before w
+                    int64_t l2, h2;
+                    sweep_window_range(pos[j], W, window, stride, n_windows, l2, h2);
+                    if (l2 >= hi) break;                             // monotone: nothing further on starts before hi >= w
+                    if (h2 >= l2 && l2 < w) idx += (w < h2 + 1 ? w : h2 + 1) - l2;
+                }
+                seq_idx_out[idx] = w;
+                pos_out[idx] = g - w * stride;
+                score_out[idx] = sc;
+                strand_out[idx] = sd;
+                if (prev_hi < w) n_first++;
+            }
+        }
+    }
+    // windows with >= 1 site per motif (stats.py:29-31): one atomic per (wave, motif)
+    unsigned long long todo = __ballot(live && n_first > 0);
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const int32_t mm = __shfl(m, leader);
+        const unsigned long long same = __ballot(live && n_first > 0 && m == mm);
+        int v = (live && m == mm) ? n_first : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((int) (threadIdx.x & 63) == leader) atomicAdd(&region_counts[mm], (unsigned long long) v);
+        todo &= ~same;
     }
 }
 
-__global__ void __launch_bounds__(256) sweep_finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, int wbits, int pbits,
-                                                             int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
-                                                             int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
-                                                             unsigned long long *__restrict__ region_counts) {
-    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    uint32_t motif = 0xFFFFFFFFu;
-    bool new_pair = false;
-    if (live) {
-        const uint64_t k = keys[i];
-        const uint64_t pair = k >> (pbits + 1);                 // (motif, window)
-        motif = (uint32_t) (pair >> wbits);
-        seq_idx[i] = (int64_t) (pair & ((1ULL << wbits) - 1ULL));
-        pos[i] = (int64_t) ((k >> 1) & ((1ULL << pbits) - 1ULL));
-        strand[i] = (int8_t) ((k & 1ULL) ? 2 : 1);
-        const uint64_t prev = i > 0 ? keys[i - 1] >> (pbits + 1) : ~0ULL;
-        new_pair = prev != pair;
-        if (i == 0 || (uint32_t) (prev >> wbits) != motif) motif_first[motif] = i;
-    }
-    unsigned long long todo = __ballot(live && new_pair);       // windows with >= 1 hit per motif: one atomic per (wave, motif)
-    while (todo) {
-        const int leader = __ffsll((long long) todo) - 1;
-        const uint32_t m = __shfl(motif, leader);
-        const unsigned long long same = __ballot(live && new_pair && motif == m);
-        if ((int) (threadIdx.x & 63) == leader) atomicAdd(&region_counts[m], (unsigned long long) __popcll(same));
-        todo &= ~same;
-    }
+// per-motif offsets of the handed-out sites: where the motif's first hit went
+__global__ void sweep_offsets_kernel(const int64_t *__restrict__ motif_off, int32_t P, int64_t n, const uint32_t *__restrict__ dst,
+                                     int64_t total, int64_t *__restrict__ out) {
+    const int32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m > P) return;
+    const int64_t f = m < P ? motif_off[m] : n;
+    out[m] = f < n ? (int64_t) dst[f] : total;
 }
 
 __global__ void fill_nan_kernel(double *__restrict__ a, int64_t n) {
@@ -1288,21 +1316,16 @@ int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int
     return MS_OK;
 }
 
-int launch_sweep_expand(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
-                        const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
-                        int64_t n_windows, int wbits, int pbits, uint64_t *keys, double *vals, hipStream_t st) {
-    if (n == 0) return MS_OK;
-    hipLaunchKernelGGL(sweep_expand_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, pos,
-                       score, strand, dst, window, stride, n_windows, wbits, pbits, keys, vals);
+int launch_sweep_scatter(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                         const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
+                         int64_t n_windows, int64_t total, int64_t *seq_idx_out, int64_t *pos_out, double *score_out,
+                         int8_t *strand_out, int64_t *motif_off_out, unsigned long long *region_counts, hipStream_t st) {
+    hipLaunchKernelGGL(sweep_offsets_kernel, dim3((unsigned) ((P + 1 + 255) / 256)), dim3(256), 0, st, motif_off, P, n, dst, total,
+                       motif_off_out);
     MS_HIP(hipGetLastError());
-    return MS_OK;
-}
-
-int launch_sweep_finalize(const uint64_t *keys, int64_t n, int wbits, int pbits, int64_t *seq_idx, int64_t *pos,
-                          int8_t *strand, int64_t *motif_first, unsigned long long *region_counts, hipStream_t st) {
     if (n == 0) return MS_OK;
-    hipLaunchKernelGGL(sweep_finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, wbits, pbits,
-                       seq_idx, pos, strand, motif_first, region_counts);
+    hipLaunchKernelGGL(sweep_scatter_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, pos,
+                       score, strand, dst, window, stride, n_windows, seq_idx_out, pos_out, score_out, strand_out, region_counts);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -535,7 +535,8 @@ def test_fuzz_decision_boundary(oracle):
     assert n_hits > 5000
 
 
-@pytest.mark.parametrize("window,stride,strand", [(200, 50, 3), (37, 10, 3), (64, 64, 1), (30, 7, 2), (12, 5, 3)])
+@pytest.mark.parametrize("window,stride,strand", [(200, 50, 3), (37, 10, 3), (64, 64, 1), (30, 7, 2), (12, 5, 3), (30, 1, 3),
+                                                  (20, 19, 3), (25, 40, 3)])
 def test_window_sweep_equals_per_window_regions(oracle, jaspar579, window, stride, strand):
     """ms_scan_sweep (span scanned once, hits handed to every window that holds them whole) == the reference's result
     for the same windows as separate regions (scanner.py:71-87 cuts them, cscore.c:336-390 scans each): positions,
@@ -545,7 +546,18 @@ def test_window_sweep_equals_per_window_regions(oracle, jaspar579, window, strid
     n_pw = 120
     vals, widths = vals[:4 * int(widths[:n_pw].sum())], widths[:n_pw]
     cutoffs = jaspar579["cutoffs"]["1e-3"][:n_pw]
-    chroms = {}
+    # two motifs that match low-complexity sequence at EVERY position (dense neighbourhoods for the hand-out walk)
+    extra = []
+    for w, pattern in ((9, "A"), (6, "AC")):
+        m = np.full((4, w), -3.0)
+        for c in range(w):
+            m["ACGT".index(pattern[c % len(pattern)]), c] = 1.25
+        extra.append(m)
+    vals = np.concatenate([vals] + [m.ravel() for m in extra])
+    widths = np.concatenate([widths, [m.shape[1] for m in extra]]).astype(np.int32)
+    cutoffs = np.concatenate([cutoffs, [0.9, 0.9]])
+    n_pw += 2
+    chroms = {"chrC": "A" * 700 + "T" * 300 + "AC" * 400 + "GT" * 100 + "ACGT" * 50}
     for name, L in (("chrA", 3000), ("chrB", 9137)):
         s = rng.choice(list("ACGTacgt"), size=L)
         for _ in range(6):                                         # assembly gaps / soft-masked stretches
@@ -554,7 +566,8 @@ def test_window_sweep_equals_per_window_regions(oracle, jaspar579, window, strid
         chroms[name] = "".join(s)
     genome = _lib.ResidentGenome(chroms)
     pw = _lib.PwmSet(vals, widths, cutoffs)
-    for chrom, begin, end in (("chrB", 0, 9137), ("chrB", 123, 8001), ("chrA", 2950, 3000), ("chrA", 10, 10 + window - 1)):
+    for chrom, begin, end in (("chrB", 0, 9137), ("chrB", 123, 8001), ("chrA", 2950, 3000), ("chrA", 10, 10 + window - 1),
+                              ("chrC", 0, len(chroms["chrC"])), ("chrC", 13, 1999)):
         n_win = (end - begin - window) // stride + 1 if end - begin >= window else 0
         seqs = [chroms[chrom][begin + k * stride: begin + k * stride + window] for k in range(n_win)]
         raw = "".join(seqs).encode()
