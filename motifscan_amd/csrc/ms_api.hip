@@ -934,6 +934,17 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
 
     int gbits = 1;
     while ((1LL << gbits) <= seqs->n_bases) gbits++;
+    // hit coordinate = (region, position in the region) when that costs at most 2 more key bits than the global base
+    // position: finalize_rp_kernel then needs no position -> region look-ups.  MS_HIT_COORD=global forces the other form.
+    int rbits = 1, pbits = 0;
+    {
+        const int64_t max_len = seqs->len_sorted.empty() ? 0 : seqs->len_sorted.back();
+        int pb = 1;
+        while ((1LL << pb) < std::max<int64_t>(max_len, 1)) pb++;
+        while ((1LL << rbits) < std::max<int64_t>(seqs->R, 1)) rbits++;
+        const char *e = getenv("MS_HIT_COORD");
+        if (rbits + pb <= gbits + 2 && !(e && e[0] == 'g')) { pbits = pb; gbits = rbits + pb; }
+    }
     int mbits = 1;
     while ((1 << mbits) < std::max(pwms->P, 1)) mbits++;
 
@@ -989,7 +1000,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         if ((rc = scratch_reserve(sc, want_cand, want_hits, want_nlist))) return fail(rc);
         stt.n_passes = pass;
         HitOut H;
-        H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits;
+        H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
         he = hipMemsetAsync(sc.counters, 0, 4 * sizeof(unsigned long long), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         (void) hipEventRecord(c->ev[0], c->stream);
@@ -1086,7 +1097,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
                                  gbits + 1 + mbits, c->stream))) return fail2(rc);
     }
     (void) hipEventRecord(c->ev[4], c->stream);
-    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, S, raw->d_seq_idx, raw->d_pos,
+    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, S, raw->d_seq_idx, raw->d_pos,
                               raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
     (void) hipEventRecord(c->ev[5], c->stream);
     std::vector<int64_t> first((size_t) pwms->P + 1);

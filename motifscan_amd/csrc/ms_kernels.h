@@ -30,11 +30,13 @@ struct DevPwm {
 };
 
 struct HitOut {
-    uint64_t *keys;           // motif << (gbits+1) | position << 1 | strand bit
+    uint64_t *keys;           // motif << (gbits+1) | coordinate << 1 | strand bit; coordinate = (region << pbits | position in
+                              // the region) when pbits > 0 (gbits = rbits + pbits), else the global base position
     double *vals;             // normalised fp64 score
     unsigned long long *n_hits;
     uint64_t cap;
-    int gbits;                // bits needed for a base position
+    int gbits;                // bits of the coordinate field
+    int pbits;                // > 0: bits of the position inside a region (see keys)
 };
 
 struct PfArgs {
@@ -61,7 +63,7 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
                    uint64_t cand_cap, const int32_t *group_motifs, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S, int64_t *seq_idx,
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);
 int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,

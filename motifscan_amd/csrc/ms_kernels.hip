@@ -130,6 +130,12 @@ __device__ __forceinline__ void score_window32(const double2 *__restrict__ tab, 
     }
 }
 
+// The middle field of a hit key: (region << pbits) | position inside the region when the set's regions are short
+// enough for that to fit (H.pbits > 0: finalize then only unpacks bits), else the global base position.
+__device__ __forceinline__ int64_t hit_coord(const HitOut &H, const DevSeq &S, int64_t r, int64_t g) {
+    return H.pbits ? (int64_t) (((uint64_t) r << H.pbits) | (uint64_t) (g - S.offsets[r])) : g;
+}
+
 __device__ __forceinline__ void emit_hit(const HitOut &H, uint32_t motif, int64_t g, uint32_t sbit, double score) {
     const unsigned long long i = atomicAdd(H.n_hits, 1ULL);
     if (i < H.cap) {
@@ -807,13 +813,14 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
         const uint64_t cw = code_window(S.codes, g);
         const int64_t r = find_region(S, g);
         const int64_t end = S.offsets[r + 1];
+        const int64_t gk = hit_coord(H, S, r, g);
         for (int m = 0; m < cnt; m++) {
             const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
             if ((nw & low_mask(W)) == 0) continue;
             if (g + W > end) continue;
             double fwd, rev;
             score_window32(s_tab + s_off[m], W, cw, nw, fwd, rev);
-            test_and_emit(H, Pw, (uint32_t) s_motif[m], g, fwd, rev, strand_mask);
+            test_and_emit(H, Pw, (uint32_t) s_motif[m], gk, fwd, rev, strand_mask);
         }
     }
 }
@@ -830,7 +837,7 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
     if (g + W > S.offsets[r + 1]) return;
     double fwd, rev;
     score_window(S, Pw.tab2 + Pw.tab_off[p], W, g, fwd, rev);
-    test_and_emit(H, Pw, (uint32_t) p, g, fwd, rev, strand_mask);
+    test_and_emit(H, Pw, (uint32_t) p, hit_coord(H, S, r, g), fwd, rev, strand_mask);
 }
 
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
@@ -854,6 +861,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             const int64_t g = (int64_t) (c >> 30);
             const int64_t r = find_region(S, g);
             const int64_t end = S.offsets[r + 1];
+            const int64_t gk = hit_coord(H, S, r, g);
             const uint32_t nw = n_window(S.nmask, g);
             const uint64_t cw = code_window(S.codes, g);
             while (flags) {
@@ -866,7 +874,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
                 if (nw & low_mask(W)) continue;                         // scored by neval_kernel
                 double fwd, rev;
                 score_window32(Pw.tab2 + Pw.tab_off[pm], W, cw, 0u, fwd, rev);      // no N in the window (checked above)
-                test_and_stage(st, H, Pw, (uint32_t) pm, g, fwd, rev, strand_mask);
+                test_and_stage(st, H, Pw, (uint32_t) pm, gk, fwd, rev, strand_mask);
             }
         }
         __syncthreads();
@@ -915,6 +923,70 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
         const uint32_t m = __shfl(motif, leader);
         const unsigned long long same = __ballot(live && new_pair && motif == m);
         if ((int) (threadIdx.x & 63) == leader) atomicAdd(&region_counts[m], (unsigned long long) __popcll(same));
+        todo &= ~same;
+    }
+}
+
+// The same when the keys carry (region, position inside the region): nothing to look up, only bits to unpack.
+// Four consecutive hits per thread: 16-byte loads and stores, the four strand bytes as one word.
+__global__ void __launch_bounds__(256) finalize_rp_kernel(const uint64_t *__restrict__ keys, int64_t n, int rbits, int pbits,
+                                                          int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
+                                                          int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
+                                                          unsigned long long *__restrict__ region_counts) {
+    const int64_t i0 = 4 * ((int64_t) blockIdx.x * blockDim.x + threadIdx.x);
+    const bool live = i0 < n;
+    uint32_t motif0 = 0xFFFFFFFFu;
+    int n_new = 0;                                              // new (motif, region) pairs among this thread's hits of motif0
+    if (live) {
+        uint64_t k[4];
+        const bool full = i0 + 4 <= n;
+        if (full) {
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(keys + i0), b2 = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
+            k[0] = a.x; k[1] = a.y; k[2] = b2.x; k[3] = b2.y;
+        } else {
+            for (int j = 0; j < 4; j++) k[j] = i0 + j < n ? keys[i0 + j] : 0;
+        }
+        uint64_t prev = i0 > 0 ? keys[i0 - 1] >> (pbits + 1) : ~0ULL;
+        int64_t sq[4], ps[4];
+        uint32_t sd = 0;
+        const uint64_t rmask = (1ULL << rbits) - 1ULL, pmask = (1ULL << pbits) - 1ULL;
+        motif0 = (uint32_t) (k[0] >> (pbits + 1 + rbits));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j < n) {
+                const uint64_t pair = k[j] >> (pbits + 1);      // (motif, region)
+                const uint32_t motif = (uint32_t) (pair >> rbits);
+                sq[j] = (int64_t) (pair & rmask);
+                ps[j] = (int64_t) ((k[j] >> 1) & pmask);
+                sd |= ((k[j] & 1ULL) ? 2u : 1u) << (8 * j);
+                if (prev == ~0ULL || (uint32_t) (prev >> rbits) != motif) motif_first[motif] = i0 + j;
+                if (prev != pair) {
+                    if (motif == motif0) n_new++;
+                    else atomicAdd(&region_counts[motif], 1ULL);    // a thread's hits rarely span two motifs
+                }
+                prev = pair;
+            }
+        }
+        if (full) {
+            *reinterpret_cast<longlong2 *>(seq_idx + i0) = make_longlong2(sq[0], sq[1]);
+            *reinterpret_cast<longlong2 *>(seq_idx + i0 + 2) = make_longlong2(sq[2], sq[3]);
+            *reinterpret_cast<longlong2 *>(pos + i0) = make_longlong2(ps[0], ps[1]);
+            *reinterpret_cast<longlong2 *>(pos + i0 + 2) = make_longlong2(ps[2], ps[3]);
+            *reinterpret_cast<uint32_t *>(strand + i0) = sd;
+        } else {
+            for (int j = 0; j < 4 && i0 + j < n; j++) { seq_idx[i0 + j] = sq[j]; pos[i0 + j] = ps[j]; strand[i0 + j] = (int8_t) ((sd >> (8 * j)) & 0xFFu); }
+        }
+    }
+    // regions with >= 1 hit per motif (stats.py:29-31): one atomic per (wave, motif)
+    unsigned long long todo = __ballot(live && n_new > 0);
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const uint32_t m = __shfl(motif0, leader);
+        const unsigned long long same = __ballot(live && n_new > 0 && motif0 == m);
+        int v = (live && motif0 == m) ? n_new : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((int) (threadIdx.x & 63) == leader) atomicAdd(&region_counts[m], (unsigned long long) v);
         todo &= ~same;
     }
 }
@@ -1297,10 +1369,16 @@ int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, cons
     return MS_OK;
 }
 
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, const DevSeq &S, int64_t *seq_idx,
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st) {
     if (n == 0) return MS_OK;
+    if (pbits > 0) {
+        hipLaunchKernelGGL(finalize_rp_kernel, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, st, keys, n, rbits, pbits,
+                           seq_idx, pos, strand, motif_first, region_counts);
+        MS_HIP(hipGetLastError());
+        return MS_OK;
+    }
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, S,
                        seq_idx, pos, strand, motif_first, region_counts);
     MS_HIP(hipGetLastError());
