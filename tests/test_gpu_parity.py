@@ -591,3 +591,21 @@ def test_window_sweep_equals_per_window_regions(oracle, jaspar579, window, strid
         _lib.scan_sweep(pw, genome, "chrA", 0, 4000, window, stride, strand)       # past the chromosome end
     with pytest.raises(ValueError):
         _lib.scan_sweep(pw, genome, "chrA", 0, 3000, window, 0, strand)
+
+
+def test_c_program_through_the_cabi(oracle, tmp_path):
+    """The boundary bound from C, not Python: tests/cabi/cabi_parity.c includes include/motifscan_amd.h, links
+    libmotifscan_amd.so, and compares ms_scan with the oracle's C entry point bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_parity")
+    libdir, ordir = os.path.join(root, "motifscan_amd"), os.path.join(root, "oracle")
+    subprocess.run(["gcc", "-O2", "-std=c99", os.path.join(root, "tests", "cabi", "cabi_parity.c"), "-I" + os.path.join(root, "include"),
+                    "-L" + libdir, "-lmotifscan_amd", "-L" + ordir, "-loracle", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath," + ordir,
+                    "-o", exe], check=True)
+    env = dict(os.environ)
+    # the library was linked against /opt/rocm's HIP runtime; a bare C process has no torch copy to share
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "hits identical" in r.stdout
