@@ -300,7 +300,8 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
                                  {"MS_PF_ENGINE": "0", "MS_PF_FIELD_BITS": "16", "MS_PF_BLOCKS_PER_CU": "2", "MS_PF_VARIANT": "0"},
                                  {"MS_PF_ENGINE": "1", "MS_PF_VARIANT": "17"},
                                  {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4"},
-                                 {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "17"}])
+                                 {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "17"},
+                                 {"MS_PF_ENGINE": "1", "MS_HIT_COORD": "global"}])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
     """Pre-filter engine (matrix-core product / packed LDS lookups), field width, number of LDS tiles
     and kernel variant are tuning knobs: every setting must give the same (bit-exact) hits.  Small
@@ -318,7 +319,7 @@ def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch,
         assert_same_hits(res.hits(), want)
         st = res.stats()
         assert st["pf_engine"] == int(env["MS_PF_ENGINE"])
-        if len(env) > 1 and "MS_PF_BLOCKS_PER_CU" in env or "MS_PF_FIELD_BITS" in env:
+        if "MS_PF_BLOCKS_PER_CU" in env or "MS_PF_FIELD_BITS" in env:
             assert st["n_tiles"] >= 2
 
 
@@ -609,3 +610,21 @@ def test_c_program_through_the_cabi(oracle, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "hits identical" in r.stdout
+
+
+def test_one_long_region_among_many_short_ones(oracle):
+    """Hit keys carry (region, position in region) only while that costs <= 2 more bits than the global base position;
+    thousands of tiny regions plus one long one exceed that, so this set takes the other key form and the
+    region-look-up finalize kernel."""
+    rng = np.random.default_rng(77)
+    vals, widths, cutoffs = synth.load_motif_set(40, p_value="1e-3")
+    seqs = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(0, 14, size=6000)]
+    seqs.insert(1234, "".join(rng.choice(list("ACGTN"), p=[.245, .245, .245, .245, .02], size=300_000)))
+    raw = "".join(seqs).encode()
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
+    want = oracle.scan_arrays(vals, widths, cutoffs, raw, offsets, 3, 8)
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(raw, offsets), 3)
+    assert_same_hits(res.hits(), want)
+    pair = np.unique((np.repeat(np.arange(40), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
+    assert np.array_equal(res.region_counts(), np.bincount(pair >> 32, minlength=40))
+    assert len(want["pos"]) > 5000
