@@ -185,7 +185,7 @@ def main():
         engine = all_stats[0]["pf_engine"]
         hbm = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                "traffic": traffic, "kernel": "prefilter_kernel", "kernel_ms": pf_ms, "algorithmic_bytes_per_launch": alg_bytes}
-        if engine == 1:
+        if engine >= 1:
             # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe: algorithmic ops =
             # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the
             # kernel ISSUES is 4x that (one-hot: 4 k-slots per base) plus padding of widths to 8 columns
@@ -213,6 +213,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f64 (every hit decision and score, as in the reference) behind an int8 one-hot matrix-core pre-filter (i32 accumulate)"
                       if engine == 1 else
+                      "f64 (every hit decision and score, as in the reference) behind an int8 Walsh-form matrix-core pre-filter (i32 accumulate)"
+                      if engine == 2 else
                       "f64 (every hit decision and score, as in the reference) behind a u32 pre-filter of three packed 10-bit fixed-point fields"),
             "data": "synthetic",
             "config": {"workload": {"c4shard": "BASELINE configs[3] per-GPU shard: (125k input + 125k control) regions x 500 bp x 579 PWMs "

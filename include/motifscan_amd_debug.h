@@ -26,12 +26,13 @@ int ms_debug_plan_dims(const ms_pwmset *pwms, int strand_mask, int64_t lds_budge
 int ms_debug_plan_tables(const ms_pwmset *pwms, int32_t *group_motifs, int32_t *group_G, int32_t *group_fb,
                          uint32_t *tables, int32_t *exact_motifs, int32_t *tile_first_group);
 
-/* The int8 / matrix-core form of the plan (environment MS_PF_ENGINE=1 when ms_debug_plan_dims ran), decoded
- * from the operand image the kernel reads: rows [n_groups][16 fields][32 motif columns][4 bases]
- * (field n: motif slot n >> 1, even n forward, odd n reverse; a window is a candidate for a field iff
- * the sum over its columns of rows[..][column][base at window start + column] is >= 0),
- * group_kb [n_groups] = 8-column blocks evaluated for the group. */
-int ms_debug_plan_mfma_rows(const ms_pwmset *pwms, int8_t *rows, int32_t *group_kb);
+/* The int8 / matrix-core forms of the plan (environment MS_PF_ENGINE=1 or 2 when ms_debug_plan_dims ran), decoded
+ * from the operand image the kernel reads: rows [n_groups][16 fields][32 motif columns][4 bases] = what the product
+ * adds for that base at that column, bias [n_groups][16] (engine 2: the row constant held in the spare k-slots;
+ * engine 1: 0); field n: motif slot n >> 1, even n forward, odd n reverse; a window is a candidate for a field iff
+ * bias + the sum over its columns of rows[..][column][base at window start + column] is >= 0;
+ * group_kb [n_groups] = k-blocks evaluated for the group (8 columns each for engine 1, 10 for engine 2). */
+int ms_debug_plan_mfma_rows(const ms_pwmset *pwms, int16_t *rows, int32_t *bias, int32_t *group_kb);
 
 /* Free the current device's grow-only work buffers (candidate list, hit list, sort space), so a
  * test can force the "buffer too small -> grow -> run the pass again" path.  Needs a GPU. */

@@ -114,7 +114,7 @@ def lib():
         "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
         "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
         "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pi32, pu32, pi32, pi32]),
-        "ms_debug_plan_mfma_rows": (c_int, [vp, pi8, pi32]),
+        "ms_debug_plan_mfma_rows": (c_int, [vp, ctypes.POINTER(ctypes.c_int16), pi32, pi32]),
         "ms_debug_release_scratch": (c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -219,7 +219,7 @@ class PwmSet:
                 "tables": tb, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 
     def plan_mfma(self, strand_mask=3, lds_budget=143 * 1024):
-        """Host-side view of the int8 / matrix-core plan (tests only; needs MS_PF_ENGINE=1 in the environment)."""
+        """Host-side view of the int8 / matrix-core plan (tests only; MS_PF_ENGINE = 1 or 2 in the environment picks the form)."""
         L = lib()
         nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
         check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
@@ -229,11 +229,13 @@ class PwmSet:
         tf = np.zeros(nt.value + 1, dtype=np.int32)
         check(L.ms_debug_plan_tables(self.h, ptr(gm, ctypes.c_int32), None, None, None, ptr(ex, ctypes.c_int32),
                                      ptr(tf, ctypes.c_int32)))
-        rows = np.zeros((nq.value, 16, 32, 4), dtype=np.int8)
+        rows = np.zeros((nq.value, 16, 32, 4), dtype=np.int16)
+        bias = np.zeros((nq.value, 16), dtype=np.int32)
         kb = np.zeros(nq.value, dtype=np.int32)
-        check(L.ms_debug_plan_mfma_rows(self.h, ptr(rows, ctypes.c_int8), ptr(kb, ctypes.c_int32)))
-        return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "group_motifs": gm, "rows": rows,
-                "group_kb": kb, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
+        check(L.ms_debug_plan_mfma_rows(self.h, ptr(rows, ctypes.c_int16), ptr(bias, ctypes.c_int32), ptr(kb, ctypes.c_int32)))
+        cols = 10 if os.environ.get("MS_PF_ENGINE") == "2" else 8
+        return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "group_motifs": gm, "rows": rows, "bias": bias,
+                "group_kb": kb, "cols_per_kb": cols, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 
     def close(self):
         if getattr(self, "h", None):

@@ -396,7 +396,7 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
 
 // Pre-filter engine: 0 = packed 2-mer tables read per lane from LDS, 1 = int8 one-hot product on the matrix cores.
 static int pf_engine() {
-    if (const char *e = getenv("MS_PF_ENGINE")) return atoi(e) == 0 ? 0 : 1;     // measurement / A-B switch
+    if (const char *e = getenv("MS_PF_ENGINE")) { const int v = atoi(e); return v == 0 ? 0 : (v == 2 ? 2 : 1); }     // measurement / A-B switch
     return 1;
 }
 
@@ -414,9 +414,9 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
             p->plan.strand_mask = strand_mask;
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
-            int rc = engine == 1
+            int rc = engine >= 1
                          ? build_plan_mfma(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
-                                           p->max_raw.data(), p->P, strand_mask, lds_budget, &p->plan)
+                                           p->max_raw.data(), p->P, strand_mask, lds_budget, engine, &p->plan)
                          : build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
                                       p->max_raw.data(), p->P, strand_mask, lds_budget, min_fb, &p->plan);
             if (rc) return rc;
@@ -888,7 +888,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : 0);      // wave queues (+ one-hot table) follow the tables
+    const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
     size_t lds_budget = c->lds_max - lds_fixed;
     int pf_blocks_per_cu = 1;
     if (const char *e = getenv("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
@@ -920,7 +920,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         int64_t cells = 0;                                                          // (window, column) pairs of one strand
         for (int32_t p : plan.fast_motifs) cells += windows_for_width(seqs, pwms->widths[p]) * pwms->widths[p];
         stt.mfma_ops_algorithmic = 2 * (strand_mask == 3 ? 2 : 1) * cells;           // one multiply-add per cell and strand
-        if (plan.engine == 1) {
+        if (plan.engine >= 1) {
             int64_t kb_sum = 0;                                                     // k-blocks over all row tiles (2 groups each)
             for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_sum += plan.group_G[q];
             const int64_t padded = ((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads;
@@ -981,10 +981,11 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
     // measurement switches (not part of the interface): kernel variant, drop candidates
-    int pf_variant = plan.engine == 1 ? 16 : 4, pf_no_emit = 0;
+    int pf_variant = plan.engine == 2 ? 24 : plan.engine == 1 ? 16 : 4, pf_no_emit = 0;
     if (const char *e = getenv("MS_PF_VARIANT")) {
         const int v = atoi(e) & 31;
-        if ((v >= 16) == (plan.engine == 1)) pf_variant = v;          // a variant of the other engine cannot read this plan
+        const int v_engine = v >= 24 ? 2 : v >= 16 ? 1 : 0;
+        if (v_engine == plan.engine) pf_variant = v;                   // a variant of another engine cannot read this plan
     }
     if (const char *e = getenv("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
     const bool pf_clock = getenv("MS_PF_CLOCK") && atoi(getenv("MS_PF_CLOCK")) != 0;
@@ -1577,26 +1578,46 @@ int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *group_motifs, int32_t
     return MS_OK;
 }
 
-// Engine 1 plan (MS_PF_ENGINE=1 at ms_debug_plan_dims time), decoded from the PHYSICAL operand image the
-// kernel reads: rows [n_groups][16 fields][32 columns][4 bases] int8, group_kb [n_groups] k-blocks.
-int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int8_t *rows, int32_t *group_kb) {
+// Matrix-core plan (MS_PF_ENGINE=1 or 2 at ms_debug_plan_dims time), decoded from the PHYSICAL operand image the
+// kernel reads: rows [n_groups][16 fields][32 columns][4 bases] int16 (what the product adds for that base at that
+// column), bias [n_groups][16] (engine 2: the spare k-slots; engine 1: 0), group_kb [n_groups] k-blocks.
+int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int16_t *rows, int32_t *bias, int32_t *group_kb) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     std::lock_guard<std::mutex> lk(pwms->mu);
     const PrefilterPlan &pl = pwms->plan;
-    if (pwms->plan_strand < 0 || pl.engine != 1) { set_error("no engine-1 plan: set MS_PF_ENGINE=1 and call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
+    if (pwms->plan_strand < 0 || pl.engine < 1) { set_error("no matrix-core plan: set MS_PF_ENGINE=1 or 2 and call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
     const size_t nq = pl.group_G.size();
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(pl.tables.data());
+    const int cols = pl.engine == 2 ? kW2Cols : 8;
     size_t off = 0;
     for (size_t q = 0; q < nq; q++) {
         const int kb_n = pl.group_G[q];
         const int h = (int) (q & 1);
         if (group_kb) group_kb[q] = kb_n;
-        for (int f = 0; f < 16; f++)
+        for (int f = 0; f < 16; f++) {
+            const int row = mfma_row_of(h, f);
+            int32_t bs = 0;
+            if (pl.engine == 2)                                       // spare k-slots of k-block 0: 64 * a_hi + a_lo
+                bs = 64 * (int8_t) bytes[off + mfma2_spare_index(row, 0)] + (int8_t) bytes[off + mfma2_spare_index(row, 1)];
+            if (bias) bias[q * 16 + f] = bs;
             for (int c = 0; c < 32; c++)
-                for (int b = 0; b < 4; b++)
-                    rows[((q * 16 + f) * 32 + c) * 4 + b] =
-                        c < 8 * kb_n ? (int8_t) bytes[off + mfma_byte_index(c >> 3, mfma_row_of(h, f), c & 7, b)] : (int8_t) 0;
+                for (int b = 0; b < 4; b++) {
+                    int v = 0;
+                    if (c < cols * kb_n) {
+                        if (pl.engine == 2) {
+                            const int s1 = (b & 1) ? -1 : 1, s2 = (b & 2) ? -1 : 1;
+                            const int c1 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 0)];
+                            const int c2 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 1)];
+                            const int c3 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 2)];
+                            v = c1 * s1 + c2 * s2 + c3 * s1 * s2;
+                        } else {
+                            v = (int8_t) bytes[off + mfma_byte_index(c >> 3, row, c & 7, b)];
+                        }
+                    }
+                    rows[((q * 16 + f) * 32 + c) * 4 + b] = (int16_t) v;
+                }
+        }
         if (h == 1) off += (size_t) kb_n * kMfmaRowTileBytesPerKb;
     }
     return MS_OK;

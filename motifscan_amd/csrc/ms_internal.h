@@ -60,7 +60,7 @@ struct TileDesc {
 // 2-mer tables in groups that share 16-byte entries, and how groups are cut into LDS tiles.
 struct PrefilterPlan {
     int strand_mask = 0;
-    int engine = 0;                      // 0: packed 2-mer tables read per lane from LDS; 1: int8 one-hot MFMA (below)
+    int engine = 0;                      // 0: packed 2-mer tables read per lane from LDS; 1: int8 one-hot MFMA; 2: int8 Walsh-form MFMA (below)
     std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in group order
     std::vector<int32_t> exact_motifs;   // motif ids scored in fp64 at every window
     std::vector<int32_t> group_motifs;   // [n_groups][kGroupSlots], -1 = empty slot
@@ -94,12 +94,30 @@ inline size_t mfma_byte_index(int kb, int row, int col_in_kb, int base) {     //
     return (size_t) kb * kMfmaRowTileBytesPerKb + (size_t) (khalf * 32 + row) * 16 + (size_t) (col_in_kb & 3) * 4 + base;
 }
 
+// ---- engine 2: the same product with THREE k-slots per base instead of four ---------------------
+// A base has four states, so any per-column score table is  c0 + c1*s1 + c2*s2 + c3*s1*s2  with
+// s1 = +1/-1 by bit 0 of the base code and s2 = +1/-1 by bit 1 (Walsh form): three k-slots per column, the
+// constants c0 summed into a per-row bias.  32 k-slots = 10 columns (5 per lane half: bytes 3j..3j+2 of the
+// half hold c1, c2, c3 of its j-th column) + one spare byte per half; the B operand carries (s1, s2, s1*s2) per
+// base and the constants 64 (half 0) / 1 (half 1) in the spare bytes, so the A-side spare bytes of k-block 0
+// give the row bias 64 * a_hi + a_lo.  Rows tiles need ceil(W / 10) k-blocks: 18 % fewer matrix instructions on
+// the JASPAR width distribution than engine 1's 8 columns per k-block.
+constexpr int kW2Cols = 10;            // motif columns per k-block
+constexpr int kW2MaxWidth = 30;        // 3 k-blocks
+inline size_t mfma2_byte_index(int kb, int row, int col_in_kb, int slot) {      // slot 0..2 = c1, c2, c3; inside a row tile
+    const int khalf = col_in_kb / 5;
+    return (size_t) kb * kMfmaRowTileBytesPerKb + (size_t) (khalf * 32 + row) * 16 + (size_t) (col_in_kb % 5) * 3 + slot;
+}
+inline size_t mfma2_spare_index(int row, int khalf) {                           // k-block 0
+    return (size_t) (khalf * 32 + row) * 16 + 15;
+}
+
 // Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes; min_field_bits 10 or 16.
 // engine 1 (build_plan_mfma): ClassDesc.G = k-blocks per row tile, .n_groups = ROW TILES in the class,
 // .first_group = table group of its first row tile; group_G = k-blocks, group_fb = 8.
 int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t *widths,
                     const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
-                    size_t lds_budget, PrefilterPlan *plan);
+                    size_t lds_budget, int engine, PrefilterPlan *plan);
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths,
                const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
                size_t lds_budget, int min_field_bits, PrefilterPlan *plan);

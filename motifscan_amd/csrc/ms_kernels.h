@@ -9,6 +9,7 @@ constexpr int kNwMotifChunk = 8;      // motifs per neval_kernel block (their fp
 constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spilled to HBM when the next append would not fit
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
 constexpr size_t kMfmaLutBytes = 256 * 16;   // engine 1: byte of four 2-bit codes -> 16 one-hot operand bytes, after the wave queues
+constexpr size_t kMfma2LutBytes = 1024 * 16; // engine 2: ten bits of five 2-bit codes -> 15 Walsh operand bytes + the spare
 
 struct DevSeq {
     const uint32_t *codes;

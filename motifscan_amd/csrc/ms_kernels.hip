@@ -577,6 +577,24 @@ __device__ __forceinline__ i32x4 onehot4(uint32_t codes8) {
     return r;
 }
 
+// engine 2: 5 bases (10 bits of 2-bit codes) -> bytes 3j, 3j+1, 3j+2 = s1, s2, s1*s2 of base j (s1 = -1 if bit 0 of the
+// code is set, s2 = -1 if bit 1 is); byte 15 (the spare k-slot) is filled in by the reader
+__device__ __forceinline__ uint4 walsh5(uint32_t codes10) {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint32_t code = (codes10 >> (2 * j)) & 3u;
+        const int s1 = (code & 1u) ? -1 : 1, s2 = (code & 2u) ? -1 : 1;
+        const int v[3] = {s1, s2, s1 * s2};
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int byte = 3 * j + t;
+            w[byte >> 2] |= ((uint32_t) v[t] & 0xFFu) << (8 * (byte & 3));
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __device__ __forceinline__ int max16(const i32x16 &c) {
     int a = max(max(c[0], c[1]), c[2]);             // v_max3_i32
     int b = max(max(c[3], c[4]), c[5]);
@@ -640,7 +658,7 @@ __device__ __forceinline__ void mfma_emit(const PfArgs &A, MfWave &W, const i32x
 // All row tiles of one class (NK k-blocks each): per tile NK ds_read_b128 (A operand), 2 * NK matrix
 // instructions, 16 v_max3 and one compare.  The B operands (one-hot image of the lane's bases) come from a
 // 256-entry table in LDS: 4 bases (one byte of 2-bit codes) -> 16 operand bytes.
-template <int NK, int V>
+template <int NK, int V, int ENG>
 __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                            uint32_t byte_off, int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
                                            int64_t g0, bool live0, bool live1) {
@@ -650,8 +668,17 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
     i32x4 b0[NK], b1[NK];
 #pragma unroll
     for (int kb = 0; kb < NK; kb++) {
-        b0[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
-        b1[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
+        if constexpr (ENG == 2) {
+            // 5 bases per lane half; the spare k-slot (byte 15) carries the bias scale: 64 in half 0, 1 in half 1
+            const int spare = h ? (1 << 24) : (64 << 24);
+            b0[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw0 >> (20 * kb + 10 * h)) & 0x3FFu) << 4));
+            b1[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw1 >> (20 * kb + 10 * h)) & 0x3FFu) << 4));
+            b0[kb].w |= spare;
+            b1[kb].w |= spare;
+        } else {
+            b0[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
+            b1[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
+        }
     }
     const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto product = [&](const char *q, i32x16 &c0, i32x16 &c1) {
@@ -690,14 +717,14 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
 
 // grid = (blocks per tile, tiles); NT / 64 waves per block, each takes 64 consecutive window starts
 // per iteration (lanes l and l + 32 share window l & 31 and hold the two halves of every k-block).
-// Dynamic LDS: operand tables of the tile | wave queues | one-hot table (kMfmaLutBytes).
+// Dynamic LDS: operand tables of the tile | wave queues | B-operand table (kMfmaLutBytes / kMfma2LutBytes).
 // V (A/B measurement): 1 = two row tiles' products in flight per wave in the narrow classes.
 // (Measured and dropped, tools/pf_variants.py: fetching the next chunk's sequence words early, class descriptors
 // in registers, waves walking the classes in rotated order, tiles software-pipelined in pairs -- each within noise;
 // 5 waves per SIMD (two 640-thread blocks per CU at <= 96 VGPRs) spills and is 35 % slower; software-pipelining the
 // one-k-block class alone: 66 -> 63 cycles per matrix instruction on an all-W=8 set, < 1 % on the benchmark set;
 // s_setprio raised around the matrix instructions: within noise.)
-template <int NT, int V>
+template <int NT, int V, int ENG>
 __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -705,9 +732,13 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     const uint4 *__restrict__ src = A.tables + T->table_off16;
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     uint4 *lut4 = lds4 + A.wq_off16 + kWqBytes / 16;
-    for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
-        const i32x4 v = onehot4(i);
-        lut4[i] = make_uint4((uint32_t) v.x, (uint32_t) v.y, (uint32_t) v.z, (uint32_t) v.w);
+    if constexpr (ENG == 2) {
+        for (uint32_t i = threadIdx.x; i < 1024u; i += NT) lut4[i] = walsh5(i);
+    } else {
+        for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
+            const i32x4 v = onehot4(i);
+            lut4[i] = make_uint4((uint32_t) v.x, (uint32_t) v.y, (uint32_t) v.z, (uint32_t) v.w);
+        }
     }
     __syncthreads();
     const char *lds = reinterpret_cast<const char *>(lds4);
@@ -730,10 +761,10 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
             switch (cd.G) {
-                case 1: mfma_class<1, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 2: mfma_class<2, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 3: mfma_class<3, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 4: mfma_class<4, V>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 1: mfma_class<1, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 2: mfma_class<2, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 3: mfma_class<3, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 4: if constexpr (ENG == 1) mfma_class<4, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 default: break;
             }
         }
@@ -1311,9 +1342,11 @@ static PfKernel pf_kernel_for(int variant, int *threads) {
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
         case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
-        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, 1>;  // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU (default)
-        case 17: *threads = 512; return prefilter_mfma_kernel<512, 1>;    // engine 1, 8 waves per block
-        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0>;  // A/B: one row tile in flight per wave
+        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 1>;  // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU
+        case 17: *threads = 512; return prefilter_mfma_kernel<512, 1, 1>;    // engine 1, 8 waves per block
+        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 1>;  // A/B: one row tile in flight per wave
+        case 24: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 2>;  // engine 2 (Walsh form: 10 columns per k-block)
+        case 25: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 2>;  // engine 2, one row tile in flight per wave
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }

@@ -322,47 +322,124 @@ bool quantize_strand_i8(const double e[4][kMaxFastWidth], int W, double T, I8Str
     return false;
 }
 
+// Engine 2 (ms_internal.h): the same deficits, stored as Walsh coefficients.  Per column the integers
+// w(b) = -dq(b) <= 0 are nudged UP (never down: the bound only loosens; never above 0: no window gains a bonus)
+// by the smallest amounts that make c = H w / 4 integral -- w(1), w(2), w(3) of one parity and the sum
+// divisible by 4 -- and then
+//     w'(b) = c0 + c1*s1(b) + c2*s2(b) + c3*s1(b)*s2(b)      exactly,
+// with c1..c3 in int8 (|c| <= 127 at dq <= 254) and the c0 summed into the row bias next to Bq:
+//     acc = bias + sum_c (c1 s1 + c2 s2 + c3 s1 s2)(base_c) = Bq + sum_c w'_c(base_c) >= Bq - sum dq.
+struct W2Strand {
+    int8_t c[kMaxFastWidth][3];
+    int32_t bias;
+    int levels;
+};
+
+bool quantize_strand_w2(const double e[4][kMaxFastWidth], int W, double T, W2Strand *out) {
+    std::memset(out->c, 0, sizeof(out->c));
+    out->bias = -1;                             // dead until proven otherwise: acc = -1 everywhere
+    out->levels = 0;
+    double hi[kMaxFastWidth], Mx = 0, lowest = 0;
+    for (int c = 0; c < W; c++) {
+        hi[c] = std::max(std::max(e[0][c], e[1][c]), std::max(e[2][c], e[3][c]));
+        Mx += hi[c];
+        lowest += std::min(std::min(e[0][c], e[1][c]), std::min(e[2][c], e[3][c]));
+    }
+    const double budget = Mx - T;
+    if (!(budget >= 0)) return true;            // no N-free window reaches T
+    if (!(T > lowest)) return false;            // every window passes
+    for (int Bq = 251; Bq >= 1; Bq--) {
+        const double s = budget > 0 ? ((double) Bq + 0.5) / budget : 1e300;
+        int8_t cc[kMaxFastWidth][3];
+        long bias = Bq;
+        bool ok = true;
+        for (int c = 0; c < W && ok; c++) {
+            // a deficit beyond the budget is stored as Bq + 4: it may be nudged by up to 3 and still sinks the window alone
+            int w[4];
+            bool clamped[4];
+            for (int b = 0; b < 4; b++) {
+                const double d = hi[c] - e[b][c];
+                double q = d <= 0 ? 0.0 : std::floor(std::min(d * s * (1 - 1e-12) - 1e-7, 1e6));
+                if (!(q >= 0)) q = 0;
+                clamped[b] = q > Bq;
+                w[b] = clamped[b] ? -(Bq + 4) : -(int) q;
+            }
+            // smallest upward nudges (none above 0, so no window ever gains a bonus; clamped entries are free):
+            // w1, w2, w3 of one parity, sum = 0 mod 4
+            int best = 1 << 30, bd[4] = {0, 0, 0, 0};
+            for (int code = 0; code < 256; code++) {
+                const int dd[4] = {code & 3, (code >> 2) & 3, (code >> 4) & 3, (code >> 6) & 3};
+                const int v0 = w[0] + dd[0], v1 = w[1] + dd[1], v2 = w[2] + dd[2], v3 = w[3] + dd[3];
+                if (v0 > 0 || v1 > 0 || v2 > 0 || v3 > 0) continue;
+                if (((v1 ^ v2) & 1) || ((v1 ^ v3) & 1)) continue;
+                if ((v0 + v1 + v2 + v3) & 3) continue;
+                int cost = 0;
+                for (int b = 0; b < 4; b++) cost += clamped[b] ? 0 : dd[b];
+                if (cost < best) { best = cost; for (int b = 0; b < 4; b++) bd[b] = dd[b]; }
+            }
+            if (best == (1 << 30)) { ok = false; break; }              // (values too close to 0 to fix the parities: try a coarser scale)
+            const int v0 = w[0] + bd[0], v1 = w[1] + bd[1], v2 = w[2] + bd[2], v3 = w[3] + bd[3];
+            // base code b: s1 = +1 for b in {0, 2}, -1 for {1, 3};  s2 = +1 for {0, 1}, -1 for {2, 3}
+            const int c0 = (v0 + v1 + v2 + v3) / 4, c1 = (v0 - v1 + v2 - v3) / 4, c2 = (v0 + v1 - v2 - v3) / 4, c3 = (v0 - v1 - v2 + v3) / 4;
+            if (c1 < -127 || c1 > 127 || c2 < -127 || c2 > 127 || c3 < -127 || c3 > 127) { ok = false; break; }
+            cc[c][0] = (int8_t) c1; cc[c][1] = (int8_t) c2; cc[c][2] = (int8_t) c3;
+            bias += c0;
+        }
+        if (!ok) continue;
+        if (bias < -64 * 127 - 32 || bias > 64 * 127 + 32) continue;       // must fit 64 * a_hi + a_lo with int8 parts
+        for (int c = 0; c < W; c++) for (int t = 0; t < 3; t++) out->c[c][t] = cc[c][t];
+        out->bias = (int32_t) bias;
+        out->levels = Bq;
+        return true;
+    }
+    return false;
+}
+
 struct FastMotifI8 {
     int32_t id;
     int32_t W;
     I8Strand strand[2];
+    W2Strand w2[2];
 };
 
 }  // namespace
 
 int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t *widths,
                     const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
-                    size_t lds_budget, PrefilterPlan *plan) {
+                    size_t lds_budget, int engine, PrefilterPlan *plan) {
     *plan = PrefilterPlan();
     plan->strand_mask = strand_mask;
-    plan->engine = 1;
+    plan->engine = engine == 2 ? 2 : 1;
+    const int cols = plan->engine == 2 ? kW2Cols : 8;              // motif columns per k-block
+    const int max_w = plan->engine == 2 ? kW2MaxWidth : kMaxFastWidth;
     std::vector<FastMotifI8> fast;
     fast.reserve(n_pwms);
     for (int32_t p = 0; p < n_pwms; p++) {
         const int W = widths[p];
         const double *m = values + val_off[p];
         double T = 0;
-        bool ok = filter_threshold(m, W, cutoffs[p], max_raw[p], &T);
+        bool ok = W <= max_w && filter_threshold(m, W, cutoffs[p], max_raw[p], &T);
         FastMotifI8 fm;
         fm.id = p;
         fm.W = W;
         for (int sd = 0; ok && sd < 2; sd++) {
-            if (!(strand_mask & (1 << sd))) {                    // strand not asked for: never a candidate
-                std::memset(&fm.strand[sd], 0, sizeof(I8Strand));
-                for (int b = 0; b < 4; b++) fm.strand[sd].v[0][b] = -1;
-                continue;
-            }
+            std::memset(&fm.strand[sd], 0, sizeof(I8Strand));
+            std::memset(&fm.w2[sd], 0, sizeof(W2Strand));
+            for (int b = 0; b < 4; b++) fm.strand[sd].v[0][b] = -1;      // never a candidate unless quantised below
+            fm.w2[sd].bias = -1;
+            if (!(strand_mask & (1 << sd))) continue;                    // strand not asked for
             double e[4][kMaxFastWidth];
             for (int b = 0; b < 4; b++)
                 for (int c = 0; c < W; c++)
                     e[b][c] = sd == 0 ? m[(int64_t) b * W + c] : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
-            ok = quantize_strand_i8(e, W, T, &fm.strand[sd]);
+            ok = plan->engine == 2 ? quantize_strand_w2(e, W, T, &fm.w2[sd]) : quantize_strand_i8(e, W, T, &fm.strand[sd]);
         }
         if (ok) fast.push_back(fm);
         else plan->exact_motifs.push_back(p);
     }
-    std::stable_sort(fast.begin(), fast.end(), [](const FastMotifI8 &a, const FastMotifI8 &b) {
-        return (a.W + 7) / 8 != (b.W + 7) / 8 ? (a.W + 7) / 8 < (b.W + 7) / 8 : a.W < b.W;
+    std::stable_sort(fast.begin(), fast.end(), [cols](const FastMotifI8 &a, const FastMotifI8 &b) {
+        const int ka = (a.W + cols - 1) / cols, kb = (b.W + cols - 1) / cols;
+        return ka != kb ? ka < kb : a.W < b.W;
     });
 
     // row tiles of 16 motifs (2 table groups), narrow to wide
@@ -370,7 +447,7 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
     std::vector<int> rt_kb(n_rt, 0);
     std::vector<size_t> rt_off(n_rt + 1, 0);
     for (size_t t = 0; t < n_rt; t++) {
-        for (size_t j = 16 * t; j < std::min(fast.size(), 16 * (t + 1)); j++) rt_kb[t] = std::max(rt_kb[t], (fast[j].W + 7) / 8);
+        for (size_t j = 16 * t; j < std::min(fast.size(), 16 * (t + 1)); j++) rt_kb[t] = std::max(rt_kb[t], (fast[j].W + cols - 1) / cols);
         rt_off[t + 1] = rt_off[t] + (size_t) rt_kb[t] * kMfmaRowTileBytesPerKb;
     }
     std::vector<uint8_t> bytes(rt_off[n_rt], 0);
@@ -386,6 +463,20 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
                 const size_t j = 16 * t + 8 * h + slot;
                 for (int sd = 0; sd < 2; sd++) {
                     const int row = mfma_row_of(h, 2 * slot + sd);
+                    if (plan->engine == 2) {
+                        // bias = 64 * a_hi + a_lo in the spare bytes of k-block 0; an empty slot or dead strand: bias -1, no coefficients
+                        const int32_t bias = j < fast.size() ? fast[j].w2[sd].bias : -1;
+                        int a_hi = (int) std::lround((double) bias / 64.0);
+                        a_hi = std::max(-127, std::min(127, a_hi));
+                        const int a_lo = bias - 64 * a_hi;               // |a_lo| <= 32 by the quantiser's range check
+                        tab[mfma2_spare_index(row, 0)] = (uint8_t) (int8_t) a_hi;
+                        tab[mfma2_spare_index(row, 1)] = (uint8_t) (int8_t) a_lo;
+                        if (j < fast.size())
+                            for (int c = 0; c < fast[j].W; c++)
+                                for (int s3 = 0; s3 < 3; s3++)
+                                    tab[mfma2_byte_index(c / cols, row, c % cols, s3)] = (uint8_t) fast[j].w2[sd].c[c][s3];
+                        continue;
+                    }
                     if (j >= fast.size()) {                      // empty slot: never a candidate
                         for (int b = 0; b < 4; b++) tab[mfma_byte_index(0, row, 0, b)] = (uint8_t) (int8_t) -1;
                         continue;

@@ -150,11 +150,11 @@ def emulate_mfma_prefilter(plan, seq_codes_2bit):
     flagged = set()
     rows = plan["rows"].astype(np.int64)
     for q in range(rows.shape[0]):
-        ncol = 8 * int(plan["group_kb"][q])
+        ncol = min(32, plan["cols_per_kb"] * int(plan["group_kb"][q]))
         assert not rows[q, :, ncol:, :].any()
         for n in range(16):
             m = int(plan["group_motifs"][q, n >> 1])
-            acc = np.zeros(L, dtype=np.int64)
+            acc = np.full(L, int(plan["bias"][q, n]), dtype=np.int64)
             for c in range(ncol):
                 acc += rows[q, n, c][padded[c:c + L]]
             hot = np.nonzero(acc >= 0)[0]
@@ -166,10 +166,11 @@ def emulate_mfma_prefilter(plan, seq_codes_2bit):
     return flagged
 
 
+@pytest.mark.parametrize("engine", ["1", "2"])
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
 @pytest.mark.parametrize("strand", [1, 2, 3])
-def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch):
-    monkeypatch.setenv("MS_PF_ENGINE", "1")
+def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch, engine):
+    monkeypatch.setenv("MS_PF_ENGINE", engine)
     mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
     pw = _lib.PwmSet.from_matrices(mats, cut)
     plan = pw.plan_mfma(strand)
@@ -196,10 +197,11 @@ def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, m
     assert n_flag <= 2.0 * n_hit + 200, (n_flag, n_hit)
 
 
-def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch):
-    """The fuzzer's tie-heavy cases (cutoffs exactly on attainable scores): the int8 plan keeps every hit."""
+@pytest.mark.parametrize("engine", ["1", "2"])
+def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch, engine):
+    """The fuzzer's tie-heavy cases (cutoffs exactly on attainable scores): the int8 plans keep every hit."""
     import fuzz_parity
-    monkeypatch.setenv("MS_PF_ENGINE", "1")
+    monkeypatch.setenv("MS_PF_ENGINE", engine)
     lut = {c: i for i, c in enumerate("ACGT")}
     checked = 0
     for seed in range(40):
@@ -262,6 +264,13 @@ def test_mfma_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
     monkeypatch.setenv("MS_PF_ENGINE", "1")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     widths = jaspar579["widths"]
+    monkeypatch.setenv("MS_PF_ENGINE", "2")                    # Walsh form: 10 columns per k-block, fewer k-blocks in total
+    p2 = pw.plan_mfma(3, 143 * 1024)
+    assert p2["n_fast"] == 579 and int(p2["group_kb"][0::2].sum()) == 62 and p2["group_kb"].max() == 3
+    for q in range(len(p2["group_kb"])):
+        ws = widths[p2["group_motifs"][q][p2["group_motifs"][q] >= 0]]
+        assert len(ws) == 0 or (ws <= 10 * p2["group_kb"][q]).all()
+    monkeypatch.setenv("MS_PF_ENGINE", "1")
     for budget in (32 * 1024, 143 * 1024):
         plan = pw.plan_mfma(3, budget)
         assert plan["n_exact"] == 0 and plan["n_fast"] == 579

@@ -17,7 +17,7 @@ for rep in range(2):
     for noemit in (0, 1):
         for v, b in combos:
             os.environ["MS_PF_VARIANT"] = str(v)
-            os.environ["MS_PF_ENGINE"] = "1" if v >= 16 else "0"       # variants >= 16: int8 matrix-core engine
+            os.environ["MS_PF_ENGINE"] = "2" if v >= 24 else "1" if v >= 16 else "0"       # variants >= 16: int8 matrix-core engines
             os.environ["MS_PF_BLOCKS_PER_CU"] = str(b)
             os.environ["MS_PF_NOEMIT"] = str(noemit)
             ms = []
