@@ -75,7 +75,32 @@ __global__ void __launch_bounds__(1024) kt(int iters, int *out, unsigned long lo
         const int m0 = max16(c0), m1 = MODE == 5 ? c1[3] : max16(c1);
         if (__any((m0 & m1) >= 0)) { sink += t; out[threadIdx.x] = t; }
     };
-    if (MODE == 6) {
+    if (MODE == 7) {
+        // the same tile (32 rows x 64 windows x K = 64) from eight 16x16x64 instructions: 2 row halves x 4 window quarters
+        typedef int i32x4v __attribute__((ext_vector_type(4)));
+        const i32x4v z4 = {0, 0, 0, 0};
+        for (int t = 0; t < iters; t++) {
+            const char *q = p + (t & 31) * 2048;
+            const i32x4 a0 = *reinterpret_cast<const i32x4 *>(q), a1 = *reinterpret_cast<const i32x4 *>(q + 1024);
+            i32x4v c[8];
+            c[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z4, 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, z4, 0, 0, 0);
+            c[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, z4, 0, 0, 0);
+            c[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b3, z4, 0, 0, 0);
+            c[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, z4, 0, 0, 0);
+            c[5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, z4, 0, 0, 0);
+            c[6] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, z4, 0, 0, 0);
+            c[7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b3, z4, 0, 0, 0);
+            int m[11];
+            for (int i = 0; i < 8; i++) m[i] = max(max(c[i][0], c[i][1]), c[i][2]);
+            m[8] = max(max(c[0][3], c[1][3]), c[2][3]);
+            m[9] = max(max(c[3][3], c[4][3]), c[5][3]);
+            m[10] = max(c[6][3], c[7][3]);
+            const int x = max(max(m[0], m[1]), m[2]), y = max(max(m[3], m[4]), m[5]), w = max(max(m[6], m[7]), m[8]);
+            const int r = max(max(x, y), max(max(w, m[9]), m[10]));
+            if (__any(r >= 0)) { sink += t; out[threadIdx.x] = t; }
+        }
+    } else if (MODE == 6) {
         // software pipeline with the A operands fetched one tile ahead: per iteration  read(t+2) | product(t+1) | reduce(t)
         auto rd = [&](int t, i32x4 &a0, i32x4 &a1) {
             const char *q = p + (t & 31) * 2048;
@@ -154,6 +179,7 @@ int main() {
             run<4>("production tile, pipelined in pairs", threads, blocks);
             run<5>("production tile, one max16 only", threads, blocks);
             run<6>("production tile, pipelined + operand prefetch", threads, blocks);
+            run<7>("production tile from 8 x 16x16x64", threads, blocks);
         }
     }
     return 0;
