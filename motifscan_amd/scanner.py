@@ -95,6 +95,21 @@ class Scanner:
             return g.extract(idx, self.seq_starts, self.seq_ends)
         return _lib.SeqSet.from_strings(self._sequences)
 
+    def _as_sweep(self):
+        """(genome, chromosome index, begin, end, window, stride) if the regions are the windows of ONE fixed-stride
+        sweep of one chromosome of a ResidentGenome, in order -- then ms_scan_sweep gives the identical result while
+        scoring every base once; None otherwise."""
+        if self._resident is None or len(self.seq_starts) < 2:
+            return None
+        g, idx = self._resident
+        st = np.asarray(self.seq_starts, dtype=np.int64)
+        en = np.asarray(self.seq_ends, dtype=np.int64)
+        ci = np.asarray(idx, dtype=np.int64)
+        window, stride = int(en[0] - st[0]), int(st[1] - st[0])
+        if window < 1 or stride < 1 or (ci != ci[0]).any() or ((en - st) != window).any() or (np.diff(st) != stride).any():
+            return None
+        return g, int(ci[0]), int(st[0]), int(en[-1]), window, stride
+
     # ------------------------------------------------------------------ scanning --
 
     def _marshal(self, pwms):
@@ -116,8 +131,14 @@ class Scanner:
         matrices, cutoffs, lengths = self._marshal(pwms)
         logger.debug("Scanning motif PWMs")
         pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
-        sq = self._seqset()
-        res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
+        sweep = self._as_sweep()
+        if sweep is not None:
+            g, chrom, begin, end, window, stride = sweep
+            sq = None
+            res = _lib.scan_sweep(pw, g, chrom, begin, end, window, stride, _STRAND_FLAG[self.strand])
+        else:
+            sq = self._seqset()
+            res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
         try:
             if self.remove_dup:
                 res.dedup(pw)                      # scanner.py:156-193 on the device, order preserved
@@ -128,7 +149,8 @@ class Scanner:
             res.close()
             raise
         finally:
-            sq.close()
+            if sq is not None:
+                sq.close()
             pw.close()
         starts = np.asarray(self.seq_starts, dtype=np.int64)
         out = {"motif": h["motif"], "region": h["seq_idx"],

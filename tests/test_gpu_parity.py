@@ -630,3 +630,34 @@ def test_one_long_region_among_many_short_ones(oracle):
     pair = np.unique((np.repeat(np.arange(40), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
     assert np.array_equal(res.region_counts(), np.bincount(pair >> 32, minlength=40))
     assert len(want["pos"]) > 5000
+
+
+def test_scanner_takes_the_sweep_path_transparently(oracle):
+    """Regions that are the windows of a fixed-stride sweep of one chromosome of a ResidentGenome go through
+    ms_scan_sweep inside the Scanner mirror; the nested result equals the string path (and so the reference's)."""
+    from collections import namedtuple
+    Region = namedtuple("Region", "chrom start end summit")
+    Pwm = namedtuple("Pwm", "matrix cutoffs length")
+    rng = np.random.default_rng(3)
+    chroms = {"c1": "".join(rng.choice(list("ACGTN"), p=[.245, .245, .245, .245, .02], size=4000)),
+              "c2": "".join(rng.choice(list("ACGT"), size=1500))}
+    vals, widths, cutoffs = synth.load_motif_set(30, p_value="1e-3")
+    pwms = [Pwm(m, {"1e-3": c}, m.shape[1]) for m, c in zip(synth.matrices_of(vals, widths), cutoffs)]
+    regions = [Region("c1", s, s + 120, s + 60) for s in range(200, 3800, 40)]
+
+    class HostGenome:                                              # plain string genome: the ordinary path
+        chrom_sizes = {k: len(v) for k, v in chroms.items()}
+        def fetch_sequence(self, chrom, start, end):
+            return chroms[chrom][start:end]
+
+    for remove_dup in (False, True):
+        a = scanner.Scanner(_lib.ResidentGenome(chroms), regions, window_size=0, strand="both", p_value="1e-3", remove_dup=remove_dup)
+        assert a._as_sweep() is not None
+        b = scanner.Scanner(HostGenome(), regions, window_size=0, strand="both", p_value="1e-3", remove_dup=remove_dup)
+        assert b._as_sweep() is None
+        ra, rb = a.scan_motifs(pwms), b.scan_motifs(pwms)
+        assert ra == rb
+        assert sum(len(x) for per in ra for x in per) > 100
+    # not a sweep: one window moved
+    odd = regions[:10] + [Region("c1", 1001, 1121, 1061)] + regions[10:]
+    assert scanner.Scanner(_lib.ResidentGenome(chroms), odd, p_value="1e-3")._as_sweep() is None
