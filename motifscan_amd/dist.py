@@ -87,6 +87,18 @@ def scan_sharded(pwm_values, widths, cutoffs, sets, rank, world_size, strand=3, 
     return {"hits": all_hits, "counts": counts, "shards": shards}
 
 
+def sweep_shard(begin, end, window, stride, rank, world_size):
+    """Rank's share of the windows [begin + k*stride, begin + k*stride + window), k = 0..n-1, of a sweep over [begin, end):
+    (k0, k1, span_begin, span_end) -- contiguous window indices, and the base span that holds exactly those windows (spans
+    of neighbouring ranks overlap by window - stride bases: each rank re-reads that much, nothing is exchanged).
+    Scanning the span with ms_scan_sweep and adding k0 to seq_idx gives the rank's slice of the single-GPU result."""
+    n = (end - begin - window) // stride + 1 if end - begin >= window else 0
+    k0, k1 = n * rank // world_size, n * (rank + 1) // world_size
+    if k1 <= k0:
+        return k0, k0, begin, begin
+    return k0, k1, begin + k0 * stride, begin + (k1 - 1) * stride + window
+
+
 def enrichment(n_input_with_site, n_control_with_site, n_input, n_control):
     """What stats.py:18-45 computes from the reduced counts: fold change and the two one-sided
     Fisher exact p-values per motif (Bonferroni-corrected by the number of motifs)."""

@@ -98,3 +98,18 @@ def test_enrichment_consumes_reduced_counts():
     assert np.isnan(rows[1][2])
     assert rows[0][3] == fisher_exact([[30, 70], [10, 190]], alternative="greater")[1]
     assert rows[2][5] == min(min(rows[2][3], rows[2][4]) * 3, 1)
+
+
+def test_sweep_shards_cover_every_window_once():
+    from motifscan_amd import dist as msdist
+    for begin, end, window, stride in ((0, 10_000, 200, 50), (17, 5003, 37, 10), (0, 150, 200, 50), (5, 1000, 64, 64)):
+        n = (end - begin - window) // stride + 1 if end - begin >= window else 0
+        for world in (1, 2, 3, 8):
+            seen = []
+            for rank in range(world):
+                k0, k1, b, e = msdist.sweep_shard(begin, end, window, stride, rank, world)
+                seen.extend(range(k0, k1))
+                if k1 > k0:
+                    assert b == begin + k0 * stride and e == begin + (k1 - 1) * stride + window and e <= end
+                    assert (e - b - window) // stride + 1 == k1 - k0          # the span holds exactly the rank's windows
+            assert seen == list(range(n))
