@@ -183,15 +183,77 @@ def run_case(seed, oracle, _lib):
     return True, len(want["pos"]), st
 
 
+def run_sweep_case(seed, oracle, _lib):
+    """ms_scan_sweep (every base scored once, hits handed to the windows that hold them) vs the oracle over the same
+    windows as separate regions; random window / stride incl. stride > window and windows narrower than motifs."""
+    rng = np.random.default_rng(1_000_003 * 7 + seed)
+    n_motifs = int(rng.choice([1, 3, 20, 60]))
+    mats = [random_matrix(rng, int(rng.integers(1, 34))) for _ in range(n_motifs)]
+    L = int(rng.choice([50, 400, 3000]))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+        chrom = (unit * (L // len(unit) + 1))[:L]                       # low complexity: dense neighbourhoods
+    else:
+        chrom = "".join(rng.choice(list("ACGTNacgt"), p=[.22, .22, .22, .22, .04, .02, .02, .02, .02], size=L))
+    window = int(rng.choice([5, 12, 30, 64, 200]))
+    stride = int(rng.choice([1, 3, 7, 25, 50, 300]))
+    begin = int(rng.integers(0, max(1, L // 4)))
+    end = int(rng.integers(begin, L + 1))
+    n_win = (end - begin - window) // stride + 1 if end - begin >= window else 0
+    if n_win > 20000:
+        stride = max(stride, (end - begin) // 20000 + 1)
+        n_win = (end - begin - window) // stride + 1
+    seqs = [chrom[begin + k * stride: begin + k * stride + window] for k in range(n_win)]
+    cutoffs = np.array([attainable_cutoff(rng, m, seqs[:50] + [chrom]) for m in mats], dtype=np.float64)
+    strand = int(rng.integers(1, 4))
+    vals = np.concatenate([m.ravel() for m in mats])
+    widths = np.array([m.shape[1] for m in mats], dtype=np.int32)
+    raw = "".join(seqs).encode()
+    offsets = np.arange(n_win + 1, dtype=np.int64) * window
+    want = oracle.scan_arrays(vals, widths, cutoffs, raw, offsets, strand, 4)
+    genome = _lib.ResidentGenome({"x": "ACGT" * 3, "chr": chrom})
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    res = _lib.scan_sweep(pw, genome, "chr", begin, end, window, stride, strand)
+    try:
+        got = {k: v.copy() for k, v in res.hits().items()}
+        counts = res.region_counts()
+    finally:
+        res.close()
+        pw.close()
+        genome.close()
+    for k in ("motif_offsets", "seq_idx", "pos", "score"):
+        if not np.array_equal(got[k], want[k]):
+            return False, f"sweep seed {seed}: {k} differs ({len(got['pos'])} vs {len(want['pos'])} sites)"
+    if not np.array_equal(got["strand"].astype(np.int32), want["strand"].astype(np.int32)):
+        return False, f"sweep seed {seed}: strand differs"
+    pair = np.unique((np.repeat(np.arange(n_motifs), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
+    if not np.array_equal(counts, np.bincount(pair >> 32, minlength=n_motifs)):
+        return False, f"sweep seed {seed}: window counts differ"
+    return True, len(want["pos"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--sweep", action="store_true", help="fuzz ms_scan_sweep instead of ms_scan")
     a = ap.parse_args()
     from oracle import oracle
     oracle.build()
     from motifscan_amd import _lib
     _lib.set_device(0)
+    if a.sweep:
+        bad, total = 0, 0
+        for k in range(a.cases):
+            ok, info = run_sweep_case(a.seed + k, oracle, _lib)
+            if not ok:
+                bad += 1
+                print("MISMATCH", info, flush=True)
+            else:
+                total += info
+        print(f"sweep fuzz: {a.cases} cases from seed {a.seed}: {bad} mismatches, {total} sites compared")
+        return 1 if bad else 0
     bad, total_hits, fast, exact = 0, 0, 0, 0
     for k in range(a.cases):
         ok, info, st = run_case(a.seed + k, oracle, _lib)
