@@ -8,10 +8,15 @@ _lib.set_device(0)
 vals, widths, cutoffs = synth.load_motif_set(579)
 bases, offsets = synth.make_regions(125_000, 500, seed=1)
 sq = _lib.SeqSet(bases, offsets)
+pw = _lib.PwmSet(vals, widths, cutoffs)
+t0 = time.time()
+while time.time() - t0 < 2.0:                        # bring the clocks to their loaded state first
+    _lib.scan(pw, sq, 3).close()
+pw.close()
 for rep in (1, 2, 3, 6):
     pw = _lib.PwmSet(np.tile(vals, rep), np.tile(widths, rep), np.tile(cutoffs, rep))
     best = None
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter(); r = _lib.scan(pw, sq, 3); dt = time.perf_counter() - t0
         st = r.stats(); r.close()
         if best is None or dt < best[0]:
