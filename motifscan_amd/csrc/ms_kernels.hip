@@ -724,7 +724,9 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
 // 5 waves per SIMD (two 640-thread blocks per CU at <= 96 VGPRs) spills and is 35 % slower; software-pipelining the
 // one-k-block class alone: 66 -> 63 cycles per matrix instruction on an all-W=8 set, < 1 % on the benchmark set;
 // s_setprio raised around the matrix instructions: within noise; 12 waves per CU: +7 % time at +3 % clock;
-// A operands fetched one row tile ahead (first fetch before the class's B operands are waited for): +4 % time.)
+// A operands fetched one row tile ahead (first fetch before the class's B operands are waited for): +4 % time;
+// 128 windows per wave in the narrow classes (each A operand serves four B operands): 64 + 32 + 8 registers of tiles
+// do not fit 128 VGPRs, 80 spills, +70 % time.)
 template <int NT, int V, int ENG>
 __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
