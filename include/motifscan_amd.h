@@ -41,6 +41,13 @@
  *   ms_score_ranks        c_score + the sort / rank pick of get_score_cutoffs   motif/__init__.py:378-401
  *   ms_dedup_hits         _deduplicate_sites / deduplicate_motif_sites  scanner.py:156-193
  *                         (host-side, on the sparse hit arrays)
+ *   ms_stream_*           the same scan_motifs path (scanner.py:89-132) for region lists handed over in batches: host ASCII
+ *                         in -> hit arrays in pinned host memory out, with the upload + packing of batch i+2, the scan of
+ *                         batch i+1 and the copy-out of batch i overlapped per device (SURVEY.md 8(d) "pack + H2D + kernel +
+ *                         D2H", 8(e) "double-buffered chunks"); ms_stream_submit_span does the same for the spans of a
+ *                         host-streamed window sweep (BASELINE configs[4]: cli/scan.py:43-48 over a whole genome)
+ *   ms_sweep_spans        the windows of a fixed-stride sweep over all chromosomes (Scanner._extract_seq per window,
+ *                         scanner.py:71-87) cut into spans of bounded size, each with the global index of its first window
  */
 #ifndef MOTIFSCAN_AMD_H
 #define MOTIFSCAN_AMD_H
@@ -165,6 +172,52 @@ int ms_result_dedup(ms_result *res, const ms_pwmset *pwms);
  * aggregates the reference's site tables are made of (io/__init__.py:23-33).  Host buffers [P][R]. */
 int ms_result_site_tables(const ms_result *res, int32_t *n_sites, double *max_score);
 void ms_result_free(ms_result *res);
+
+/* The hit arrays in COMPACT form in library-owned pinned host memory: coord[i] = seq_idx << 32 | pos << 1 | (strand - 1),
+ * score[i] -- 16 bytes per hit on the host link instead of 25.  Needs seq_idx < 2^32 and pos < 2^31 (MS_ERR_INVALID
+ * otherwise).  Valid until the result is freed or de-duplicated. */
+int ms_result_hits_packed_host(ms_result *res, const uint64_t **coord, const double **score);
+
+/* ---- pinned host memory -------------------------------------------------------------------- */
+/* Page-locked host memory for sequence input: uploads from it run at the full link rate and overlap with scans. */
+int ms_host_alloc(size_t bytes, void **out);
+void ms_host_free(void *p);
+
+/* ---- batch streams: upload + pack | scan | copy-out overlapped ------------------------------- */
+#define MS_STREAM_DEDUP       1u   /* de-duplicate every batch on the device (scanner.py:156-193) before the copy-out      */
+#define MS_STREAM_NO_HITS     2u   /* counts only: hit arrays stay on the device (control regions: stats.py:29-31)         */
+#define MS_STREAM_EXACT_ONLY  4u   /* MS_SCAN_EXACT_ONLY for every batch (validation)                                      */
+#define MS_STREAM_PACKED      8u   /* copy the hits out in the compact form of ms_result_hits_packed_host                  */
+typedef struct ms_stream ms_stream;
+/* depth: batches that may wait between two stages (>= 1; 2 overlaps all three stages).  The stream is bound to the
+ * calling thread's device (ms_set_device).  The PWM set must outlive the stream. */
+int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int depth, ms_stream **out);
+/* Queue one batch of regions (same arguments as ms_seqset_create).  offsets is copied; bases is BORROWED until
+ * ms_stream_next has returned this batch.  Fails with MS_ERR_INVALID when ms_stream_capacity batches are in flight. */
+int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs);
+/* Queue one span of a window sweep: n_bases of ONE chromosome starting at a window start; the result is what
+ * ms_scan_sweep gives for it (seq_idx = window index inside the span: add ms_span.first_window). */
+int ms_stream_submit_span(ms_stream *st, const char *bases, int64_t n_bases, int32_t window, int32_t stride);
+/* The oldest batch's result (submission order), its hit arrays already in pinned host memory (ms_result_hits_host /
+ * ms_result_hits_packed_host return at once).  *out = NULL when nothing is in flight.  The caller frees the result. */
+int ms_stream_next(ms_stream *st, ms_result **out);
+int ms_stream_in_flight(const ms_stream *st, int *n);
+int ms_stream_capacity(const ms_stream *st, int *n);
+void ms_stream_free(ms_stream *st);          /* drains and discards whatever is still in flight */
+
+/* ---- sweep planning ------------------------------------------------------------------------ */
+typedef struct ms_span {
+    int32_t chrom;            /* chromosome index                                                       */
+    int32_t reserved;
+    int64_t begin, end;       /* bases [begin, end) of the chromosome; begin is a window start          */
+    int64_t first_window;     /* global index (over all chromosomes, in order) of the span's first window */
+    int64_t n_windows;
+} ms_span;
+/* Cut the sweep "windows [k*stride, k*stride + window) of every chromosome" (chromosomes shorter than a window have
+ * none) into spans of at most max_span_bases bases; neighbouring spans of a chromosome overlap by window - stride bases.
+ * spans may be NULL (count only); at most cap entries are written; *n_spans is the number needed. */
+int ms_sweep_spans(const int64_t *chrom_len, int32_t n_chroms, int32_t window, int32_t stride, int64_t max_span_bases,
+                   ms_span *spans, int64_t cap, int64_t *n_spans);
 
 /* ---- score (c_score) -------------------------------------------------------------------- */
 /* out: host, [P][R] row-major.  A sequence shorter than a PWM scores its missing bases as

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmotifscan_amd.so")
 
 MS_OK, MS_ERR_INVALID, MS_ERR_NOMEM, MS_ERR_RUNTIME = 0, 1, 2, 3
 MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY = 0, 1
+MS_STREAM_DEDUP, MS_STREAM_NO_HITS, MS_STREAM_EXACT_ONLY, MS_STREAM_PACKED = 1, 2, 4, 8
 
 
 class ScanStats(ctypes.Structure):
@@ -31,6 +32,12 @@ class ScanStats(ctypes.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Span(ctypes.Structure):
+    """ms_span: one span of a host-streamed window sweep."""
+    _fields_ = [("chrom", ctypes.c_int32), ("reserved", ctypes.c_int32), ("begin", ctypes.c_int64), ("end", ctypes.c_int64),
+                ("first_window", ctypes.c_int64), ("n_windows", ctypes.c_int64)]
 
 
 _lib = None
@@ -103,6 +110,17 @@ def lib():
         "ms_result_motif_offsets": (c_int, [vp, pi64]),
         "ms_result_hits": (c_int, [vp, pi64, pi64, pd, pi8]),
         "ms_result_hits_host": (c_int, [vp, ctypes.POINTER(pi64), ctypes.POINTER(pi64), ctypes.POINTER(pd), ctypes.POINTER(pi8)]),
+        "ms_result_hits_packed_host": (c_int, [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64)), ctypes.POINTER(pd)]),
+        "ms_host_alloc": (c_int, [ctypes.c_size_t, pvp]),
+        "ms_host_free": (None, [vp]),
+        "ms_stream_create": (c_int, [vp, c_int, c_u32, c_int, pvp]),
+        "ms_stream_submit": (c_int, [vp, vp, pi64, c_i64]),
+        "ms_stream_submit_span": (c_int, [vp, vp, c_i64, c_i32, c_i32]),
+        "ms_stream_next": (c_int, [vp, pvp]),
+        "ms_stream_in_flight": (c_int, [vp, ctypes.POINTER(c_int)]),
+        "ms_stream_capacity": (c_int, [vp, ctypes.POINTER(c_int)]),
+        "ms_stream_free": (None, [vp]),
+        "ms_sweep_spans": (c_int, [pi64, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(Span), c_i64, pi64]),
         "ms_result_region_counts": (c_int, [vp, pi64]),
         "ms_result_region_counts_device": (c_int, [vp, pvp]),
         "ms_result_stats": (c_int, [vp, ctypes.POINTER(ScanStats)]),
@@ -354,6 +372,18 @@ class ResidentGenome:
     __del__ = close
 
 
+class _OwnedArray(np.ndarray):
+    """A view of library-owned memory that keeps its owner (the ScanResult / pinned block) alive: slices and further views
+    reference this array as their base, so the owner lives as long as any of them does."""
+    _owner = None
+
+
+def _owned_view(arr, owner):
+    v = arr.view(_OwnedArray)
+    v._owner = owner
+    return v
+
+
 class ScanResult:
     """Hits of one ms_scan call, in the reference's order (cscore.c:336-390, 443-471)."""
 
@@ -368,9 +398,13 @@ class ScanResult:
         self._hits = None
         self._hits_owned = True
 
-    def hits(self, copy=True):
+    def hits(self, copy=True, packed=False):
         """dict of numpy arrays: seq_idx, pos, score, strand (1 '+', 2 '-'), motif.
-        copy=False returns views of the library's pinned host buffers (valid until close())."""
+        copy=False returns views of the library's pinned host buffers; the views keep this result alive (they are only
+        invalidated by an explicit close() or dedup()).  packed=True moves 16 instead of 25 bytes per hit over the host
+        link (ms_result_hits_packed_host) and unpacks on the host -- the arrays are then always fresh copies."""
+        if packed:
+            return self._hits_packed()
         if self._hits is None or (copy and not self._hits_owned):
             n = self.n_hits
             ps, pp = ctypes.POINTER(ctypes.c_int64)(), ctypes.POINTER(ctypes.c_int64)()
@@ -378,15 +412,33 @@ class ScanResult:
             check(lib().ms_result_hits_host(self.h, ctypes.byref(ps), ctypes.byref(pp), ctypes.byref(pv), ctypes.byref(pd_)))
             if n:
                 arrs = [np.ctypeslib.as_array(q, shape=(n,)) for q in (ps, pp, pv, pd_)]
-                if copy:
-                    arrs = [a.copy() for a in arrs]
+                arrs = [a.copy() for a in arrs] if copy else [_owned_view(a, self) for a in arrs]
             else:
                 arrs = [np.zeros(0, dtype=t) for t in (np.int64, np.int64, np.float64, np.int8)]
             motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
             self._hits = {"seq_idx": arrs[0], "pos": arrs[1], "score": arrs[2], "strand": arrs[3], "motif": motif,
                           "motif_offsets": self.motif_offsets}
             self._hits_owned = copy or n == 0
+            if not self._hits_owned:
+                out, self._hits = self._hits, None       # the views reference this object: caching them here would be a cycle
+                return out
         return self._hits
+
+    def _hits_packed(self):
+        n = self.n_hits
+        pc, pv = ctypes.POINTER(ctypes.c_uint64)(), ctypes.POINTER(ctypes.c_double)()
+        check(lib().ms_result_hits_packed_host(self.h, ctypes.byref(pc), ctypes.byref(pv)))
+        if n:
+            coord = np.ctypeslib.as_array(pc, shape=(n,))
+            score_ = np.ctypeslib.as_array(pv, shape=(n,)).copy()
+            seq_idx = (coord >> np.uint64(32)).astype(np.int64)
+            pos = ((coord & np.uint64(0xFFFFFFFF)) >> np.uint64(1)).astype(np.int64)
+            strand = ((coord & np.uint64(1)) + np.uint64(1)).astype(np.int8)
+        else:
+            seq_idx, pos, score_, strand = (np.zeros(0, dtype=t) for t in (np.int64, np.int64, np.float64, np.int8))
+        motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
+        return {"seq_idx": seq_idx, "pos": pos, "score": score_, "strand": strand, "motif": motif,
+                "motif_offsets": self.motif_offsets}
 
     def dedup(self, pwms):
         """Device-side de-duplication in place (scanner.py:156-193)."""
@@ -442,6 +494,159 @@ def scan_sweep(pwms, genome, chrom, begin, end, window, stride, strand_mask=3, f
     check(lib().ms_scan_sweep(pwms.h, genome.h, ci, int(begin), int(end), int(window), int(stride), int(strand_mask),
                               int(flags), ctypes.byref(h)))
     return ScanResult(h, pwms.n)
+
+
+class PinnedBuffer:
+    """Page-locked host memory (ms_host_alloc) as a uint8 numpy array: uploads from it run at the full link rate and
+    overlap with scans."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        check(lib().ms_host_alloc(int(nbytes), ctypes.byref(p)))
+        self.ptr = p
+        self.nbytes = int(nbytes)
+        raw = (ctypes.c_uint8 * max(self.nbytes, 1)).from_address(p.value)
+        self.array = _owned_view(np.frombuffer(raw, dtype=np.uint8, count=self.nbytes), self)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            lib().ms_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
+class Stream:
+    """ms_stream: batches of regions (or spans of a window sweep) flow through upload + pack | scan | copy-out, the three
+    stages of consecutive batches overlapped on one device.  Results come back in submission order."""
+
+    def __init__(self, pwms, strand_mask=3, flags=0, depth=2):
+        self.pwms = pwms                               # keep alive
+        h = ctypes.c_void_p()
+        check(lib().ms_stream_create(pwms.h, int(strand_mask), int(flags), int(depth), ctypes.byref(h)))
+        self.h = h
+        n = ctypes.c_int()
+        check(lib().ms_stream_capacity(self.h, ctypes.byref(n)))
+        self.capacity = n.value
+        self._keep = []                                # buffers borrowed by batches still in flight
+
+    @property
+    def in_flight(self):
+        n = ctypes.c_int()
+        check(lib().ms_stream_in_flight(self.h, ctypes.byref(n)))
+        return n.value
+
+    def submit(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8) if isinstance(bases, np.ndarray) else np.frombuffer(bytes(bases), dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if offsets.ndim != 1 or offsets.size < 1 or int(offsets[0]) != 0 or int(offsets[-1]) != bases.size:
+            raise ValueError("offsets must run from 0 to the number of bases")
+        check(lib().ms_stream_submit(self.h, ctypes.c_void_p(bases.ctypes.data), ptr(offsets, ctypes.c_int64), offsets.size - 1))
+        self._keep.append(bases)
+
+    def submit_span(self, bases, window, stride):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8) if isinstance(bases, np.ndarray) else np.frombuffer(bytes(bases), dtype=np.uint8)
+        check(lib().ms_stream_submit_span(self.h, ctypes.c_void_p(bases.ctypes.data), bases.size, int(window), int(stride)))
+        self._keep.append(bases)
+
+    def next(self):
+        """The oldest batch's ScanResult (hits already on the host), or None when nothing is in flight."""
+        if self.in_flight == 0:
+            self._keep.clear()
+            return None
+        h = ctypes.c_void_p()
+        try:
+            check(lib().ms_stream_next(self.h, ctypes.byref(h)))
+        finally:
+            if self._keep:
+                self._keep.pop(0)                      # returned or failed: either way the batch no longer borrows its buffer
+        return ScanResult(h, self.pwms.n) if h.value else None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ms_stream_free(self.h)
+            self.h = None
+            self._keep = []
+
+    __del__ = close
+
+
+def merge_hits(parts, n_pwms):
+    """Concatenate per-batch hit dicts into the single-call result: parts = [(hits dict, seq_idx offset), ...] in batch
+    order.  Within a motif the reference orders hits by sequence index (cscore.c:336-390), so motif p's hits are batch 0's
+    hits of p, then batch 1's, ... -- one slice copy per (motif, batch)."""
+    offs = np.zeros(n_pwms + 1, dtype=np.int64)
+    for h, _ in parts:
+        offs[1:] += np.diff(h["motif_offsets"])
+    offs = np.concatenate([[0], np.cumsum(offs[1:])]).astype(np.int64)
+    n = int(offs[-1])
+    out = {"seq_idx": np.empty(n, np.int64), "pos": np.empty(n, np.int64), "score": np.empty(n, np.float64),
+           "strand": np.empty(n, np.int8)}
+    cur = offs[:-1].copy()
+    for h, shift in parts:
+        mo = h["motif_offsets"]
+        for p in np.nonzero(np.diff(mo))[0].tolist():
+            a, b = int(mo[p]), int(mo[p + 1])
+            d = int(cur[p])
+            out["seq_idx"][d:d + b - a] = h["seq_idx"][a:b] + shift
+            out["pos"][d:d + b - a] = h["pos"][a:b]
+            out["score"][d:d + b - a] = h["score"][a:b]
+            out["strand"][d:d + b - a] = h["strand"][a:b]
+            cur[p] += b - a
+    out["motif"] = np.repeat(np.arange(n_pwms, dtype=np.int32), np.diff(offs))
+    out["motif_offsets"] = offs
+    return out
+
+
+def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False):
+    """Generator: push (bases, offsets) batches through a Stream, yield each batch's ScanResult in order (the caller
+    closes them).  Keeps the stream as full as its capacity allows."""
+    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
+    try:
+        for bases, offsets in batches:
+            while st.in_flight >= st.capacity:
+                yield st.next()
+            st.submit(bases, offsets)
+        while st.in_flight:
+            yield st.next()
+    finally:
+        st.close()
+
+
+def sweep_stream(pwms, chroms, window, stride, max_span_bases, strand_mask=3, flags=0, depth=2, spans=None, packed=False):
+    """Host-streamed window sweep over a whole genome (BASELINE configs[4]): chroms = list of uint8 arrays (host memory,
+    ideally pinned); the windows [k*stride, k*stride + window) of every chromosome are cut into spans of at most
+    max_span_bases bases (ms_sweep_spans), and the spans flow through a Stream (upload + pack | scan-once + hand-out |
+    copy-out).  Yields (span, ScanResult) in order; span = (chrom, begin, end, first_window, n_windows) and the result's
+    seq_idx counts windows from the span's first one: add span[3] for the genome-wide window index.  `spans` restricts
+    the sweep to a subset (a rank's share)."""
+    if spans is None:
+        spans = sweep_spans([len(c) for c in chroms], window, stride, max_span_bases)
+    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
+    try:
+        pending = []
+        for sp in spans:
+            while st.in_flight >= st.capacity:
+                yield pending.pop(0), st.next()
+            st.submit_span(chroms[sp[0]][sp[1]:sp[2]], window, stride)
+            pending.append(sp)
+        while st.in_flight:
+            yield pending.pop(0), st.next()
+    finally:
+        st.close()
+
+
+def sweep_spans(chrom_lens, window, stride, max_span_bases):
+    """ms_sweep_spans: [(chrom, begin, end, first_window, n_windows), ...] for the windows [k*stride, k*stride + window)
+    of every chromosome, in spans of at most max_span_bases bases."""
+    lens = np.ascontiguousarray(chrom_lens, dtype=np.int64)
+    n = ctypes.c_int64()
+    check(lib().ms_sweep_spans(ptr(lens, ctypes.c_int64), len(lens), int(window), int(stride), int(max_span_bases), None, 0,
+                               ctypes.byref(n)))
+    arr = (Span * max(n.value, 1))()
+    check(lib().ms_sweep_spans(ptr(lens, ctypes.c_int64), len(lens), int(window), int(stride), int(max_span_bases), arr, n.value,
+                               ctypes.byref(n)))
+    return [(a.chrom, a.begin, a.end, a.first_window, a.n_windows) for a in arr[:n.value]]
 
 
 def score(pwms, seqs, strand_mask=3):

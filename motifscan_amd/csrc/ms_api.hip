@@ -14,12 +14,15 @@
 #include <string>
 #include <thread>
 
-#include "ms_kernels.h"
+#include "ms_handles.h"
 
 namespace ms {
 
 static thread_local std::string g_err;
 static thread_local int g_device = 0;
+
+int current_device() { return g_device; }
+void set_current_device(int device) { g_device = device; }
 
 void set_error(const char *fmt, ...) {
     char buf[1024];
@@ -32,42 +35,10 @@ void set_error(const char *fmt, ...) {
 
 // ----------------------------------------------------------------- per-device state --
 
-struct Scratch {                 // grow-only work buffers of the scan pipeline
-    uint64_t *cand = nullptr;     size_t cand_cap = 0;
-    uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
-    void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
-    int64_t *nlist = nullptr;     size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
-    unsigned long long *counters = nullptr;      // [0] candidates, [1] hits, [2] N-window positions
-    unsigned long long *h_counters = nullptr;    // pinned
-};
-
-// Free list of result blocks (ms_result keeps its arrays in HBM until freed; a scan loop would
-// otherwise pay a hipMalloc + hipFree of ~200 MB per call).
-struct BlockPool {
-    std::mutex mu;
-    std::vector<std::pair<void *, size_t>> free_;
-    size_t bytes = 0;
-    static constexpr size_t kMaxBytes = 8ull << 30;
-};
-
-struct DeviceCtx {
-    int device = -1;
-    BlockPool pool;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;           // side stream: the N-window kernels run beside the candidate re-scoring
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev[6] = {};
-    int n_cu = 0;
-    size_t lds_max = 0;
-    size_t lds_set[32] = {};
-    Scratch sc;
-    std::mutex mu;               // one scan at a time per device (shared scratch)
-};
-
 static std::mutex g_ctx_mu;
 static std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 
-static int get_ctx(int device, DeviceCtx **out) {
+int get_ctx(int device, DeviceCtx **out) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     auto it = g_ctx.find(device);
     if (it != g_ctx.end()) { *out = it->second.get(); MS_HIP(hipSetDevice(device)); return MS_OK; }
@@ -91,6 +62,8 @@ static int get_ctx(int device, DeviceCtx **out) {
     if (c->lds_max > 163840) c->lds_max = 163840;
     MS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     MS_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream_down, hipStreamNonBlocking));
     MS_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     MS_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (auto &ev : c->ev) MS_HIP(hipEventCreate(&ev));
@@ -101,25 +74,7 @@ static int get_ctx(int device, DeviceCtx **out) {
     return MS_OK;
 }
 
-template <typename T>
-static int dev_alloc(T **p, size_t n) {
-    *p = nullptr;
-    if (n == 0) n = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
-    if (e != hipSuccess) {
-        set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
-        return e == hipErrorOutOfMemory ? MS_ERR_NOMEM : MS_ERR_RUNTIME;
-    }
-    return MS_OK;
-}
-
-template <typename T>
-static void dev_free(T *&p) {
-    if (p) (void) hipFree(p);
-    p = nullptr;
-}
-
-static int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
+int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
     {
         std::lock_guard<std::mutex> lk(c->pool.mu);
         size_t best = (size_t) -1;
@@ -154,7 +109,7 @@ static int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
 static std::mutex g_pin_mu;
 static std::vector<std::pair<void *, size_t>> g_pin_free;
 
-static void *pinned_alloc(size_t bytes, size_t *got) {
+void *pinned_alloc(size_t bytes, size_t *got) {
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         size_t best = (size_t) -1;
@@ -175,16 +130,16 @@ static void *pinned_alloc(size_t bytes, size_t *got) {
     return p;
 }
 
-static void pinned_free(void *p, size_t bytes) {
+void pinned_free(void *p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pin_mu);
     size_t total = bytes;
     for (auto &b : g_pin_free) total += b.second;
-    if (g_pin_free.size() >= 4 || total > (4ull << 30)) { (void) hipHostFree(p); return; }
+    if (g_pin_free.size() >= 16 || total > (16ull << 30)) { (void) hipHostFree(p); return; }
     g_pin_free.emplace_back(p, bytes);
 }
 
-static void pool_free(DeviceCtx *c, void *p, size_t bytes) {
+void pool_free(DeviceCtx *c, void *p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(c->pool.mu);
     if (c->pool.bytes + bytes > BlockPool::kMaxBytes || c->pool.free_.size() >= 16) { (void) hipFree(p); return; }
@@ -197,79 +152,6 @@ static void pool_free(DeviceCtx *c, void *p, size_t bytes) {
 using namespace ms;
 
 // ------------------------------------------------------------------------- handles --
-
-struct ms_pwmset {
-    int32_t P = 0;
-    std::vector<double> values;       // concatenated [4][W] row-major, as given
-    std::vector<int64_t> val_off;     // [P+1] in doubles
-    std::vector<int32_t> widths;
-    std::vector<double> cutoffs;
-    std::vector<double> max_raw;
-    int max_width = 0;
-    uint64_t cutoff_version = 1;
-    // device copies (lazy)
-    int device = -1;
-    uint64_t dev_cutoff_version = 0;
-    double2 *d_tab2 = nullptr;
-    int64_t *d_tab_off = nullptr;
-    int32_t *d_width = nullptr;
-    double *d_max_raw = nullptr;
-    double *d_cutoff = nullptr;
-    double *d_raw_floor = nullptr;
-    // pre-filter plan (lazy, keyed by strand mask / cutoffs / LDS budget / exact-only)
-    PrefilterPlan plan;
-    int plan_strand = -1;
-    uint64_t plan_cutoff_version = 0;
-    size_t plan_lds = 0;
-    bool plan_exact_only = false;
-    int plan_min_fb = 0;
-    int plan_engine = -1;
-    int plan_device = -1;
-    uint4 *d_tables = nullptr;
-    TileDesc *d_tiles = nullptr;
-    int32_t *d_group_motifs = nullptr;
-    int32_t *d_fast_motifs = nullptr;
-    int32_t *d_exact_motifs = nullptr;
-    std::mutex mu;
-};
-
-struct ms_seqset {
-    int device = 0;
-    int64_t R = 0;
-    int64_t n_bases = 0;
-    std::vector<int64_t> offsets;         // host copy [R+1]
-    std::vector<int64_t> len_sorted;      // DISTINCT region lengths ascending
-    std::vector<int64_t> len_cnt_ge;      // [i]: number of regions with length >= len_sorted[i]   (+ trailing 0)
-    std::vector<int64_t> len_sum_ge;      // [i]: their total length                              (+ trailing 0)
-    void *block = nullptr;                // one pooled device block holding codes / nmask / offsets / blk2reg
-    size_t block_bytes = 0;
-    uint8_t *d_ascii = nullptr;           // kept only when asked to
-    uint32_t *d_codes = nullptr;
-    uint32_t *d_nmask = nullptr;
-    int64_t *d_offsets = nullptr;
-    int32_t *d_blk2reg = nullptr;         // region of position 64*b
-};
-
-struct ms_result {
-    int device = 0;
-    int32_t P = 0;
-    int64_t R = 0;                                    // sequences of the scanned set
-    int64_t n_hits = 0;
-    bool deduped = false;
-    void *block = nullptr;                            // one device block holding everything below
-    size_t block_bytes = 0;
-    int64_t *d_seq_idx = nullptr;
-    int64_t *d_pos = nullptr;
-    double *d_score = nullptr;
-    int8_t *d_strand = nullptr;
-    unsigned long long *d_region_counts = nullptr;   // [P]
-    int64_t *d_motif_first = nullptr;                 // [P+1]: after ms_scan returns, the per-motif offsets
-    std::vector<int64_t> motif_offsets;               // [P+1]
-    void *h_pinned = nullptr;                         // host copy of the hit arrays (pinned), made on demand
-    size_t h_pinned_bytes = 0;
-    int64_t h_pinned_hits = -1;
-    ms_scan_stats stats;
-};
 
 // Lay the result arrays out in one device block: [counts P+1][offsets P+1][seq_idx n][pos n][score n][strand n]
 static size_t result_block_bytes(int32_t P, size_t n) {
@@ -326,7 +208,7 @@ static void pwmset_free_device(ms_pwmset *p) {
     p->dev_cutoff_version = 0;
 }
 
-static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
+int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
     if (p->device != device) {
         pwmset_free_device(p);
         MS_HIP(hipSetDevice(device));
@@ -396,7 +278,7 @@ static int pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
 
 // Pre-filter engine: 0 = packed 2-mer tables read per lane from LDS, 1 = int8 one-hot product on the matrix cores.
 static int pf_engine() {
-    if (const char *e = getenv("MS_PF_ENGINE")) { const int v = atoi(e); return v == 0 ? 0 : (v == 2 ? 2 : 1); }     // measurement / A-B switch
+    if (const char *e = measure_env("MS_PF_ENGINE")) { const int v = atoi(e); return v == 0 ? 0 : (v == 2 ? 2 : 1); }     // measurement / A-B switch
     return 1;
 }
 
@@ -404,7 +286,7 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
                        int device) {
     const int engine = pf_engine();
     int min_fb = 10;                                   // measurement switch: MS_PF_FIELD_BITS=16 forces 16-bit fields
-    if (const char *e = getenv("MS_PF_FIELD_BITS")) min_fb = atoi(e) >= 16 ? 16 : 10;
+    if (const char *e = measure_env("MS_PF_FIELD_BITS")) min_fb = atoi(e) >= 16 ? 16 : 10;
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
                        p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_min_fb != min_fb ||
                        p->plan_engine != engine;
@@ -666,9 +548,10 @@ static int seqset_alloc_packed(ms_seqset *s) {
     s->d_offsets = reinterpret_cast<int64_t *>(b + up(b_codes) + up(b_nmask));
     s->d_blk2reg = reinterpret_cast<int32_t *>(b + up(b_codes) + up(b_nmask) + up(b_off));
     // only the pad words behind the packed data need clearing: the kernels write everything else
-    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), c->stream));
-    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), c->stream));
-    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, c->stream));
+    // sequence sets are built on the upload stream: a batch can be packed while the previous one is being scanned
+    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), c->stream_up));
+    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), c->stream_up));
+    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, c->stream_up));
     return MS_OK;
 }
 
@@ -684,16 +567,20 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
     ms_seqset *raw = s.release();
     auto fail = [&](int code) { ms_seqset_free(raw); return code; };
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
-    if ((rc = dev_alloc(&raw->d_ascii, (size_t) raw->n_bases + 64))) return fail(rc);
+    {
+        void *blk = nullptr;
+        if ((rc = pool_alloc(c, (size_t) raw->n_bases + 64, &blk, &raw->ascii_bytes))) return fail(rc);
+        raw->d_ascii = static_cast<uint8_t *>(blk);
+    }
     if (raw->n_bases > 0) {
-        hipError_t e = hipMemcpy(raw->d_ascii, bases, (size_t) raw->n_bases, hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpyAsync(raw->d_ascii, bases, (size_t) raw->n_bases, hipMemcpyHostToDevice, c->stream_up);
         if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     }
-    if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream))) return fail(rc);
-    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream))) return fail(rc);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
-    if (!keep_ascii) dev_free(raw->d_ascii);
+    if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream_up))) return fail(rc);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream_up))) return fail(rc);
+    hipError_t e = hipStreamSynchronize(c->stream_up);
+    if (e != hipSuccess) { set_error("upload / pack failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    if (!keep_ascii) { pool_free(c, raw->d_ascii, raw->ascii_bytes); raw->d_ascii = nullptr; raw->ascii_bytes = 0; }
     *out = raw;
     return MS_OK;
 }
@@ -710,10 +597,10 @@ int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n
     ms_seqset *raw = s.release();
     auto fail = [&](int code) { ms_seqset_free(raw); return code; };
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
-    if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, c->stream)))
+    if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, c->stream_up)))
         return fail(rc);
-    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream))) return fail(rc);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream_up))) return fail(rc);
+    hipError_t e = hipStreamSynchronize(c->stream_up);
     if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     *out = raw;
     return MS_OK;
@@ -725,9 +612,9 @@ int ms_seqset_repack(ms_seqset *s) {
     DeviceCtx *c;
     int rc = get_ctx(s->device, &c);
     if (rc) return rc;
-    if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, c->stream))) return rc;
-    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, c->stream))) return rc;
-    MS_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, c->stream_up))) return rc;
+    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, c->stream_up))) return rc;
+    MS_HIP(hipStreamSynchronize(c->stream_up));
     return MS_OK;
 }
 
@@ -741,12 +628,10 @@ int ms_seqset_size(const ms_seqset *s, int64_t *n_seqs, int64_t *n_bases) {
 void ms_seqset_free(ms_seqset *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
-    dev_free(s->d_ascii);
-    if (s->block) {
-        DeviceCtx *c = nullptr;
-        if (get_ctx(s->device, &c) == MS_OK) pool_free(c, s->block, s->block_bytes);
-        else (void) hipFree(s->block);
-    }
+    DeviceCtx *c = nullptr;
+    const bool have = get_ctx(s->device, &c) == MS_OK;
+    if (s->d_ascii) { if (have) pool_free(c, s->d_ascii, s->ascii_bytes); else (void) hipFree(s->d_ascii); }
+    if (s->block) { if (have) pool_free(c, s->block, s->block_bytes); else (void) hipFree(s->block); }
     delete s;
 }
 
@@ -836,11 +721,11 @@ int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
     int64_t *d_src = nullptr;
     if ((rc = dev_alloc(&d_src, (size_t) n_regions + 1))) return fail(rc);
-    hipError_t he = hipMemcpy(d_src, src.data(), ((size_t) n_regions + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    hipError_t he = hipMemcpyAsync(d_src, src.data(), ((size_t) n_regions + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream_up);
     if (he == hipSuccess) {
-        rc = launch_extract(G->d_codes, G->d_nmask, d_src, raw->d_offsets, raw->R, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream);
-        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream);
-        if (!rc) he = hipStreamSynchronize(c->stream);
+        rc = launch_extract(G->d_codes, G->d_nmask, d_src, raw->d_offsets, raw->R, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream_up);
+        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream_up);
+        if (!rc) he = hipStreamSynchronize(c->stream_up);
     }
     dev_free(d_src);
     if (rc) return fail(rc);
@@ -876,22 +761,19 @@ static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap, size_t 
     return MS_OK;
 }
 
-int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
-    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
-    *out = nullptr;
-    if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
-    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
-    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);       // lazily cached device copies / plan
-    DeviceCtx *c;
-    int rc = get_ctx(seqs->device, &c);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk_dev(c->mu);
-    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+}  // extern "C"
+
+namespace ms {
+
+// The scan pipeline: pre-filter -> fp64 re-score (+ N windows, + motifs the filter cannot take) -> order -> coordinates.
+// The caller holds c->mu (one scan at a time per device: shared scratch) and pwms->mu (lazily cached device copies / plan).
+int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
+    int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
     const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
     size_t lds_budget = c->lds_max - lds_fixed;
     int pf_blocks_per_cu = 1;
-    if (const char *e = getenv("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
+    if (const char *e = measure_env("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
         pf_blocks_per_cu = std::max(1, atoi(e));
         lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - lds_fixed;
     }
@@ -942,7 +824,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         int pb = 1;
         while ((1LL << pb) < std::max<int64_t>(max_len, 1)) pb++;
         while ((1LL << rbits) < std::max<int64_t>(seqs->R, 1)) rbits++;
-        const char *e = getenv("MS_HIT_COORD");
+        const char *e = measure_env("MS_HIT_COORD");
         if (rbits + pb <= gbits + 2 && !(e && e[0] == 'g')) { pbits = pb; gbits = rbits + pb; }
     }
     int mbits = 1;
@@ -982,18 +864,20 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     lds_bytes += lds_fixed;
     // measurement switches (not part of the interface): kernel variant, drop candidates
     int pf_variant = plan.engine == 2 ? 24 : plan.engine == 1 ? 16 : 4, pf_no_emit = 0;
-    if (const char *e = getenv("MS_PF_VARIANT")) {
+    if (const char *e = measure_env("MS_PF_VARIANT")) {
         const int v = atoi(e) & 31;
         const int v_engine = v >= 24 ? 2 : v >= 16 ? 1 : 0;
         if (v_engine == plan.engine) pf_variant = v;                   // a variant of another engine cannot read this plan
     }
-    if (const char *e = getenv("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
-    const bool pf_clock = getenv("MS_PF_CLOCK") && atoi(getenv("MS_PF_CLOCK")) != 0;
+    if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
+    const bool pf_clock = measure_env("MS_PF_CLOCK") && atoi(measure_env("MS_PF_CLOCK")) != 0;
     unsigned long long *d_clk = nullptr;
     int clk_blocks = 0;
-    if (lds_bytes > c->lds_set[pf_variant]) {
-        if ((rc = prefilter_set_lds(pf_variant, lds_bytes))) return fail(rc);
-        c->lds_set[pf_variant] = lds_bytes;
+    const bool pf_meas = pf_no_emit != 0 || pf_clock;              // the measurement instantiation of the kernel
+    raw->invalid = pf_no_emit != 0;                                // stage times only: the hit accessors refuse such a result
+    if (lds_bytes > c->lds_set[pf_variant + (pf_meas ? 32 : 0)]) {
+        if ((rc = prefilter_set_lds(pf_variant, pf_meas, lds_bytes))) return fail(rc);
+        c->lds_set[pf_variant + (pf_meas ? 32 : 0)] = lds_bytes;
     }
 
     unsigned long long n_cand = 0, n_hits = 0;
@@ -1019,7 +903,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
                 (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * 2 * clk_blocks, c->stream);
                 A.clk = d_clk;
             }
-            if ((rc = launch_prefilter(A, pf_variant, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
+            if ((rc = launch_prefilter(A, pf_variant, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
         }
         (void) hipEventRecord(c->ev[1], c->stream);
         if (!plan.fast_motifs.empty()) {
@@ -1075,7 +959,6 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
         result_carve(raw, blk, (size_t) n_hits);
         const size_t P1 = (size_t) pwms->P + 1;
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
-        if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0xFF, 8 * P1, c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
     }
     int64_t *d_motif_first = raw->d_motif_first;
@@ -1098,18 +981,13 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
                                  gbits + 1 + mbits, c->stream))) return fail2(rc);
     }
     (void) hipEventRecord(c->ev[4], c->stream);
-    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, S, raw->d_seq_idx, raw->d_pos,
+    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
                               raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
     (void) hipEventRecord(c->ev[5], c->stream);
-    std::vector<int64_t> first((size_t) pwms->P + 1);
-    he = hipMemcpyAsync(first.data(), d_motif_first, first.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    // finalize leaves the complete per-motif offsets on the device; one copy brings them to the host
+    he = hipMemcpyAsync(raw->motif_offsets.data(), d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
-    raw->motif_offsets[(size_t) pwms->P] = (int64_t) n_hits;
-    for (int32_t p = pwms->P - 1; p >= 0; p--)
-        raw->motif_offsets[(size_t) p] = first[(size_t) p] >= 0 ? first[(size_t) p] : raw->motif_offsets[(size_t) p + 1];
-    he = hipMemcpy(raw->d_motif_first, raw->motif_offsets.data(), raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice);
-    if (he != hipSuccess) { set_error("offset upload failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
 
     float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
     (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
@@ -1127,6 +1005,24 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     return MS_OK;
 }
 
+}  // namespace ms
+
+extern "C" {
+
+int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);       // lazily cached device copies / plan
+    DeviceCtx *c;
+    int rc = get_ctx(seqs->device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    return scan_locked(c, pwms, seqs, strand_mask, flags, out);
+}
+
 int ms_result_num_hits(const ms_result *r, int64_t *n_hits) {
     if (!r || !n_hits) { set_error("NULL argument"); return MS_ERR_INVALID; }
     *n_hits = r->n_hits;
@@ -1141,6 +1037,7 @@ int ms_result_motif_offsets(const ms_result *r, int64_t *out) {
 
 int ms_result_hits(const ms_result *r, int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
     if (r->n_hits == 0) return MS_OK;
     MS_HIP(hipSetDevice(r->device));
     const size_t n = (size_t) r->n_hits;
@@ -1153,24 +1050,30 @@ int ms_result_hits(const ms_result *r, int64_t *seq_idx, int64_t *pos, double *s
 
 // Hit arrays in library-owned PINNED host memory (one D2H copy at PCIe rate instead of four copies
 // into pageable buffers).  The pointers stay valid until the result is freed or de-duplicated.
+// The copy runs on the device's copy-out stream, beside whatever scan is running.
 int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **pos, const double **score,
                         const int8_t **strand) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
     const size_t bytes = 25 * n_round + 64;
-    if (r->h_pinned_hits != r->n_hits || !r->h_pinned) {
+    if (r->h_pinned_hits != r->n_hits || !r->h_pinned || r->h_packed) {
         if (r->h_pinned && r->h_pinned_bytes < bytes) { pinned_free(r->h_pinned, r->h_pinned_bytes); r->h_pinned = nullptr; }
         if (!r->h_pinned) {
             r->h_pinned = pinned_alloc(bytes, &r->h_pinned_bytes);
             if (!r->h_pinned) { set_error("pinned host allocation of %zu bytes failed", bytes); return MS_ERR_NOMEM; }
         }
         if (n > 0) {
-            MS_HIP(hipSetDevice(r->device));
+            DeviceCtx *c;
+            int rc = get_ctx(r->device, &c);
+            if (rc) return rc;
             // seq_idx | pos | score | strand are consecutive in the device block (n_round elements apart)
-            MS_HIP(hipMemcpy(r->h_pinned, r->d_seq_idx, 24 * n_round + n, hipMemcpyDeviceToHost));
+            MS_HIP(hipMemcpyAsync(r->h_pinned, r->d_seq_idx, 24 * n_round + n, hipMemcpyDeviceToHost, c->stream_down));
+            MS_HIP(hipStreamSynchronize(c->stream_down));
         }
         r->h_pinned_hits = r->n_hits;
+        r->h_packed = false;
     }
     char *b = static_cast<char *>(r->h_pinned);
     if (seq_idx) *seq_idx = reinterpret_cast<const int64_t *>(b);
@@ -1179,6 +1082,66 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
     if (strand) *strand = reinterpret_cast<const int8_t *>(b + 24 * n_round);
     return MS_OK;
 }
+
+// The same in 16 bytes per hit: coord = seq_idx << 32 | pos << 1 | (strand - 1), score.  The device packs the three
+// coordinate arrays into one word per hit first, so only 16 of the 25 bytes cross the host link.
+int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const double **score) {
+    if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
+    const size_t n = (size_t) r->n_hits;
+    const size_t n_round = (n + 65535) & ~(size_t) 65535;
+    const size_t bytes = 16 * n_round + 64;
+    if (r->h_pinned_hits != r->n_hits || !r->h_pinned || !r->h_packed) {
+        if (r->h_pinned && r->h_pinned_bytes < bytes) { pinned_free(r->h_pinned, r->h_pinned_bytes); r->h_pinned = nullptr; }
+        if (!r->h_pinned) {
+            r->h_pinned = pinned_alloc(bytes, &r->h_pinned_bytes);
+            if (!r->h_pinned) { set_error("pinned host allocation of %zu bytes failed", bytes); return MS_ERR_NOMEM; }
+        }
+        if (n > 0) {
+            DeviceCtx *c;
+            int rc = get_ctx(r->device, &c);
+            if (rc) return rc;
+            void *blk = nullptr;
+            size_t got = 0;
+            if ((rc = pool_alloc(c, 8 * n_round + 256, &blk, &got))) return rc;
+            uint64_t *d_coord = static_cast<uint64_t *>(blk);
+            unsigned int *d_bad = reinterpret_cast<unsigned int *>(d_coord + n_round);
+            unsigned int bad = 0;
+            hipError_t he = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), c->stream_down);
+            if (he == hipSuccess) rc = launch_pack_hits((int64_t) n, r->d_seq_idx, r->d_pos, r->d_strand, d_coord, d_bad, c->stream_down);
+            char *hb = static_cast<char *>(r->h_pinned);
+            if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb, d_coord, 8 * n, hipMemcpyDeviceToHost, c->stream_down);
+            if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb + 8 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, c->stream_down);
+            if (he == hipSuccess && !rc) he = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream_down);
+            const hipError_t hs = hipStreamSynchronize(c->stream_down);
+            pool_free(c, blk, got);
+            if (rc) return rc;
+            if (he != hipSuccess || hs != hipSuccess) { set_error("compact copy-out failed: %s", hipGetErrorString(he != hipSuccess ? he : hs)); return MS_ERR_RUNTIME; }
+            if (bad) { set_error("a hit does not fit the compact form (needs seq_idx < 2^32 and pos < 2^31): use ms_result_hits_host"); return MS_ERR_INVALID; }
+        }
+        r->h_pinned_hits = r->n_hits;
+        r->h_packed = true;
+    }
+    char *b = static_cast<char *>(r->h_pinned);
+    if (coord) *coord = reinterpret_cast<const uint64_t *>(b);
+    if (score) *score = reinterpret_cast<const double *>(b + 8 * n_round);
+    return MS_OK;
+}
+
+int ms_host_alloc(size_t bytes, void **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    DeviceCtx *c;
+    int rc = get_ctx(g_device, &c);                       // pinned memory needs a live HIP runtime: fails loudly without a device
+    if (rc) return rc;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { set_error("hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return MS_ERR_NOMEM; }
+    *out = p;
+    return MS_OK;
+}
+
+void ms_host_free(void *p) { if (p) (void) hipHostFree(p); }
 
 int ms_result_region_counts(const ms_result *r, int64_t *out) {
     if (!r || (!out && r->P > 0)) { set_error("NULL argument"); return MS_ERR_INVALID; }
@@ -1215,7 +1178,8 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     const size_t n = (size_t) r->n_hits;
-    uint32_t *d_keep = nullptr, *d_dst = nullptr;
+    uint32_t *d_keep = nullptr;
+    uint64_t *d_dst = nullptr;
     void *d_tmp = nullptr, *blk = nullptr;
     size_t tmp_bytes = 0, got = 0;
     auto cleanup = [&]() { dev_free(d_keep); dev_free(d_dst); if (d_tmp) (void) hipFree(d_tmp); };
@@ -1225,9 +1189,10 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     if (!rc) rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_keep, d_dst, n, c->stream);
     if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
     if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_keep, d_dst, n, c->stream);
-    uint32_t last_dst = 0, last_keep = 0;
+    uint64_t last_dst = 0;
+    uint32_t last_keep = 0;
     if (!rc) {
-        hipError_t he = hipMemcpyAsync(&last_dst, d_dst + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        hipError_t he = hipMemcpyAsync(&last_dst, d_dst + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(&last_keep, d_keep + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("de-dup kernels failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; }
@@ -1305,30 +1270,18 @@ void ms_result_free(ms_result *r) {
 // cscore.c:336-390 scans each) -- but every base is scored ONCE: the span is scanned as one region and each hit is
 // handed to all windows that contain it whole (window / stride of them), written straight to its place in the
 // reference's order (motif, window, position, strand) -- sweep_scatter_kernel, no second sort.
-int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, int64_t begin, int64_t end, int32_t window,
-                  int32_t stride, int strand_mask, uint32_t flags, ms_result **out) {
-    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
-    *out = nullptr;
-    if (!pwms_c || !g) { set_error("NULL handle"); return MS_ERR_INVALID; }
-    if (window < 1 || stride < 1) { set_error("window and stride must be positive"); return MS_ERR_INVALID; }
-    if (begin < 0 || end < begin) { set_error("bad span [%lld, %lld)", (long long) begin, (long long) end); return MS_ERR_INVALID; }
-    const int64_t n_windows = end - begin >= window ? (end - begin - window) / stride + 1 : 0;
-    const int64_t span_end = n_windows > 0 ? begin + (n_windows - 1) * stride + window : begin;
-    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
-    ms_seqset *span = nullptr;
-    int rc = ms_seqset_from_genome(g, &chrom, &begin, &span_end, 1, &span);       // validates chrom / coordinates
-    if (rc) return rc;
-    ms_result *r1 = nullptr;
-    rc = ms_scan(pwms_c, span, strand_mask, flags, &r1);
-    const int64_t span_bases = span->n_bases;
-    ms_seqset_free(span);
-    if (rc) return rc;
-    auto fail = [&](int code) { ms_result_free(r1); return code; };
 
-    DeviceCtx *c;
-    if ((rc = get_ctx(r1->device, &c))) return fail(rc);
-    std::lock_guard<std::mutex> lk_dev(c->mu);
-    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+}  // extern "C"
+
+namespace ms {
+
+// r1: the scan of the span as ONE region.  Consumes r1 (also on failure).
+int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *r1, int64_t span_bases, int32_t window, int32_t stride,
+                         int64_t n_windows, ms_result **out) {
+    int rc;
+    auto fail = [&](int code) { ms_result_free(r1); return code; };
+    // the device copies of the widths may have moved since the scan if the set was used on another device in between
+    if ((rc = pwmset_upload(pwms, c->device, c->stream))) return fail(rc);
     const size_t n1 = (size_t) r1->n_hits;
 
     std::unique_ptr<ms_result> res(new (std::nothrow) ms_result());
@@ -1337,11 +1290,13 @@ int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, in
     res->P = pwms->P;
     res->R = n_windows;
     res->stats = r1->stats;
+    res->invalid = r1->invalid;
     res->motif_offsets.assign((size_t) pwms->P + 1, 0);
     ms_result *raw = res.release();
     auto fail2 = [&](int code) { ms_result_free(raw); return fail(code); };
 
-    uint32_t *d_cnt = nullptr, *d_dst = nullptr;
+    uint32_t *d_cnt = nullptr;
+    uint64_t *d_dst = nullptr;
     void *d_tmp = nullptr;
     auto cleanup = [&]() { dev_free(d_cnt); dev_free(d_dst); if (d_tmp) (void) hipFree(d_tmp); };
     uint64_t total = 0;
@@ -1355,17 +1310,16 @@ int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, in
         if (!rc) rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
         if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
         if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
-        uint32_t last[2] = {0, 0};
+        uint32_t last_cnt = 0;
+        uint64_t last_dst = 0;
         if (!rc) {
-            he = hipMemcpyAsync(&last[0], d_cnt + (n1 - 1), 4, hipMemcpyDeviceToHost, c->stream);
-            if (he == hipSuccess) he = hipMemcpyAsync(&last[1], d_dst + (n1 - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            he = hipMemcpyAsync(&last_cnt, d_cnt + (n1 - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(&last_dst, d_dst + (n1 - 1), 8, hipMemcpyDeviceToHost, c->stream);
             if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
             if (he != hipSuccess) { set_error("sweep count failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; }
         }
         if (rc) { cleanup(); return fail2(rc); }
-        total = (uint64_t) last[0] + last[1];
-        // the 32-bit prefix sum wraps silently: bound it by the largest possible expansion
-        if ((double) n1 * (double) (window / stride + 1) >= 4.0e9) { cleanup(); set_error("sweep yields more than 2^32 sites: split the span"); return fail2(MS_ERR_INVALID); }
+        total = last_dst + last_cnt;                          // 64-bit prefix sums: > 2^32 sites per call are fine
     }
     raw->n_hits = (int64_t) total;
     {
@@ -1407,6 +1361,37 @@ int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, in
     ms_result_free(r1);
     *out = raw;
     return MS_OK;
+}
+
+}  // namespace ms
+
+extern "C" {
+
+int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, int64_t begin, int64_t end, int32_t window,
+                  int32_t stride, int strand_mask, uint32_t flags, ms_result **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!pwms_c || !g) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    if (window < 1 || stride < 1) { set_error("window and stride must be positive"); return MS_ERR_INVALID; }
+    if (begin < 0 || end < begin) { set_error("bad span [%lld, %lld)", (long long) begin, (long long) end); return MS_ERR_INVALID; }
+    const int64_t n_windows = end - begin >= window ? (end - begin - window) / stride + 1 : 0;
+    const int64_t span_end = n_windows > 0 ? begin + (n_windows - 1) * stride + window : begin;
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    ms_seqset *span = nullptr;
+    int rc = ms_seqset_from_genome(g, &chrom, &begin, &span_end, 1, &span);       // validates chrom / coordinates
+    if (rc) return rc;
+    DeviceCtx *c;
+    if ((rc = get_ctx(span->device, &c))) { ms_seqset_free(span); return rc; }
+    // both locks are held across the span scan AND the hand-out: nothing can move the PWM set's device copies in between
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    ms_result *r1 = nullptr;
+    rc = scan_locked(c, pwms, span, strand_mask, flags, &r1);
+    const int64_t span_bases = span->n_bases;
+    ms_seqset_free(span);
+    if (rc) return rc;
+    return sweep_handout_locked(c, pwms, r1, span_bases, window, stride, n_windows, out);
 }
 
 // --------------------------------------------------------------------------- score --

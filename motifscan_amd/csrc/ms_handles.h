@@ -1,0 +1,168 @@
+// ms_handles.h -- private to libmotifscan_amd: per-device state and the structs behind the opaque handles of
+// include/motifscan_amd.h, shared by ms_api.hip (scan pipeline) and ms_stream.hip (batch streams, host-streamed sweeps).
+#pragma once
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ms_kernels.h"
+
+namespace ms {
+
+struct Scratch {                 // grow-only work buffers of the scan pipeline
+    uint64_t *cand = nullptr;     size_t cand_cap = 0;
+    uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
+    void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
+    int64_t *nlist = nullptr;     size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
+    unsigned long long *counters = nullptr;      // [0] candidates, [1] hits, [2] N-window positions
+    unsigned long long *h_counters = nullptr;    // pinned
+};
+
+// Free list of result blocks (ms_result keeps its arrays in HBM until freed; a scan loop would
+// otherwise pay a hipMalloc + hipFree of ~200 MB per call).
+struct BlockPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_;
+    size_t bytes = 0;
+    static constexpr size_t kMaxBytes = 8ull << 30;
+};
+
+struct DeviceCtx {
+    int device = -1;
+    BlockPool pool;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // side stream: the N-window kernels run beside the candidate re-scoring
+    hipStream_t stream_up = nullptr;         // sequence upload + packing (runs beside a scan of the previous batch)
+    hipStream_t stream_down = nullptr;       // copy-out of hit arrays (runs beside a scan of the next batch)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev[6] = {};
+    int n_cu = 0;
+    size_t lds_max = 0;
+    size_t lds_set[64] = {};                // dynamic-LDS attribute already raised to this, per kernel variant (+32: measurement instantiation)
+    Scratch sc;
+    std::mutex mu;               // one scan at a time per device (shared scratch)
+};
+
+int get_ctx(int device, DeviceCtx **out);
+int current_device();                 // the calling thread's device (ms_set_device)
+void set_current_device(int device);  // thread-local only; no HIP call
+
+template <typename T>
+inline int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? MS_ERR_NOMEM : MS_ERR_RUNTIME;
+    }
+    return MS_OK;
+}
+
+template <typename T>
+inline void dev_free(T *&p) {
+    if (p) (void) hipFree(p);
+    p = nullptr;
+}
+
+int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got);
+void pool_free(DeviceCtx *c, void *p, size_t bytes);
+void *pinned_alloc(size_t bytes, size_t *got);
+void pinned_free(void *p, size_t bytes);
+
+}  // namespace ms
+
+// ------------------------------------------------------------------------- handles --
+
+struct ms_pwmset {
+    int32_t P = 0;
+    std::vector<double> values;       // concatenated [4][W] row-major, as given
+    std::vector<int64_t> val_off;     // [P+1] in doubles
+    std::vector<int32_t> widths;
+    std::vector<double> cutoffs;
+    std::vector<double> max_raw;
+    int max_width = 0;
+    uint64_t cutoff_version = 1;
+    // device copies (lazy)
+    int device = -1;
+    uint64_t dev_cutoff_version = 0;
+    double2 *d_tab2 = nullptr;
+    int64_t *d_tab_off = nullptr;
+    int32_t *d_width = nullptr;
+    double *d_max_raw = nullptr;
+    double *d_cutoff = nullptr;
+    double *d_raw_floor = nullptr;
+    // pre-filter plan (lazy, keyed by strand mask / cutoffs / LDS budget / exact-only)
+    ms::PrefilterPlan plan;
+    int plan_strand = -1;
+    uint64_t plan_cutoff_version = 0;
+    size_t plan_lds = 0;
+    bool plan_exact_only = false;
+    int plan_min_fb = 0;
+    int plan_engine = -1;
+    int plan_device = -1;
+    uint4 *d_tables = nullptr;
+    ms::TileDesc *d_tiles = nullptr;
+    int32_t *d_group_motifs = nullptr;
+    int32_t *d_fast_motifs = nullptr;
+    int32_t *d_exact_motifs = nullptr;
+    std::mutex mu;
+};
+
+struct ms_seqset {
+    int device = 0;
+    int64_t R = 0;
+    int64_t n_bases = 0;
+    std::vector<int64_t> offsets;         // host copy [R+1]
+    std::vector<int64_t> len_sorted;      // DISTINCT region lengths ascending
+    std::vector<int64_t> len_cnt_ge;      // [i]: number of regions with length >= len_sorted[i]   (+ trailing 0)
+    std::vector<int64_t> len_sum_ge;      // [i]: their total length                              (+ trailing 0)
+    void *block = nullptr;                // one pooled device block holding codes / nmask / offsets / blk2reg
+    size_t block_bytes = 0;
+    uint8_t *d_ascii = nullptr;           // pooled block; kept only when asked to
+    size_t ascii_bytes = 0;
+    uint32_t *d_codes = nullptr;
+    uint32_t *d_nmask = nullptr;
+    int64_t *d_offsets = nullptr;
+    int32_t *d_blk2reg = nullptr;         // region of position 64*b
+};
+
+struct ms_result {
+    int device = 0;
+    int32_t P = 0;
+    int64_t R = 0;                                    // sequences of the scanned set
+    int64_t n_hits = 0;
+    bool deduped = false;
+    bool invalid = false;                             // a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1): stage times only, no hits
+    void *block = nullptr;                            // one device block holding everything below
+    size_t block_bytes = 0;
+    int64_t *d_seq_idx = nullptr;
+    int64_t *d_pos = nullptr;
+    double *d_score = nullptr;
+    int8_t *d_strand = nullptr;
+    unsigned long long *d_region_counts = nullptr;   // [P]
+    int64_t *d_motif_first = nullptr;                 // [P+1]: after ms_scan returns, the per-motif offsets
+    std::vector<int64_t> motif_offsets;               // [P+1]
+    void *h_pinned = nullptr;                         // host copy of the hit arrays (pinned), made on demand
+    bool h_packed = false;                            // ... in the compact form (coord | score)
+    size_t h_pinned_bytes = 0;
+    int64_t h_pinned_hits = -1;
+    ms_scan_stats stats;
+};
+
+namespace ms {
+
+// The scan pipeline proper (ms_api.hip); the caller holds c->mu and pwms->mu.
+int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out);
+// Hand the hits of a span scan (one region) to the windows of a fixed-stride sweep, in place of *span_res (ms_api.hip);
+// the caller holds c->mu and pwms->mu.
+int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *span_res, int64_t span_bases, int32_t window, int32_t stride,
+                         int64_t n_windows, ms_result **out);
+int pwmset_upload(ms_pwmset *p, int device, hipStream_t st);
+
+}  // namespace ms

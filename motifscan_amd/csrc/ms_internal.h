@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/motifscan_amd.h"
@@ -21,6 +22,14 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
             return (e__ == hipErrorOutOfMemory) ? MS_ERR_NOMEM : MS_ERR_RUNTIME;            \
         }                                                                                   \
     } while (0)
+
+// Measurement / A-B switches (MS_PF_*, MS_HIT_COORD) are honoured only when MS_MEASURE=1 is set as well: a stray
+// variable in the environment must never change what the product does (tests/ and tools/ opt in explicitly).
+inline const char *measure_env(const char *name) {
+    const char *g = getenv("MS_MEASURE");
+    if (!g || g[0] != '1' || g[1] != 0) return nullptr;
+    return getenv(name);
+}
 
 // ------------------------------------------------------------------ limits / packing --
 constexpr int kMaxFastWidth = 32;      // one lane holds 32 bases (64 bits of 2-bit codes)
@@ -129,7 +138,8 @@ int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint
 // Descending sort of one row of fp64 scores (cutoff builder).  Query temp size with temp == nullptr.
 int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream);
 
-// Exclusive prefix sum (destination slots of the hits that survive de-duplication).
-int exclusive_sum_u32(void *temp, size_t *temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream);
+// Exclusive prefix sum of 32-bit counts into 64-bit slots (destinations of the hits that survive de-duplication, of the
+// sites a sweep hands out: more than 2^32 of them per call are legal).
+int exclusive_sum_u32(void *temp, size_t *temp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t stream);
 
 }  // namespace ms

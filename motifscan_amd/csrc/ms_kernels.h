@@ -49,13 +49,13 @@ struct PfArgs {
     uint64_t *cand;
     unsigned long long *n_cand;
     uint64_t cand_cap;
-    int no_emit;              // measurement only: run the filter, drop the candidates
+    int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int prefilter_set_lds(int variant, size_t bytes);
-int launch_prefilter(const PfArgs &A, int variant, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
+int prefilter_set_lds(int variant, bool meas, size_t bytes);
+int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
                    int strand_mask, int64_t *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
                    hipStream_t st);
@@ -64,7 +64,7 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
                    uint64_t cand_cap, const int32_t *group_motifs, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, const DevSeq &S, int64_t *seq_idx,
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);
 int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,
@@ -74,17 +74,19 @@ int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out
 int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                        int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st);
 int launch_sweep_scatter(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
-                         const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
+                         const double *score, const int8_t *strand, const uint64_t *dst, int32_t window, int32_t stride,
                          int64_t n_windows, int64_t total, int64_t *seq_idx_out, int64_t *pos_out, double *score_out,
                          int8_t *strand_out, int64_t *motif_off_out, unsigned long long *region_counts, hipStream_t st);
 int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *seq_idx,
                  const int64_t *pos, const double *score, const int8_t *strand, uint32_t *keep, hipStream_t st);
-int launch_compact_hits(int64_t n, const uint32_t *keep, const uint32_t *dst, const int64_t *seq_in, const int64_t *pos_in,
+int launch_compact_hits(int64_t n, const uint32_t *keep, const uint64_t *dst, const int64_t *seq_in, const int64_t *pos_in,
                         const double *score_in, const int8_t *strand_in, int64_t *seq_out, int64_t *pos_out,
                         double *score_out, int8_t *strand_out, const int64_t *off_in, int32_t P, int64_t *off_out,
                         hipStream_t st);
 int launch_site_tables(int64_t n, const int64_t *motif_off, int32_t P, int64_t R, const int64_t *seq_idx,
                        const double *score, int32_t *n_sites, double *max_score, hipStream_t st);
+int launch_pack_hits(int64_t n, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord, unsigned int *bad,
+                     hipStream_t st);
 int launch_gather_ranks(const double *sorted, int64_t n, const int64_t *ranks, int32_t n_ranks, double *out, hipStream_t st);
 
 }  // namespace ms

@@ -658,7 +658,7 @@ __device__ __forceinline__ void mfma_emit(const PfArgs &A, MfWave &W, const i32x
 // All row tiles of one class (NK k-blocks each): per tile NK ds_read_b128 (A operand), 2 * NK matrix
 // instructions, 16 v_max3 and one compare.  The B operands (one-hot image of the lane's bases) come from a
 // 256-entry table in LDS: 4 bases (one byte of 2-bit codes) -> 16 operand bytes.
-template <int NK, int V, int ENG>
+template <int NK, int V, int ENG, bool MEAS>
 __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                            uint32_t byte_off, int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
                                            int64_t g0, bool live0, bool live1) {
@@ -694,7 +694,7 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
         }
     };
     auto test = [&](const i32x16 &c0, const i32x16 &c1, int t) {
-        if (__builtin_expect(__any(max32(c0, c1) >= 0) && !A.no_emit, 0))
+        if (__builtin_expect(__any(max32(c0, c1) >= 0) && !(MEAS && A.no_emit), 0))
             mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
     };
     // ILP tiles' products are issued back to back (independent accumulators), then reduced: a wave that
@@ -727,7 +727,8 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
 // A operands fetched one row tile ahead (first fetch before the class's B operands are waited for): +4 % time;
 // 128 windows per wave in the narrow classes (each A operand serves four B operands): 64 + 32 + 8 registers of tiles
 // do not fit 128 VGPRs, 80 spills, +70 % time.)
-template <int NT, int V, int ENG>
+// MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
+template <int NT, int V, int ENG, bool MEAS>
 __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -753,7 +754,7 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
     unsigned long long t0 = 0, r0 = 0;
-    if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t g0 = chunk * NT + (threadIdx.x & ~63u) + r;          // window start of N-tile 0; N-tile 1: + 32
@@ -764,20 +765,22 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
             switch (cd.G) {
-                case 1: mfma_class<1, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 2: mfma_class<2, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 3: mfma_class<3, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 4: if constexpr (ENG == 1) mfma_class<4, V, ENG>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 1: mfma_class<1, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 2: mfma_class<2, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 3: mfma_class<3, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 4: if constexpr (ENG == 1) mfma_class<4, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 default: break;
             }
         }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
-    if (A.clk && threadIdx.x == 0) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        const size_t b = (size_t) blockIdx.y * gridDim.x + blockIdx.x;
-        A.clk[2 * b] = t1 - t0;
-        A.clk[2 * b + 1] = r1 - r0;
+    if constexpr (MEAS) {
+        if (A.clk && threadIdx.x == 0) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            const size_t b = (size_t) blockIdx.y * gridDim.x + blockIdx.x;
+            A.clk[2 * b] = t1 - t0;
+            A.clk[2 * b + 1] = r1 - r0;
+        }
     }
 }
 
@@ -913,14 +916,16 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             }
         }
         __syncthreads();
-        if (st.n > (unsigned int) (kHitStage - 1024)) stage_flush(st, H);   // block-uniform
+        const bool full = st.n > (unsigned int) (kHitStage - 1024);
+        __syncthreads();                     // every thread has read st.n before any wave can append again: the decision is block-uniform
+        if (full) stage_flush(st, H);
     }
     stage_flush(st, H);
 }
 
 // ----------------------------------------------------------------------- finalize --
 
-__global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, int gbits,
+__global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, int gbits, int32_t P,
                                                        const DevSeq S,
                                                        int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
                                                        int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
@@ -940,16 +945,19 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
         strand[i] = (int8_t) ((k & 1ULL) ? 2 : 1);
         bool first_of_motif = (i == 0);
         new_pair = true;
+        int64_t q0 = 0;                                  // per-motif offsets: every motif after the previous hit's up to this one starts here
         if (i > 0) {
             const uint64_t kp = keys[i - 1];
             const uint32_t mp = (uint32_t) (kp >> (gbits + 1));
             first_of_motif = mp != motif;
+            q0 = (int64_t) mp + 1;
             if (!first_of_motif) {
                 const int64_t gp = (int64_t) ((kp >> 1) & gmask);
                 new_pair = gp < S.offsets[r];            // previous hit of this motif lies in an earlier region
             }
         }
-        if (first_of_motif) motif_first[motif] = i;
+        if (first_of_motif) for (int64_t q = q0; q <= (int64_t) motif; q++) motif_first[q] = i;
+        if (i == n - 1) for (int64_t q = (int64_t) motif + 1; q <= P; q++) motif_first[q] = n;     // motifs after the last hit: empty
     }
     // number of regions with >= 1 hit per motif (stats.py:29-31): one atomic per (wave, motif)
     unsigned long long todo = __ballot(live && new_pair);
@@ -964,7 +972,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
 
 // The same when the keys carry (region, position inside the region): nothing to look up, only bits to unpack.
 // Four consecutive hits per thread: 16-byte loads and stores, the four strand bytes as one word.
-__global__ void __launch_bounds__(256) finalize_rp_kernel(const uint64_t *__restrict__ keys, int64_t n, int rbits, int pbits,
+__global__ void __launch_bounds__(256) finalize_rp_kernel(const uint64_t *__restrict__ keys, int64_t n, int rbits, int pbits, int32_t P,
                                                           int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
                                                           int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
                                                           unsigned long long *__restrict__ region_counts) {
@@ -994,7 +1002,9 @@ __global__ void __launch_bounds__(256) finalize_rp_kernel(const uint64_t *__rest
                 sq[j] = (int64_t) (pair & rmask);
                 ps[j] = (int64_t) ((k[j] >> 1) & pmask);
                 sd |= ((k[j] & 1ULL) ? 2u : 1u) << (8 * j);
-                if (prev == ~0ULL || (uint32_t) (prev >> rbits) != motif) motif_first[motif] = i0 + j;
+                if (prev == ~0ULL || (uint32_t) (prev >> rbits) != motif)        // every motif after the previous hit's up to this one starts here
+                    for (int64_t q = prev == ~0ULL ? 0 : (int64_t) (uint32_t) (prev >> rbits) + 1; q <= (int64_t) motif; q++) motif_first[q] = i0 + j;
+                if (i0 + j == n - 1) for (int64_t q = (int64_t) motif + 1; q <= P; q++) motif_first[q] = n;   // motifs after the last hit: empty
                 if (prev != pair) {
                     if (motif == motif0) n_new++;
                     else atomicAdd(&region_counts[motif], 1ULL);    // a thread's hits rarely span two motifs
@@ -1067,19 +1077,19 @@ __global__ void __launch_bounds__(256) dedup_kernel(int64_t n, const int64_t *__
 }
 
 __global__ void __launch_bounds__(256) compact_hits_kernel(int64_t n, const uint32_t *__restrict__ keep,
-                                                           const uint32_t *__restrict__ dst,
+                                                           const uint64_t *__restrict__ dst,
                                                            const int64_t *__restrict__ seq_in, const int64_t *__restrict__ pos_in,
                                                            const double *__restrict__ score_in, const int8_t *__restrict__ strand_in,
                                                            int64_t *__restrict__ seq_out, int64_t *__restrict__ pos_out,
                                                            double *__restrict__ score_out, int8_t *__restrict__ strand_out) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !keep[i]) return;
-    const uint32_t d = dst[i];
+    const uint64_t d = dst[i];
     seq_out[d] = seq_in[i]; pos_out[d] = pos_in[i]; score_out[d] = score_in[i]; strand_out[d] = strand_in[i];
 }
 
 // new per-motif offsets after compaction: off_out[p] = dst[off_in[p]] (or the kept total at the end)
-__global__ void remap_offsets_kernel(const int64_t *__restrict__ off_in, int32_t P, int64_t n, const uint32_t *__restrict__ dst,
+__global__ void remap_offsets_kernel(const int64_t *__restrict__ off_in, int32_t P, int64_t n, const uint64_t *__restrict__ dst,
                                      const uint32_t *__restrict__ keep, int64_t *__restrict__ off_out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > P) return;
@@ -1144,7 +1154,7 @@ __global__ void __launch_bounds__(256) sweep_count_kernel(int64_t n, const int64
 __global__ void __launch_bounds__(256) sweep_scatter_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
                                                             const int32_t *__restrict__ width, const int64_t *__restrict__ pos,
                                                             const double *__restrict__ score, const int8_t *__restrict__ strand,
-                                                            const uint32_t *__restrict__ dst, int32_t window, int32_t stride,
+                                                            const uint64_t *__restrict__ dst, int32_t window, int32_t stride,
                                                             int64_t n_windows, int64_t *__restrict__ seq_idx_out,
                                                             int64_t *__restrict__ pos_out, double *__restrict__ score_out,
                                                             int8_t *__restrict__ strand_out,
@@ -1203,7 +1213,7 @@ __global__ void __launch_bounds__(256) sweep_scatter_kernel(int64_t n, const int
 }
 
 // per-motif offsets of the handed-out sites: where the motif's first hit went
-__global__ void sweep_offsets_kernel(const int64_t *__restrict__ motif_off, int32_t P, int64_t n, const uint32_t *__restrict__ dst,
+__global__ void sweep_offsets_kernel(const int64_t *__restrict__ motif_off, int32_t P, int64_t n, const uint64_t *__restrict__ dst,
                                      int64_t total, int64_t *__restrict__ out) {
     const int32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m > P) return;
@@ -1305,6 +1315,28 @@ __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict_
     blk2reg[b] = (int32_t) find_region_bsearch(offsets, R, b * 64);
 }
 
+// ---------------------------------------------------------------- compact copy-out --
+
+// coord = seq_idx << 32 | pos << 1 | (strand - 1): 8 bytes per hit on the host link instead of 17 (ms_result_hits_packed_host).
+// bad[0] is set if a hit does not fit the format.
+__global__ void __launch_bounds__(256) pack_hits_kernel(int64_t n, const int64_t *__restrict__ seq_idx, const int64_t *__restrict__ pos,
+                                                        const int8_t *__restrict__ strand, uint64_t *__restrict__ coord,
+                                                        unsigned int *__restrict__ bad) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t sq = (uint64_t) seq_idx[i], ps = (uint64_t) pos[i];
+    if ((sq >> 32) != 0 || (ps >> 31) != 0) *bad = 1u;
+    coord[i] = (sq << 32) | ((ps & 0x7FFFFFFFull) << 1) | (uint64_t) (strand[i] == 2 ? 1 : 0);
+}
+
+int launch_pack_hits(int64_t n, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord, unsigned int *bad,
+                     hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(pack_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, seq_idx, pos, strand, coord, bad);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
 // ---------------------------------------------------------------------- launchers --
 
 int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,
@@ -1338,32 +1370,34 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 
 typedef void (*PfKernel)(const PfArgs);
 
-static PfKernel pf_kernel_for(int variant, int *threads) {
-    switch (variant) {                                                    // measurement switch MS_PF_VARIANT
+static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
+    switch (variant) {                                                    // A/B switch MS_PF_VARIANT (MS_MEASURE=1)
         case 0: *threads = 1024; return prefilter_kernel<1024, 0, 4>;     // two groups per trip, compiler-ordered reads
         case 1: *threads = 1024; return prefilter_kernel<1024, 1, 4>;     // 2-4 groups per trip, compiler-ordered reads
         case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
         case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
         case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
-        case 16: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 1>;  // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU
-        case 17: *threads = 512; return prefilter_mfma_kernel<512, 1, 1>;    // engine 1, 8 waves per block
-        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 1>;  // A/B: one row tile in flight per wave
-        case 24: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 2>;  // engine 2 (Walsh form: 10 columns per k-block)
-        case 25: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 2>;  // engine 2, one row tile in flight per wave
+        case 16: *threads = 1024;                                          // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU
+            return meas ? prefilter_mfma_kernel<1024, 1, 1, true> : prefilter_mfma_kernel<1024, 1, 1, false>;
+        case 17: *threads = 512; return prefilter_mfma_kernel<512, 1, 1, true>;    // engine 1, 8 waves per block
+        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 1, true>;  // A/B: one row tile in flight per wave
+        case 24: *threads = 1024;                                          // engine 2 (Walsh form: 10 columns per k-block)
+            return meas ? prefilter_mfma_kernel<1024, 1, 2, true> : prefilter_mfma_kernel<1024, 1, 2, false>;
+        case 25: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 2, true>;  // engine 2, one row tile in flight per wave
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
 }
 
-int prefilter_set_lds(int variant, size_t bytes) {
+int prefilter_set_lds(int variant, bool meas, size_t bytes) {
     int threads;
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel_for(variant, &threads)),
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel_for(variant, meas, &threads)),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
-int launch_prefilter(const PfArgs &A, int variant, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
     int threads;
-    PfKernel k = pf_kernel_for(variant, &threads);
+    PfKernel k = pf_kernel_for(variant, meas, &threads);
     const int64_t n_chunks = (A.n_bases + threads - 1) / threads;
     if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
     hipLaunchKernelGGL(k, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(threads), lds_bytes, st, A);
@@ -1406,17 +1440,20 @@ int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, cons
     return MS_OK;
 }
 
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, const DevSeq &S, int64_t *seq_idx,
+int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st) {
-    if (n == 0) return MS_OK;
+    if (n == 0) {                                    // no hits: every per-motif offset is 0
+        MS_HIP(hipMemsetAsync(motif_first, 0, ((size_t) P + 1) * sizeof(int64_t), st));
+        return MS_OK;
+    }
     if (pbits > 0) {
-        hipLaunchKernelGGL(finalize_rp_kernel, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, st, keys, n, rbits, pbits,
+        hipLaunchKernelGGL(finalize_rp_kernel, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, st, keys, n, rbits, pbits, P,
                            seq_idx, pos, strand, motif_first, region_counts);
         MS_HIP(hipGetLastError());
         return MS_OK;
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, S,
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, P, S,
                        seq_idx, pos, strand, motif_first, region_counts);
     MS_HIP(hipGetLastError());
     return MS_OK;
@@ -1432,7 +1469,7 @@ int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int
 }
 
 int launch_sweep_scatter(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
-                         const double *score, const int8_t *strand, const uint32_t *dst, int32_t window, int32_t stride,
+                         const double *score, const int8_t *strand, const uint64_t *dst, int32_t window, int32_t stride,
                          int64_t n_windows, int64_t total, int64_t *seq_idx_out, int64_t *pos_out, double *score_out,
                          int8_t *strand_out, int64_t *motif_off_out, unsigned long long *region_counts, hipStream_t st) {
     hipLaunchKernelGGL(sweep_offsets_kernel, dim3((unsigned) ((P + 1 + 255) / 256)), dim3(256), 0, st, motif_off, P, n, dst, total,
@@ -1454,7 +1491,7 @@ int launch_dedup(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *
     return MS_OK;
 }
 
-int launch_compact_hits(int64_t n, const uint32_t *keep, const uint32_t *dst, const int64_t *seq_in, const int64_t *pos_in,
+int launch_compact_hits(int64_t n, const uint32_t *keep, const uint64_t *dst, const int64_t *seq_in, const int64_t *pos_in,
                         const double *score_in, const int8_t *strand_in, int64_t *seq_out, int64_t *pos_out,
                         double *score_out, int8_t *strand_out, const int64_t *off_in, int32_t P, int64_t *off_out,
                         hipStream_t st) {

@@ -293,7 +293,7 @@ bool quantize_strand_i8(const double e[4][kMaxFastWidth], int W, double T, I8Str
     }
     if (!(T > lowest)) return false;            // every window passes
     int bq_max = 254;
-    if (const char *e = getenv("MS_PF_BQ_MAX")) bq_max = std::max(1, std::min(254, atoi(e)));      // experiment: coarser levels, smaller operand magnitudes
+    if (const char *e = measure_env("MS_PF_BQ_MAX")) bq_max = std::max(1, std::min(254, atoi(e)));      // experiment: coarser levels, smaller operand magnitudes
     for (int Bq = bq_max; Bq >= 1; Bq--) {
         const double s = budget > 0 ? ((double) Bq + 0.5) / budget : 1e300;
         int dq[kMaxFastWidth][4], cap[kMaxFastWidth];

@@ -25,8 +25,8 @@ int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *
     return MS_OK;
 }
 
-int exclusive_sum_u32(void *temp, size_t *temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream) {
-    MS_HIP(rocprim::exclusive_scan(temp, *temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), stream));
+int exclusive_sum_u32(void *temp, size_t *temp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t stream) {
+    MS_HIP(rocprim::exclusive_scan(temp, *temp_bytes, in, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), stream));
     return MS_OK;
 }
 

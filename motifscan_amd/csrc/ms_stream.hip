@@ -1,0 +1,296 @@
+// ms_stream.hip -- batch streams and sweep planning (include/motifscan_amd.h, "batch streams" / "sweep planning").
+//
+// SURVEY.md 8(d) defines the metric over "pack + H2D + kernel + D2H of results" and 8(e) names what multi-GPU scaling
+// needs: "per-GPU host threads doing pack + H2D concurrently, pinned memory, and overlap (double-buffered chunks)".  A
+// stream is exactly that for one device: three host threads, one per stage, connected by bounded queues --
+//     uploader     host ASCII -> HBM (upload stream) + pack kernel              ms_seqset_create
+//     scanner      pre-filter -> fp64 -> order (-> sweep hand-out) (-> de-dup)   scan_locked, sweep_handout_locked
+//     downloader   hit arrays -> pinned host memory (copy-out stream)           ms_result_hits_host / _packed_host
+// so that batch i's copy-out, batch i+1's scan and batch i+2's upload run together.  Results leave in submission order.
+// The reference has no counterpart (its Scanner holds every sequence as a Python str and makes one c_scan_motif call,
+// scanner.py:71-87, 125); the batches' concatenation is what that one call returns.
+#include <atomic>
+
+#include "ms_handles.h"
+
+using namespace ms;
+
+namespace {
+
+struct Job {
+    int kind = 0;                     // 0: batch of regions; 1: span of a window sweep
+    const char *bases = nullptr;      // borrowed
+    std::vector<int64_t> offsets;     // [n_seqs + 1]
+    int64_t n_seqs = 0;
+    int32_t window = 0, stride = 0;
+    int64_t n_windows = 0;
+    ms_seqset *seqs = nullptr;
+    ms_result *res = nullptr;
+    int rc = MS_OK;
+    std::string err;
+};
+
+class JobQueue {
+public:
+    explicit JobQueue(size_t cap) : cap_(cap) {}
+    void push(Job *j) {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_; });
+        q_.push_back(j);
+        not_empty_.notify_one();
+    }
+    Job *pop() {                      // nullptr = closed and drained
+        std::unique_lock<std::mutex> lk(mu_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return nullptr;
+        Job *j = q_.front();
+        q_.pop_front();
+        not_full_.notify_one();
+        return j;
+    }
+    void close() {
+        std::lock_guard<std::mutex> lk(mu_);
+        closed_ = true;
+        not_empty_.notify_all();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<Job *> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+void fail_job(Job *j, int rc) {
+    j->rc = rc;
+    j->err = ms_last_error();         // the failing call left its message on THIS worker thread
+}
+
+}  // namespace
+
+struct ms_stream {
+    ms_pwmset *pwms = nullptr;
+    int strand = 3;
+    uint32_t flags = 0;
+    int device = 0;
+    int depth = 2;
+    int capacity = 0;
+    std::atomic<int> in_flight{0};
+    std::unique_ptr<JobQueue> q_in, q_up, q_scan, q_done;
+    std::thread th_up, th_scan, th_down;
+
+    void uploader() {
+        set_current_device(device);
+        (void) hipSetDevice(device);
+        while (Job *j = q_in->pop()) {
+            if (j->rc == MS_OK) {
+                const int rc = ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+                if (rc) fail_job(j, rc);
+            }
+            q_up->push(j);
+        }
+        q_up->close();
+    }
+
+    void scanner() {
+        set_current_device(device);
+        (void) hipSetDevice(device);
+        while (Job *j = q_up->pop()) {
+            if (j->rc == MS_OK) {
+                DeviceCtx *c = nullptr;
+                int rc = get_ctx(device, &c);
+                if (!rc) {
+                    std::lock_guard<std::mutex> lk_dev(c->mu);
+                    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+                    rc = scan_locked(c, pwms, j->seqs, strand, (flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT, &j->res);
+                    if (!rc && j->kind == 1) {
+                        ms_result *r1 = j->res;
+                        j->res = nullptr;
+                        rc = sweep_handout_locked(c, pwms, r1, j->seqs->n_bases, j->window, j->stride, j->n_windows, &j->res);
+                    }
+                }
+                if (!rc && (flags & MS_STREAM_DEDUP)) rc = ms_result_dedup(j->res, pwms);
+                if (rc) fail_job(j, rc);
+            }
+            if (j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
+            q_scan->push(j);
+        }
+        q_scan->close();
+    }
+
+    void downloader() {
+        set_current_device(device);
+        (void) hipSetDevice(device);
+        while (Job *j = q_scan->pop()) {
+            if (j->rc == MS_OK && !(flags & MS_STREAM_NO_HITS)) {
+                const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
+                                                          : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
+                if (rc) fail_job(j, rc);
+            }
+            q_done->push(j);
+        }
+        q_done->close();
+    }
+};
+
+extern "C" {
+
+int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int depth, ms_stream **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!pwms) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    if (depth < 1 || depth > 16) { set_error("depth must be in [1, 16]"); return MS_ERR_INVALID; }
+    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(current_device(), &c);             // no device: fail here, loudly, not in a worker
+    if (rc) return rc;
+    std::unique_ptr<ms_stream> st(new (std::nothrow) ms_stream());
+    if (!st) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    st->pwms = const_cast<ms_pwmset *>(pwms);
+    st->strand = strand_mask;
+    st->flags = flags;
+    st->device = c->device;
+    st->depth = depth;
+    st->capacity = 4 * depth + 3;                        // three bounded queues + one job inside each stage + done results
+    try {
+        st->q_in.reset(new JobQueue((size_t) depth));
+        st->q_up.reset(new JobQueue((size_t) depth));
+        st->q_scan.reset(new JobQueue((size_t) depth));
+        st->q_done.reset(new JobQueue((size_t) st->capacity + 1));      // never blocks: in_flight <= capacity
+        ms_stream *raw = st.get();
+        st->th_up = std::thread([raw] { raw->uploader(); });
+        st->th_scan = std::thread([raw] { raw->scanner(); });
+        st->th_down = std::thread([raw] { raw->downloader(); });
+    } catch (const std::exception &e) {
+        set_error("could not start the stream's threads: %s", e.what());
+        if (st->q_in) st->q_in->close();
+        if (st->th_up.joinable()) st->th_up.join();
+        if (st->th_scan.joinable()) st->th_scan.join();
+        if (st->th_down.joinable()) st->th_down.join();
+        return MS_ERR_RUNTIME;
+    }
+    *out = st.release();
+    return MS_OK;
+}
+
+static int stream_enqueue(ms_stream *st, std::unique_ptr<Job> j) {
+    if (st->in_flight.load() >= st->capacity) {
+        set_error("%d batches are in flight: collect results with ms_stream_next first", st->capacity);
+        return MS_ERR_INVALID;
+    }
+    st->in_flight.fetch_add(1);
+    st->q_in->push(j.release());                         // may wait for the uploader; never for the consumer
+    return MS_OK;
+}
+
+int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs) {
+    if (!st) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (n_seqs < 0 || !offsets) { set_error("bad offsets / n_seqs"); return MS_ERR_INVALID; }
+    if (offsets[n_seqs] > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    std::unique_ptr<Job> j(new (std::nothrow) Job());
+    if (!j) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    try { j->offsets.assign(offsets, offsets + n_seqs + 1); }
+    catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    j->bases = bases;
+    j->n_seqs = n_seqs;
+    return stream_enqueue(st, std::move(j));
+}
+
+int ms_stream_submit_span(ms_stream *st, const char *bases, int64_t n_bases, int32_t window, int32_t stride) {
+    if (!st) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (window < 1 || stride < 1) { set_error("window and stride must be positive"); return MS_ERR_INVALID; }
+    if (n_bases < 0 || (n_bases > 0 && !bases)) { set_error("bad span"); return MS_ERR_INVALID; }
+    std::unique_ptr<Job> j(new (std::nothrow) Job());
+    if (!j) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    j->kind = 1;
+    j->window = window;
+    j->stride = stride;
+    j->n_windows = n_bases >= window ? (n_bases - window) / stride + 1 : 0;
+    const int64_t used = j->n_windows > 0 ? (j->n_windows - 1) * stride + window : 0;      // bases past the last whole window are not scanned
+    j->offsets = {0, used};
+    j->bases = bases;
+    j->n_seqs = 1;
+    return stream_enqueue(st, std::move(j));
+}
+
+int ms_stream_next(ms_stream *st, ms_result **out) {
+    if (!st || !out) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (st->in_flight.load() == 0) return MS_OK;
+    std::unique_ptr<Job> j(st->q_done->pop());
+    if (!j) { set_error("stream is closed"); return MS_ERR_RUNTIME; }
+    st->in_flight.fetch_sub(1);
+    if (j->rc != MS_OK) {
+        set_error("%s", j->err.c_str());
+        if (j->res) ms_result_free(j->res);
+        return j->rc;
+    }
+    *out = j->res;
+    return MS_OK;
+}
+
+int ms_stream_in_flight(const ms_stream *st, int *n) {
+    if (!st || !n) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *n = st->in_flight.load();
+    return MS_OK;
+}
+
+int ms_stream_capacity(const ms_stream *st, int *n) {
+    if (!st || !n) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *n = st->capacity;
+    return MS_OK;
+}
+
+void ms_stream_free(ms_stream *st) {
+    if (!st) return;
+    st->q_in->close();
+    if (st->th_up.joinable()) st->th_up.join();
+    if (st->th_scan.joinable()) st->th_scan.join();
+    if (st->th_down.joinable()) st->th_down.join();
+    while (Job *j = st->q_done->pop()) {                 // closed by the downloader: drains, then nullptr
+        if (j->res) ms_result_free(j->res);
+        delete j;
+    }
+    delete st;
+}
+
+// ---------------------------------------------------------------------- sweep planning --
+
+int ms_sweep_spans(const int64_t *chrom_len, int32_t n_chroms, int32_t window, int32_t stride, int64_t max_span_bases,
+                   ms_span *spans, int64_t cap, int64_t *n_spans) {
+    if (!n_spans) { set_error("n_spans is NULL"); return MS_ERR_INVALID; }
+    *n_spans = 0;
+    if (n_chroms < 0 || (n_chroms > 0 && !chrom_len)) { set_error("bad chromosome lengths"); return MS_ERR_INVALID; }
+    if (window < 1 || stride < 1) { set_error("window and stride must be positive"); return MS_ERR_INVALID; }
+    if (max_span_bases < window) { set_error("a span must hold at least one window (%d bases)", window); return MS_ERR_INVALID; }
+    if (max_span_bases > kMaxBases) max_span_bases = kMaxBases;                 // a span is one sequence set
+    const int64_t per_span = (max_span_bases - window) / stride + 1;            // windows that fit one span
+    int64_t first = 0, count = 0;
+    for (int32_t ch = 0; ch < n_chroms; ch++) {
+        const int64_t L = chrom_len[ch];
+        if (L < 0) { set_error("chromosome %d has a negative length", ch); return MS_ERR_INVALID; }
+        const int64_t n_w = L >= window ? (L - window) / stride + 1 : 0;
+        if (n_w == 0) continue;
+        const int64_t n_sp = (n_w + per_span - 1) / per_span;
+        for (int64_t k = 0; k < n_sp; k++) {                                    // near-equal spans
+            const int64_t k0 = n_w * k / n_sp, k1 = n_w * (k + 1) / n_sp;
+            if (spans && count < cap) {
+                ms_span &sp = spans[count];
+                sp.chrom = ch;
+                sp.reserved = 0;
+                sp.begin = k0 * stride;
+                sp.end = (k1 - 1) * stride + window;
+                sp.first_window = first + k0;
+                sp.n_windows = k1 - k0;
+            }
+            count++;
+        }
+        first += n_w;
+    }
+    *n_spans = count;
+    return MS_OK;
+}
+
+}  // extern "C"

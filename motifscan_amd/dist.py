@@ -39,17 +39,25 @@ def take_shard(bases, offsets, r0, r1):
     return bases[lo:hi], offsets[r0:r1 + 1] - lo
 
 
-def gpu_scan(pwm_values, widths, cutoffs, bases, offsets, strand):
-    """Local scan on this process's GPU -> (hits dict, region_counts)."""
+def gpu_scan(pwm_values, widths, cutoffs, bases, offsets, strand, batch_regions=125_000):
+    """Local scan on this process's GPU -> (hits dict, region_counts).  The shard goes through an ms_stream in batches of
+    batch_regions regions (upload + pack | scan | copy-out overlapped, SURVEY.md 8(e) "Scaling risks"); the batches are
+    merged back into the single-call order."""
     from . import _lib
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
     pw = _lib.PwmSet(pwm_values, widths, cutoffs)
-    sq = _lib.SeqSet(bases, offsets)
-    res = _lib.scan(pw, sq, strand)
+    bounds = [(r0, min(n, r0 + batch_regions)) for r0 in range(0, max(n, 1), max(1, int(batch_regions)))]
+    counts = np.zeros(len(widths), dtype=np.int64)
+    parts = []
     try:
-        return res.hits(), res.region_counts()
+        gen = _lib.scan_stream(pw, (take_shard(bases, offsets, r0, r1) for r0, r1 in bounds), strand)
+        for (r0, _), res in zip(bounds, gen):
+            parts.append((res.hits(), r0))
+            counts += res.region_counts()
+            res.close()
+        return _lib.merge_hits(parts, len(widths)), counts
     finally:
-        res.close()
-        sq.close()
         pw.close()
 
 
@@ -85,6 +93,16 @@ def scan_sharded(pwm_values, widths, cutoffs, sets, rank, world_size, strand=3, 
         shards.append((r0, r1))
     counts = allreduce_counts(local_counts.ravel(), device).reshape(len(sets), n_pwms)
     return {"hits": all_hits, "counts": counts, "shards": shards}
+
+
+def span_shard(spans, rank, world_size):
+    """A rank's share of the spans of a host-streamed genome sweep (_lib.sweep_spans): contiguous, balanced by bases.
+    Windows never straddle two spans, so the per-motif window counts of the ranks simply add up (the one all-reduce) and
+    a span's first_window makes every rank's window indices global."""
+    sizes = np.array([sp[2] - sp[1] for sp in spans], dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(sizes)])
+    a, b = shard_bounds(cum, world_size)[rank]
+    return spans[a:b]
 
 
 def sweep_shard(begin, end, window, stride, rank, world_size):

@@ -162,6 +162,52 @@ class Scanner:
             out["n_sites"], out["max_score"] = tables      # what write_sites_table prints (io/__init__.py:23-33)
         return out
 
+    def scan_batches(self, pwms, batch_regions=100_000, depth=2):
+        """Generator over consecutive batches of regions, for region lists whose sequences / hit lists should not sit in
+        memory at once: yields (r0, r1, arrays) with `arrays` as scan_motifs_arrays returns them for regions [r0, r1)
+        ('region' holds the GLOBAL region index).  The batches go through an ms_stream: the upload + packing of one batch,
+        the scan of the previous one and the copy-out of the one before overlap on the device.  Concatenated per motif
+        (_lib.merge_hits) the batches are exactly the single-call result."""
+        matrices, cutoffs, lengths = self._marshal(pwms)
+        n = len(self.seq_starts)
+        pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
+        starts = np.asarray(self.seq_starts, dtype=np.int64)
+        bounds = [(r0, min(n, r0 + batch_regions)) for r0 in range(0, n, max(1, int(batch_regions)))]
+
+        def arrays(r0, res):
+            h = res.hits(copy=False)
+            region = h["seq_idx"] + r0
+            return {"motif": h["motif"], "region": region, "start": (starts[region] + h["pos"]) if len(region) else h["pos"],
+                    "score": h["score"], "strand": h["strand"], "motif_offsets": h["motif_offsets"],
+                    "n_regions_with_site": res.region_counts()}
+
+        def batches():
+            for r0, r1 in bounds:
+                seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in self._sequences[r0:r1]]
+                offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+                if seqs:
+                    offsets[1:] = np.cumsum([len(b) for b in seqs])
+                yield np.frombuffer(b"".join(seqs), dtype=np.uint8), offsets
+
+        try:
+            if self._resident is not None:               # regions are cut on the device: nothing to upload, batches run in turn
+                g, idx = self._resident
+                for r0, r1 in bounds:
+                    sq = g.extract(idx[r0:r1], self.seq_starts[r0:r1], self.seq_ends[r0:r1])
+                    try:
+                        res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
+                    finally:
+                        sq.close()
+                    if self.remove_dup:
+                        res.dedup(pw)
+                    yield r0, r1, arrays(r0, res)
+            else:
+                flags = _lib.MS_STREAM_DEDUP if self.remove_dup else 0
+                for (r0, r1), res in zip(bounds, _lib.scan_stream(pw, batches(), _STRAND_FLAG[self.strand], flags, depth)):
+                    yield r0, r1, arrays(r0, res)
+        finally:
+            pw.close()
+
     def scan_motifs(self, pwms):
         pwms = list(pwms)
         a = self.scan_motifs_arrays(pwms)

@@ -308,6 +308,7 @@ def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch,
     """Pre-filter engine (matrix-core product / packed LDS lookups), field width, number of LDS tiles
     and kernel variant are tuning knobs: every setting must give the same (bit-exact) hits.  Small
     LDS budgets force several tiles."""
+    monkeypatch.setenv("MS_MEASURE", "1")                       # the A/B switches are only honoured with the explicit opt-in
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     vals, widths = jaspar579["pwm_values"], jaspar579["widths"]

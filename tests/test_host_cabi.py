@@ -115,6 +115,7 @@ def fields_never_overflow(plan):
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
 @pytest.mark.parametrize("strand", [1, 2, 3])
 def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch):
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", "0")
     mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
     pw = _lib.PwmSet.from_matrices(mats, cut)
@@ -170,6 +171,7 @@ def emulate_mfma_prefilter(plan, seq_codes_2bit):
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
 @pytest.mark.parametrize("strand", [1, 2, 3])
 def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch, engine):
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", engine)
     mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
     pw = _lib.PwmSet.from_matrices(mats, cut)
@@ -201,6 +203,7 @@ def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, m
 def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch, engine):
     """The fuzzer's tie-heavy cases (cutoffs exactly on attainable scores): the int8 plans keep every hit."""
     import fuzz_parity
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", engine)
     lut = {c: i for i, c in enumerate("ACGT")}
     checked = 0
@@ -226,6 +229,7 @@ def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch, engine):
 
 @pytest.mark.parametrize("engine", ["0", "1"])
 def test_prefilter_routes_degenerate_pwms_to_exact_path(monkeypatch, engine):
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", engine)
     wide = np.zeros((4, 40))
     wide[0] = 1.0
@@ -241,6 +245,7 @@ def test_prefilter_routes_degenerate_pwms_to_exact_path(monkeypatch, engine):
 
 
 def test_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", "0")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     for budget in (64 * 1024, 143 * 1024):
@@ -261,15 +266,18 @@ def test_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
 def test_mfma_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
     """Engine 1: 16 motifs x {fwd, rev} per 32-row operand tile, ceil(W_max / 8) KiB each, narrow to wide;
     LDS tiles hold whole row tiles and stay inside the budget."""
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", "1")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     widths = jaspar579["widths"]
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", "2")                    # Walsh form: 10 columns per k-block, fewer k-blocks in total
     p2 = pw.plan_mfma(3, 143 * 1024)
     assert p2["n_fast"] == 579 and int(p2["group_kb"][0::2].sum()) == 62 and p2["group_kb"].max() == 3
     for q in range(len(p2["group_kb"])):
         ws = widths[p2["group_motifs"][q][p2["group_motifs"][q] >= 0]]
         assert len(ws) == 0 or (ws <= 10 * p2["group_kb"][q]).all()
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", "1")
     for budget in (32 * 1024, 143 * 1024):
         plan = pw.plan_mfma(3, budget)
@@ -289,6 +297,7 @@ def test_mfma_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
 
 
 def test_field_width_switch(jaspar579, monkeypatch):
+    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
     monkeypatch.setenv("MS_PF_ENGINE", "0")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     monkeypatch.setenv("MS_PF_FIELD_BITS", "16")

@@ -11,6 +11,7 @@ sq = _lib.SeqSet(*wl["sets"][0])
 t0 = time.time()
 while time.time() - t0 < 2.5:
     _lib.scan(pw, sq, 3).close()
+os.environ["MS_MEASURE"] = "1"          # opt in to the library's measurement switches
 os.environ["MS_PF_CLOCK"] = "1"
 for _ in range(5):
     r = _lib.scan(pw, sq, 3); st = r.stats(); r.close()

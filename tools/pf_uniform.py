@@ -6,6 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from motifscan_amd import _lib, synth
 _lib.set_device(0)
+os.environ["MS_MEASURE"] = "1"          # opt in to the library's measurement switches
 os.environ["MS_PF_CLOCK"] = "1"
 vals, widths, cutoffs = synth.load_motif_set(579)
 mats = synth.matrices_of(vals, widths)

@@ -12,6 +12,7 @@ wl = synth.workload(wl_name)
 n_pw = int(os.environ.get("N_PWMS", "0")) or len(wl["widths"])       # optional: first N motifs only
 pw = _lib.PwmSet(wl["pwm_values"][:4 * int(wl["widths"][:n_pw].sum())], wl["widths"][:n_pw], wl["cutoffs"][:n_pw])
 sq = _lib.SeqSet(*wl["sets"][0])
+os.environ["MS_MEASURE"] = "1"          # opt in to the library's measurement switches
 os.environ["MS_PF_CLOCK"] = "1"
 for rep in range(2):
     for noemit in (0, 1):
