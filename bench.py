@@ -2,25 +2,29 @@
 """
 bench.py -- the measurement contract of the PWM scan path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c3|c2]
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c2|c5|c5shard|tiny]
 
-A "step" is one pass of the hot path over this rank's synthetic batch, starting from ASCII bases
-resident in HBM: for each region set (input, control)  pack (sequence extraction -> 2-bit codes +
-N mask)  ->  integer pre-filter  ->  fp64 re-scoring  ->  ordering  ->  coordinates / per-motif
-region counts;  then the single all-reduce of the per-motif region counts (N > 1).  Results stay
-in HBM (hits are not copied to the host inside the timed region; the PCIe-inclusive figure is in
-DESIGN.md).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (fresh processes through
+torch.distributed.run, before anything in this process has touched the GPU) and relays rank 0's line; under the
+driver's torchrun it simply is one of the ranks.
 
-Metric: scanned bp x motifs per second (BASELINE.json), whole job over all ranks; weak scaling
-(every rank scans its own fixed-size shard; at N = 8 the default workload is BASELINE.json
-configs[3]: 1M input + 1M control regions x 500 bp x 579 PWMs).
+Workload (default "c4" = BASELINE.json configs[3] IN FULL: 1M input + 1M control regions x 500 bp x 579 PWMs): every
+rank takes its contiguous share of both region sets (dist.shard_bounds arithmetic), so 1 -> 8 GPUs is STRONG scaling on
+the north-star workload.  A "step" is one pass of the hot path over the rank's share, starting from ASCII bases resident
+in HBM: per region set  pack (extraction -> 2-bit codes + N mask) -> int8 matrix-core pre-filter -> fp64 re-scoring ->
+ordering -> coordinates / per-motif region counts;  then the path's ONE collective, the all-reduce of the device-resident
+int64[2 x 579] count vector (stats.py:29-31 input).  Hits stay in HBM inside the timed region: `value` is the
+device-resident whole-job rate.  SURVEY.md 8(d)'s end-to-end metric (host ASCII in pinned memory -> hit arrays in pinned
+host memory, i.e. H2D + pack + scan + D2H) is measured in the same run through the library's batch stream and reported
+beside it as `value_end_to_end` -- never as `value`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,11 +38,54 @@ LDS_PEAK = 256 * 256 * 2.4e9      # B/s: 256 B/clk/CU (ds_read_b128) x 256 CUs x
 I8_MFMA_PEAK = 256 * 4 * 2048 * 2.4e9   # op/s: v_mfma_i32_32x32x32_i8 = 65536 ops per 32 cycles per SIMD (measured, tools/ubench),
                                         # 1024 SIMDs, 2.4 GHz = 5.03e15 = 2 x the dense bf16 peak of MI355X_MICROARCH.md
 
+WORKLOAD_TEXT = {
+    "c4": "BASELINE configs[3] in full: 1M input + 1M control regions x 500 bp x 579 PWMs, region-sharded over the ranks",
+    "c3": "BASELINE configs[2]: 100k x 1 kb regions x 579 PWMs",
+    "c2": "BASELINE configs[1]: 10k x 500 bp regions x 50 PWMs",
+    "c5": "BASELINE configs[4]: multi-chromosome genome on the host swept as 200 bp windows stride 50 x 579 PWMs, streamed "
+          "host -> GPU in spans (ms_stream_submit_span: every base scored once)",
+    "c5shard": "BASELINE configs[4] per-GPU shard, genome RESIDENT in HBM: 375 Mbp as 200 bp windows stride 50 (7.5M windows) "
+               "x 579 PWMs through ms_scan_sweep; value counts reference-equivalent units (window_bp x n_windows x n_motifs: "
+               "the reference scans every base window / stride = 4 times, the sweep once)",
+    "tiny": "smoke",
+}
+
+
+def self_launch(a):
+    """Start --gpus ranks as fresh processes.  Nothing in THIS process has initialised the GPU (no torch import, no HIP call)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def load_workload(name, rank, world, args):
+    """This rank's share: dict(pwm_values, widths, cutoffs, sets=[(bases, offsets)], shard, units (this rank), ...)."""
+    from motifscan_amd import dist, synth
+    if name == "c4":
+        return synth.c4_shard(rank, world, regions_per_set=args.regions_per_set)
+    wl = synth.workload(name)
+    sets, shards = [], []
+    for bases, offsets in wl["sets"]:
+        r0, r1 = dist.shard_bounds(offsets, world)[rank]
+        sets.append(dist.take_shard(bases, offsets, r0, r1))
+        shards.append((r0, r1))
+    wl["units_total"] = wl["units"]
+    wl["n_regions_total"] = wl["n_regions"]
+    wl["sets"] = sets
+    wl["shard"] = shards[0] if shards else (0, 0)
+    wl["units"] = sum(int(o[-1]) for _, o in sets) * wl["n_pwms"]
+    return wl
+
 
 def cpu_baseline(wl, seconds_target=12.0):
-    """The reference's CPU scanner on a bounded sample of the same workload, on this box's host
-    cores.  kind = "reference": the real cscore.c (oracle/_ref, built in the build container);
-    otherwise kind = "port": the oracle's C restatement."""
+    """The reference's CPU scanner on a bounded sample of the same workload, on this box's host cores, and -- the oracle
+    being the checker -- its hit list for that sample.  kind = "reference": the real cscore.c (oracle/_ref, built in the
+    build container); otherwise kind = "port": the oracle's C restatement."""
     from oracle import oracle
     from motifscan_amd import synth
     cores = os.cpu_count() or 1
@@ -47,17 +94,22 @@ def cpu_baseline(wl, seconds_target=12.0):
     mats = [m.tolist() for m in synth.matrices_of(wl["pwm_values"], wl["widths"])]
     cuts = wl["cutoffs"].tolist()
     ref = oracle.load_reference_ext()
+    last = {}
 
     def run(n_regions, threads):
         raw = bases[:int(offsets[n_regions])].tobytes()
         if ref is not None:
             seqs = [raw[int(offsets[i]):int(offsets[i + 1])].decode() for i in range(n_regions)]
             t0 = time.perf_counter()
-            ref.c_scan_motif(mats, cuts, seqs, 3, threads)
-            return time.perf_counter() - t0
+            out = ref.c_scan_motif(mats, cuts, seqs, 3, threads)
+            t = time.perf_counter() - t0
+            last["n"], last["hits"] = n_regions, out
+            return t
         t0 = time.perf_counter()
-        oracle.scan_arrays(wl["pwm_values"], wl["widths"], wl["cutoffs"], raw, offsets[:n_regions + 1], 3, threads)
-        return time.perf_counter() - t0
+        out = oracle.scan_arrays(wl["pwm_values"], wl["widths"], wl["cutoffs"], raw, offsets[:n_regions + 1], 3, threads)
+        t = time.perf_counter() - t0
+        last["n"], last["arrays"] = n_regions, out
+        return t
 
     threads = min(cores, P)                        # the reference's work unit is one whole PWM (cscore.c:181-186)
     n_max = len(offsets) - 1
@@ -75,10 +127,43 @@ def cpu_baseline(wl, seconds_target=12.0):
            "kind": "reference" if ref is not None else "port",
            "sample": f"first {n} regions x {L} bp x {P} PWMs of the same workload, both strands, {t:.1f} s wall",
            "host_cores_total": cores}
+    sample = dict(last)
     n0 = 16
     t1 = run(max(n // max(threads, 1), n0), 1)
     out["value_1thread"] = int(offsets[max(n // max(threads, 1), n0)]) * P / t1
-    return out
+    return out, sample
+
+
+def parity_sample(wl, pw, sample):
+    """The GPU's hits for the CPU baseline's sample, compared with what the reference just returned for it (checker only)."""
+    from motifscan_amd import _lib
+    n = sample["n"]
+    bases, offsets = wl["sets"][0]
+    sq = _lib.SeqSet(bases[:int(offsets[n])], offsets[:n + 1])
+    res = _lib.scan(pw, sq, 3)
+    h = res.hits()
+    res.close(); sq.close()
+    if "hits" in sample:
+        per = sample["hits"]
+        want_off = np.concatenate([[0], np.cumsum([len(x) for x in per])])
+        flat = [x for p in per for x in p]
+        w_seq = np.array([x[0] for x in flat], dtype=np.int64)
+        w_pos = np.array([x[1] for x in flat], dtype=np.int64)
+        w_sc = np.array([x[2] for x in flat], dtype=np.float64)
+        w_sd = np.array([x[3] for x in flat], dtype=np.int64)
+    else:
+        a = sample["arrays"]
+        want_off, w_seq, w_pos, w_sc, w_sd = a["motif_offsets"], a["seq_idx"], a["pos"], a["score"], a["strand"].astype(np.int64)
+    same = (np.array_equal(h["motif_offsets"], want_off) and np.array_equal(h["seq_idx"], w_seq) and np.array_equal(h["pos"], w_pos)
+            and np.array_equal(h["score"], w_sc) and np.array_equal(h["strand"].astype(np.int64), w_sd))
+    return {"regions": int(n), "hits": int(len(w_pos)), "identical_to_cpu_reference": bool(same)}
+
+
+class _DevicePtr:
+    """Lets torch wrap the library's device-resident count vector without a copy (CUDA array interface)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
 def main():
@@ -86,23 +171,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c4shard", choices=["c4shard", "c3", "c2", "c5shard", "c5regions", "tiny"])
+    ap.add_argument("--workload", default="c4", choices=list(WORKLOAD_TEXT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--min-warm-seconds", type=float, default=2.0, help="untimed warm-up steps continue until this much wall time has passed (DVFS steady state)")
+    ap.add_argument("--regions-per-set", type=int, default=None, help="c4 only: shrink the workload (development aid; the line then says so)")
+    ap.add_argument("--genome-mbp", type=int, default=3000, help="c5 only: synthetic genome size in Mbp")
+    ap.add_argument("--batch-regions", type=int, default=125_000, help="regions per batch of the end-to-end leg")
     a = ap.parse_args()
 
-    import torch                                   # device memory / streams / torch.distributed only
-    import torch.distributed as dist
-    from motifscan_amd import _lib, synth
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                             # never returns
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} disagrees with WORLD_SIZE {world}: launch one rank per GPU (or let bench.py start them itself)")
+
+    # synthetic inputs first: plain numpy in worker processes, before this process touches the GPU
+    if a.workload in ("c5", "c5shard"):
+        return main_sweep(a, world, rank, local_rank)
+    wl = load_workload(a.workload, rank, world, a)
+
+    import torch                                   # device memory / streams / torch.distributed only
+    import torch.distributed as dist
+    from motifscan_amd import _lib
+
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback")
-    # MS_BENCH_BACKEND=gloo (test aid only): lets the N > 1 code path run on a box with fewer GPUs than ranks
-    # (ranks then share devices; RCCL itself refuses two ranks on one GPU)
+    # MS_BENCH_BACKEND=gloo + MS_BENCH_SHARE_GPU=1 (test aid only): lets the N > 1 code path run on a box with fewer GPUs
+    # than ranks (ranks then share devices; RCCL itself refuses two ranks on one GPU)
     backend = os.environ.get("MS_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % _lib.device_count()
+    share = os.environ.get("MS_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % _lib.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)               # before the process group: RCCL binds to the current device
     _lib.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -112,36 +214,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world != a.gpus and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    wl = synth.workload("c5shard" if a.workload == "c5regions" else a.workload, rank=rank)
     P = wl["n_pwms"]
     pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
-    genome = None
-    if "genome" in wl:                             # configs[4]: windows cut from a genome that is resident in HBM
-        genome = _lib.ResidentGenome({"chr": wl["genome"]})
-        seqsets = [None]
-    else:
-        seqsets = [_lib.SeqSet(b, o, keep_ascii=True) for b, o in wl["sets"]]
-    counts = torch.zeros(len(seqsets) * P, dtype=torch.int64, device=dev)
+    seqsets = [_lib.SeqSet(b, o, keep_ascii=True) for b, o in wl["sets"]]
+    n_sets = len(seqsets)
+    counts = torch.zeros(n_sets * P, dtype=torch.int64, device=dev)          # this rank's counts, then the reduced vector
+    local_counts = torch.zeros(n_sets * P, dtype=torch.int64, device=dev)
 
     def step():
         stats = []
         for s, sq in enumerate(seqsets):
-            if genome is not None and a.workload == "c5shard":
-                # fixed-stride sweep: the span is scanned once, hits are handed to the windows that hold them
-                res = _lib.scan_sweep(pw, genome, "chr", 0, len(wl["genome"]), synth.C5_SHARD["window"], synth.C5_SHARD["stride"], 3)
-            elif genome is not None:               # the same windows as an explicit region list -> bit-level gather on the device
-                sq = genome.extract(*wl["windows"])
-                res = _lib.scan(pw, sq, 3)
-                sq.close()
-            else:
-                sq.repack()                        # extraction: resident ASCII -> 2-bit codes + N mask
-                res = _lib.scan(pw, sq, 3)
+            sq.repack()                            # extraction: resident ASCII -> 2-bit codes + N mask
+            res = _lib.scan(pw, sq, 3)
             stats.append(res.stats())
-            counts[s * P:(s + 1) * P] = torch.from_numpy(res.region_counts()).to(dev, non_blocking=False)
+            # the library's own device vector, wrapped in place: device -> device, no trip through the host
+            counts[s * P:(s + 1) * P].copy_(torch.as_tensor(_DevicePtr(res.region_counts_device_ptr(), P), device=dev))
+            torch.cuda.current_stream().synchronize()          # the result block returns to the pool on close()
             res.close()
+        local_counts.copy_(counts)
         if world > 1:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (stats.py:29-31 input)
         return stats
@@ -151,8 +242,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    n_warm = 0
+    t_warm = time.perf_counter()
+    while True:                                    # untimed: W steps AND at least --min-warm-seconds (DVFS steady state)
         step()
+        n_warm += 1
+        more = n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warm_seconds
+        if world > 1:                              # the ranks agree on when to stop (every step holds a collective)
+            flag = torch.tensor([1 if more else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item())
+        if not more:
+            break
     fence()
     t0 = time.perf_counter()
     all_stats = []
@@ -167,6 +268,19 @@ def main():
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     total_units = float(units.item())
+
+    # the collective, checked: all-reduced vector == sum over ranks of the vectors each rank's library handed over
+    counts_check = None
+    if world > 1:
+        gathered = [torch.zeros_like(local_counts) for _ in range(world)]
+        dist.all_gather(gathered, local_counts)
+        counts_check = {"allreduce_equals_sum_of_rank_counts": bool(torch.equal(torch.stack(gathered).sum(0), counts)),
+                        "max_regions_with_site": int(counts.max().item())}
+
+    # ---- SURVEY.md 8(d) end-to-end: host ASCII (pinned) -> hit arrays in pinned host memory, through the batch stream ----
+    e2e = None
+    if not a.no_end_to_end:
+        e2e = end_to_end(a, wl, pw, world, dev, torch, dist if world > 1 else None)
 
     if rank == 0:
         n_launch = len(all_stats)
@@ -186,7 +300,7 @@ def main():
         hbm = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                "traffic": traffic, "kernel": "prefilter_kernel", "kernel_ms": pf_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if engine >= 1:
-            # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe (DESIGN.md 5): algorithmic ops =
+            # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe (DESIGN.md 4): algorithmic ops =
             # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the
             # kernel ISSUES is 4x that (one-hot: 4 k-slots per base) plus padding of widths to 8 columns
             alg_ops = sum(s["mfma_ops_algorithmic"] for s in all_stats) / n_launch
@@ -200,33 +314,31 @@ def main():
                        "lds_TBps": lds_bytes / (pf_ms * 1e-3) / 1e12, "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
         else:
             roofline = hbm
-            # the stream that actually binds the engine-0 kernel: PWM 2-mer tables read from LDS
             on_chip = {"bound": "lds", "achieved": lds_bytes / (pf_ms * 1e-3) / 1e12, "peak": LDS_PEAK / 1e12,
                        "unit": "TB/s", "frac": lds_bytes / (pf_ms * 1e-3) / LDS_PEAK,
                        "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
+        shrunk = a.workload == "c4" and a.regions_per_set is not None
         line = {
             "metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
             "value": total_units * a.steps / elapsed,
             "unit": "bp*motifs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ("f64 (every hit decision and score, as in the reference) behind an int8 one-hot matrix-core pre-filter (i32 accumulate)"
                       if engine == 1 else
                       "f64 (every hit decision and score, as in the reference) behind an int8 Walsh-form matrix-core pre-filter (i32 accumulate)"
                       if engine == 2 else
                       "f64 (every hit decision and score, as in the reference) behind a u32 pre-filter of three packed 10-bit fixed-point fields"),
             "data": "synthetic",
-            "config": {"workload": {"c4shard": "BASELINE configs[3] per-GPU shard: (125k input + 125k control) regions x 500 bp x 579 PWMs "
-                                               "(N=8 is the full 1M+1M config)",
-                                    "c3": "BASELINE configs[2]: 100k x 1 kb regions x 579 PWMs",
-                                    "c2": "BASELINE configs[1]: 10k x 500 bp regions x 50 PWMs",
-                                    "c5shard": "BASELINE configs[4] per-GPU shard: 375 Mbp of genome resident in HBM as 200 bp windows stride 50 "
-                                               "(7.5M windows) x 579 PWMs, through ms_scan_sweep (every base scored once)",
-                                    "c5regions": "BASELINE configs[4] per-GPU shard: the same 7.5M windows handed over as an explicit region list",
-                                    "tiny": "smoke"}[a.workload],
-                       "regions_per_gpu": wl["n_regions"] * max(len(wl["sets"]), 1), "region_bp": wl["length"], "n_pwms": P,
-                       "strands": "both", "p_value": "1e-4", "sharding": f"regions over {world} GPU(s), 1 all-reduce of int64[{len(seqsets) * P}]"},
+            "config": {"workload": WORKLOAD_TEXT[a.workload] + (f" [SHRUNK to {a.regions_per_set} regions per set: development run]" if shrunk else ""),
+                       "regions_total": wl["n_regions_total"] * n_sets, "regions_per_gpu": wl["n_regions"] * n_sets,
+                       "region_bp": wl["length"], "n_pwms": P, "strands": "both", "p_value": "1e-4",
+                       "sharding": f"{wl['n_regions_total']} + {wl['n_regions_total']} regions split contiguously over {world} GPU(s)"
+                                   if n_sets == 2 else f"{wl['n_regions_total']} regions split contiguously over {world} GPU(s)",
+                       "collective": f"1 all-reduce(sum) of the device-resident int64[{n_sets * P}] count vector per step",
+                       "warmup_steps_run": n_warm, "timed_region_s": elapsed},
+            "value_definition": "device-resident: ASCII in HBM at the start of the timed region, hits left in HBM; pack + pre-filter + fp64 + order + finalize + all-reduce inside",
             "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes},
@@ -236,9 +348,244 @@ def main():
             "hits_per_scan": sum(s["n_hits"] for s in all_stats) / n_launch,
             "candidates_per_scan": sum(s["n_candidates"] for s in all_stats) / n_launch,
         }
+        if counts_check is not None:
+            line["counts_check"] = counts_check
+        if e2e is not None:
+            line["value_end_to_end"] = e2e
         if world == 1 and not a.no_cpu_baseline and wl["sets"]:
-            line["cpu_baseline"] = cpu_baseline(wl)
+            line["cpu_baseline"], sample = cpu_baseline(wl)
+            line["parity_sample"] = parity_sample(wl, pw, sample)
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def end_to_end(a, wl, pw, world, dev, torch, dist):
+    """Host ASCII in pinned memory -> hit arrays in pinned host memory, in batches of --batch-regions regions:
+       pipelined  three stages of consecutive batches overlapped by the library's stream (ms_stream_*), hits copied out in the
+                  compact 16-byte form (pipelined_25B: the int64/int64/f64/int8 arrays, 25 bytes per hit);
+       serial     one batch at a time: upload + pack, scan, copy-out.
+    Whole-job rates (max time over ranks)."""
+    from motifscan_amd import _lib, dist as msdist
+    pins, batches = [], []
+    for bases, offsets in wl["sets"]:
+        pin = _lib.PinnedBuffer(max(bases.size, 1))
+        pin.array[:bases.size] = bases
+        pins.append(pin)
+        n = len(offsets) - 1
+        for r0 in range(0, n, a.batch_regions):
+            r1 = min(n, r0 + a.batch_regions)
+            lo, hi = int(offsets[r0]), int(offsets[r1])
+            batches.append((pin.array[lo:hi], np.ascontiguousarray(offsets[r0:r1 + 1] - lo)))
+    units = float(wl["units"])
+
+    def timed(fn, passes):
+        fn()                                            # warm: pools, pinned blocks
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        hits = 0
+        for _ in range(passes):
+            hits += fn()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        u = torch.tensor([units * passes], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        return float(u.item()) / float(t.item()), float(t.item()) / passes * 1e3, hits // passes
+
+    def pipelined(packed):
+        def run():
+            n = 0
+            for res in _lib.scan_stream(pw, iter(batches), 3, 0, depth=2, packed=packed):
+                n += res.n_hits                         # the arrays are already in pinned host memory at this point
+                res.close()
+            return n
+        return run
+
+    def serial():
+        n = 0
+        for b, o in batches:
+            sq = _lib.SeqSet(b, o)
+            res = _lib.scan(pw, sq, 3)
+            res.hits(copy=False)
+            n += res.n_hits
+            res.close(); sq.close()
+        return n
+
+    passes = max(1, min(a.steps, 4))
+    v_p16, ms_p16, hits = timed(pipelined(True), passes)
+    v_p25, ms_p25, _ = timed(pipelined(False), passes)
+    v_s, ms_s, _ = timed(serial, passes)
+    for pin in pins:
+        pin.close()
+    return {"pipelined": v_p16, "pipelined_25B": v_p25, "serial": v_s, "unit": "bp*motifs/s",
+            "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s},
+            "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "hits_per_pass_per_gpu": int(hits),
+            "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "
+                          "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 16 bytes per hit "
+                          "(coord word + fp64 score), 'pipelined_25B' the four plain arrays, 'serial' runs the stages of one batch after another"}
+
+
+def main_sweep(a, world, rank, local_rank):
+    """configs[4]: window sweeps.  c5 = host-streamed whole genome (strong scaling over the spans); c5shard = one GPU's 375 Mbp
+    resident in HBM (round-1 comparison line)."""
+    from motifscan_amd import dist as msdist, synth
+    window, stride = synth.C5["window"], synth.C5["stride"]
+    if a.workload == "c5":
+        lens = synth.c5_chrom_lengths(a.genome_mbp * 1_000_000)
+        vals, widths, cutoffs = synth.load_motif_set(synth.C5["n_pwms"])
+        max_span = 375_000_000
+        # span planning needs no GPU: a pure function of the lengths (the library's ms_sweep_spans, restated for the pre-GPU phase)
+        spans_all = []
+        first = 0
+        for ch, L in enumerate(lens.tolist()):
+            n_w = (L - window) // stride + 1 if L >= window else 0
+            if not n_w:
+                continue
+            per = (max_span - window) // stride + 1
+            n_sp = -(-n_w // per)
+            for k in range(n_sp):
+                k0, k1 = n_w * k // n_sp, n_w * (k + 1) // n_sp
+                spans_all.append((ch, k0 * stride, (k1 - 1) * stride + window, first + k0, k1 - k0))
+            first += n_w
+        mine = msdist.span_shard(spans_all, rank, world)
+        need = sorted({sp[0] for sp in mine})
+        genome = synth.c5_genome(need, lens, workers=min(16, max(1, (os.cpu_count() or 1) // world)))
+    else:
+        wl = synth.workload("c5shard", rank=rank)
+
+    import torch
+    import torch.distributed as dist
+    from motifscan_amd import _lib
+    if not torch.cuda.is_available() or _lib.device_count() < 1:
+        raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback")
+    backend = os.environ.get("MS_BENCH_BACKEND", "nccl")
+    share = os.environ.get("MS_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % _lib.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    _lib.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if a.workload == "c5":
+        assert _lib.sweep_spans(lens, window, stride, max_span) == spans_all       # the library's planner agrees
+        P = len(widths)
+        pw = _lib.PwmSet(vals, widths, cutoffs)
+        pinned = {}
+        for ch in need:                                # chromosomes in pinned host memory: uploads at link rate, overlapped
+            pb = _lib.PinnedBuffer(len(genome[ch]))
+            pb.array[:] = genome[ch]
+            pinned[ch] = pb
+        chroms = {ch: pb.array for ch, pb in pinned.items()}
+        del genome
+        counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        my_units = float(sum(sp[4] for sp in mine)) * window * P
+        modes = {"counts_only": (_lib.MS_STREAM_NO_HITS, False), "hits_packed": (0, True)}
+        out = {}
+
+        def one_pass(flags, packed):
+            c = np.zeros(P, dtype=np.int64)
+            sites = 0
+            st = {"ms_prefilter": 0.0, "ms_total": 0.0, "n": 0}
+            for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, flags, depth=2, spans=mine, packed=packed):
+                c += res.region_counts()
+                sites += res.n_hits
+                s = res.stats()
+                st["ms_prefilter"] += s["ms_prefilter"]; st["ms_total"] += s["ms_total"]; st["n"] += 1
+                res.close()
+            counts.copy_(torch.from_numpy(c))
+            if world > 1:
+                dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            return sites, st
+
+        for mode, (flags, packed) in modes.items():
+            t_w = time.perf_counter()
+            n_warm = 0
+            while n_warm < max(1, a.warmup) or (time.perf_counter() - t_w < a.min_warm_seconds and world == 1):
+                one_pass(flags, packed)                # (N > 1: a fixed number of passes, every pass holds a collective)
+                n_warm += 1
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                sites, st = one_pass(flags, packed)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            un = torch.tensor([my_units], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                dist.all_reduce(un, op=dist.ReduceOp.SUM)
+            out[mode] = {"value": float(un.item()) * a.steps / float(el.item()), "ms_per_step": float(el.item()) / a.steps * 1e3,
+                         "sites_per_step_per_gpu": int(sites), "spans_per_gpu": len(mine),
+                         "prefilter_ms_per_step": st["ms_prefilter"], "device_ms_per_step": st["ms_total"]}
+        if rank == 0:
+            line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
+                    "value": out["counts_only"]["value"], "unit": "bp*motifs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                    "ms_per_step": out["counts_only"]["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "dtype": "f64 behind an int8 one-hot matrix-core pre-filter (i32 accumulate)", "data": "synthetic",
+                    "config": {"workload": WORKLOAD_TEXT["c5"], "genome_bp": int(lens.sum()), "n_chroms": len(lens), "window": window,
+                               "stride": stride, "n_windows_total": int(spans_all[-1][3] + spans_all[-1][4]), "n_pwms": P,
+                               "max_span_bases": max_span, "spans_total": len(spans_all)},
+                    "value_definition": "host-streamed END TO END (chromosomes in pinned host memory -> upload + pack | scan-once + hand-out | "
+                                        "copy-out overlapped); units are reference-equivalent (window_bp x n_windows x n_motifs: the reference "
+                                        "scans every base window / stride = 4 times, the sweep once). value = counts_only mode (per-motif window "
+                                        "counts, what the enrichment statistics consume); hits_packed also copies every site to the host",
+                    "modes": out}
+            print(json.dumps(line), flush=True)
+    else:
+        P = wl["n_pwms"]
+        pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
+        genome = _lib.ResidentGenome({"chr": wl["genome"]})
+        counts = torch.zeros(P, dtype=torch.int64, device=dev)
+
+        def step():
+            res = _lib.scan_sweep(pw, genome, "chr", 0, len(wl["genome"]), window, stride, 3)
+            st = res.stats()
+            counts.copy_(torch.as_tensor(_DevicePtr(res.region_counts_device_ptr(), P), device=dev))
+            torch.cuda.current_stream().synchronize()
+            res.close()
+            if world > 1:
+                dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            return st
+
+        t_w = time.perf_counter()
+        n_warm = 0
+        while n_warm < a.warmup or (time.perf_counter() - t_w < a.min_warm_seconds and world == 1):
+            step()
+            n_warm += 1
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = [step() for _ in range(a.steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        un = torch.tensor([float(wl["units"])], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(un, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            k = len(stats)
+            line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
+                    "value": float(un.item()) * a.steps / float(el.item()), "unit": "bp*motifs/s (reference-equivalent units)", "n_gpus": world,
+                    "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(el.item()) / a.steps * 1e3, "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "f64 behind an int8 one-hot matrix-core pre-filter (i32 accumulate)",
+                    "data": "synthetic", "config": {"workload": WORKLOAD_TEXT["c5shard"], "n_pwms": P, "windows_per_gpu": wl["n_regions"]},
+                    "stage_ms_per_scan": {q: sum(s[q] for s in stats) / k for q in ("ms_prefilter", "ms_exact", "ms_sort", "ms_finalize", "ms_total")},
+                    "hits_per_scan": sum(s["n_hits"] for s in stats) / k}
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,6 +25,8 @@
  *   ms_seqset_from_genome   genome/__init__.py:117-135: packed genome resident in HBM, regions cut on device
  *   ms_scan_sweep         the same extraction + scan for the windows of a fixed-stride sweep of one chromosome
  *                         (BASELINE configs[4]); every base is scored once instead of window / stride times
+ *   ms_scan_regions_once  the same extraction + scan for region lists that overlap (peaks +- window/2, random controls:
+ *                         cli/scan.py:43-48,76-86, region/utils.py:89-145): the union of the regions is scored once
  *   ms_scan               scan_motif / scan_motif_thread           cscore.c:317-476
  *                         (Python name c_scan_motif; "OOOII" = pwms, cutoffs, seqs, strand,
  *                          n_threads; n_threads has no meaning on the GPU and is not taken)
@@ -152,6 +154,12 @@ int ms_scan(const ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint3
  * the windows that contain all of its bases. */
 int ms_scan_sweep(const ms_pwmset *pwms, const ms_genome *genome, int32_t chrom, int64_t begin, int64_t end,
                   int32_t window, int32_t stride, int strand_mask, uint32_t flags, ms_result **out);
+/* Region lists that OVERLAP (peaks +- window/2 closer than the window; the random control set drawn around them:
+ * cli/scan.py:43-48, 76-86): the same result as ms_seqset_from_genome + ms_scan over the n_regions regions (seq_idx =
+ * index in the caller's list, any order, any overlap, empty regions allowed) -- but the union of the regions is scanned
+ * ONCE and every hit is handed to each region that holds all of its bases.  stats.n_bases = bases actually scanned. */
+int ms_scan_regions_once(const ms_pwmset *pwms, const ms_genome *genome, const int32_t *chrom, const int64_t *start,
+                         const int64_t *end, int64_t n_regions, int strand_mask, uint32_t flags, ms_result **out);
 int ms_result_num_hits(const ms_result *res, int64_t *n_hits);
 int ms_result_motif_offsets(const ms_result *res, int64_t *out /* [P+1] */);
 /* Copy the hit arrays to host buffers of length n_hits (any pointer may be NULL). */

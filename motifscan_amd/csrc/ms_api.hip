@@ -154,12 +154,12 @@ using namespace ms;
 // ------------------------------------------------------------------------- handles --
 
 // Lay the result arrays out in one device block: [counts P+1][offsets P+1][seq_idx n][pos n][score n][strand n]
-static size_t result_block_bytes(int32_t P, size_t n) {
+size_t ms::result_block_bytes(int32_t P, size_t n) {
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
     return 8 * (2 * ((size_t) P + 1) + 3 * n_round) + n_round + 256;
 }
 
-static void result_carve(ms_result *r, void *blk, size_t n) {
+void ms::result_carve(ms_result *r, void *blk, size_t n) {
     const size_t P1 = (size_t) r->P + 1, n_round = (n + 65535) & ~(size_t) 65535;
     char *b = static_cast<char *>(blk);
     r->d_region_counts = reinterpret_cast<unsigned long long *>(b);

@@ -164,5 +164,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
 int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *span_res, int64_t span_bases, int32_t window, int32_t stride,
                          int64_t n_windows, ms_result **out);
 int pwmset_upload(ms_pwmset *p, int device, hipStream_t st);
+// One pooled device block holds everything a result owns: [counts P+1][offsets P+1][seq_idx n][pos n][score n][strand n]
+size_t result_block_bytes(int32_t P, size_t n);
+void result_carve(ms_result *r, void *blk, size_t n);
 
 }  // namespace ms

@@ -1,0 +1,286 @@
+// ms_regions.hip -- scan-once for region lists that OVERLAP (ms_scan_regions_once).
+//
+// The reference scans every region on its own (scanner.py:71-87 cuts them, cscore.c:336-390 scans each), so a base that
+// lies in k regions is scored k times: peaks +- window/2 closer together than the window, and the 5x random control set
+// drawn around them (cli/scan.py:43-48, 76-86; region/utils.py:89-145), overlap heavily.  Here the union of the regions is
+// scanned ONCE: overlapping regions of a chromosome are merged into spans on the host, the spans are cut from the resident
+// genome and scanned as a sequence set, and every span hit is handed to each region that contains all of its bases
+// (cscore.c:340: a window must lie inside its sequence), re-keyed as (motif, region, position in the region, strand) and put
+// into the reference's order by the same sort + finalize the plain scan uses.  Scores are the span scan's fp64 scores: the
+// window's bases are the same bases, so they are bit-identical to what a per-region scan computes.
+#include <algorithm>
+#include <numeric>
+
+#include "ms_handles.h"
+
+namespace ms {
+
+namespace {
+
+struct RegionIndex {                 // device view of the merged layout
+    const int64_t *span_first;       // [S+1] first sorted region of every span
+    const int64_t *rel_start;        // [R] region start relative to its span's begin, ascending inside a span
+    const int64_t *rel_end;          // [R]
+    const int64_t *orig;             // [R] index of the region in the caller's list
+    const int64_t *span_maxlen;      // [S] longest region of the span
+};
+
+__device__ __forceinline__ int32_t motif_of(const int64_t *__restrict__ motif_off, int32_t P, int64_t i) {
+    int32_t lo = 0, hi = P;
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (motif_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// sorted regions [lo, hi] of span s that can hold a site at [g, g + W): start <= g, and start > g + W - maxlen
+__device__ __forceinline__ void candidate_range(const RegionIndex &X, int64_t s, int64_t g, int W, int64_t &lo, int64_t &hi) {
+    const int64_t jb = X.span_first[s], je = X.span_first[s + 1];
+    int64_t a = jb, b = je;                                   // first j with rel_start[j] > g
+    while (a < b) { const int64_t m = (a + b) >> 1; if (X.rel_start[m] <= g) a = m + 1; else b = m; }
+    hi = a - 1;
+    const int64_t need = g + W - X.span_maxlen[s];            // a region starting before this cannot reach g + W
+    a = jb; b = je;                                           // first j with rel_start[j] >= need
+    while (a < b) { const int64_t m = (a + b) >> 1; if (X.rel_start[m] < need) a = m + 1; else b = m; }
+    lo = a;
+}
+
+__global__ void __launch_bounds__(256) once_count_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                         const int32_t *__restrict__ width, const int64_t *__restrict__ seq_idx,
+                                                         const int64_t *__restrict__ pos, const RegionIndex X,
+                                                         uint32_t *__restrict__ cnt) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int W = width[motif_of(motif_off, P, i)];
+    const int64_t g = pos[i];
+    int64_t lo, hi;
+    candidate_range(X, seq_idx[i], g, W, lo, hi);
+    uint32_t c = 0;
+    for (int64_t j = lo; j <= hi; j++) c += X.rel_end[j] >= g + W ? 1u : 0u;
+    cnt[i] = c;
+}
+
+__global__ void __launch_bounds__(256) once_expand_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                          const int32_t *__restrict__ width, const int64_t *__restrict__ seq_idx,
+                                                          const int64_t *__restrict__ pos, const double *__restrict__ score,
+                                                          const int8_t *__restrict__ strand, const RegionIndex X,
+                                                          const uint64_t *__restrict__ dst, int rbits, int pbits,
+                                                          uint64_t *__restrict__ keys, double *__restrict__ vals) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = motif_of(motif_off, P, i);
+    const int W = width[m];
+    const int64_t g = pos[i];
+    int64_t lo, hi;
+    candidate_range(X, seq_idx[i], g, W, lo, hi);
+    uint64_t d = dst[i];
+    const double sc = score[i];
+    const uint64_t sbit = strand[i] == 2 ? 1u : 0u;
+    for (int64_t j = lo; j <= hi; j++)
+        if (X.rel_end[j] >= g + W) {
+            keys[d] = ((uint64_t) m << (rbits + pbits + 1)) | ((uint64_t) X.orig[j] << (pbits + 1)) | ((uint64_t) (g - X.rel_start[j]) << 1) | sbit;
+            vals[d] = sc;
+            d++;
+        }
+}
+
+}  // namespace
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g, const int32_t *chrom, const int64_t *start,
+                                    const int64_t *end, int64_t n_regions, int strand_mask, uint32_t flags, ms_result **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    if (!pwms_c || !g) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    if (n_regions < 0 || (n_regions > 0 && (!chrom || !start || !end))) { set_error("bad region arrays"); return MS_ERR_INVALID; }
+    if (n_regions >= (1LL << 31)) { set_error("too many regions"); return MS_ERR_INVALID; }
+    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
+    const ms_seqset *G = reinterpret_cast<const ms_seqset *>(g);
+    const int64_t n_chroms = G->R;
+    const int64_t *goff = G->offsets.data();
+    const size_t R = (size_t) n_regions;
+
+    // ---- host: order the regions by (chromosome, start), merge overlapping ones into spans --------------------------
+    std::vector<int64_t> order(R), rel_start(R), rel_end(R), span_first, span_maxlen, sp_start, sp_end;
+    std::vector<int32_t> sp_chrom;
+    int64_t max_len = 0;
+    try {
+        for (size_t r = 0; r < R; r++) {
+            const int64_t ch = chrom[r];
+            if (ch < 0 || ch >= n_chroms) { set_error("region %zu: chromosome index %d out of range", r, chrom[r]); return MS_ERR_INVALID; }
+            if (start[r] < 0 || end[r] < start[r] || end[r] > goff[ch + 1] - goff[ch]) {
+                set_error("region %zu: [%lld, %lld) is outside chromosome %d of length %lld", r, (long long) start[r], (long long) end[r],
+                          chrom[r], (long long) (goff[ch + 1] - goff[ch]));
+                return MS_ERR_INVALID;
+            }
+            max_len = std::max(max_len, end[r] - start[r]);
+        }
+        std::iota(order.begin(), order.end(), (int64_t) 0);
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
+            if (start[a] != start[b]) return start[a] < start[b];
+            return a < b;
+        });
+        for (size_t j = 0; j < R; j++) {
+            const int64_t r = order[j];
+            const bool joins = !sp_chrom.empty() && sp_chrom.back() == chrom[r] && start[r] < sp_end.back();     // true overlap only
+            if (!joins) {
+                sp_chrom.push_back(chrom[r]);
+                sp_start.push_back(start[r]);
+                sp_end.push_back(end[r]);
+                span_first.push_back((int64_t) j);
+                span_maxlen.push_back(end[r] - start[r]);
+            } else {
+                sp_end.back() = std::max(sp_end.back(), end[r]);
+                span_maxlen.back() = std::max(span_maxlen.back(), end[r] - start[r]);
+            }
+            rel_start[j] = start[r] - sp_start.back();
+            rel_end[j] = end[r] - sp_start.back();
+        }
+        span_first.push_back((int64_t) R);
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    const size_t S = sp_chrom.size();
+
+    // ---- device: cut the spans, scan them as a sequence set -------------------------------------------------------------
+    ms_seqset *spans = nullptr;
+    int rc = ms_seqset_from_genome(g, sp_chrom.data(), sp_start.data(), sp_end.data(), (int64_t) S, &spans);
+    if (rc) return rc;
+    DeviceCtx *c;
+    if ((rc = get_ctx(spans->device, &c))) { ms_seqset_free(spans); return rc; }
+    std::lock_guard<std::mutex> lk_dev(c->mu);
+    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    ms_result *r1 = nullptr;
+    rc = scan_locked(c, pwms, spans, strand_mask, flags, &r1);
+    const int64_t union_bases = spans->n_bases;
+    ms_seqset_free(spans);
+    if (rc) return rc;
+    auto fail = [&](int code) { ms_result_free(r1); return code; };
+    if ((rc = pwmset_upload(pwms, c->device, c->stream))) return fail(rc);
+    const size_t n1 = (size_t) r1->n_hits;
+
+    int rbits = 1, pbits = 1, mbits = 1;
+    while ((1LL << rbits) < std::max<int64_t>(n_regions, 1)) rbits++;
+    while ((1LL << pbits) < std::max<int64_t>(max_len, 1)) pbits++;
+    while ((1 << mbits) < std::max(pwms->P, 1)) mbits++;
+    if (mbits + rbits + pbits + 1 > 64) { set_error("regions too many / too long for one call"); return fail(MS_ERR_INVALID); }
+
+    std::unique_ptr<ms_result> res(new (std::nothrow) ms_result());
+    if (!res) { set_error("out of host memory"); return fail(MS_ERR_NOMEM); }
+    res->device = r1->device;
+    res->P = pwms->P;
+    res->R = n_regions;
+    res->stats = r1->stats;
+    res->invalid = r1->invalid;
+    res->motif_offsets.assign((size_t) pwms->P + 1, 0);
+    ms_result *raw = res.release();
+    auto fail2 = [&](int code) { ms_result_free(raw); return fail(code); };
+
+    // index arrays + work buffers in one pooled block
+    void *iblk = nullptr, *wblk = nullptr, *d_tmp = nullptr;
+    size_t igot = 0, wgot = 0;
+    auto cleanup = [&]() { if (iblk) pool_free(c, iblk, igot); if (wblk) pool_free(c, wblk, wgot); if (d_tmp) (void) hipFree(d_tmp); };
+    auto up8 = [](size_t x) { return (x + 31) & ~(size_t) 31; };
+    const size_t n_idx = up8(S + 1) + 3 * up8(R) + up8(S);
+    if ((rc = pool_alloc(c, 8 * n_idx + 12 * up8(n1) + 256, &iblk, &igot))) { cleanup(); return fail2(rc); }
+    int64_t *d_span_first = static_cast<int64_t *>(iblk);
+    int64_t *d_rel_start = d_span_first + up8(S + 1), *d_rel_end = d_rel_start + up8(R), *d_orig = d_rel_end + up8(R);
+    int64_t *d_maxlen = d_orig + up8(R);
+    uint64_t *d_dst = reinterpret_cast<uint64_t *>(d_maxlen + up8(S));
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(d_dst + up8(n1));
+    hipError_t he = hipMemcpyAsync(d_span_first, span_first.data(), 8 * (S + 1), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess && R) he = hipMemcpyAsync(d_rel_start, rel_start.data(), 8 * R, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess && R) he = hipMemcpyAsync(d_rel_end, rel_end.data(), 8 * R, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess && R) he = hipMemcpyAsync(d_orig, order.data(), 8 * R, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess && S) he = hipMemcpyAsync(d_maxlen, span_maxlen.data(), 8 * S, hipMemcpyHostToDevice, c->stream);
+    if (he != hipSuccess) { cleanup(); set_error("index upload failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    RegionIndex X;
+    X.span_first = d_span_first; X.rel_start = d_rel_start; X.rel_end = d_rel_end; X.orig = d_orig; X.span_maxlen = d_maxlen;
+
+    (void) hipEventRecord(c->ev[0], c->stream);
+    uint64_t total = 0;
+    if (n1 > 0) {
+        hipLaunchKernelGGL(once_count_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (int64_t) n1, r1->d_motif_first,
+                           r1->P, pwms->d_width, r1->d_seq_idx, r1->d_pos, X, d_cnt);
+        size_t tmp_bytes = 0;
+        rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
+        if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
+        if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
+        uint32_t last_cnt = 0;
+        uint64_t last_dst = 0;
+        if (!rc) {
+            he = hipMemcpyAsync(&last_cnt, d_cnt + (n1 - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(&last_dst, d_dst + (n1 - 1), 8, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            if (he != hipSuccess) { set_error("hand-out count failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; }
+        }
+        if (rc) { cleanup(); return fail2(rc); }
+        total = last_dst + last_cnt;
+    }
+    raw->n_hits = (int64_t) total;
+    {
+        void *blk = nullptr;
+        size_t got = 0;
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, (size_t) total), &blk, &got))) { cleanup(); return fail2(rc); }
+        raw->block = blk;
+        raw->block_bytes = got;
+        result_carve(raw, blk, (size_t) total);
+        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
+        if (he != hipSuccess) { cleanup(); set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    }
+    if (total > 0) {
+        const size_t nt = up8((size_t) total);
+        size_t sort_bytes = 0;
+        if ((rc = sort_hit_pairs(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t) total, mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
+        if ((rc = pool_alloc(c, 24 * nt + sort_bytes + 256, &wblk, &wgot))) { cleanup(); return fail2(rc); }
+        uint64_t *d_keys = static_cast<uint64_t *>(wblk), *d_keys_sorted = d_keys + nt;
+        double *d_vals = reinterpret_cast<double *>(d_keys_sorted + nt);
+        void *d_sort_tmp = d_vals + nt;
+        hipLaunchKernelGGL(once_expand_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (int64_t) n1, r1->d_motif_first,
+                           r1->P, pwms->d_width, r1->d_seq_idx, r1->d_pos, r1->d_score, r1->d_strand, X, d_dst, rbits, pbits, d_keys, d_vals);
+        he = hipGetLastError();
+        if (he != hipSuccess) { cleanup(); set_error("hand-out kernel failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+        if ((rc = sort_hit_pairs(d_sort_tmp, &sort_bytes, d_keys, d_keys_sorted, d_vals, raw->d_score, (size_t) total,
+                                 mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
+        DevSeq none{};
+        if ((rc = launch_finalize(d_keys_sorted, (int64_t) total, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos,
+                                  raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) { cleanup(); return fail2(rc); }
+    } else {
+        DevSeq none{};
+        if ((rc = launch_finalize(nullptr, 0, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos, raw->d_strand,
+                                  raw->d_motif_first, raw->d_region_counts, c->stream))) { cleanup(); return fail2(rc); }
+    }
+    (void) hipEventRecord(c->ev[1], c->stream);
+    he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (he != hipSuccess) { set_error("hand-out failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+
+    float ms01 = 0;
+    (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
+    ms_scan_stats &stt = raw->stats;
+    stt.ms_finalize += ms01;                                     // the hand-out (count + prefix sum + expand + order + coordinates)
+    stt.ms_total += ms01;
+    stt.n_hits = (int64_t) total;
+    stt.n_bases = union_bases;                                   // bases scanned: the union, each once (sum over regions: below)
+    stt.n_windows = 0;                                           // the reference's unit count: every region scanned on its own
+    {
+        std::vector<int64_t> lens(R), suffix(R + 1, 0);
+        for (size_t r = 0; r < R; r++) lens[r] = end[r] - start[r];
+        std::sort(lens.begin(), lens.end());
+        for (size_t r = R; r-- > 0;) suffix[r] = suffix[r + 1] + lens[r];
+        for (int32_t p = 0; p < pwms->P; p++) {
+            const int64_t W = pwms->widths[p];
+            const size_t k = (size_t) (std::lower_bound(lens.begin(), lens.end(), W) - lens.begin());      // regions with L >= W
+            stt.n_windows += suffix[k] - (int64_t) (R - k) * (W - 1);
+        }
+    }
+    stt.hbm_bytes_algorithmic += 16 * ((int64_t) total - (int64_t) n1);
+    ms_result_free(r1);
+    *out = raw;
+    return MS_OK;
+}

@@ -89,6 +89,100 @@ def sweep_windows(genome_len, window, stride):
     return np.zeros(len(starts), dtype=np.int32), starts, starts + window
 
 
+# ---- BASELINE configs[3] in full: 1M input + 1M control regions x 500 bp, as 8 blocks of 125k regions per set -----------
+# Block b of set s is make_regions(125_000, 500, seed = 1000 * b + s + 1): exactly the shard rank b scanned in round 1
+# ("c4shard" with rank = b), so the full config is their concatenation and any rank count divides it.
+C4 = {"regions_per_set": 1_000_000, "length": 500, "n_pwms": 579, "n_sets": 2, "block_regions": 125_000}
+
+
+def _c4_block(args):
+    s, b = args
+    return make_regions(C4["block_regions"], C4["length"], seed=1000 * b + s + 1)[0]
+
+
+def _pool_map(fn, jobs, workers):
+    """Generate blocks in worker processes (plain numpy work; started before anything touches the GPU)."""
+    workers = max(1, min(workers, len(jobs)))
+    if workers == 1:
+        return [fn(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(fn, jobs, chunksize=1)
+
+
+def c4_shard(rank=0, world=1, workers=None, regions_per_set=None):
+    """Rank's contiguous share of the full configs[3] workload: dict like workload() with sets = [(bases, offsets)] of the
+    rank's regions [r0, r1) of each set, plus "shard" = (r0, r1).  Only the blocks the share overlaps are generated."""
+    R = int(regions_per_set or C4["regions_per_set"])
+    L, B = C4["length"], C4["block_regions"]
+    r0, r1 = R * rank // world, R * (rank + 1) // world
+    blocks = list(range(r0 // B, (r1 + B - 1) // B)) if r1 > r0 else []
+    jobs = [(s, b) for s in range(C4["n_sets"]) for b in blocks]
+    if workers is None:
+        workers = min(16, max(1, (os.cpu_count() or 1) // max(world, 1)))
+    made = dict(zip(jobs, _pool_map(_c4_block, jobs, workers)))
+    vals, widths, cutoffs = load_motif_set(C4["n_pwms"])
+    sets = []
+    for s in range(C4["n_sets"]):
+        parts = []
+        for b in blocks:
+            lo, hi = max(r0, b * B) - b * B, min(r1, (b + 1) * B) - b * B
+            parts.append(made[(s, b)][lo * L:hi * L])
+        bases = np.concatenate(parts) if len(parts) > 1 else (parts[0] if parts else np.zeros(0, np.uint8))
+        sets.append((bases, np.arange(r1 - r0 + 1, dtype=np.int64) * L))
+    return {"name": "c4", "pwm_values": vals, "widths": widths, "cutoffs": cutoffs, "sets": sets, "shard": (r0, r1),
+            "units": sum(int(o[-1]) for _, o in sets) * C4["n_pwms"], "units_total": C4["n_sets"] * R * L * C4["n_pwms"],
+            "n_regions": r1 - r0, "n_regions_total": R, "length": L, "n_pwms": C4["n_pwms"]}
+
+
+# ---- BASELINE configs[4] in full: a multi-chromosome genome on the host, swept as 200 bp windows stride 50 ---------------
+C5 = {"genome_bp": 3_000_000_000, "n_chroms": 24, "window": 200, "stride": 50, "n_pwms": 579, "block_bp": 62_500_000}
+
+
+def c5_chrom_lengths(genome_bp=None, n_chroms=None):
+    """Chromosome lengths of the synthetic genome: human-like spread (largest ~5x the smallest), summing to genome_bp."""
+    G = int(genome_bp or C5["genome_bp"])
+    n = int(n_chroms or C5["n_chroms"])
+    w = np.linspace(5.0, 1.0, n)
+    lens = np.floor(w / w.sum() * G).astype(np.int64)
+    lens[0] += G - int(lens.sum())
+    return lens
+
+
+def _c5_block(args):
+    ch, k, n = args
+    b = make_regions(1, n, seed=7000 + 131 * ch + k, frac_n=0.0)[0]
+    rng = np.random.default_rng(9000 + 131 * ch + k)
+    for _ in range(max(1, n // 2_000_000)):                         # assembly gaps: runs of N
+        st = int(rng.integers(0, max(1, n - 5000)))
+        b[st:st + int(rng.integers(50, 5000))] = ord("N")
+    return b
+
+
+def c5_genome(chroms, lens, workers=None, out=None):
+    """The listed chromosomes (indices into lens) as uint8 arrays, generated block-wise in worker processes.  `out`:
+    optional dict chrom -> preallocated uint8 array (e.g. pinned host memory) to fill instead of allocating."""
+    jobs = []
+    for ch in chroms:
+        L, B = int(lens[ch]), C5["block_bp"]
+        jobs += [(ch, k, min(B, L - k * B)) for k in range((L + B - 1) // B)]
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
+    made = _pool_map(_c5_block, jobs, workers)
+    res = {}
+    for ch in chroms:
+        parts = [m for (c, k, n), m in zip(jobs, made) if c == ch]
+        if out is not None:
+            o = 0
+            for m in parts:
+                out[ch][o:o + len(m)] = m
+                o += len(m)
+            res[ch] = out[ch]
+        else:
+            res[ch] = np.concatenate(parts) if len(parts) > 1 else (parts[0] if parts else np.zeros(0, np.uint8))
+    return res
+
+
 def workload(name, rank=0):
     """Returns dict(pwm_values, widths, cutoffs, sets=[(bases, offsets), ...], units) for a named
     workload; rank shifts the sequence seeds so every GPU scans different regions."""

@@ -1,0 +1,405 @@
+"""
+GPU tests on the BASELINE.json workloads themselves (configs[3] shard, configs[4] shard), on the batch-stream / host-streamed
+sweep API, and on the rows either side of the path fed from DEVICE output (N4 writers, make_motif_sites).  Run with -m gpu.
+Everything goes through the C-ABI; the oracle and the goldens are only the checker.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from motifscan_amd import _lib, cscore, dist, formats, scanner, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests need an MI355X (there is no CPU fallback)")
+    _lib.set_device(0)
+
+
+def assert_same_hits(got, want):
+    assert np.array_equal(got["motif_offsets"], want["motif_offsets"])
+    assert np.array_equal(got["seq_idx"], want["seq_idx"])
+    assert np.array_equal(got["pos"], want["pos"])
+    assert np.array_equal(np.asarray(got["strand"]).astype(np.int32), np.asarray(want["strand"]).astype(np.int32))
+    assert np.array_equal(got["score"], want["score"])          # bit-exact fp64
+
+
+def order_key_increasing(h, pos_bits, chunk=1 << 26):
+    """(motif, seq, pos, strand) strictly increasing = the reference's order (cscore.c:336-390), checked in chunks."""
+    n = len(h["pos"])
+    prev = None
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        key = (h["motif"][a:b].astype(np.int64) << 52) | (h["seq_idx"][a:b] << (pos_bits + 1)) | (h["pos"][a:b] << 1) | (h["strand"][a:b] == 2)
+        if prev is not None and not key[0] > prev:
+            return False
+        if not (np.diff(key) > 0).all():
+            return False
+        prev = key[-1]
+    return True
+
+
+def recount_regions(h, n_pwms):
+    """per motif: number of distinct sequences with a hit (stats.py:29-31) -- recomputed from the hit list itself."""
+    if len(h["pos"]) == 0:
+        return np.zeros(n_pwms, dtype=np.int64)
+    motif = h["motif"] if "motif" in h else np.repeat(np.arange(n_pwms), np.diff(h["motif_offsets"]))
+    new_pair = np.ones(len(h["pos"]), dtype=bool)
+    new_pair[1:] = (motif[1:] != motif[:-1]) | (h["seq_idx"][1:] != h["seq_idx"][:-1])
+    return np.bincount(motif[new_pair], minlength=n_pwms).astype(np.int64)
+
+
+# ------------------------------------------------------------- configs[3]: the 1M + 1M shard --
+
+def test_c4shard_workload_both_sets_and_count_vector(oracle):
+    """BASELINE configs[3] per-GPU shard (synth.workload("c4shard"): 125k input + 125k control regions x 500 bp x 579
+    PWMs): size-independent properties of each set, a 300-region sample of EACH set bit for bit against the oracle, and the
+    int64[2 * 579] vector that feeds the all-reduce recounted from the hits."""
+    wl = synth.workload("c4shard")
+    vals, widths, cutoffs, P = wl["pwm_values"], wl["widths"], wl["cutoffs"], wl["n_pwms"]
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    mr = pw.max_raw()
+    count_vector = []
+    for s, (bases, offsets) in enumerate(wl["sets"]):
+        sq = _lib.SeqSet(bases, offsets)
+        res = _lib.scan(pw, sq, 3)
+        h = res.hits()
+        st = res.stats()
+        n = len(h["pos"])
+        assert n == st["n_hits"] > 5_000_000 and st["n_pwms_exact"] == 0 and st["n_passes"] == 1
+        assert st["n_windows"] == int(sum(500 - int(w) + 1 for w in widths)) * 125_000
+        assert order_key_increasing(h, 10)
+        assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= 500).all() and (h["seq_idx"] < 125_000).all()
+        assert (h["score"] - cutoffs[h["motif"]] >= -1e-10).all() and (h["score"] * mr[h["motif"]] <= mr[h["motif"]] + 1e-9).all()
+        counts = res.region_counts()
+        assert np.array_equal(counts, recount_regions(h, P))
+        count_vector.append(counts)
+        # idempotence
+        res2 = _lib.scan(pw, sq, 3)
+        h2 = res2.hits(packed=True)                      # ... through the compact copy-out
+        assert all(np.array_equal(h[k], h2[k]) for k in ("seq_idx", "pos", "score", "strand", "motif_offsets"))
+        res2.close()
+        # strand 3 = strand 1 U strand 2
+        h1, hr = _lib.scan(pw, sq, 1).hits(), _lib.scan(pw, sq, 2).hits()
+        f = h["strand"] == 1
+        assert np.array_equal(h["pos"][f], h1["pos"]) and np.array_equal(h["score"][f], h1["score"])
+        assert np.array_equal(h["pos"][~f], hr["pos"]) and np.array_equal(h["score"][~f], hr["score"])
+        # a 300-region sample from the middle of the set == the oracle, and == the same rows of the full scan
+        r0 = 61_000 + 17 * s
+        sub_b, sub_o = dist.take_shard(bases, offsets, r0, r0 + 300)
+        want = oracle.scan_arrays(vals, widths, cutoffs, sub_b.tobytes(), sub_o, 3, 8)
+        m = (h["seq_idx"] >= r0) & (h["seq_idx"] < r0 + 300)
+        assert m.sum() == len(want["pos"]) > 0
+        assert np.array_equal(h["seq_idx"][m] - r0, want["seq_idx"]) and np.array_equal(h["pos"][m], want["pos"])
+        assert np.array_equal(h["score"][m], want["score"]) and np.array_equal(h["strand"][m].astype(np.int32), want["strand"])
+        res.close(); sq.close()
+    vec = np.concatenate(count_vector)                  # what dist.allreduce_counts sums over the ranks
+    assert vec.shape == (2 * P,) and vec.dtype == np.int64 and (vec > 0).all() and (vec <= 125_000).all()
+    # the rank-level entry point gives the same vector (batched through a stream, merged)
+    out = dist.scan_sharded(vals, widths, cutoffs, wl["sets"], 0, 1, 3)
+    assert np.array_equal(out["counts"].ravel(), vec)
+
+
+# ------------------------------------------------------------- configs[4]: the sweep shard --
+
+def test_c5shard_sweep_all_579_motifs(oracle):
+    """BASELINE configs[4] per-GPU shard (375 Mbp as 200 bp windows, stride 50 = 7.5 M windows, 579 PWMs) through
+    ms_scan_sweep: properties of the 1.8e8-site result, the window counts recounted from the sites, and the last 400
+    windows bit for bit against the oracle."""
+    wl = synth.workload("c5shard")
+    vals, widths, cutoffs, P = wl["pwm_values"], wl["widths"], wl["cutoffs"], wl["n_pwms"]
+    genome = wl["genome"]
+    window, stride = synth.C5_SHARD["window"], synth.C5_SHARD["stride"]
+    n_win = wl["n_regions"]
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    rg = _lib.ResidentGenome({"chr": genome})
+    res = _lib.scan_sweep(pw, rg, "chr", 0, len(genome), window, stride, 3)
+    h = res.hits(copy=False)
+    n = len(h["pos"])
+    assert n == res.stats()["n_hits"] > 100_000_000
+    assert res.stats()["n_bases"] == (n_win - 1) * stride + window       # every base scanned once
+    assert order_key_increasing(h, 8)
+    assert (h["seq_idx"] >= 0).all() and (h["seq_idx"] < n_win).all()
+    assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= window).all()
+    assert np.array_equal(res.region_counts(), recount_regions(h, P))
+    # every site appears in each of the windows that hold it whole: the same site seen from window k and k+1
+    # (genome position = 50 k + pos) -- spot-check on one motif that the multiset of genome positions has the right multiplicity
+    mo = h["motif_offsets"]
+    p = int(np.argmax(widths == 8))
+    a, b = int(mo[p]), int(mo[p + 1])
+    gpos = h["seq_idx"][a:b] * stride + h["pos"][a:b]
+    interior = (gpos >= window) & (gpos + 8 <= len(genome) - window)
+    uniq, mult = np.unique(gpos[interior] * 2 + (h["strand"][a:b][interior] == 2), return_counts=True)
+    # a width-8 site at genome position g lies in floor(g / 50) - ceil((g + 8 - 200) / 50) + 1 windows (3 or 4)
+    g = uniq >> 1
+    expect = g // stride - -((g + 8 - window) // -stride) + 1
+    assert np.array_equal(mult, expect)
+    n_tail = 400
+    r0 = n_win - n_tail
+    st = np.arange(r0, n_win, dtype=np.int64) * stride
+    tail_bases = np.concatenate([genome[x:x + window] for x in st])
+    tail_off = np.arange(n_tail + 1, dtype=np.int64) * window
+    want = oracle.scan_arrays(vals, widths, cutoffs, tail_bases.tobytes(), tail_off, 3, 8)
+    m = h["seq_idx"] >= r0
+    assert m.sum() == len(want["pos"]) > 0
+    assert np.array_equal(h["seq_idx"][m] - r0, want["seq_idx"]) and np.array_equal(h["pos"][m], want["pos"])
+    assert np.array_equal(h["score"][m], want["score"]) and np.array_equal(h["strand"][m].astype(np.int32), want["strand"])
+    del h
+    res.close(); rg.close()
+
+
+# ------------------------------------------------------------------------- batch streams --
+
+@pytest.mark.parametrize("flags,packed", [(0, False), (0, True), (_lib.MS_STREAM_DEDUP, False), (_lib.MS_STREAM_EXACT_ONLY, True)])
+def test_stream_batches_equal_single_call_and_oracle(oracle, flags, packed):
+    """Batched through ms_stream (upload + pack | scan | copy-out overlapped) == one ms_scan call == the oracle; ragged
+    regions with N runs, uneven batch sizes incl. an empty batch, more batches than the stream's capacity."""
+    vals, widths, cutoffs = synth.load_motif_set(96)
+    bases, offsets = synth.make_regions(5000, 400, seed=21, frac_n=0.05, ragged=True)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    single = _lib.scan(pw, _lib.SeqSet(bases, offsets), 3, _lib.MS_SCAN_EXACT_ONLY if flags & _lib.MS_STREAM_EXACT_ONLY else 0)
+    if flags & _lib.MS_STREAM_DEDUP:
+        single.dedup(pw)
+    want = single.hits()
+    cuts = [0, 1, 400, 400, 900, 1700, 1701, 2500, 2600, 3000, 3100, 3600, 3700, 4100, 4200, 4800, 4990, 5000]
+    bounds = list(zip(cuts[:-1], cuts[1:]))
+    assert len(bounds) > _lib.Stream(pw).capacity
+    parts, counts = [], np.zeros(len(widths), dtype=np.int64)
+    gen = _lib.scan_stream(pw, (dist.take_shard(bases, offsets, a, b) for a, b in bounds), 3, flags, depth=2, packed=packed)
+    for (a, b), res in zip(bounds, gen):
+        parts.append((res.hits(packed=packed), a))
+        counts += res.region_counts()
+        res.close()
+    got = _lib.merge_hits(parts, len(widths))
+    assert_same_hits(got, want)
+    assert np.array_equal(counts, single.region_counts())
+    if not flags & _lib.MS_STREAM_DEDUP:
+        assert_same_hits(got, oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8))
+
+
+def test_stream_counts_only_errors_and_pinned_input(oracle):
+    vals, widths, cutoffs = synth.load_motif_set(40)
+    bases, offsets = synth.make_regions(3000, 300, seed=22)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    want = _lib.scan(pw, _lib.SeqSet(bases, offsets), 3)
+    pin = _lib.PinnedBuffer(bases.size)                        # page-locked input: the upload overlaps the previous scan
+    pin.array[:] = bases
+    st = _lib.Stream(pw, 3, _lib.MS_STREAM_NO_HITS, depth=1)
+    for a, b in ((0, 1500), (1500, 3000)):
+        lo, hi = int(offsets[a]), int(offsets[b])
+        st.submit(pin.array[lo:hi], offsets[a:b + 1] - lo)
+    c = np.zeros(len(widths), dtype=np.int64)
+    n = 0
+    while st.in_flight:
+        r = st.next()
+        c += r.region_counts()
+        n += r.n_hits
+        r.close()
+    assert st.next() is None
+    assert np.array_equal(c, want.region_counts()) and n == want.n_hits
+    # a bad batch fails at next(), in order, with the library's message; the stream stays usable
+    st.submit(bases[:600], np.array([0, 300, 600], dtype=np.int64))
+    with pytest.raises(ValueError):
+        st.submit(bases[:10], np.array([0, 20], dtype=np.int64))           # offsets past the buffer: refused at submit
+    bad = np.array([0, 400, 300, 600], dtype=np.int64)                      # not monotone: refused by the uploader
+    _lib.check(_lib.lib().ms_stream_submit(st.h, bases.ctypes.data, _lib.ptr(bad, _lib.ctypes.c_int64), 3))
+    st._keep.append(bases)
+    ok = st.next()
+    assert ok.n_hits >= 0
+    ok.close()
+    with pytest.raises(ValueError, match="non-decreasing"):
+        st.next()
+    st.close(); pin.close()
+    with pytest.raises(ValueError):
+        _lib.Stream(pw, 3, 0, depth=0)
+
+
+def test_owned_views_keep_the_result_alive():
+    """views of the library's pinned buffers must not dangle when the caller drops the result object."""
+    import gc
+    vals, widths, cutoffs = synth.load_motif_set(30)
+    bases, offsets = synth.make_regions(2000, 300, seed=23)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    sq = _lib.SeqSet(bases, offsets)
+    h = _lib.scan(pw, sq, 3).hits(copy=False)              # the ScanResult itself is dropped right here
+    keep = h["score"][10:200]                              # a slice of a view
+    snap = keep.copy()
+    del h
+    gc.collect()
+    for _ in range(4):                                      # scans that would reuse a freed pinned block
+        _lib.scan(pw, sq, 1).hits(copy=False)
+        gc.collect()
+    assert np.array_equal(keep, snap)
+
+
+# --------------------------------------------------------- host-streamed multi-chromosome sweep --
+
+@pytest.mark.parametrize("window,stride,max_span", [(200, 50, 3000), (64, 64, 1000), (30, 7, 500)])
+def test_host_streamed_multi_chromosome_sweep_equals_oracle(oracle, jaspar579, window, stride, max_span):
+    """BASELINE configs[4] proper: a genome of several chromosomes on the HOST, swept in spans of bounded size through an
+    ms_stream (spans overlap by window - stride, window indices global over spans and chromosomes, scanner.py:71-87
+    per window) == the oracle over the same windows as separate regions == the resident-genome sweep per chromosome."""
+    rng = np.random.default_rng(31)
+    sel = rng.choice(579, size=120, replace=False)
+    mats = synth.matrices_of(jaspar579["pwm_values"], jaspar579["widths"])
+    vals = np.concatenate([mats[i].ravel() for i in sel])
+    widths = jaspar579["widths"][sel]
+    cutoffs = jaspar579["cutoffs"]["1e-3"][sel]
+    lens = [7000, 150, 9000, window - 1, 4100, window]
+    chroms = []
+    for i, L in enumerate(lens):
+        b, _ = synth.make_regions(1, L, seed=40 + i, frac_n=0.0)
+        if L > 600:
+            b[300:340] = ord("N")
+            b[L - 90:L - 60] = ord("n")
+        chroms.append(b)
+    spans = _lib.sweep_spans(lens, window, stride, max_span)
+    assert len(spans) >= 8 and len({s[0] for s in spans}) >= 3
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    parts, counts = [], np.zeros(len(widths), dtype=np.int64)
+    for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, spans=spans):
+        assert sp[2] - sp[1] <= max_span and (sp[4] - 1) * stride + window == sp[2] - sp[1]
+        parts.append((res.hits(), sp[3]))
+        counts += res.region_counts()
+        res.close()
+    got = _lib.merge_hits(parts, len(widths))
+    # the oracle over every window as a region of its own
+    win_bases, n_win = [], 0
+    for b in chroms:
+        for k in range((len(b) - window) // stride + 1 if len(b) >= window else 0):
+            win_bases.append(b[k * stride:k * stride + window])
+            n_win += 1
+    assert n_win == sum(s[4] for s in spans) == spans[-1][3] + spans[-1][4]
+    want = oracle.scan_arrays(vals, widths, cutoffs, np.concatenate(win_bases).tobytes(),
+                              np.arange(n_win + 1, dtype=np.int64) * window, 3, 8)
+    assert len(want["pos"]) > 1000
+    assert_same_hits(got, want)
+    assert np.array_equal(counts, recount_regions(want, len(widths)))
+    # the same through the resident genome, chromosome by chromosome
+    rg = _lib.ResidentGenome({f"c{i}": b for i, b in enumerate(chroms)})
+    parts2, first = [], 0
+    for i, b in enumerate(chroms):
+        r = _lib.scan_sweep(pw, rg, f"c{i}", 0, len(b), window, stride, 3)
+        parts2.append((r.hits(), first))
+        first += (len(b) - window) // stride + 1 if len(b) >= window else 0
+    assert_same_hits(_lib.merge_hits(parts2, len(widths)), want)
+    # a rank's share of the spans: contiguous, complete, disjoint
+    shares = [dist.span_shard(spans, r, 3) for r in range(3)]
+    assert sum(shares, []) == spans and all(shares)
+
+
+def test_sweep_hands_out_more_than_2_to_the_32_sites_arithmetic():
+    """The hand-out's prefix sums are 64-bit: exercised at a size the box can hold (a dense-hit sweep whose site count
+    needs > 32 bits cannot be checked here), so check the widened path by a sweep with window / stride = 64."""
+    vals, widths, _ = synth.load_motif_set(12)
+    cut2 = np.load(os.path.join(synth._GOLDEN, "synth_jaspar579.npz"))["cutoffs"][:12, 0]      # p = 1e-2: dense hits
+    genome, _ = synth.make_regions(1, 3_000_000, seed=33, frac_n=0.0)
+    pw = _lib.PwmSet(vals, widths, cut2)
+    rg = _lib.ResidentGenome({"chr": genome})
+    res = _lib.scan_sweep(pw, rg, "chr", 0, len(genome), 256, 4, 3)
+    span = _lib.scan(pw, rg.extract([0], [0], [len(genome)]), 3)
+    hs = span.hits()
+    lo = np.maximum(0, -((hs["pos"] + widths[hs["motif"]] - 256) // -4))
+    hi = np.minimum(hs["pos"] // 4, (len(genome) - 256) // 4)
+    assert res.n_hits == int(np.maximum(hi - lo + 1, 0).sum()) > 20_000_000
+
+
+# ----------------------------------------------------- rows either side, fed from the device --
+
+def test_n4_writers_from_device_tables_byte_identical(small, tmp_path):
+    """N4 on the GPU box: Scanner.scan_motifs_arrays(with_tables=True) -> write_sites_table / _bed / _enrich_table ==
+    what the reference's io module wrote (io/__init__.py:12-71), byte for byte."""
+    d = small["N4"]
+    for rel, text in d["files"].items():
+        path = tmp_path / rel
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(text)
+    w = d["writers"]
+    chroms = small["G2"]["chroms"]
+    pwms = formats.read_motifscan_pwms(tmp_path / "test/test_pwms.motifscan")
+
+    class Reg:
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end, self.summit = c, s, e, (s + e) // 2
+
+    def scan(rows, resident):
+        regs = [Reg(*r) for r in rows]
+        genome = _lib.ResidentGenome(chroms, keep_host=True) if resident else type("G", (), {
+            "chrom_sizes": {k: len(v) for k, v in chroms.items()},
+            "fetch_sequence": staticmethod(lambda c, s, e: chroms[c][s:e])})
+        sc = scanner.Scanner(genome, regs, window_size=0, strand="both", p_value=w["p_value"], remove_dup=True)
+        return regs, sc.scan_motifs_arrays(pwms, with_tables=True)
+
+    for resident in (False, True):
+        regs, a = scan(w["regions"], resident)
+        out = tmp_path / f"out{int(resident)}"
+        formats.write_sites_table(out, pwms, regs, a["n_sites"], a["max_score"])
+        hits = {"motif": a["motif"], "region": a["region"], "start": a["start"], "score": a["score"], "strand": a["strand"],
+                "motif_offsets": a["motif_offsets"]}
+        formats.write_sites_bed(out, pwms, regs, hits)
+        assert (out / "motif_sites_number.xls").read_text() == w["motif_sites_number.xls"]
+        assert (out / "motif_sites_score.xls").read_text() == w["motif_sites_score.xls"]
+        assert {f: (out / "motif_sites" / f).read_text() for f in os.listdir(out / "motif_sites")} == w["bed"]
+        cregs, ca = scan(w["control_regions"], resident)
+        rows = dist.enrichment(a["n_regions_with_site"], ca["n_regions_with_site"], len(regs), len(cregs))
+        formats.write_enrich_table(out, [p.matrix_id + "," + p.name for p in pwms], rows)
+        assert (out / "motif_enrichment.xls").read_text() == w["motif_enrichment.xls"]
+        assert np.array_equal(a["n_regions_with_site"], (a["n_sites"] > 0).sum(axis=1))
+
+
+def test_make_motif_sites_on_device_c_scan_motif_output(small):
+    """a9: scanner.make_motif_sites (scanner.py:135-153) applied to cscore.c_scan_motif's pooled hits == the reference
+    Scanner's nested lists on the toy genome (G2), with and without de-duplication (scanner.py:171-193)."""
+    g = small["G2"]
+    seq = g["chroms"]["chr1"][1:5]                                     # chr1:2-5, window 4 -> 'aTtC' (tests/test_scanner.py:29-54)
+    m = [[[1, 0], [0, 1], [0, 0], [1, 0]]]
+    for cutoff, n_raw in ((1.0, 1), (0.5, 5)):
+        sites = cscore.c_scan_motif(m, [cutoff], [seq], 3, 1)
+        assert len(sites[0]) == n_raw
+        ms = scanner.make_motif_sites(sites, [1])
+        assert [len(x) for x in ms[0]] == [n_raw]
+        assert all(isinstance(s, scanner.MotifSite) and s.strand in "+-" for s in ms[0][0])
+        assert [s.start for s in ms[0][0]] == [1 + hit[1] for hit in sites[0]]
+        dd = scanner.deduplicate_motif_sites(ms, [2])
+        if cutoff == 1.0:
+            assert [tuple(s) for s in dd[0][0]] == [(3, 1.0, "+")]
+        else:
+            assert [tuple(s) for s in dd[0][0]] == [(1, .5, "+"), (1, .5, "-"), (3, 1.0, "+")]
+    # the same through the Scanner's own nested-list path on a multi-region list
+    rows = [["chr1", 0, 10], ["chr2", 0, 17], ["chrX", 0, 16]]
+    seqs = [g["chroms"][c][s:e] for c, s, e in rows]
+    pw = small["N4"]["pwms"]
+    mats = [p["matrix"] for p in pw]
+    cuts = [p["cutoffs"]["1e-2"] for p in pw]
+    pooled = cscore.c_scan_motif(mats, cuts, seqs, 3, 1)
+    nested = scanner.make_motif_sites(pooled, [r[1] for r in rows])
+    flat = [(mi, ri, s.start, s.score, s.strand) for mi, per in enumerate(nested) for ri, ss in enumerate(per) for s in ss]
+    assert flat == [(mi, h[0], rows[h[0]][1] + h[1], h[2], "+" if h[3] == 1 else "-") for mi, per in enumerate(pooled) for h in per]
+    assert len(flat) >= 2
+
+
+# ------------------------------------------------------------------- N > 1 code path --
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` starts its own two ranks (fresh processes, before anything touches the GPU) and reports
+    n_gpus = 2.  RCCL refuses two ranks on one device, so on this 1-GPU box the ranks talk over gloo (MS_BENCH_BACKEND, a test
+    aid); everything else -- sharding of the full workload, per-rank scans through the library, the all-reduce of the
+    device-resident count vector, max-over-ranks timing -- is the N > 1 path the driver runs over RCCL."""
+    env = dict(os.environ, MS_BENCH_BACKEND="gloo", MS_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "tiny", "--no-cpu-baseline", "--min-warm-seconds", "0"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["counts_check"]["allreduce_equals_sum_of_rank_counts"] is True

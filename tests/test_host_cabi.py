@@ -426,3 +426,58 @@ def test_scanner_ctor_semantics_without_gpu(small):
 
     with pytest.raises(ValueError):                           # missing cutoff: before any device work
         scanner.Scanner(G, [R], window_size=4, p_value="1e-2").scan_motifs([P])
+
+
+def test_sweep_span_planning_is_pure_host_arithmetic():
+    """ms_sweep_spans (no GPU needed): every window of every chromosome lies in exactly one span, spans respect the
+    size bound, start on a window start, overlap their neighbour by window - stride, and number the windows globally."""
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        window, stride = int(rng.integers(1, 300)), int(rng.integers(1, 120))
+        lens = rng.integers(0, 20_000, size=int(rng.integers(1, 9))).tolist() + [window, max(window - 1, 0)]
+        max_span = int(window + rng.integers(0, 6000))
+        spans = _lib.sweep_spans(lens, window, stride, max_span)
+        expect_first = 0
+        by_chrom = {}
+        for ch, b, e, first, n in spans:
+            assert e - b <= max_span and b % stride == 0 and n >= 1 and (n - 1) * stride + window == e - b and e <= lens[ch]
+            by_chrom.setdefault(ch, []).append((b, e, first, n))
+            assert first == expect_first
+            expect_first += n
+        total = 0
+        for ch, L in enumerate(lens):
+            n_w = (L - window) // stride + 1 if L >= window else 0
+            total += n_w
+            got = by_chrom.get(ch, [])
+            assert sum(x[3] for x in got) == n_w
+            for (b0, e0, f0, n0), (b1, e1, f1, n1) in zip(got, got[1:]):
+                assert b1 == b0 + n0 * stride and e0 - b1 == window - stride        # next span starts one stride after the last window
+        assert expect_first == total
+    with pytest.raises(ValueError):
+        _lib.sweep_spans([100], 50, 10, 49)                     # a span must hold at least one window
+    with pytest.raises(ValueError):
+        _lib.sweep_spans([100], 0, 10, 100)
+
+
+def test_streams_and_pinned_memory_fail_loudly_without_a_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    pw = _lib.PwmSet.from_matrices([np.zeros((4, 3))], cutoffs=[0.5])
+    with pytest.raises(RuntimeError):
+        _lib.Stream(pw)
+    with pytest.raises(RuntimeError):
+        _lib.PinnedBuffer(1024)
+
+
+def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
+    """MS_PF_* variables alone must not change what the library does (host-visible part: the plan)."""
+    vals, widths, cutoffs = (np.load(os.path.join(ROOT, "tests", "golden", "synth_jaspar579.npz"))[k] for k in ("pwm_values", "widths", "cutoffs"))
+    n = 40
+    pw = _lib.PwmSet(vals[:4 * int(widths[:n].sum())], widths[:n], cutoffs[:n, 2])
+    monkeypatch.delenv("MS_MEASURE", raising=False)
+    monkeypatch.setenv("MS_PF_ENGINE", "0")
+    base = pw.plan_mfma(3)                                       # engine 0 requested without the opt-in: still the matrix-core plan
+    assert base["group_kb"].size > 0
+    monkeypatch.setenv("MS_MEASURE", "1")
+    with pytest.raises(ValueError):
+        pw.plan_mfma(3)                                          # now engine 0 is really selected: no matrix-core plan to show
