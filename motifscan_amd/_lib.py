@@ -106,6 +106,7 @@ def lib():
         "ms_seqset_from_genome": (c_int, [vp, pi32, pi64, pi64, c_i64, pvp]),
         "ms_scan": (c_int, [vp, vp, c_int, c_u32, pvp]),
         "ms_scan_sweep": (c_int, [vp, vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_int, c_u32, pvp]),
+        "ms_scan_regions_once": (c_int, [vp, vp, pi32, pi64, pi64, c_i64, c_int, c_u32, pvp]),
         "ms_result_num_hits": (c_int, [vp, pi64]),
         "ms_result_motif_offsets": (c_int, [vp, pi64]),
         "ms_result_hits": (c_int, [vp, pi64, pi64, pd, pi8]),
@@ -647,6 +648,36 @@ def sweep_spans(chrom_lens, window, stride, max_span_bases):
     check(lib().ms_sweep_spans(ptr(lens, ctypes.c_int64), len(lens), int(window), int(stride), int(max_span_bases), arr, n.value,
                                ctypes.byref(n)))
     return [(a.chrom, a.begin, a.end, a.first_window, a.n_windows) for a in arr[:n.value]]
+
+
+def scan_regions_once(pwms, genome, chrom_idx, starts, ends, strand_mask=3, flags=MS_SCAN_DEFAULT):
+    """ms_scan_regions_once: the regions (chromosome indices, 0-based half-open, clipped; any order, any overlap) of a
+    ResidentGenome, with the result of extract() + scan() over them but every base of their union scored once."""
+    ci = np.ascontiguousarray(chrom_idx, dtype=np.int32)
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    en = np.ascontiguousarray(ends, dtype=np.int64)
+    if not (len(ci) == len(st) == len(en)):
+        raise ValueError("chrom / start / end must have the same length")
+    h = ctypes.c_void_p()
+    check(lib().ms_scan_regions_once(pwms.h, genome.h, ptr(ci, ctypes.c_int32), ptr(st, ctypes.c_int64), ptr(en, ctypes.c_int64),
+                                     len(ci), int(strand_mask), int(flags), ctypes.byref(h)))
+    return ScanResult(h, pwms.n)
+
+
+def union_bases(chrom_idx, starts, ends):
+    """Bases covered by at least one region (the regions' union), by chromosome-wise interval merging."""
+    ci = np.asarray(chrom_idx, dtype=np.int64)
+    st = np.asarray(starts, dtype=np.int64)
+    en = np.asarray(ends, dtype=np.int64)
+    if len(ci) == 0:
+        return 0
+    o = np.lexsort((st, ci))
+    c, s, e = ci[o], st[o], en[o]
+    big = int(e.max()) + 1
+    reach = np.maximum.accumulate(e + c * big) - c * big          # furthest end seen so far on this chromosome
+    prev = np.concatenate([[0], reach[:-1]])
+    prev[np.concatenate([[True], c[1:] != c[:-1]])] = 0
+    return int(np.maximum(e - np.maximum(s, prev), 0).sum())
 
 
 def score(pwms, seqs, strand_mask=3):

@@ -67,8 +67,8 @@ int get_ctx(int device, DeviceCtx **out) {
     MS_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     MS_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (auto &ev : c->ev) MS_HIP(hipEventCreate(&ev));
-    MS_HIP(hipMalloc(&c->sc.counters, 4 * sizeof(unsigned long long)));
-    MS_HIP(hipHostMalloc(&c->sc.h_counters, 4 * sizeof(unsigned long long)));
+    MS_HIP(hipMalloc(&c->sc.counters, 8 * sizeof(unsigned long long)));
+    MS_HIP(hipHostMalloc(&c->sc.h_counters, 8 * sizeof(unsigned long long)));
     *out = c.get();
     g_ctx[device] = std::move(c);
     return MS_OK;
@@ -202,7 +202,7 @@ static void pwmset_free_device(ms_pwmset *p) {
     if (p->device >= 0 || p->plan_device >= 0) (void) hipSetDevice(p->device >= 0 ? p->device : p->plan_device);
     dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff); dev_free(p->d_raw_floor);
     dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
-    dev_free(p->d_exact_motifs);
+    dev_free(p->d_exact_motifs); dev_free(p->d_rt_off16); dev_free(p->d_rt_nk);
     p->device = -1;
     p->plan_device = -1;
     p->dev_cutoff_version = 0;
@@ -312,7 +312,7 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         if (p->plan_device >= 0) {
             (void) hipSetDevice(p->plan_device);
             dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
-            dev_free(p->d_exact_motifs);
+            dev_free(p->d_exact_motifs); dev_free(p->d_rt_off16); dev_free(p->d_rt_nk);
             p->plan_device = -1;
         }
     }
@@ -338,6 +338,19 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         if (!pl.exact_motifs.empty())
             MS_HIP(hipMemcpy(p->d_exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t),
                              hipMemcpyHostToDevice));
+        if (pl.engine >= 1) {                                   // row tiles of the matrix-core tables, for expand_kernel
+            const size_t n_rt = pl.group_G.size() / 2;
+            std::vector<uint32_t> off16(n_rt + 1, 0);
+            std::vector<int32_t> nk(n_rt + 1, 0);
+            for (size_t t = 0; t < n_rt; t++) {
+                nk[t] = pl.group_G[2 * t];
+                off16[t + 1] = off16[t] + (uint32_t) nk[t] * (kMfmaRowTileBytesPerKb / 16);
+            }
+            if ((rc = dev_alloc(&p->d_rt_off16, n_rt + 1))) return rc;
+            if ((rc = dev_alloc(&p->d_rt_nk, n_rt + 1))) return rc;
+            MS_HIP(hipMemcpy(p->d_rt_off16, off16.data(), off16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            MS_HIP(hipMemcpy(p->d_rt_nk, nk.data(), nk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
         p->plan_device = device;
     }
     return MS_OK;
@@ -845,6 +858,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     }
 
     Scratch &sc = c->sc;
+    // tail form: 1 (default) = re-score the candidates unordered -> sort (key, score) pairs -> unpack;
+    // 2 (A/B, MS_MEASURE=1 MS_TAIL=2) = expand -> key-only sort -> ordered fp64 re-scoring that writes the final arrays
+    // (ms_tail.hip): measured slower on the benchmark set (profiles/r02_tail_forms.log), kept as the comparison
+    int tail = 1;
+    if (const char *e = measure_env("MS_TAIL")) tail = atoi(e) == 2 ? 2 : 1;
     // expected density at the CLI default p = 1e-4 is ~1.5e-4 candidates per window and strand; 4x head room
     size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
     size_t want_hits = want_cand;
@@ -862,12 +880,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
-    // measurement switches (not part of the interface): kernel variant, drop candidates
-    int pf_variant = plan.engine == 2 ? 24 : plan.engine == 1 ? 16 : 4, pf_no_emit = 0;
+    // kernel variant: engine 1 queues records without flags for the second tail form (expand_kernel decodes them)
+    int pf_variant = plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_VARIANT")) {
         const int v = atoi(e) & 31;
-        const int v_engine = v >= 24 ? 2 : v >= 16 ? 1 : 0;
-        if (v_engine == plan.engine) pf_variant = v;                   // a variant of another engine cannot read this plan
+        const int v_engine = (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;
+        if (v_engine == plan.engine && !(v == 20 && tail != 2)) pf_variant = v;     // a variant of another engine cannot read this plan
     }
     if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
     const bool pf_clock = measure_env("MS_PF_CLOCK") && atoi(measure_env("MS_PF_CLOCK")) != 0;
@@ -880,13 +898,16 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         c->lds_set[pf_variant + (pf_meas ? 32 : 0)] = lds_bytes;
     }
 
+    // counters: [0] candidate records, [1] hits (tail 1) / entries (tail 2), [2] N-window positions, [3] hits written by the
+    // ordered re-scoring, [4] its tile dispenser (32-bit), [5] its error flag (32-bit)
     unsigned long long n_cand = 0, n_hits = 0;
     for (int pass = 1;; pass++) {
         if ((rc = scratch_reserve(sc, want_cand, want_hits, want_nlist))) return fail(rc);
         stt.n_passes = pass;
         HitOut H;
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
-        he = hipMemsetAsync(sc.counters, 0, 4 * sizeof(unsigned long long), c->stream);
+        H.entries = tail == 2 ? 1 : 0;
+        he = hipMemsetAsync(sc.counters, 0, 8 * sizeof(unsigned long long), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         (void) hipEventRecord(c->ev[0], c->stream);
         if (!plan.tiles.empty()) {
@@ -907,14 +928,23 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         }
         (void) hipEventRecord(c->ev[1], c->stream);
         if (!plan.fast_motifs.empty()) {
-            // two independent latency-bound jobs, both appending hits: run them side by side
+            // two independent latency-bound jobs, both appending to the same list: run them side by side
             // (forked AFTER the pre-filter, whose blocks need whole CUs to themselves)
             (void) hipEventRecord(c->ev_fork, c->stream);
             (void) hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
             if ((rc = launch_nwindow(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), fast_max_w, strand_mask,
                                      sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->stream2))) return fail(rc);
             (void) hipEventRecord(c->ev_join, c->stream2);
-            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+            if (tail == 2) {
+                ExpandArgs E;
+                E.cand = sc.cand; E.n_cand = sc.counters; E.cand_cap = sc.cand_cap;
+                E.tables = pwms->d_tables; E.rt_off16 = pwms->d_rt_off16; E.rt_nk = pwms->d_rt_nk;
+                E.group_motifs = pwms->d_group_motifs; E.width = pwms->d_width; E.S = S;
+                E.entries = sc.keys; E.n_entries = sc.counters + 1; E.entry_cap = sc.hit_cap; E.cbits = gbits; E.pbits = pbits;
+                if ((rc = launch_expand(E, c->n_cu * 8, c->stream))) return fail(rc);
+            } else {
+                if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+            }
             (void) hipStreamWaitEvent(c->stream, c->ev_join, 0);
         }
         if (!plan.exact_motifs.empty())
@@ -924,7 +954,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         n_cand = sc.h_counters[0];
-        n_hits = sc.h_counters[1];
+        n_hits = sc.h_counters[1];                                 // tail 2: entries
         const unsigned long long n_nlist = sc.h_counters[2];
         if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap && n_nlist <= sc.nlist_cap) break;
         if (pass >= 5) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
@@ -937,7 +967,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (n_nlist > sc.nlist_cap) want_hits = std::max<size_t>(want_hits, 2 * sc.hit_cap);   // its hits were not all counted
     }
     stt.n_candidates = (int64_t) n_cand;
-    stt.n_hits = (int64_t) n_hits;
     if (d_clk) {                                             // median over blocks of cycles per 10 ns tick
         std::vector<unsigned long long> h((size_t) 2 * clk_blocks);
         if (hipMemcpy(h.data(), d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -948,15 +977,18 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         }
         dev_free(d_clk);
     }
-    raw->n_hits = (int64_t) n_hits;
 
-    {   // one pooled block for everything the result owns
+    // one pooled block for everything the result owns.  Tail 2 learns the number of hits only at the very end: the block
+    // is sized by the bound "every entry hits on every scanned strand"
+    const unsigned long long n_entries = n_hits;
+    const size_t res_cap = tail == 2 ? (size_t) n_entries * (strand_mask == 3 ? 2 : 1) : (size_t) n_hits;
+    {
         void *blk = nullptr;
         size_t got = 0;
-        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, (size_t) n_hits), &blk, &got))) return fail(rc);
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, res_cap), &blk, &got))) return fail(rc);
         raw->block = blk;
         raw->block_bytes = got;
-        result_carve(raw, blk, (size_t) n_hits);
+        result_carve(raw, blk, res_cap);
         const size_t P1 = (size_t) pwms->P + 1;
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
@@ -966,9 +998,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
 
     (void) hipEventRecord(c->ev[3], c->stream);
     if (n_hits > 0) {
+        const int end_bit = tail == 2 ? gbits + mbits : gbits + 1 + mbits;
         size_t need = 0;
-        if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits,
-                                 gbits + 1 + mbits, c->stream))) return fail2(rc);
+        if (tail == 2) rc = sort_keys(nullptr, &need, sc.keys, sc.keys_sorted, (size_t) n_hits, end_bit, c->stream);
+        else rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream);
+        if (rc) return fail2(rc);
         if (need > sc.sort_tmp_bytes) {
             if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
             sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
@@ -977,17 +1011,53 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             sc.sort_tmp_bytes = need;
         }
         size_t have = sc.sort_tmp_bytes;
-        if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits,
-                                 gbits + 1 + mbits, c->stream))) return fail2(rc);
+        if (tail == 2) rc = sort_keys(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, (size_t) n_hits, end_bit, c->stream);
+        else rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream);
+        if (rc) return fail2(rc);
     }
     (void) hipEventRecord(c->ev[4], c->stream);
-    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
-                              raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
+    if (tail == 2) {
+        if (n_entries == 0) {
+            he = hipMemsetAsync(d_motif_first, 0, 8 * ((size_t) pwms->P + 1), c->stream);       // no hits: every per-motif offset is 0
+            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+        } else {
+            const size_t n_tiles_r = ordered_tiles(n_entries);
+            if (n_tiles_r > sc.tile_cap) {
+                dev_free(sc.tile_state);
+                sc.tile_cap = 0;
+                if ((rc = dev_alloc(&sc.tile_state, n_tiles_r + n_tiles_r / 4 + 64))) return fail2(rc);
+                sc.tile_cap = n_tiles_r + n_tiles_r / 4 + 64;
+            }
+            he = hipMemsetAsync(sc.tile_state, 0, n_tiles_r * sizeof(unsigned long long), c->stream);
+            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+            OrderedArgs O;
+            O.S = S; O.Pw = Pw; O.keys = sc.keys_sorted; O.n = n_entries; O.cbits = gbits; O.pbits = pbits; O.strand_mask = strand_mask;
+            O.P = pwms->P; O.tile_state = sc.tile_state;
+            O.tile_counter = reinterpret_cast<unsigned int *>(sc.counters + 4);
+            O.error = reinterpret_cast<unsigned int *>(sc.counters + 5);
+            O.seq_idx = raw->d_seq_idx; O.pos = raw->d_pos; O.score = raw->d_score; O.strand = raw->d_strand;
+            O.motif_first = d_motif_first; O.n_hits = sc.counters + 3; O.cap = res_cap;
+            if ((rc = launch_rescore_ordered(O, c->stream))) return fail2(rc);
+            if ((rc = launch_pair_counts(sc.counters + 3, res_cap, d_motif_first, pwms->P, raw->d_seq_idx, raw->d_region_counts,
+                                         c->n_cu * 8, c->stream))) return fail2(rc);
+        }
+    } else {
+        if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
+                                  raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
+    }
     (void) hipEventRecord(c->ev[5], c->stream);
-    // finalize leaves the complete per-motif offsets on the device; one copy brings them to the host
+    // the complete per-motif offsets (and, tail 2, the number of hits) are on the device; one copy brings them to the host
     he = hipMemcpyAsync(raw->motif_offsets.data(), d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess && tail == 2) he = hipMemcpyAsync(sc.h_counters, sc.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+    if (tail == 2) {
+        n_hits = n_entries ? sc.h_counters[3] : 0;
+        if (reinterpret_cast<const unsigned int *>(sc.h_counters + 5)[0] != 0) { set_error("ordered re-scoring: a block waited too long for its predecessors"); return fail2(MS_ERR_RUNTIME); }
+        if (n_hits > res_cap) { set_error("ordered re-scoring produced more hits than its bound (%llu > %zu)", n_hits, res_cap); return fail2(MS_ERR_RUNTIME); }
+    }
+    stt.n_hits = (int64_t) n_hits;
+    raw->n_hits = (int64_t) n_hits;
 
     float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
     (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
@@ -1068,8 +1138,13 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
             DeviceCtx *c;
             int rc = get_ctx(r->device, &c);
             if (rc) return rc;
-            // seq_idx | pos | score | strand are consecutive in the device block (n_round elements apart)
-            MS_HIP(hipMemcpyAsync(r->h_pinned, r->d_seq_idx, 24 * n_round + n, hipMemcpyDeviceToHost, c->stream_down));
+            // the device block may have been carved for more hits than there are (the ordered re-scoring sizes it by a bound):
+            // four copies, packed n_round elements apart on the host
+            char *hb = static_cast<char *>(r->h_pinned);
+            MS_HIP(hipMemcpyAsync(hb, r->d_seq_idx, 8 * n, hipMemcpyDeviceToHost, c->stream_down));
+            MS_HIP(hipMemcpyAsync(hb + 8 * n_round, r->d_pos, 8 * n, hipMemcpyDeviceToHost, c->stream_down));
+            MS_HIP(hipMemcpyAsync(hb + 16 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, c->stream_down));
+            MS_HIP(hipMemcpyAsync(hb + 24 * n_round, r->d_strand, n, hipMemcpyDeviceToHost, c->stream_down));
             MS_HIP(hipStreamSynchronize(c->stream_down));
         }
         r->h_pinned_hits = r->n_hits;
@@ -1616,8 +1691,9 @@ int ms_debug_release_scratch(void) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     Scratch &sc = c->sc;
-    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.nlist);
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.nlist); dev_free(sc.tile_state);
     sc.nlist_cap = 0;
+    sc.tile_cap = 0;
     if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
     sc.sort_tmp = nullptr;
     sc.cand_cap = sc.hit_cap = sc.sort_tmp_bytes = 0;

@@ -19,7 +19,8 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
     int64_t *nlist = nullptr;     size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
-    unsigned long long *counters = nullptr;      // [0] candidates, [1] hits, [2] N-window positions
+    unsigned long long *tile_state = nullptr;  size_t tile_cap = 0;   // look-back states of the ordered re-scoring
+    unsigned long long *counters = nullptr;      // 8 words, see scan_locked
     unsigned long long *h_counters = nullptr;    // pinned
 };
 
@@ -111,6 +112,8 @@ struct ms_pwmset {
     int32_t *d_group_motifs = nullptr;
     int32_t *d_fast_motifs = nullptr;
     int32_t *d_exact_motifs = nullptr;
+    uint32_t *d_rt_off16 = nullptr;               // matrix-core plans: start of every row tile in d_tables (16-byte units) ...
+    int32_t *d_rt_nk = nullptr;                   // ... and its k-blocks (expand_kernel)
     std::mutex mu;
 };
 

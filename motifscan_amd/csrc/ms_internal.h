@@ -135,6 +135,9 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
 int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                    const double *vals_in, double *vals_out, size_t n, int end_bit, hipStream_t stream);
 
+// Keys-only sort of the candidate entries (motif | coordinate) over bits [0, end_bit).
+int sort_keys(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, size_t n, int end_bit, hipStream_t stream);
+
 // Descending sort of one row of fp64 scores (cutoff builder).  Query temp size with temp == nullptr.
 int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream);
 

@@ -38,6 +38,43 @@ struct HitOut {
     uint64_t cap;
     int gbits;                // bits of the coordinate field
     int pbits;                // > 0: bits of the position inside a region (see keys)
+    int entries;              // != 0: emit ENTRIES instead of hits -- motif << gbits | coordinate, once per window that passes on
+                              // either strand, no score (ms_tail.hip re-scores the entries in order); vals is unused
+};
+
+// ms_tail.hip
+struct ExpandArgs {
+    const uint64_t *cand;              // candidate records of the pre-filter
+    const unsigned long long *n_cand;
+    uint64_t cand_cap;
+    const uint4 *tables;               // int8 operand tables of the matrix-core pre-filter (global memory)
+    const uint32_t *rt_off16;          // [row tiles] start of the row tile in `tables`, 16-byte units
+    const int32_t *rt_nk;              // [row tiles] k-blocks
+    const int32_t *group_motifs;       // [table groups][kGroupSlots]
+    const int32_t *width;              // [P]
+    DevSeq S;
+    uint64_t *entries;                 // motif << cbits | coordinate
+    unsigned long long *n_entries;
+    uint64_t entry_cap;
+    int cbits, pbits;
+};
+
+struct OrderedArgs {
+    DevSeq S;
+    DevPwm Pw;
+    const uint64_t *keys;              // sorted entries
+    uint64_t n;
+    int cbits, pbits, strand_mask;
+    int32_t P;
+    unsigned long long *tile_state;    // [tiles], zeroed
+    unsigned int *tile_counter;        // zeroed
+    unsigned int *error;               // set if a look-back spin ran out (never expected)
+    int64_t *seq_idx, *pos;
+    double *score;
+    int8_t *strand;
+    int64_t *motif_first;              // [P+1] per-motif offsets, complete after the kernel
+    unsigned long long *n_hits;
+    uint64_t cap;
 };
 
 struct PfArgs {
@@ -87,6 +124,11 @@ int launch_site_tables(int64_t n, const int64_t *motif_off, int32_t P, int64_t R
                        const double *score, int32_t *n_sites, double *max_score, hipStream_t st);
 int launch_pack_hits(int64_t n, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord, unsigned int *bad,
                      hipStream_t st);
+int launch_expand(const ExpandArgs &A, int n_blocks, hipStream_t st);
+size_t ordered_tiles(uint64_t n_entries);
+int launch_rescore_ordered(const OrderedArgs &A, hipStream_t st);
+int launch_pair_counts(const unsigned long long *n_hits, uint64_t cap, const int64_t *motif_first, int32_t P, const int64_t *seq_idx,
+                       unsigned long long *region_counts, int n_blocks, hipStream_t st);
 int launch_gather_ranks(const double *sorted, int64_t n, const int64_t *ranks, int32_t n_ranks, double *out, hipStream_t st);
 
 }  // namespace ms

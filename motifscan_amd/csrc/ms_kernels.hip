@@ -25,110 +25,9 @@
 //   dedup / compact / site_tables kernels   scanner.py:156-193 and io/__init__.py:23-33 on the sorted hits
 //   extract_kernel    regions cut out of a genome that is resident as 2-bit codes (scanner.py:71-87)
 //   blk2reg_kernel    region of every 64th position, so later position -> region lookups are O(1)
-#include "ms_kernels.h"
+#include "ms_device.h"
 
 namespace ms {
-
-// ------------------------------------------------------------------------ helpers --
-
-__device__ __forceinline__ uint64_t code_window(const uint32_t *__restrict__ codes, int64_t g) {
-    const int64_t wi = g >> 4;
-    const uint32_t sh = ((uint32_t) g & 15u) * 2u;
-    const uint32_t w0 = codes[wi], w1 = codes[wi + 1], w2 = codes[wi + 2];
-    const uint64_t lo = ((uint64_t) w1 << 32) | w0;
-    return sh ? (lo >> sh) | ((uint64_t) w2 << (64u - sh)) : lo;
-}
-
-__device__ __forceinline__ uint32_t n_window(const uint32_t *__restrict__ nmask, int64_t g) {
-    const int64_t wi = g >> 5;
-    const uint32_t sh = (uint32_t) g & 31u;
-    const uint32_t w0 = nmask[wi], w1 = nmask[wi + 1];
-    return sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
-}
-
-__device__ __forceinline__ uint32_t low_mask(int w) { return w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u); }
-
-// region r with offsets[r] <= g < offsets[r+1]  (empty regions are skipped by construction).
-// blk2reg[g >> 6] is the region of position (g & ~63): a short forward walk finds g's region for
-// ordinary region lengths; tiny regions fall back to a binary search from there.
-__device__ __forceinline__ int64_t find_region(const DevSeq &S, int64_t g) {
-    int64_t lo = S.blk2reg[g >> 6];
-#pragma unroll 1
-    for (int step = 0; step < 4; step++) {
-        if (S.offsets[lo + 1] > g) return lo;
-        lo++;
-    }
-    int64_t hi = S.R;                 // invariant: offsets[lo] <= g, answer in [lo, hi)
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (S.offsets[mid] <= g) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ int64_t find_region_bsearch(const int64_t *__restrict__ offsets, int64_t R, int64_t g) {
-    int64_t lo = 0, hi = R;
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (offsets[mid] <= g) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// fp64 scores of one window in the reference's order: c = 0..W-1, forward adds M[row][c],
-// reverse adds M[3-row][W-1-c], non-ACGT adds nothing (cscore.c:345-354).  The table entries of
-// eight columns are fetched together (independent loads), then added strictly in column order.
-__device__ __forceinline__ void score_window(const DevSeq &S, const double2 *__restrict__ tab, int W,
-                                             int64_t g, double &fwd, double &rev) {
-    fwd = 0.0;
-    rev = 0.0;
-    for (int c0 = 0; c0 < W; c0 += 32) {
-        const uint64_t cw = code_window(S.codes, g + c0);
-        const uint32_t nw = n_window(S.nmask, g + c0);
-        const int n = (W - c0) < 32 ? (W - c0) : 32;
-        for (int c1 = 0; c1 < n; c1 += 8) {
-            double2 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int c = c1 + k;
-                const uint32_t b = (uint32_t) (cw >> (2 * (c & 31))) & 3u;
-                t[k] = tab[(c0 + (c < n ? c : n - 1)) * 4 + b];               // clamped: always a valid entry
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int c = c1 + k;
-                if (c < n && !((nw >> c) & 1u)) {
-                    fwd += t[k].x;
-                    rev += t[k].y;
-                }
-            }
-        }
-    }
-}
-
-// The same for W <= 32 with the lane's code / mask windows already in registers
-__device__ __forceinline__ void score_window32(const double2 *__restrict__ tab, int W, uint64_t cw, uint32_t nw,
-                                               double &fwd, double &rev) {
-    fwd = 0.0;
-    rev = 0.0;
-    for (int c1 = 0; c1 < W; c1 += 8) {
-        double2 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int c = c1 + k;
-            const uint32_t b = (uint32_t) (cw >> (2 * (c & 31))) & 3u;
-            t[k] = tab[(c < W ? c : W - 1) * 4 + b];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int c = c1 + k;
-            if (c < W && !((nw >> c) & 1u)) {
-                fwd += t[k].x;
-                rev += t[k].y;
-            }
-        }
-    }
-}
 
 // The middle field of a hit key: (region << pbits) | position inside the region when the set's regions are short
 // enough for that to fit (H.pbits > 0: finalize then only unpacks bits), else the global base position.
@@ -156,14 +55,17 @@ __device__ __forceinline__ void test_and_emit(const HitOut &H, const DevPwm &Pw,
     if (!try_f && !try_r) return;
     const double max_raw = Pw.max_raw[motif];
     const double cutoff = Pw.cutoff[motif];
-    if (try_f) {
-        const double s = fwd / max_raw;
-        if (s - cutoff >= -1e-10) emit_hit(H, motif, g, 0u, s);
+    const double s_f = try_f ? fwd / max_raw : 0.0, s_r = try_r ? rev / max_raw : 0.0;
+    const bool hit_f = try_f && s_f - cutoff >= -1e-10, hit_r = try_r && s_r - cutoff >= -1e-10;
+    if (H.entries) {                                     // one entry per window: rescore_ordered_kernel repeats this very test
+        if (hit_f || hit_r) {
+            const unsigned long long i = atomicAdd(H.n_hits, 1ULL);
+            if (i < H.cap) H.keys[i] = ((uint64_t) motif << H.gbits) | (uint64_t) g;
+        }
+        return;
     }
-    if (try_r) {
-        const double s = rev / max_raw;
-        if (s - cutoff >= -1e-10) emit_hit(H, motif, g, 1u, s);
-    }
+    if (hit_f) emit_hit(H, motif, g, 0u, s_f);
+    if (hit_r) emit_hit(H, motif, g, 1u, s_r);
 }
 
 // Block-level staging of hits in LDS: one global atomicAdd per ~2000 hits instead of one per wave
@@ -633,6 +535,20 @@ __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, 
     W.n += n_new;
 }
 
+// the record without flags (flags = 0): expand_kernel recomputes the group's 16 row sums for the flagged lanes
+__device__ __forceinline__ void emit_rec_noflags(const PfArgs &A, MfWave &W, bool flagged, uint64_t gkey, int32_t group) {
+    const unsigned long long mask = __ballot(flagged);
+    if (mask == 0) return;
+    const uint32_t n_new = (uint32_t) __popcll(mask);
+    if (W.n + n_new > (uint32_t) kWqCap) {
+        wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
+        W.n = 0;
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    if (flagged) W.wbuf[W.n + rank] = gkey | ((uint64_t) (uint32_t) group << 16);
+    W.n += n_new;
+}
+
 // any of the 32 result registers of the two 32-window operands non-negative?  (16 x v_max3_i32)
 __device__ __forceinline__ int max32(const i32x16 &c, const i32x16 &d) {
     int m[11];
@@ -694,19 +610,48 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
         }
     };
     auto test = [&](const i32x16 &c0, const i32x16 &c1, int t) {
-        if (__builtin_expect(__any(max32(c0, c1) >= 0) && !(MEAS && A.no_emit), 0))
-            mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
+        if constexpr (V & 4) {
+            // default: the rare path only queues (position, table group) of the lanes that flagged anything; which of the group's
+            // 16 fields it was is recomputed by expand_kernel from the same int8 tables (ms_tail.hip)
+            const int m0 = max16(c0), m1 = max16(c1);
+            if (__builtin_expect(__any(max(m0, m1) >= 0) && !(MEAS && A.no_emit), 0)) {
+                const int32_t group = first_group + 2 * t + (int32_t) h;
+                emit_rec_noflags(A, W, live0 && m0 >= 0, (uint64_t) g0 << 30, group);
+                emit_rec_noflags(A, W, live1 && m1 >= 0, (uint64_t) (g0 + 32) << 30, group);
+            }
+        } else if constexpr (V & 2) {
+            // A/B: the two halves' maxima are kept (17 instead of 16 max instructions per tile), so the rare path does not
+            // recompute them (2 x 8 fewer there)
+            const int m0 = max16(c0), m1 = max16(c1);
+            if (__builtin_expect(__any(max(m0, m1) >= 0) && !(MEAS && A.no_emit), 0)) {
+                const int32_t group = first_group + 2 * t + (int32_t) h;
+                if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
+                if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
+            }
+        } else {
+            if (__builtin_expect(__any(max32(c0, c1) >= 0) && !(MEAS && A.no_emit), 0))
+                mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
+        }
     };
     // ILP tiles' products are issued back to back (independent accumulators), then reduced: a wave that
     // spends more of its time issuing matrix instructions leaves the pipe idle less often (4 waves per SIMD)
-    constexpr int ILP = (V & 1) && NK <= 2 ? 2 : 1;
+    constexpr int ILP = (V & 1) && NK <= 2 ? 2 : 1;      // V: bit 0 two tiles in flight, bit 1 per-half maxima (A/B), bit 2 flag-free records
     int t = 0;
     for (; t + ILP <= n_row_tiles; t += ILP, p += ILP * kStep) {
         i32x16 c0[ILP], c1[ILP];
 #pragma unroll
         for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
+        if constexpr ((V & 8) && ILP == 2) {
+            // A/B: ONE branch for the pair of tiles (the vector -> scalar -> branch chain is paid once per two tiles)
+            const int ma = max32(c0[0], c1[0]), mb = max32(c0[1], c1[1]);
+            if (__builtin_expect(__any(max(ma, mb) >= 0) && !(MEAS && A.no_emit), 0)) {
+                if (__any(ma >= 0)) mfma_emit(A, W, c0[0], c1[0], first_group + 2 * t + (int32_t) h, g0, live0, live1);
+                if (__any(mb >= 0)) mfma_emit(A, W, c0[1], c1[1], first_group + 2 * (t + 1) + (int32_t) h, g0, live0, live1);
+            }
+        } else {
 #pragma unroll
-        for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
+            for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
+        }
     }
     for (; t < n_row_tiles; t++, p += kStep) {
         i32x16 c0, c1;
@@ -728,8 +673,10 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
 // 128 windows per wave in the narrow classes (each A operand serves four B operands): 64 + 32 + 8 registers of tiles
 // do not fit 128 VGPRs, 80 spills, +70 % time.)
 // MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
-template <int NT, int V, int ENG, bool MEAS>
-__global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
+// MAXNK / WPS (A/B): a kernel that only knows row tiles of <= MAXNK k-blocks needs fewer registers (B operands: 8 per k-block),
+// WPS = waves per SIMD the register allocation must leave room for (two 768-thread blocks per CU = 6).
+template <int NT, int V, int ENG, bool MEAS, int MAXNK = 4, int WPS = NT / 256>
+__global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
     const uint32_t len16 = T->table_len16;
@@ -767,8 +714,8 @@ __global__ void __launch_bounds__(NT) prefilter_mfma_kernel(const PfArgs A) {
             switch (cd.G) {
                 case 1: mfma_class<1, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 case 2: mfma_class<2, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 3: mfma_class<3, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 4: if constexpr (ENG == 1) mfma_class<4, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 3: if constexpr (MAXNK >= 3) mfma_class<3, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+                case 4: if constexpr (ENG == 1 && MAXNK >= 4) mfma_class<4, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 default: break;
             }
         }
@@ -1381,6 +1328,14 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
             return meas ? prefilter_mfma_kernel<1024, 1, 1, true> : prefilter_mfma_kernel<1024, 1, 1, false>;
         case 17: *threads = 512; return prefilter_mfma_kernel<512, 1, 1, true>;    // engine 1, 8 waves per block
         case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 1, true>;  // A/B: one row tile in flight per wave
+        case 19: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 1, true>;  // A/B: per-half maxima kept for the rare path
+        case 21: *threads = 768; return prefilter_mfma_kernel<768, 2, 1, true, 2, 6>;    // A/B: row tiles of <= 2 k-blocks only, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
+        case 22: *threads = 1024; return prefilter_mfma_kernel<1024, 2, 1, true, 2, 4>;  // A/B: the same code at 16 waves per CU
+        case 23: *threads = 512; return prefilter_mfma_kernel<512, 2, 1, true, 2, 6>;    // A/B: <= 2 k-blocks, 3 x 8 waves per CU (MS_PF_BLOCKS_PER_CU=3)
+        case 26: *threads = 640; return prefilter_mfma_kernel<640, 2, 1, true, 2, 5>;    // A/B: <= 2 k-blocks, 2 x 10 waves per CU (MS_PF_BLOCKS_PER_CU=2), <= 96 VGPRs
+        case 27: *threads = 1024; return prefilter_mfma_kernel<1024, 9, 1, true>;  // A/B: one branch per pair of tiles
+        case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default
+            return meas ? prefilter_mfma_kernel<1024, 5, 1, true> : prefilter_mfma_kernel<1024, 5, 1, false>;
         case 24: *threads = 1024;                                          // engine 2 (Walsh form: 10 columns per k-block)
             return meas ? prefilter_mfma_kernel<1024, 1, 2, true> : prefilter_mfma_kernel<1024, 1, 2, false>;
         case 25: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 2, true>;  // engine 2, one row tile in flight per wave

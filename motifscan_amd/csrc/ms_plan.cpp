@@ -292,8 +292,12 @@ bool quantize_strand_i8(const double e[4][kMaxFastWidth], int W, double T, I8Str
         return true;
     }
     if (!(T > lowest)) return false;            // every window passes
-    int bq_max = 254;
-    if (const char *e = measure_env("MS_PF_BQ_MAX")) bq_max = std::max(1, std::min(254, atoi(e)));      // experiment: coarser levels, smaller operand magnitudes
+    // Levels of the budget.  The matrix-core kernel is power-limited: operand bytes of small magnitude let the
+    // chip hold a higher clock, and with <= 127 levels the best base of every column is 0x00 and a clamped one 0x80.  Motifs of
+    // up to 16 columns lose little resolution at 127 levels (the budget is shared by few columns); wider ones keep 254.
+    // MS_MEASURE=1 MS_PF_BQ_MAX=n forces one value for all motifs (A/B: profiles/r02_operand_activity_bq127.log).
+    int bq_max = W <= 16 ? 127 : 254;
+    if (const char *e = measure_env("MS_PF_BQ_MAX")) bq_max = std::max(1, std::min(254, atoi(e)));
     for (int Bq = bq_max; Bq >= 1; Bq--) {
         const double s = budget > 0 ? ((double) Bq + 0.5) / budget : 1e300;
         int dq[kMaxFastWidth][4], cap[kMaxFastWidth];

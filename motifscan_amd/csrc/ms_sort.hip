@@ -20,6 +20,13 @@ int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint
     return MS_OK;
 }
 
+int sort_keys(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, size_t n, int end_bit, hipStream_t stream) {
+    if (end_bit < 1) end_bit = 1;
+    if (end_bit > 64) end_bit = 64;
+    MS_HIP(rocprim::radix_sort_keys(temp, *temp_bytes, keys_in, keys_out, n, 0u, (unsigned int) end_bit, stream));
+    return MS_OK;
+}
+
 int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream) {
     MS_HIP(rocprim::radix_sort_keys_desc(temp, *temp_bytes, in, out, n, 0u, 64u, stream));
     return MS_OK;

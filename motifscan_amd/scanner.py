@@ -110,6 +110,18 @@ class Scanner:
             return None
         return g, int(ci[0]), int(st[0]), int(en[-1]), window, stride
 
+    def _as_overlapping(self):
+        """(genome, chromosome indices) if the regions lie on a ResidentGenome and overlap enough (their union is under 80 % of
+        their summed length: peaks +- window/2 closer than the window, cli/scan.py:43-48) for ms_scan_regions_once to pay:
+        it scores the union once and hands every site to each region that holds it -- the identical result."""
+        if self._resident is None or len(self.seq_starts) < 2:
+            return None
+        g, idx = self._resident
+        total = int(np.sum(np.asarray(self.seq_ends, dtype=np.int64) - np.asarray(self.seq_starts, dtype=np.int64)))
+        if total == 0 or _lib.union_bases(idx, self.seq_starts, self.seq_ends) > 0.8 * total:
+            return None
+        return g, idx
+
     # ------------------------------------------------------------------ scanning --
 
     def _marshal(self, pwms):
@@ -132,10 +144,15 @@ class Scanner:
         logger.debug("Scanning motif PWMs")
         pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
         sweep = self._as_sweep()
+        overlapping = self._as_overlapping() if sweep is None else None
         if sweep is not None:
             g, chrom, begin, end, window, stride = sweep
             sq = None
             res = _lib.scan_sweep(pw, g, chrom, begin, end, window, stride, _STRAND_FLAG[self.strand])
+        elif overlapping is not None:
+            g, idx = overlapping
+            sq = None
+            res = _lib.scan_regions_once(pw, g, idx, self.seq_starts, self.seq_ends, _STRAND_FLAG[self.strand])
         else:
             sq = self._seqset()
             res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])

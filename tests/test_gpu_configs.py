@@ -403,3 +403,73 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["counts_check"]["allreduce_equals_sum_of_rank_counts"] is True
+
+
+# ----------------------------------------------------------- scan-once for overlapping regions --
+
+@pytest.mark.parametrize("strand,dedup", [(3, False), (1, True), (2, False)])
+def test_overlapping_regions_are_scanned_once_with_identical_result(oracle, jaspar579, strand, dedup):
+    """Peaks +- window/2 closer together than the window, nested / duplicate / empty / clipped regions, in shuffled order
+    (cli/scan.py:43-48, 76-86): ms_scan_regions_once == the per-region scan == the oracle, while scanning only the union."""
+    rng = np.random.default_rng(77)
+    sel = rng.choice(579, size=150, replace=False)
+    mats = synth.matrices_of(jaspar579["pwm_values"], jaspar579["widths"])
+    vals = np.concatenate([mats[i].ravel() for i in sel])
+    widths = jaspar579["widths"][sel]
+    cutoffs = jaspar579["cutoffs"]["1e-3"][sel]
+    lens = [60_000, 25_000, 900, 40_000]
+    chroms = {}
+    for i, L in enumerate(lens):
+        b, _ = synth.make_regions(1, L, seed=90 + i, frac_n=0.0)
+        b[L // 3:L // 3 + 70] = ord("N")
+        chroms[f"c{i}"] = b
+    ci, st, en = [], [], []
+    for i, L in enumerate(lens):
+        summits = np.cumsum(rng.integers(40, 460, size=max(2, L // 250)))          # mean spacing 250 < window 500: ~50 % overlap
+        summits = summits[summits < L]
+        for sm in summits.tolist():
+            ci.append(i); st.append(max(sm - 250, 0)); en.append(min(sm + 250, L))      # scanner.py:81-83 clipping
+    for _ in range(60):                                                                 # nested, duplicate, tiny and empty regions
+        i = int(rng.integers(0, len(lens)))
+        a = int(rng.integers(0, lens[i]))
+        ci.append(i); st.append(a); en.append(min(lens[i], a + int(rng.choice([0, 3, 17, 120, 2000]))))
+    ci += ci[:15]; st += st[:15]; en += en[:15]
+    perm = rng.permutation(len(ci))
+    ci, st, en = np.array(ci)[perm], np.array(st)[perm], np.array(en)[perm]
+    total, union = int((en - st).sum()), _lib.union_bases(ci, st, en)
+    assert union < 0.62 * total
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    rg = _lib.ResidentGenome(chroms)
+    once = _lib.scan_regions_once(pw, rg, ci, st, en, strand)
+    assert once.stats()["n_bases"] <= union + 1 and once.stats()["n_bases"] >= 0.9 * union      # spans = merged overlapping regions
+    sq = rg.extract(ci, st, en)
+    per_region = _lib.scan(pw, sq, strand)
+    assert once.stats()["n_windows"] == per_region.stats()["n_windows"]
+    if dedup:
+        once.dedup(pw); per_region.dedup(pw)
+    got, want = once.hits(), per_region.hits()
+    assert len(want["pos"]) > 20_000
+    assert_same_hits(got, want)
+    assert np.array_equal(once.region_counts(), per_region.region_counts())
+    if not dedup:
+        names = list(chroms)
+        seqs = b"".join(chroms[names[c]][a:b].tobytes() for c, a, b in zip(ci, st, en))
+        off = np.concatenate([[0], np.cumsum(en - st)])
+        assert_same_hits(got, oracle.scan_arrays(vals, widths, cutoffs, seqs, off, strand, 8))
+    # the Scanner takes this path by itself for such a list
+
+    class Reg:
+        def __init__(self, c, s, e):
+            self.chrom, self.start, self.end, self.summit = c, s, e, (s + e) // 2
+
+    class P:
+        def __init__(self, m, c, w):
+            self.matrix, self.cutoffs, self.length = m, {"1e-3": c}, int(w)
+
+    names = list(chroms)
+    sc = scanner.Scanner(rg, [Reg(names[c], int(a), int(b)) for c, a, b in zip(ci, st, en)], 0, {3: "both", 1: "+", 2: "-"}[strand],
+                         "1e-3", remove_dup=dedup)
+    assert sc._as_overlapping() is not None
+    a = sc.scan_motifs_arrays([P(mats[i], c, w) for i, c, w in zip(sel, cutoffs, widths)])
+    assert np.array_equal(a["region"], want["seq_idx"]) and np.array_equal(a["start"], st[want["seq_idx"]] + want["pos"])
+    assert np.array_equal(a["score"], want["score"])

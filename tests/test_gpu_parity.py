@@ -303,7 +303,10 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
                                  {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "17"},
                                  {"MS_PF_ENGINE": "1", "MS_HIT_COORD": "global"},
                                  {"MS_PF_ENGINE": "2"},
-                                 {"MS_PF_ENGINE": "2", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "25"}])
+                                 {"MS_PF_ENGINE": "2", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "25"},
+                                 {"MS_PF_ENGINE": "1", "MS_TAIL": "2"},                       # second tail form (ms_tail.hip)
+                                 {"MS_PF_ENGINE": "0", "MS_TAIL": "2"},
+                                 {"MS_PF_ENGINE": "1", "MS_TAIL": "2", "MS_PF_BLOCKS_PER_CU": "4", "MS_HIT_COORD": "global"}])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
     """Pre-filter engine (matrix-core product / packed LDS lookups), field width, number of LDS tiles
     and kernel variant are tuning knobs: every setting must give the same (bit-exact) hits.  Small
