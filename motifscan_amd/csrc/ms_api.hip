@@ -863,6 +863,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // (ms_tail.hip): measured slower on the benchmark set (profiles/r02_tail_forms.log), kept as the comparison
     int tail = 1;
     if (const char *e = measure_env("MS_TAIL")) tail = atoi(e) == 2 ? 2 : 1;
+    if (flags & MS_SCAN_RAW_INTERNAL) tail = 1;
     // expected density at the CLI default p = 1e-4 is ~1.5e-4 candidates per window and strand; 4x head room
     size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
     size_t want_hits = want_cand;
@@ -978,6 +979,22 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         dev_free(d_clk);
     }
 
+    if (flags & MS_SCAN_RAW_INTERNAL) {                      // the caller takes the unordered hits from the scratch
+        float ms01 = 0, ms12 = 0;
+        (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
+        (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
+        stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_total = ms01 + ms12;
+        stt.n_hits = (int64_t) n_hits;
+        raw->n_hits = (int64_t) n_hits;
+        raw->raw_gbits = gbits;
+        raw->raw_pbits = pbits;
+        int64_t pwm_bytes = 0;
+        for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
+        stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
+        *out = raw;
+        return MS_OK;
+    }
+
     // one pooled block for everything the result owns.  Tail 2 learns the number of hits only at the very end: the block
     // is sized by the bound "every entry hits on every scanned strand"
     const unsigned long long n_entries = n_hits;
@@ -1084,6 +1101,7 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     *out = nullptr;
     if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    if (flags & ~(uint32_t) MS_SCAN_EXACT_ONLY) { set_error("unknown scan flags 0x%x", flags); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);       // lazily cached device copies / plan
     DeviceCtx *c;
     int rc = get_ctx(seqs->device, &c);

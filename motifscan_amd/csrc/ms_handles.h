@@ -141,6 +141,7 @@ struct ms_result {
     int64_t R = 0;                                    // sequences of the scanned set
     int64_t n_hits = 0;
     bool deduped = false;
+    int raw_gbits = 0, raw_pbits = 0;                 // MS_SCAN_RAW_INTERNAL: layout of the unordered hit keys left in the device scratch
     bool invalid = false;                             // a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1): stage times only, no hits
     void *block = nullptr;                            // one device block holding everything below
     size_t block_bytes = 0;
@@ -159,6 +160,12 @@ struct ms_result {
 };
 
 namespace ms {
+
+// Internal scan flag: stop after the fp64 stage -- the hits stay UNORDERED in the device scratch (c->sc.keys / vals, key =
+// motif << (gbits + 1) | coordinate << 1 | strand bit, coordinate = sequence << pbits | position when pbits > 0, else the
+// global base position); the result holds only the count, the key layout and the stage times.  For callers that re-key the
+// hits anyway (ms_scan_regions_once) and keep holding c->mu until they are done with the scratch.
+#define MS_SCAN_RAW_INTERNAL 0x80000000u
 
 // The scan pipeline proper (ms_api.hip); the caller holds c->mu and pwms->mu.
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out);

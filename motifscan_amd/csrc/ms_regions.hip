@@ -25,15 +25,6 @@ struct RegionIndex {                 // device view of the merged layout
     const int64_t *span_maxlen;      // [S] longest region of the span
 };
 
-__device__ __forceinline__ int32_t motif_of(const int64_t *__restrict__ motif_off, int32_t P, int64_t i) {
-    int32_t lo = 0, hi = P;
-    while (hi - lo > 1) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (motif_off[mid] <= i) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 // sorted regions [lo, hi] of span s that can hold a site at [g, g + W): start <= g, and start > g + W - maxlen
 __device__ __forceinline__ void candidate_range(const RegionIndex &X, int64_t s, int64_t g, int W, int64_t &lo, int64_t &hi) {
     const int64_t jb = X.span_first[s], je = X.span_first[s + 1];
@@ -46,37 +37,56 @@ __device__ __forceinline__ void candidate_range(const RegionIndex &X, int64_t s,
     lo = a;
 }
 
-__global__ void __launch_bounds__(256) once_count_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
-                                                         const int32_t *__restrict__ width, const int64_t *__restrict__ seq_idx,
-                                                         const int64_t *__restrict__ pos, const RegionIndex X,
+// an unordered span hit: key = motif << (gbits + 1) | coordinate << 1 | strand bit (ms_handles.h, MS_SCAN_RAW_INTERNAL)
+struct RawKeys {
+    const uint64_t *keys;
+    const double *vals;
+    int gbits, pbits;
+    const int64_t *span_off;         // [S+1] span offsets in the scanned sequence set (pbits == 0: global positions)
+    int64_t S;
+};
+
+__device__ __forceinline__ void raw_decode(const RawKeys &K, uint64_t k, int32_t &m, int64_t &s, int64_t &g, uint64_t &sbit) {
+    sbit = k & 1ULL;
+    m = (int32_t) (k >> (K.gbits + 1));
+    const uint64_t coord = (k >> 1) & ((1ULL << K.gbits) - 1ULL);
+    if (K.pbits) {
+        s = (int64_t) (coord >> K.pbits);
+        g = (int64_t) (coord & ((1ULL << K.pbits) - 1ULL));
+    } else {
+        int64_t lo = 0, hi = K.S;                             // span_off[lo] <= coord < span_off[hi]
+        while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if ((uint64_t) K.span_off[mid] <= coord) lo = mid; else hi = mid; }
+        s = lo;
+        g = (int64_t) coord - K.span_off[lo];
+    }
+}
+
+__global__ void __launch_bounds__(256) once_count_kernel(int64_t n, const RawKeys K, const int32_t *__restrict__ width, const RegionIndex X,
                                                          uint32_t *__restrict__ cnt) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int W = width[motif_of(motif_off, P, i)];
-    const int64_t g = pos[i];
+    int32_t m; int64_t s, g; uint64_t sbit;
+    raw_decode(K, K.keys[i], m, s, g, sbit);
+    const int W = width[m];
     int64_t lo, hi;
-    candidate_range(X, seq_idx[i], g, W, lo, hi);
+    candidate_range(X, s, g, W, lo, hi);
     uint32_t c = 0;
     for (int64_t j = lo; j <= hi; j++) c += X.rel_end[j] >= g + W ? 1u : 0u;
     cnt[i] = c;
 }
 
-__global__ void __launch_bounds__(256) once_expand_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
-                                                          const int32_t *__restrict__ width, const int64_t *__restrict__ seq_idx,
-                                                          const int64_t *__restrict__ pos, const double *__restrict__ score,
-                                                          const int8_t *__restrict__ strand, const RegionIndex X,
+__global__ void __launch_bounds__(256) once_expand_kernel(int64_t n, const RawKeys K, const int32_t *__restrict__ width, const RegionIndex X,
                                                           const uint64_t *__restrict__ dst, int rbits, int pbits,
                                                           uint64_t *__restrict__ keys, double *__restrict__ vals) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int32_t m = motif_of(motif_off, P, i);
+    int32_t m; int64_t s, g; uint64_t sbit;
+    raw_decode(K, K.keys[i], m, s, g, sbit);
     const int W = width[m];
-    const int64_t g = pos[i];
     int64_t lo, hi;
-    candidate_range(X, seq_idx[i], g, W, lo, hi);
+    candidate_range(X, s, g, W, lo, hi);
     uint64_t d = dst[i];
-    const double sc = score[i];
-    const uint64_t sbit = strand[i] == 2 ? 1u : 0u;
+    const double sc = K.vals[i];
     for (int64_t j = lo; j <= hi; j++)
         if (X.rel_end[j] >= g + W) {
             keys[d] = ((uint64_t) m << (rbits + pbits + 1)) | ((uint64_t) X.orig[j] << (pbits + 1)) | ((uint64_t) (g - X.rel_start[j]) << 1) | sbit;
@@ -120,12 +130,30 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
             }
             max_len = std::max(max_len, end[r] - start[r]);
         }
-        std::iota(order.begin(), order.end(), (int64_t) 0);
-        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-            if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
-            if (start[a] != start[b]) return start[a] < start[b];
-            return a < b;
-        });
+        // order by (chromosome, start, index): LSD radix sort of the packed key, 16 bits a pass, only the passes the data needs
+        // (an indirect std::sort of 200k regions costs more than scanning them)
+        {
+            int64_t max_start = 0;
+            for (size_t r = 0; r < R; r++) max_start = std::max(max_start, start[r]);
+            int sbits = 1, cbits = 1;
+            while ((1LL << sbits) <= max_start) sbits++;
+            while ((1LL << cbits) < std::max<int64_t>(n_chroms, 1)) cbits++;
+            std::vector<uint64_t> key(R), key2(R);
+            std::vector<int64_t> order2(R);
+            for (size_t r = 0; r < R; r++) { key[r] = ((uint64_t) chrom[r] << sbits) | (uint64_t) start[r]; order[r] = (int64_t) r; }
+            for (int shift = 0; shift < sbits + cbits; shift += 16) {
+                std::vector<size_t> count(65537, 0);
+                for (size_t r = 0; r < R; r++) count[((key[r] >> shift) & 0xFFFFu) + 1]++;
+                for (size_t b = 0; b < 65536; b++) count[b + 1] += count[b];
+                for (size_t r = 0; r < R; r++) {
+                    const size_t d = count[(key[r] >> shift) & 0xFFFFu]++;
+                    key2[d] = key[r];
+                    order2[d] = order[r];
+                }
+                key.swap(key2);
+                order.swap(order2);
+            }
+        }
         for (size_t j = 0; j < R; j++) {
             const int64_t r = order[j];
             const bool joins = !sp_chrom.empty() && sp_chrom.back() == chrom[r] && start[r] < sp_end.back();     // true overlap only
@@ -154,14 +182,16 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
     if ((rc = get_ctx(spans->device, &c))) { ms_seqset_free(spans); return rc; }
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+    // the span hits are re-keyed anyway: take them unordered from the scan's scratch (no sort / unpack of the span result)
     ms_result *r1 = nullptr;
-    rc = scan_locked(c, pwms, spans, strand_mask, flags, &r1);
+    rc = scan_locked(c, pwms, spans, strand_mask, flags | MS_SCAN_RAW_INTERNAL, &r1);
     const int64_t union_bases = spans->n_bases;
-    ms_seqset_free(spans);
-    if (rc) return rc;
-    auto fail = [&](int code) { ms_result_free(r1); return code; };
+    if (rc) { ms_seqset_free(spans); return rc; }
+    auto fail = [&](int code) { ms_result_free(r1); ms_seqset_free(spans); return code; };
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return fail(rc);
     const size_t n1 = (size_t) r1->n_hits;
+    RawKeys K;
+    K.keys = c->sc.keys; K.vals = c->sc.vals; K.gbits = r1->raw_gbits; K.pbits = r1->raw_pbits; K.span_off = spans->d_offsets; K.S = spans->R;
 
     int rbits = 1, pbits = 1, mbits = 1;
     while ((1LL << rbits) < std::max<int64_t>(n_regions, 1)) rbits++;
@@ -182,8 +212,8 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
 
     // index arrays + work buffers in one pooled block
     void *iblk = nullptr, *wblk = nullptr, *d_tmp = nullptr;
-    size_t igot = 0, wgot = 0;
-    auto cleanup = [&]() { if (iblk) pool_free(c, iblk, igot); if (wblk) pool_free(c, wblk, wgot); if (d_tmp) (void) hipFree(d_tmp); };
+    size_t igot = 0, wgot = 0, tgot = 0;
+    auto cleanup = [&]() { if (iblk) pool_free(c, iblk, igot); if (wblk) pool_free(c, wblk, wgot); if (d_tmp) pool_free(c, d_tmp, tgot); };
     auto up8 = [](size_t x) { return (x + 31) & ~(size_t) 31; };
     const size_t n_idx = up8(S + 1) + 3 * up8(R) + up8(S);
     if ((rc = pool_alloc(c, 8 * n_idx + 12 * up8(n1) + 256, &iblk, &igot))) { cleanup(); return fail2(rc); }
@@ -204,11 +234,10 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
     (void) hipEventRecord(c->ev[0], c->stream);
     uint64_t total = 0;
     if (n1 > 0) {
-        hipLaunchKernelGGL(once_count_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (int64_t) n1, r1->d_motif_first,
-                           r1->P, pwms->d_width, r1->d_seq_idx, r1->d_pos, X, d_cnt);
+        hipLaunchKernelGGL(once_count_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (int64_t) n1, K, pwms->d_width, X, d_cnt);
         size_t tmp_bytes = 0;
         rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
-        if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
+        if (!rc) rc = pool_alloc(c, tmp_bytes ? tmp_bytes : 256, &d_tmp, &tgot);
         if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
         uint32_t last_cnt = 0;
         uint64_t last_dst = 0;
@@ -240,8 +269,8 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
         uint64_t *d_keys = static_cast<uint64_t *>(wblk), *d_keys_sorted = d_keys + nt;
         double *d_vals = reinterpret_cast<double *>(d_keys_sorted + nt);
         void *d_sort_tmp = d_vals + nt;
-        hipLaunchKernelGGL(once_expand_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (int64_t) n1, r1->d_motif_first,
-                           r1->P, pwms->d_width, r1->d_seq_idx, r1->d_pos, r1->d_score, r1->d_strand, X, d_dst, rbits, pbits, d_keys, d_vals);
+        hipLaunchKernelGGL(once_expand_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, c->stream, (int64_t) n1, K, pwms->d_width, X,
+                           d_dst, rbits, pbits, d_keys, d_vals);
         he = hipGetLastError();
         if (he != hipSuccess) { cleanup(); set_error("hand-out kernel failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
         if ((rc = sort_hit_pairs(d_sort_tmp, &sort_bytes, d_keys, d_keys_sorted, d_vals, raw->d_score, (size_t) total,
@@ -281,6 +310,7 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
     }
     stt.hbm_bytes_algorithmic += 16 * ((int64_t) total - (int64_t) n1);
     ms_result_free(r1);
+    ms_seqset_free(spans);
     *out = raw;
     return MS_OK;
 }

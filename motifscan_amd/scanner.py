@@ -111,14 +111,16 @@ class Scanner:
         return g, int(ci[0]), int(st[0]), int(en[-1]), window, stride
 
     def _as_overlapping(self):
-        """(genome, chromosome indices) if the regions lie on a ResidentGenome and overlap enough (their union is under 80 % of
-        their summed length: peaks +- window/2 closer than the window, cli/scan.py:43-48) for ms_scan_regions_once to pay:
-        it scores the union once and hands every site to each region that holds it -- the identical result."""
+        """(genome, chromosome indices) if the regions lie on a ResidentGenome and overlap enough (their union is under half of
+        their summed length: peaks +- window/2 much closer than the window, dense random controls, cli/scan.py:43-48, 76-86) for
+        ms_scan_regions_once to pay: it scores the union once and hands every site to each region that holds it -- the identical
+        result.  At half it breaks even with the per-region scan (profiles/r02_scan_once_overlap.log): the hand-out re-keys and
+        re-orders every site."""
         if self._resident is None or len(self.seq_starts) < 2:
             return None
         g, idx = self._resident
         total = int(np.sum(np.asarray(self.seq_ends, dtype=np.int64) - np.asarray(self.seq_starts, dtype=np.int64)))
-        if total == 0 or _lib.union_bases(idx, self.seq_starts, self.seq_ends) > 0.8 * total:
+        if total == 0 or _lib.union_bases(idx, self.seq_starts, self.seq_ends) > 0.5 * total:
             return None
         return g, idx
 

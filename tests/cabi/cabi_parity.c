@@ -84,8 +84,106 @@ int main(void) {
         ms_result_free(res);
     }
     ms_seqset_free(sq);
+
+    /* ---- batch stream (ms_stream_*): the same regions in three batches, pinned input, compact copy-out ---------------- */
+    long long streamed = 0;
+    {
+        char *pin = NULL;
+        CHECK(ms_host_alloc((size_t) n_bases + 1, (void **) &pin));
+        memcpy(pin, bases, (size_t) n_bases);
+        int64_t *w_off, *w_seq, *w_pos; double *w_score; int32_t *w_sd;
+        if (oracle_scan(vals, widths, cutoffs, P, bases, seq_off, R, 3, 4, &w_off, &w_seq, &w_pos, &w_score, &w_sd)) return 4;
+        ms_stream *st = NULL;
+        CHECK(ms_stream_create(pw, 3, MS_STREAM_PACKED, 2, &st));
+        const int cut[4] = {0, 90, 91, R};
+        int64_t boff[3][R + 1];
+        for (int b = 0; b < 3; b++) {
+            for (int r = cut[b]; r <= cut[b + 1]; r++) boff[b][r - cut[b]] = seq_off[r] - seq_off[cut[b]];
+            CHECK(ms_stream_submit(st, pin + seq_off[cut[b]], boff[b], cut[b + 1] - cut[b]));
+        }
+        int64_t seen[P];                           /* hits of motif p already matched (batches arrive in order) */
+        for (int p = 0; p < P; p++) seen[p] = 0;
+        for (int b = 0; b < 3; b++) {
+            ms_result *res = NULL;
+            CHECK(ms_stream_next(st, &res));
+            if (!res) { fprintf(stderr, "stream ran dry\n"); return 1; }
+            int64_t n = 0, off[P + 1];
+            const uint64_t *coord; const double *score;
+            CHECK(ms_result_num_hits(res, &n));
+            CHECK(ms_result_motif_offsets(res, off));
+            CHECK(ms_result_hits_packed_host(res, &coord, &score));
+            for (int p = 0; p < P; p++)
+                for (int64_t i = off[p]; i < off[p + 1]; i++) {
+                    const int64_t k = w_off[p] + seen[p]++;
+                    const int64_t seq = (int64_t) (coord[i] >> 32) + cut[b], pos = (int64_t) ((coord[i] & 0xFFFFFFFFu) >> 1);
+                    const int sd = (int) (coord[i] & 1u) + 1;
+                    if (k >= w_off[p + 1] || seq != w_seq[k] || pos != w_pos[k] || sd != w_sd[k] || memcmp(&score[i], &w_score[k], 8) != 0) {
+                        fprintf(stderr, "stream batch %d motif %d: hit %lld differs\n", b, p, (long long) i);
+                        return 1;
+                    }
+                }
+            streamed += n;
+            ms_result_free(res);
+        }
+        for (int p = 0; p < P; p++) if (seen[p] != w_off[p + 1] - w_off[p]) { fprintf(stderr, "stream: motif %d lost hits\n", p); return 1; }
+        ms_result *none = (ms_result *) 1;
+        CHECK(ms_stream_next(st, &none));
+        if (none != NULL) return 1;
+        ms_stream_free(st);
+        ms_host_free(pin);
+        oracle_free(w_off); oracle_free(w_seq); oracle_free(w_pos); oracle_free(w_score); oracle_free(w_sd);
+    }
+
+    /* ---- span planning + scan-once for overlapping regions against the per-region scan ----------------------------------- */
+    long long once_sites = 0;
+    {
+        const int64_t chrom_len[2] = {n_bases / 2, n_bases - n_bases / 2};
+        int64_t n_spans = 0;
+        CHECK(ms_sweep_spans(chrom_len, 2, 200, 50, 5000, NULL, 0, &n_spans));
+        ms_span *spans = malloc(sizeof(ms_span) * (size_t) n_spans);
+        CHECK(ms_sweep_spans(chrom_len, 2, 200, 50, 5000, spans, n_spans, &n_spans));
+        int64_t wins = 0;
+        for (int64_t k = 0; k < n_spans; k++) {
+            if (spans[k].first_window != wins || spans[k].end - spans[k].begin > 5000) { fprintf(stderr, "bad span %lld\n", (long long) k); return 1; }
+            wins += spans[k].n_windows;
+        }
+        if (wins != (chrom_len[0] - 200) / 50 + 1 + (chrom_len[1] - 200) / 50 + 1) { fprintf(stderr, "span windows do not add up\n"); return 1; }
+        free(spans);
+        const int64_t goff[3] = {0, chrom_len[0], n_bases};
+        ms_genome *gn = NULL;
+        CHECK(ms_genome_create(bases, goff, 2, &gn));
+        enum { NR = 400 };
+        int32_t rc_[NR]; int64_t rs[NR], re[NR];
+        for (int r = 0; r < NR; r++) {
+            rc_[r] = (int32_t) (rnd() % 2);
+            rs[r] = (int64_t) (rnd() % (uint64_t) (chrom_len[rc_[r]] - 10));
+            re[r] = rs[r] + (int64_t) (rnd() % 600);
+            if (re[r] > chrom_len[rc_[r]]) re[r] = chrom_len[rc_[r]];
+        }
+        ms_seqset *cut_ = NULL;
+        ms_result *a = NULL, *b = NULL;
+        CHECK(ms_seqset_from_genome(gn, rc_, rs, re, NR, &cut_));
+        CHECK(ms_scan(pw, cut_, 3, 0, &a));
+        CHECK(ms_scan_regions_once(pw, gn, rc_, rs, re, NR, 3, 0, &b));
+        int64_t na = 0, nb = 0;
+        CHECK(ms_result_num_hits(a, &na));
+        CHECK(ms_result_num_hits(b, &nb));
+        if (na != nb) { fprintf(stderr, "scan-once: %lld sites, per-region scan %lld\n", (long long) nb, (long long) na); return 1; }
+        const int64_t *sa, *pa, *sb, *pb; const double *va, *vb; const int8_t *da, *db;
+        CHECK(ms_result_hits_host(a, &sa, &pa, &va, &da));
+        CHECK(ms_result_hits_host(b, &sb, &pb, &vb, &db));
+        if (memcmp(sa, sb, 8 * (size_t) na) || memcmp(pa, pb, 8 * (size_t) na) || memcmp(va, vb, 8 * (size_t) na) || memcmp(da, db, (size_t) na)) {
+            fprintf(stderr, "scan-once differs from the per-region scan\n");
+            return 1;
+        }
+        once_sites = na;
+        ms_result_free(a); ms_result_free(b);
+        ms_seqset_free(cut_);
+        ms_genome_free(gn);
+    }
     ms_pwmset_free(pw);
     free(vals); free(bases);
-    printf("cabi_parity: %lld hits identical over strands 1, 2, 3 (version %d)\n", total, ms_version());
-    return total > 1000 ? 0 : 5;
+    printf("cabi_parity: %lld hits identical over strands 1, 2, 3; %lld through a 3-batch stream (compact form); %lld sites scan-once == per-region "
+           "(version %d)\n", total, streamed, once_sites, ms_version());
+    return total > 1000 && streamed > 300 && once_sites > 300 ? 0 : 5;
 }

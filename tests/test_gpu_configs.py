@@ -425,7 +425,7 @@ def test_overlapping_regions_are_scanned_once_with_identical_result(oracle, jasp
         chroms[f"c{i}"] = b
     ci, st, en = [], [], []
     for i, L in enumerate(lens):
-        summits = np.cumsum(rng.integers(40, 460, size=max(2, L // 250)))          # mean spacing 250 < window 500: ~50 % overlap
+        summits = np.cumsum(rng.integers(20, 300, size=max(2, L // 160)))          # mean spacing 160 << window 500: every base in ~3 regions
         summits = summits[summits < L]
         for sm in summits.tolist():
             ci.append(i); st.append(max(sm - 250, 0)); en.append(min(sm + 250, L))      # scanner.py:81-83 clipping
@@ -437,7 +437,7 @@ def test_overlapping_regions_are_scanned_once_with_identical_result(oracle, jasp
     perm = rng.permutation(len(ci))
     ci, st, en = np.array(ci)[perm], np.array(st)[perm], np.array(en)[perm]
     total, union = int((en - st).sum()), _lib.union_bases(ci, st, en)
-    assert union < 0.62 * total
+    assert union < 0.45 * total
     pw = _lib.PwmSet(vals, widths, cutoffs)
     rg = _lib.ResidentGenome(chroms)
     once = _lib.scan_regions_once(pw, rg, ci, st, en, strand)
