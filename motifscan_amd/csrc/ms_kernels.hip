@@ -791,6 +791,36 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
         if (i < s_width[m] * 4) s_tab[s_off[m] + i] = Pw.tab2[s_src[m] + i];
     }
     __syncthreads();
+    // Upper bound of a window's raw score when one contiguous run of columns [a, b) is non-ACGT (adds nothing, cscore.c:345-353):
+    // the best base of every other column = pre[a] + suf[b].  Most windows that overlap a run of N lose too many columns to
+    // reach the cutoff; they are dismissed by two table reads instead of 2 W fp64 adds.
+    __shared__ double s_pre[kNwMotifChunk][2][kMaxFastWidth + 1], s_suf[kNwMotifChunk][2][kMaxFastWidth + 1];
+    __shared__ double s_floor[kNwMotifChunk];
+    if ((int) threadIdx.x < 2 * cnt) {
+        const int m = threadIdx.x >> 1, sd = threadIdx.x & 1, W = s_width[m];
+        const double2 *t = s_tab + s_off[m];
+        double acc = 0.0;
+        s_pre[m][sd][0] = 0.0;
+        for (int c = 0; c < W; c++) {
+            double hi = -INFINITY;
+            for (int b = 0; b < 4; b++) hi = fmax(hi, sd ? t[c * 4 + b].y : t[c * 4 + b].x);
+            acc += hi;
+            s_pre[m][sd][c + 1] = acc;
+        }
+        acc = 0.0;
+        s_suf[m][sd][W] = 0.0;
+        for (int c = W - 1; c >= 0; c--) {
+            double hi = -INFINITY;
+            for (int b = 0; b < 4; b++) hi = fmax(hi, sd ? t[c * 4 + b].y : t[c * 4 + b].x);
+            acc += hi;
+            s_suf[m][sd][c] = acc;
+        }
+        if (sd == 0) {                                          // the raw-sum floor of the hit test (ms_api.hip), minus room for this bound's own rounding
+            const double fl = Pw.raw_floor[s_motif[m]];
+            s_floor[m] = fl - 1e-9 * (1.0 + fabs(fl));
+        }
+    }
+    __syncthreads();
     for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long) gridDim.x * blockDim.x) {
         const int64_t g = list[i];
@@ -801,8 +831,16 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
         const int64_t gk = hit_coord(H, S, r, g);
         for (int m = 0; m < cnt; m++) {
             const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
-            if ((nw & low_mask(W)) == 0) continue;
+            const uint32_t nm = nw & low_mask(W);
+            if (nm == 0) continue;
             if (g + W > end) continue;
+            const int a = __ffs((int) nm) - 1, b = 32 - __clz((int) nm);
+            if (__popc(nm) == b - a) {                           // one contiguous run (the usual case): bound by the columns outside it
+                const double fl = s_floor[m];
+                const bool dead_f = !(strand_mask & 1) || s_pre[m][0][a] + s_suf[m][0][b] < fl;
+                const bool dead_r = !(strand_mask & 2) || s_pre[m][1][a] + s_suf[m][1][b] < fl;
+                if (dead_f && dead_r) continue;
+            }
             double fwd, rev;
             score_window32(s_tab + s_off[m], W, cw, nw, fwd, rev);
             test_and_emit(H, Pw, (uint32_t) s_motif[m], gk, fwd, rev, strand_mask);
@@ -825,6 +863,11 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
     test_and_emit(H, Pw, (uint32_t) p, hit_coord(H, S, r, g), fwd, rev, strand_mask);
 }
 
+// U candidate records per thread and round, their loads issued side by side: the kernel is a chain of dependent gathers
+// (record -> region hint / sequence words / motif id -> offsets / width / table offset -> table entries), so the records in
+// flight per thread -- not the arithmetic -- set its speed; one barrier pair per round of U records instead of per record.
+constexpr int kRescoreU = 4;
+
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
                                                       const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
                                                       const int32_t *__restrict__ group_motifs, int strand_mask,
@@ -834,36 +877,75 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
     __syncthreads();
     unsigned long long n = *n_cand;
     if (n > cand_cap) n = cand_cap;
-    const unsigned long long per_round = (unsigned long long) gridDim.x * blockDim.x;
+    constexpr int U = kRescoreU;
+    const unsigned long long per_sub = (unsigned long long) gridDim.x * blockDim.x;
+    const unsigned long long per_round = per_sub * U;
     const unsigned long long rounds = (n + per_round - 1) / per_round;
     for (unsigned long long rd = 0; rd < rounds; rd++) {
-        const unsigned long long i = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < n) {
-            const uint64_t c = cand[i];
-            uint32_t flags = (uint32_t) c & 0xFFFFu;                   // bit n = field n; motif slot n >> 1
-            flags = (flags | (flags >> 1)) & 0x5555u;                  // both strands are re-scored anyway
-            const int32_t group = (int32_t) ((c >> 16) & 0x3FFFu);
-            const int64_t g = (int64_t) (c >> 30);
-            const int64_t r = find_region(S, g);
-            const int64_t end = S.offsets[r + 1];
-            const int64_t gk = hit_coord(H, S, r, g);
-            const uint32_t nw = n_window(S.nmask, g);
-            const uint64_t cw = code_window(S.codes, g);
-            while (flags) {
-                const int slot = (__ffs((int) flags) - 1) >> 1;
-                flags &= flags - 1u;
-                const int32_t pm = group_motifs[group * kGroupSlots + slot];
-                if (pm < 0) continue;
-                const int W = Pw.width[pm];
-                if (g + W > end) continue;                              // window runs past its region (cscore.c:340)
-                if (nw & low_mask(W)) continue;                         // scored by neval_kernel
+        const unsigned long long i0 = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+        uint64_t c[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            live[u] = i0 + u * per_sub < n;
+            c[u] = live[u] ? cand[i0 + u * per_sub] : 0;
+        }
+        // independent of each other: region hint, sequence words, N words, first flagged motif
+        int64_t g[U], lo[U];
+        uint64_t cw[U];
+        uint32_t nw[U], flags[U];
+        int32_t group[U], pm[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            g[u] = (int64_t) (c[u] >> 30);
+            group[u] = (int32_t) ((c[u] >> 16) & 0x3FFFu);
+            uint32_t f = (uint32_t) c[u] & 0xFFFFu;                    // bit n = field n; motif slot n >> 1
+            flags[u] = (f | (f >> 1)) & 0x5555u;                        // both strands are re-scored anyway
+            lo[u] = S.blk2reg[g[u] >> 6];
+            cw[u] = code_window(S.codes, g[u]);
+            nw[u] = n_window(S.nmask, g[u]);
+            pm[u] = flags[u] ? group_motifs[group[u] * kGroupSlots + ((__ffs((int) flags[u]) - 1) >> 1)] : -1;
+        }
+        // second hop: the region's bounds, the first motif's width / table offset
+        int64_t r[U], beg[U], end[U];
+        int W[U];
+        int64_t toff[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t o0 = S.offsets[lo[u]], o1 = S.offsets[lo[u] + 1];
+            const int64_t o2 = lo[u] + 2 <= S.R ? S.offsets[lo[u] + 2] : o1;
+            if (g[u] < o1) { r[u] = lo[u]; beg[u] = o0; end[u] = o1; }
+            else if (g[u] < o2) { r[u] = lo[u] + 1; beg[u] = o1; end[u] = o2; }
+            else { r[u] = find_region(S, g[u]); beg[u] = S.offsets[r[u]]; end[u] = S.offsets[r[u] + 1]; }      // tiny regions
+            W[u] = pm[u] >= 0 ? Pw.width[pm[u]] : 0;
+            toff[u] = pm[u] >= 0 ? Pw.tab_off[pm[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!live[u]) continue;
+            const int64_t gk = H.pbits ? (int64_t) (((uint64_t) r[u] << H.pbits) | (uint64_t) (g[u] - beg[u])) : g[u];
+            bool first = true;
+            while (flags[u]) {
+                const int slot = (__ffs((int) flags[u]) - 1) >> 1;
+                flags[u] &= flags[u] - 1u;
+                int32_t m = pm[u];
+                int w = W[u];
+                int64_t to = toff[u];
+                if (!first) {                                            // further motifs of the group: rare
+                    m = group_motifs[group[u] * kGroupSlots + slot];
+                    if (m >= 0) { w = Pw.width[m]; to = Pw.tab_off[m]; }
+                }
+                first = false;
+                if (m < 0) continue;
+                if (g[u] + w > end[u]) continue;                         // window runs past its region (cscore.c:340)
+                if (nw[u] & low_mask(w)) continue;                       // scored by neval_kernel
                 double fwd, rev;
-                score_window32(Pw.tab2 + Pw.tab_off[pm], W, cw, 0u, fwd, rev);      // no N in the window (checked above)
-                test_and_stage(st, H, Pw, (uint32_t) pm, gk, fwd, rev, strand_mask);
+                score_window32(Pw.tab2 + to, w, cw[u], 0u, fwd, rev);    // no N in the window (checked above)
+                test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask);
             }
         }
         __syncthreads();
-        const bool full = st.n > (unsigned int) (kHitStage - 1024);
+        const bool full = st.n > (unsigned int) (kHitStage - 256 * 2 * U);
         __syncthreads();                     // every thread has read st.n before any wave can append again: the decision is block-uniform
         if (full) stage_flush(st, H);
     }
