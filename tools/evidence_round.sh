@@ -1,27 +1,36 @@
-# Round evidence on the GPU box: tests, bench lines, profiles.  Usage: bash tools/evidence_round.sh <tag>
-TAG=${1:-r01}
+# Round evidence on the GPU box: tests, bench lines, profiles.  Usage: bash tools/evidence_round.sh <tag> [quick]
+TAG=${1:-r02}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
-python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
+python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -n 2 $OUT/pytest_gpu.log
 if [ "$2" = "quick" ]; then QUICK=1; fi
-python bench.py > $OUT/bench_c4shard.json 2> $OUT/bench_c4shard.err
+python bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+MS_BENCH_BACKEND=gloo MS_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 5 --no-cpu-baseline > $OUT/bench_c4_2ranks_one_gpu_gloo.json 2> $OUT/bench_c4_2ranks_one_gpu_gloo.log
 if [ -z "$QUICK" ]; then
-python bench.py --workload c3 > $OUT/bench_c3.json 2> /dev/null
-python bench.py --workload c2 --steps 200 --warmup 20 > $OUT/bench_c2.json 2> /dev/null
+python bench.py --workload c3 --no-end-to-end > $OUT/bench_c3.json 2> /dev/null
+python bench.py --workload c2 --steps 200 --warmup 20 --no-end-to-end > $OUT/bench_c2.json 2> /dev/null
 python bench.py --workload c5shard --steps 4 --warmup 1 > $OUT/bench_c5shard.json 2> /dev/null
+python bench.py --workload c5 --genome-mbp 3000 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_3000mbp.json 2> $OUT/bench_c5.err
 python tools/pf_clock.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_clock.log
 python tools/pf_uniform.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_uniform_width.log
-python tools/pf_variants.py c4shard 16:1 18:1 17:2 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
-python tools/e2e_time.py 2>&1 | grep -v amdgpu.ids > $OUT/end_to_end_pcie.log
+python tools/pf_variants.py c4shard 16:1 19:1 18:1 17:2 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
+python tools/once_overlap.py 2>&1 | grep -v amdgpu.ids > $OUT/scan_once_overlap.log
 ./tools/ubench/mfma_i8_rate > $OUT/mfma_i8_rate.log 2>&1
+./tools/ubench/mfma_f6_probe > $OUT/mfma_f6_probe.log 2>&1
+python tests/fuzz_parity.py --cases 1500 --seed 20000 > $OUT/fuzz.log 2>&1
+python tests/fuzz_parity.py --cases 300 --seed 30000 --sweep >> $OUT/fuzz.log 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 P=$OUT/prof
 mkdir -p $P
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $P/bench_under_rocprof.json 2> $P/stats.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $P/sq1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/sq1.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $P/sq2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/sq2.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/write.err
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/lds -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/lds.err
-ls $OUT $P
+B="python3 bench.py --no-cpu-baseline --no-end-to-end"
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $B --steps 5 --warmup 2 > $P/bench_under_rocprof.json 2> $P/stats.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $P/sq1 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq1.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $P/sq2 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq2.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/write.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/lds -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/lds.err
+for q in sq1 sq2 fetch write lds; do python3 tools/pmc_summary.py $P/$q $OUT/pmc_$q.csv; done
+cp $(ls $P/stats/*/*kernel_stats.csv | head -n 1) $OUT/kernel_stats_c4.csv
+rm -rf $P/sq1 $P/sq2 $P/fetch $P/write $P/lds $P/stats
+ls $OUT
