@@ -1466,6 +1466,7 @@ int ms_scan_sweep(const ms_pwmset *pwms_c, const ms_genome *g, int32_t chrom, in
     *out = nullptr;
     if (!pwms_c || !g) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
+    if (flags & ~(uint32_t) MS_SCAN_EXACT_ONLY) { set_error("unknown scan flags 0x%x", flags); return MS_ERR_INVALID; }
     if (window < 1 || stride < 1) { set_error("window and stride must be positive"); return MS_ERR_INVALID; }
     if (begin < 0 || end < begin) { set_error("bad span [%lld, %lld)", (long long) begin, (long long) end); return MS_ERR_INVALID; }
     const int64_t n_windows = end - begin >= window ? (end - begin - window) / stride + 1 : 0;

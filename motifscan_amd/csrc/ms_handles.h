@@ -18,7 +18,7 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     uint64_t *cand = nullptr;     size_t cand_cap = 0;
     uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
-    int64_t *nlist = nullptr;     size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
+    NPos *nlist = nullptr;        size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
     unsigned long long *tile_state = nullptr;  size_t tile_cap = 0;   // look-back states of the ordered re-scoring
     unsigned long long *counters = nullptr;      // 8 words, see scan_locked
     unsigned long long *h_counters = nullptr;    // pinned

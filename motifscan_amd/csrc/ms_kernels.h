@@ -20,6 +20,16 @@ struct DevSeq {
     int64_t n_bases;
 };
 
+// One position whose window may overlap a non-ACGT base, prepared once (nprep_kernel) for the 73 motif-chunk rows of
+// neval_kernel blocks that all visit it: 32 bytes, read with two 16-byte loads.
+struct NPos {
+    int64_t g;                // global base position
+    uint64_t cw;              // the next 32 bases (2-bit codes)
+    int64_t coord;            // hit coordinate (HitOut: region << pbits | position, or the global position)
+    uint32_t nw;              // the next 32 bases' non-ACGT bits
+    int32_t room;             // bases left in the position's region (capped at 64)
+};
+
 struct DevPwm {
     const double2 *tab2;      // see ms_kernels.hip header
     const int64_t *tab_off;   // [P] offset of motif p in tab2 (double2 units)
@@ -94,7 +104,7 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 int prefilter_set_lds(int variant, bool meas, size_t bytes);
 int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
-                   int strand_mask, int64_t *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
+                   int strand_mask, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
                    hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);

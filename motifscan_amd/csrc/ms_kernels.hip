@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
 //   nlist_kernel  one thread per 32 positions: list the positions whose next max_w bases hold an N
 //   neval_kernel  one thread per (listed position, chunk of kNwMotifChunk motifs)
 __global__ void __launch_bounds__(256) nlist_kernel(const uint32_t *__restrict__ nmask, int64_t n_bases, int max_w,
-                                                    int64_t *__restrict__ list, unsigned long long *__restrict__ n_list,
+                                                    NPos *__restrict__ list, unsigned long long *__restrict__ n_list,
                                                     uint64_t cap) {
     const int64_t n_words = (n_bases + 31) / 32;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
@@ -756,14 +756,33 @@ __global__ void __launch_bounds__(256) nlist_kernel(const uint32_t *__restrict__
         while (qual) {
             const int b = __ffs((int) qual) - 1;
             qual &= qual - 1u;
-            if (i < cap) list[i] = j * 32 + b;
+            if (i < cap) list[i].g = j * 32 + b;
             i++;
         }
     }
 }
 
+// everything about a listed position that does not depend on the motif, computed once
+__global__ void __launch_bounds__(256) nprep_kernel(const DevSeq S, NPos *__restrict__ list, const unsigned long long *__restrict__ n_list,
+                                                    uint64_t cap, const HitOut H) {
+    unsigned long long n = *n_list;
+    if (n > cap) n = cap;
+    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long) gridDim.x * blockDim.x) {
+        const int64_t g = list[i].g;
+        const int64_t r = find_region(S, g);
+        const int64_t room = S.offsets[r + 1] - g;
+        NPos q;
+        q.g = g;
+        q.cw = code_window(S.codes, g);
+        q.nw = n_window(S.nmask, g);
+        q.coord = hit_coord(H, S, r, g);
+        q.room = (int32_t) (room < 64 ? room : 64);
+        list[i] = q;
+    }
+}
+
 __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm Pw, const int32_t *__restrict__ motifs,
-                                                    int32_t n_motifs, int strand_mask, const int64_t *__restrict__ list,
+                                                    int32_t n_motifs, int strand_mask, const NPos *__restrict__ list,
                                                     const unsigned long long *__restrict__ n_list, uint64_t cap,
                                                     const HitOut H) {
     // the block's motifs never change: their fp64 tables are read from LDS, not through L1/L2
@@ -823,17 +842,15 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
     __syncthreads();
     for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long) gridDim.x * blockDim.x) {
-        const int64_t g = list[i];
-        const uint32_t nw = n_window(S.nmask, g);
-        const uint64_t cw = code_window(S.codes, g);
-        const int64_t r = find_region(S, g);
-        const int64_t end = S.offsets[r + 1];
-        const int64_t gk = hit_coord(H, S, r, g);
+        const NPos q = list[i];
+        const uint32_t nw = q.nw;
+        const uint64_t cw = q.cw;
+        const int64_t gk = q.coord;
         for (int m = 0; m < cnt; m++) {
             const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
             const uint32_t nm = nw & low_mask(W);
             if (nm == 0) continue;
-            if (g + W > end) continue;
+            if (W > q.room) continue;                           // window runs past its region (cscore.c:340)
             const int a = __ffs((int) nm) - 1, b = 32 - __clz((int) nm);
             if (__popc(nm) == b - a) {                           // one contiguous run (the usual case): bound by the columns outside it
                 const double fl = s_floor[m];
@@ -1443,12 +1460,14 @@ int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_til
 }
 
 int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
-                   int strand_mask, int64_t *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
+                   int strand_mask, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
                    hipStream_t st) {
     if (S.n_bases == 0 || n_motifs == 0) return MS_OK;
     const int64_t want = ((S.n_bases + 31) / 32 + 255) / 256;
     hipLaunchKernelGGL(nlist_kernel, dim3((unsigned) (want < 4096 ? want : 4096)), dim3(256), 0, st, S.nmask, S.n_bases,
                        max_w, list, n_list, list_cap);
+    MS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nprep_kernel, dim3(1024), dim3(256), 0, st, S, list, n_list, list_cap, H);
     MS_HIP(hipGetLastError());
     dim3 grid(64, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));      // few, fat blocks: block dispatch, not work, bounds this kernel
     hipLaunchKernelGGL(neval_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, list, n_list, list_cap, H);

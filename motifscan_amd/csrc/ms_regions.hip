@@ -109,6 +109,7 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
     if (n_regions < 0 || (n_regions > 0 && (!chrom || !start || !end))) { set_error("bad region arrays"); return MS_ERR_INVALID; }
     if (n_regions >= (1LL << 31)) { set_error("too many regions"); return MS_ERR_INVALID; }
+    if (flags & ~(uint32_t) MS_SCAN_EXACT_ONLY) { set_error("unknown scan flags 0x%x", flags); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     const ms_seqset *G = reinterpret_cast<const ms_seqset *>(g);
     const int64_t n_chroms = G->R;
