@@ -11,7 +11,7 @@ driver's torchrun it simply is one of the ranks.
 Workload (default "c4" = BASELINE.json configs[3] IN FULL: 1M input + 1M control regions x 500 bp x 579 PWMs): every
 rank takes its contiguous share of both region sets (dist.shard_bounds arithmetic), so 1 -> 8 GPUs is STRONG scaling on
 the north-star workload.  A "step" is one pass of the hot path over the rank's share, starting from ASCII bases resident
-in HBM: per region set  pack (extraction -> 2-bit codes + N mask) -> int8 matrix-core pre-filter -> fp64 re-scoring ->
+in HBM: per region set  pack (extraction -> 2-bit codes + N mask) -> fp6 x fp4 matrix-core pre-filter -> fp64 re-scoring ->
 ordering -> coordinates / per-motif region counts;  then the path's ONE collective, the all-reduce of the device-resident
 int64[2 x 579] count vector (stats.py:29-31 input).  Hits stay in HBM inside the timed region: `value` is the
 device-resident whole-job rate.  SURVEY.md 8(d)'s end-to-end metric (host ASCII in pinned memory -> hit arrays in pinned
@@ -37,6 +37,8 @@ HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 LDS_PEAK = 256 * 256 * 2.4e9      # B/s: 256 B/clk/CU (ds_read_b128) x 256 CUs x 2.4 GHz
 I8_MFMA_PEAK = 256 * 4 * 2048 * 2.4e9   # op/s: v_mfma_i32_32x32x32_i8 = 65536 ops per 32 cycles per SIMD (measured, tools/ubench),
                                         # 1024 SIMDs, 2.4 GHz = 5.03e15 = 2 x the dense bf16 peak of MI355X_MICROARCH.md
+F6_MFMA_PEAK = 2 * I8_MFMA_PEAK         # op/s: v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 / fp4 operands = 131072 ops per 32 cycles per SIMD
+                                        # (measured 32.6, tools/ubench/mfma_f6_probe) = 1.0e16 = the guide's ~10 PF dense FP6/FP4 peak
 
 WORKLOAD_TEXT = {
     "c4": "BASELINE configs[3] in full: 1M input + 1M control regions x 500 bp x 579 PWMs, region-sharded over the ranks",
@@ -300,17 +302,21 @@ def main():
         hbm = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                "traffic": traffic, "kernel": "prefilter_kernel", "kernel_ms": pf_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if engine >= 1:
-            # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe: algorithmic ops =
+            # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe / VALU issue: algorithmic ops =
             # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the
-            # kernel ISSUES is 4x that (one-hot: 4 k-slots per base) plus padding of widths to 8 columns
+            # kernel ISSUES is 4x that (one-hot: 4 k-slots per base) plus padding of widths to 8 (engine 3: 16) columns.
+            # peak = the dense matrix peak of the operand types the kernel feeds the pipe (engine 3: fp6 x fp4, 2x the int8 peak)
             alg_ops = sum(s["mfma_ops_algorithmic"] for s in all_stats) / n_launch
             issued = sum(s["mfma_ops"] for s in all_stats) / n_launch
-            roofline = {"bound": "mfma", "achieved": alg_ops / (pf_ms * 1e-3) / 1e12, "peak": I8_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                        "frac": alg_ops / (pf_ms * 1e-3) / I8_MFMA_PEAK, "traffic": traffic, "kernel": "prefilter_mfma_kernel",
-                        "kernel_ms": pf_ms, "algorithmic_ops_per_launch": alg_ops, "dtype": "int8 x int8 -> int32"}
-            on_chip = {"bound": "matrix pipe (issued int8 ops incl. one-hot zeros and width padding)",
-                       "achieved": issued / (pf_ms * 1e-3) / 1e12, "peak": I8_MFMA_PEAK / 1e12, "unit": "TOP/s",
-                       "frac": issued / (pf_ms * 1e-3) / I8_MFMA_PEAK, "issued_ops_per_launch": issued,
+            peak = F6_MFMA_PEAK if engine == 3 else I8_MFMA_PEAK
+            roofline = {"bound": "mfma", "achieved": alg_ops / (pf_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": alg_ops / (pf_ms * 1e-3) / peak, "traffic": traffic, "kernel": "prefilter_mfma_kernel",
+                        "kernel_ms": pf_ms, "algorithmic_ops_per_launch": alg_ops,
+                        "dtype": "fp6 (e2m3) x fp4 (e2m1, one-hot) -> f32, exact" if engine == 3 else "int8 x int8 -> int32",
+                        "frac_of_int8_peak": alg_ops / (pf_ms * 1e-3) / I8_MFMA_PEAK}
+            on_chip = {"bound": "matrix pipe (issued ops incl. one-hot zeros and width padding)",
+                       "achieved": issued / (pf_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TOP/s",
+                       "frac": issued / (pf_ms * 1e-3) / peak, "issued_ops_per_launch": issued,
                        "lds_TBps": lds_bytes / (pf_ms * 1e-3) / 1e12, "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
         else:
             roofline = hbm
@@ -325,7 +331,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f64 (every hit decision and score, as in the reference) behind an int8 one-hot matrix-core pre-filter (i32 accumulate)"
+            "dtype": ("f64 (every hit decision and score, as in the reference) behind an fp6 x fp4 one-hot matrix-core pre-filter (exact f32 accumulate)"
+                      if engine == 3 else
+                      "f64 (every hit decision and score, as in the reference) behind an int8 one-hot matrix-core pre-filter (i32 accumulate)"
                       if engine == 1 else
                       "f64 (every hit decision and score, as in the reference) behind an int8 Walsh-form matrix-core pre-filter (i32 accumulate)"
                       if engine == 2 else
@@ -532,7 +540,7 @@ def main_sweep(a, world, rank, local_rank):
             line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
                     "value": out["counts_only"]["value"], "unit": "bp*motifs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                     "ms_per_step": out["counts_only"]["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                    "dtype": "f64 behind an int8 one-hot matrix-core pre-filter (i32 accumulate)", "data": "synthetic",
+                    "dtype": "f64 behind an fp6 x fp4 one-hot matrix-core pre-filter (exact f32 accumulate)", "data": "synthetic",
                     "config": {"workload": WORKLOAD_TEXT["c5"], "genome_bp": int(lens.sum()), "n_chroms": len(lens), "window": window,
                                "stride": stride, "n_windows_total": int(spans_all[-1][3] + spans_all[-1][4]), "n_pwms": P,
                                "max_span_bases": max_span, "spans_total": len(spans_all)},
@@ -581,7 +589,7 @@ def main_sweep(a, world, rank, local_rank):
             line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
                     "value": float(un.item()) * a.steps / float(el.item()), "unit": "bp*motifs/s (reference-equivalent units)", "n_gpus": world,
                     "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(el.item()) / a.steps * 1e3, "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": "f64 behind an int8 one-hot matrix-core pre-filter (i32 accumulate)",
+                    "scaling": "weak", "vs_baseline": None, "dtype": "f64 behind an fp6 x fp4 one-hot matrix-core pre-filter (exact f32 accumulate)",
                     "data": "synthetic", "config": {"workload": WORKLOAD_TEXT["c5shard"], "n_pwms": P, "windows_per_gpu": wl["n_regions"]},
                     "stage_ms_per_scan": {q: sum(s[q] for s in stats) / k for q in ("ms_prefilter", "ms_exact", "ms_sort", "ms_finalize", "ms_total")},
                     "hits_per_scan": sum(s["n_hits"] for s in stats) / k}

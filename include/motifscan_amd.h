@@ -96,9 +96,9 @@ typedef struct ms_scan_stats {
     int64_t lds_bytes_read;     /* bytes the pre-filter reads from LDS (operand tables)              */
     int64_t hbm_bytes_algorithmic; /* codes + mask + offsets + PWMs + 16 B/hit + 8 B/PWM */
     double  pf_clock_mhz;       /* shader clock held inside the pre-filter kernel; 0 unless MS_PF_CLOCK=1 */
-    int64_t mfma_ops;           /* int8 multiply-adds x 2 the pre-filter issues on the matrix cores (0: LDS-lookup engine) */
+    int64_t mfma_ops;           /* multiply-adds x 2 the pre-filter issues on the matrix cores (0: LDS-lookup engine) */
     int64_t mfma_ops_algorithmic; /* 2 x windows x strands x W: the adds the reference performs */
-    int32_t pf_engine;          /* 1: int8 one-hot product on the matrix cores (default); 0: packed 2-mer LDS lookups */
+    int32_t pf_engine;          /* 3: fp6 x fp4 one-hot product on the matrix cores (default); 1 / 2: int8 forms; 0: packed 2-mer LDS lookups */
     int32_t reserved;
 } ms_scan_stats;
 

@@ -252,7 +252,7 @@ class PwmSet:
         bias = np.zeros((nq.value, 16), dtype=np.int32)
         kb = np.zeros(nq.value, dtype=np.int32)
         check(L.ms_debug_plan_mfma_rows(self.h, ptr(rows, ctypes.c_int16), ptr(bias, ctypes.c_int32), ptr(kb, ctypes.c_int32)))
-        cols = 10 if os.environ.get("MS_PF_ENGINE") == "2" else 8
+        cols = {"2": 10, "3": 16}.get(os.environ.get("MS_PF_ENGINE"), 8)
         return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "group_motifs": gm, "rows": rows, "bias": bias,
                 "group_kb": kb, "cols_per_kb": cols, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 

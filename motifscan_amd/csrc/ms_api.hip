@@ -276,10 +276,12 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
     return MS_OK;
 }
 
-// Pre-filter engine: 0 = packed 2-mer tables read per lane from LDS, 1 = int8 one-hot product on the matrix cores.
+// Pre-filter engine: 3 (default) = fp6 x fp4 one-hot product on the matrix cores (16 motif columns per instruction);
+// A/B (MS_MEASURE=1 MS_PF_ENGINE=n): 1 = int8 one-hot product (8 columns), 2 = int8 Walsh form (10 columns),
+// 0 = packed 2-mer tables read per lane from LDS.  All four are rigorous upper bounds: the result never depends on the choice.
 static int pf_engine() {
-    if (const char *e = measure_env("MS_PF_ENGINE")) { const int v = atoi(e); return v == 0 ? 0 : (v == 2 ? 2 : 1); }     // measurement / A-B switch
-    return 1;
+    if (const char *e = measure_env("MS_PF_ENGINE")) { const int v = atoi(e); return v == 0 ? 0 : (v == 2 ? 2 : (v == 1 ? 1 : 3)); }
+    return 3;
 }
 
 static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
@@ -344,7 +346,7 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
             std::vector<int32_t> nk(n_rt + 1, 0);
             for (size_t t = 0; t < n_rt; t++) {
                 nk[t] = pl.group_G[2 * t];
-                off16[t + 1] = off16[t] + (uint32_t) nk[t] * (kMfmaRowTileBytesPerKb / 16);
+                off16[t + 1] = off16[t] + (uint32_t) nk[t] * ((pl.engine == 3 ? kF6BytesPerKb : kMfmaRowTileBytesPerKb) / 16);
             }
             if ((rc = dev_alloc(&p->d_rt_off16, n_rt + 1))) return rc;
             if ((rc = dev_alloc(&p->d_rt_nk, n_rt + 1))) return rc;
@@ -783,7 +785,7 @@ namespace ms {
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
+    const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : pf_engine() == 3 ? kF6LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
     size_t lds_budget = c->lds_max - lds_fixed;
     int pf_blocks_per_cu = 1;
     if (const char *e = measure_env("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
@@ -819,7 +821,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             int64_t kb_sum = 0;                                                     // k-blocks over all row tiles (2 groups each)
             for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_sum += plan.group_G[q];
             const int64_t padded = ((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads;
-            stt.mfma_ops = padded / 32 * kb_sum * (2LL * 32 * 32 * 32);               // one 32x32x32 instruction per (32 windows, row tile, k-block)
+            stt.mfma_ops = padded / 32 * kb_sum * (2LL * 32 * 32 * (plan.engine == 3 ? 64 : 32));     // one 32x32x32 (engine 3: 32x32x64) instruction per (32 windows, row tile, k-block)
         }
     }
 
@@ -882,10 +884,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
     // kernel variant: engine 1 queues records without flags for the second tail form (expand_kernel decodes them)
-    int pf_variant = plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
+    int pf_variant = plan.engine == 3 ? 31 : plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_VARIANT")) {
         const int v = atoi(e) & 31;
-        const int v_engine = (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;
+        const int v_engine = (v >= 28 && v <= 31) ? 3 : (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;
         if (v_engine == plan.engine && !(v == 20 && tail != 2)) pf_variant = v;     // a variant of another engine cannot read this plan
     }
     if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
@@ -1668,7 +1670,8 @@ int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int16_t *rows, int32_t *bia
     if (pwms->plan_strand < 0 || pl.engine < 1) { set_error("no matrix-core plan: set MS_PF_ENGINE=1 or 2 and call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
     const size_t nq = pl.group_G.size();
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(pl.tables.data());
-    const int cols = pl.engine == 2 ? kW2Cols : 8;
+    const int cols = pl.engine == 2 ? kW2Cols : pl.engine == 3 ? kF6Cols : 8;
+    const size_t kb_bytes = pl.engine == 3 ? (size_t) kF6BytesPerKb : (size_t) kMfmaRowTileBytesPerKb;
     size_t off = 0;
     for (size_t q = 0; q < nq; q++) {
         const int kb_n = pl.group_G[q];
@@ -1684,7 +1687,9 @@ int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int16_t *rows, int32_t *bia
                 for (int b = 0; b < 4; b++) {
                     int v = 0;
                     if (c < cols * kb_n) {
-                        if (pl.engine == 2) {
+                        if (pl.engine == 3) {
+                            v = f6_value(f6_get(bytes + off, c / cols, row, c % cols, b));       // units of 1/8
+                        } else if (pl.engine == 2) {
                             const int s1 = (b & 1) ? -1 : 1, s2 = (b & 2) ? -1 : 1;
                             const int c1 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 0)];
                             const int c2 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 1)];
@@ -1697,7 +1702,7 @@ int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int16_t *rows, int32_t *bia
                     rows[((q * 16 + f) * 32 + c) * 4 + b] = (int16_t) v;
                 }
         }
-        if (h == 1) off += (size_t) kb_n * kMfmaRowTileBytesPerKb;
+        if (h == 1) off += (size_t) kb_n * kb_bytes;
     }
     return MS_OK;
 }

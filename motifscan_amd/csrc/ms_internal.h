@@ -69,7 +69,7 @@ struct TileDesc {
 // 2-mer tables in groups that share 16-byte entries, and how groups are cut into LDS tiles.
 struct PrefilterPlan {
     int strand_mask = 0;
-    int engine = 0;                      // 0: packed 2-mer tables read per lane from LDS; 1: int8 one-hot MFMA; 2: int8 Walsh-form MFMA (below)
+    int engine = 0;                      // 0: packed 2-mer tables read per lane from LDS; 1: int8 one-hot MFMA; 2: int8 Walsh-form MFMA; 3: fp6 x fp4 one-hot MFMA (below)
     std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in group order
     std::vector<int32_t> exact_motifs;   // motif ids scored in fp64 at every window
     std::vector<int32_t> group_motifs;   // [n_groups][kGroupSlots], -1 = empty slot
@@ -119,6 +119,65 @@ inline size_t mfma2_byte_index(int kb, int row, int col_in_kb, int slot) {      
 }
 inline size_t mfma2_spare_index(int row, int khalf) {                           // k-block 0
     return (size_t) (khalf * 32 + row) * 16 + 15;
+}
+
+// ---- engine 3: the product on the FP6 x FP4 block-scaled matrix instruction ---------------------------------------------
+// v_mfma_scale_f32_32x32x64_f8f6f4 takes K = 64 per instruction in the time the int8 instruction takes for K = 32 (measured:
+// profiles/r02_mfma_f6_probe.log), i.e. SIXTEEN motif columns per k-block.  A (PWM side) is fp6 e2m3, B (sequence side) the
+// one-hot image in fp4 e2m1 (1.0 = code 0x2), both with block scale 127 = 2^0; the f32 result is exact (entries are multiples
+// of 1/8 of magnitude <= 7.5, at most 32 of them add up).  Operand layout, probed with exact data: lane l = 32 * khalf + r
+// holds row (A) / window (B) r and the 32 consecutive k = 32 * khalf + j, value j at bits [6j, 6j + 6) of the lane's 192 bits
+// (A) / bits [4j, 4j + 4) of its 128 bits (B); here k-slot j of lane half khalf = motif column 8 * khalf + (j >> 2), base j & 3.
+// A row tile is stored per k-block as [plane 0..2][lane 0..63][8 bytes] (plane p = bits [64p, 64p + 64) of the lane's field):
+// three conflict-free ds_read_b64 at lane * 8.
+// Entries are in units of 1/8: v_c(b) = t_c - dq_c(b) with dq on the e2m3 grid {0..16, 18..32 step 2, 36..60 step 4}, 56 budget
+// levels, a clamped deficit = 60, and the offsets t = 16, 16, 16, 8 on the first four columns (multiples of 4 keep every
+// difference on the grid), so that acc = (56 - sum dq) / 8 >= 0  <=>  candidate: the sign bit of the f32 result.
+constexpr int kF6Cols = 16;                     // motif columns per k-block
+constexpr int kF6BytesPerKb = 3 * 64 * 8;       // 1536
+constexpr int kF6Levels = 56;
+inline bool f6_representable(int u) {           // |u| in units of 1/8
+    const int m = u < 0 ? -u : u;
+    return m <= 16 || (m <= 32 && (m & 1) == 0) || (m <= 60 && (m & 3) == 0);
+}
+inline uint32_t f6_code(int u) {                // e2m3: sign | exp(2) | mant(3), bias 1; u must be representable
+    const uint32_t sgn = u < 0 ? 32u : 0u;
+    const int m = u < 0 ? -u : u;
+    if (m == 0) return 0u;                      // never -0
+    if (m < 8) return sgn | (uint32_t) m;
+    if (m < 16) return sgn | (1u << 3) | (uint32_t) (m - 8);
+    if (m < 32) return sgn | (2u << 3) | (uint32_t) (m / 2 - 8);
+    return sgn | (3u << 3) | (uint32_t) (m / 4 - 8);
+}
+inline int f6_value(uint32_t code) {            // back to units of 1/8
+    const int e = (int) (code >> 3) & 3, m = (int) code & 7;
+    const int v = e == 0 ? m : (8 + m) << (e - 1);
+    return (code & 32u) ? -v : v;
+}
+inline size_t f6_bit_index(int kb, int row, int col_in_kb, int base, int *bit_in_lane) {   // byte offset of the lane's plane 0 word inside a row tile
+    const int khalf = col_in_kb >> 3;
+    *bit_in_lane = 6 * ((col_in_kb & 7) * 4 + base);
+    return (size_t) kb * kF6BytesPerKb + (size_t) (khalf * 32 + row) * 8;
+}
+inline void f6_put(uint8_t *tile, int kb, int row, int col_in_kb, int base, uint32_t code) {
+    int bit;
+    const size_t lane_off = f6_bit_index(kb, row, col_in_kb, base, &bit);
+    for (int i = 0; i < 6; i++) {
+        const int bb = bit + i;                 // plane bb / 64, bit bb % 64 of that plane's 8-byte word
+        uint8_t *byte = tile + lane_off + (size_t) (bb >> 6) * 512 + (size_t) ((bb & 63) >> 3);
+        if ((code >> i) & 1u) *byte |= (uint8_t) (1u << (bb & 7)); else *byte &= (uint8_t) ~(1u << (bb & 7));
+    }
+}
+inline uint32_t f6_get(const uint8_t *tile, int kb, int row, int col_in_kb, int base) {
+    int bit;
+    const size_t lane_off = f6_bit_index(kb, row, col_in_kb, base, &bit);
+    uint32_t code = 0;
+    for (int i = 0; i < 6; i++) {
+        const int bb = bit + i;
+        const uint8_t byte = tile[lane_off + (size_t) (bb >> 6) * 512 + (size_t) ((bb & 63) >> 3)];
+        code |= (uint32_t) ((byte >> (bb & 7)) & 1u) << i;
+    }
+    return code;
 }
 
 // Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes; min_field_bits 10 or 16.

@@ -10,6 +10,7 @@ constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spille
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
 constexpr size_t kMfmaLutBytes = 256 * 16;   // engine 1: byte of four 2-bit codes -> 16 one-hot operand bytes, after the wave queues
 constexpr size_t kMfma2LutBytes = 1024 * 16; // engine 2: ten bits of five 2-bit codes -> 15 Walsh operand bytes + the spare
+constexpr size_t kF6LutBytes = 256 * 8;      // engine 3: byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes)
 
 struct DevSeq {
     const uint32_t *codes;

@@ -660,6 +660,82 @@ __device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const cha
     }
 }
 
+// ---- engine 3: the same tiles on v_mfma_scale_f32_32x32x64_f8f6f4 (A fp6 e2m3, B fp4 one-hot), 16 motif columns per k-block
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ i32x16 as_bits(const f32x16 &c) {           // the f32 results as bit patterns: sign bit clear <=> value >= +0
+    i32x16 r;
+#pragma unroll
+    for (int j = 0; j < 16; j++) r[j] = __float_as_int(c[j]);
+    return r;
+}
+
+template <int NK, int V, bool MEAS>
+__device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
+                                              uint32_t byte_off, int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
+                                              int64_t g0, bool live0, bool live1) {
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
+    const char *p = lds + byte_off + lane * 8u;
+    constexpr int kStep = NK * kF6BytesPerKb;
+    // B operands: the lane's 8 bases of k-block kb (columns 16 kb + 8 h ...) as 32 fp4 one-hot k-slots = two table reads of 8 bytes
+    i32x8 b0[NK], b1[NK];
+#pragma unroll
+    for (int kb = 0; kb < NK; kb++) {
+        const uint32_t c0 = (uint32_t) (cw0 >> (32 * kb + 16 * h)) & 0xFFFFu, c1 = (uint32_t) (cw1 >> (32 * kb + 16 * h)) & 0xFFFFu;
+        const int2 l0 = *reinterpret_cast<const int2 *>(lut + ((c0 & 0xFFu) << 3)), h0 = *reinterpret_cast<const int2 *>(lut + ((c0 >> 8) << 3));
+        const int2 l1 = *reinterpret_cast<const int2 *>(lut + ((c1 & 0xFFu) << 3)), h1 = *reinterpret_cast<const int2 *>(lut + ((c1 >> 8) << 3));
+        b0[kb] = i32x8{l0.x, l0.y, h0.x, h0.y, 0, 0, 0, 0};
+        b1[kb] = i32x8{l1.x, l1.y, h1.x, h1.y, 0, 0, 0, 0};
+    }
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
+        i32x8 a[NK];
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) {
+            const int2 w0 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb);
+            const int2 w1 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 512);
+            const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
+            a[kb] = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+        }
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], z, 2, 4, 0, 127, 0, 127);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], z, 2, 4, 0, 127, 0, 127);
+#pragma unroll
+        for (int kb = 1; kb < NK; kb++) {
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b0[kb], c0, 2, 4, 0, 127, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, 127, 0, 127);
+        }
+    };
+    auto test = [&](const f32x16 &f0, const f32x16 &f1, int t) {
+        const i32x16 c0 = as_bits(f0), c1 = as_bits(f1);
+        if constexpr (V & 2) {                                // the two halves' maxima are kept for the rare path (this engine is VALU-issue bound)
+            const int m0 = max16(c0), m1 = max16(c1);
+            if (__builtin_expect(__any(max(m0, m1) >= 0) && !(MEAS && A.no_emit), 0)) {
+                const int32_t group = first_group + 2 * t + (int32_t) h;
+                if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
+                if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
+            }
+        } else {
+            if (__builtin_expect(__any(max32(c0, c1) >= 0) && !(MEAS && A.no_emit), 0))
+                mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
+        }
+    };
+    constexpr int ILP = (V & 1) ? 2 : 1;
+    int t = 0;
+    for (; t + ILP <= n_row_tiles; t += ILP, p += ILP * kStep) {
+        f32x16 c0[ILP], c1[ILP];
+#pragma unroll
+        for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
+#pragma unroll
+        for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
+    }
+    for (; t < n_row_tiles; t++, p += kStep) {
+        f32x16 c0, c1;
+        product(p, c0, c1);
+        test(c0, c1, t);
+    }
+}
+
 // grid = (blocks per tile, tiles); NT / 64 waves per block, each takes 64 consecutive window starts
 // per iteration (lanes l and l + 32 share window l & 31 and hold the two halves of every k-block).
 // Dynamic LDS: operand tables of the tile | wave queues | B-operand table (kMfmaLutBytes / kMfma2LutBytes).
@@ -683,7 +759,16 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
     const uint4 *__restrict__ src = A.tables + T->table_off16;
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     uint4 *lut4 = lds4 + A.wq_off16 + kWqBytes / 16;
-    if constexpr (ENG == 2) {
+    if constexpr (ENG == 3) {
+        // byte of four 2-bit codes -> 16 fp4 k-slots (8 bytes): slot 4 c + code_c = 1.0 (e2m1 code 0x2)
+        uint2 *lut2 = reinterpret_cast<uint2 *>(lut4);
+        for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
+            unsigned long long w = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) w |= 2ULL << (4 * (4 * c + (int) ((i >> (2 * c)) & 3u)));
+            lut2[i] = make_uint2((uint32_t) w, (uint32_t) (w >> 32));
+        }
+    } else if constexpr (ENG == 2) {
         for (uint32_t i = threadIdx.x; i < 1024u; i += NT) lut4[i] = walsh5(i);
     } else {
         for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
@@ -711,6 +796,11 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
         for (int i = 0; i < n_classes; i++) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
+            if constexpr (ENG == 3) {
+                if (cd.G == 1) mfma_class_f6<1, V, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1);
+                else if (cd.G == 2) mfma_class_f6<2, V, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1);
+                continue;
+            }
             switch (cd.G) {
                 case 1: mfma_class<1, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
                 case 2: mfma_class<2, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
@@ -1433,6 +1523,11 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
         case 23: *threads = 512; return prefilter_mfma_kernel<512, 2, 1, true, 2, 6>;    // A/B: <= 2 k-blocks, 3 x 8 waves per CU (MS_PF_BLOCKS_PER_CU=3)
         case 26: *threads = 640; return prefilter_mfma_kernel<640, 2, 1, true, 2, 5>;    // A/B: <= 2 k-blocks, 2 x 10 waves per CU (MS_PF_BLOCKS_PER_CU=2), <= 96 VGPRs
         case 27: *threads = 1024; return prefilter_mfma_kernel<1024, 9, 1, true>;  // A/B: one branch per pair of tiles
+        case 28: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 3, true>;       // engine 3 (fp6 x fp4, 16 columns per k-block), two row tiles in flight
+        case 29: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true>;       // engine 3, one row tile in flight
+        case 30: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 2, 6>;   // engine 3, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
+        case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path: the default
+            return meas ? prefilter_mfma_kernel<1024, 3, 3, true> : prefilter_mfma_kernel<1024, 3, 3, false>;
         case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default
             return meas ? prefilter_mfma_kernel<1024, 5, 1, true> : prefilter_mfma_kernel<1024, 5, 1, false>;
         case 24: *threads = 1024;                                          // engine 2 (Walsh form: 10 columns per k-block)

@@ -402,11 +402,53 @@ bool quantize_strand_w2(const double e[4][kMaxFastWidth], int W, double T, W2Str
     return false;
 }
 
+// Engine 3 (ms_internal.h): the same deficits on the fp6 e2m3 grid, in units of 1/8.
+struct F6Strand {
+    int8_t u[kMaxFastWidth][4];     // t_c - dq_c(b)
+    int levels;
+};
+
+inline int f6_grid_floor(int q) { return q <= 16 ? q : (q <= 32 ? (q & ~1) : (q & ~3)); }
+
+bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, F6Strand *out) {
+    std::memset(out->u, 0, sizeof(out->u));
+    out->levels = 0;
+    double hi[kMaxFastWidth], Mx = 0, lowest = 0;
+    for (int c = 0; c < W; c++) {
+        hi[c] = std::max(std::max(e[0][c], e[1][c]), std::max(e[2][c], e[3][c]));
+        Mx += hi[c];
+        lowest += std::min(std::min(e[0][c], e[1][c]), std::min(e[2][c], e[3][c]));
+    }
+    const double budget = Mx - T;
+    if (!(budget >= 0)) {                       // dead: no N-free window reaches T -> acc = -1/8 everywhere
+        for (int b = 0; b < 4; b++) out->u[0][b] = -1;
+        return true;
+    }
+    if (!(T > lowest)) return false;            // every window passes
+    if (W < 4) return false;                    // the offsets need four columns
+    const int Bq = kF6Levels;
+    const double s = budget > 0 ? ((double) Bq + 0.5) / budget : 1e300;
+    static const int t[4] = {16, 16, 16, 8};
+    for (int c = 0; c < W; c++)
+        for (int b = 0; b < 4; b++) {
+            const double d = hi[c] - e[b][c];
+            double q = d <= 0 ? 0.0 : std::floor(std::min(d * s * (1 - 1e-12) - 1e-7, 1e6));
+            if (!(q >= 0)) q = 0;
+            const int dq = q > Bq ? 60 : f6_grid_floor((int) q);          // down to the grid; beyond the budget: 60 sinks the window alone
+            const int u = (c < 4 ? t[c] : 0) - dq;
+            if (!f6_representable(u)) return false;                       // (cannot happen: offsets are multiples of 4)
+            out->u[c][b] = (int8_t) u;
+        }
+    out->levels = Bq;
+    return true;
+}
+
 struct FastMotifI8 {
     int32_t id;
     int32_t W;
     I8Strand strand[2];
     W2Strand w2[2];
+    F6Strand f6[2];
 };
 
 }  // namespace
@@ -416,9 +458,10 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
                     size_t lds_budget, int engine, PrefilterPlan *plan) {
     *plan = PrefilterPlan();
     plan->strand_mask = strand_mask;
-    plan->engine = engine == 2 ? 2 : 1;
-    const int cols = plan->engine == 2 ? kW2Cols : 8;              // motif columns per k-block
+    plan->engine = engine == 2 ? 2 : engine == 3 ? 3 : 1;
+    const int cols = plan->engine == 2 ? kW2Cols : plan->engine == 3 ? kF6Cols : 8;              // motif columns per k-block
     const int max_w = plan->engine == 2 ? kW2MaxWidth : kMaxFastWidth;
+    const size_t kb_bytes = plan->engine == 3 ? (size_t) kF6BytesPerKb : (size_t) kMfmaRowTileBytesPerKb;
     std::vector<FastMotifI8> fast;
     fast.reserve(n_pwms);
     for (int32_t p = 0; p < n_pwms; p++) {
@@ -432,14 +475,17 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
         for (int sd = 0; ok && sd < 2; sd++) {
             std::memset(&fm.strand[sd], 0, sizeof(I8Strand));
             std::memset(&fm.w2[sd], 0, sizeof(W2Strand));
+            std::memset(&fm.f6[sd], 0, sizeof(F6Strand));
             for (int b = 0; b < 4; b++) fm.strand[sd].v[0][b] = -1;      // never a candidate unless quantised below
+            for (int b = 0; b < 4; b++) fm.f6[sd].u[0][b] = -1;
             fm.w2[sd].bias = -1;
             if (!(strand_mask & (1 << sd))) continue;                    // strand not asked for
             double e[4][kMaxFastWidth];
             for (int b = 0; b < 4; b++)
                 for (int c = 0; c < W; c++)
                     e[b][c] = sd == 0 ? m[(int64_t) b * W + c] : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
-            ok = plan->engine == 2 ? quantize_strand_w2(e, W, T, &fm.w2[sd]) : quantize_strand_i8(e, W, T, &fm.strand[sd]);
+            ok = plan->engine == 2 ? quantize_strand_w2(e, W, T, &fm.w2[sd])
+                 : plan->engine == 3 ? quantize_strand_f6(e, W, T, &fm.f6[sd]) : quantize_strand_i8(e, W, T, &fm.strand[sd]);
         }
         if (ok) fast.push_back(fm);
         else plan->exact_motifs.push_back(p);
@@ -455,7 +501,7 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
     std::vector<size_t> rt_off(n_rt + 1, 0);
     for (size_t t = 0; t < n_rt; t++) {
         for (size_t j = 16 * t; j < std::min(fast.size(), 16 * (t + 1)); j++) rt_kb[t] = std::max(rt_kb[t], (fast[j].W + cols - 1) / cols);
-        rt_off[t + 1] = rt_off[t] + (size_t) rt_kb[t] * kMfmaRowTileBytesPerKb;
+        rt_off[t + 1] = rt_off[t] + (size_t) rt_kb[t] * kb_bytes;
     }
     std::vector<uint8_t> bytes(rt_off[n_rt], 0);
     plan->group_motifs.assign(2 * n_rt * kGroupSlots, -1);
@@ -470,6 +516,17 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
                 const size_t j = 16 * t + 8 * h + slot;
                 for (int sd = 0; sd < 2; sd++) {
                     const int row = mfma_row_of(h, 2 * slot + sd);
+                    if (plan->engine == 3) {
+                        // empty slot / dead strand: -1/8 at column 0 for every base -> never a candidate; columns past W stay +0
+                        for (int c = 0; c < kF6Cols * rt_kb[t] && c < kMaxFastWidth; c++)
+                            for (int b = 0; b < 4; b++) {
+                                int u = 0;
+                                if (j >= fast.size()) u = c == 0 ? -1 : 0;
+                                else if (c < fast[j].W) u = fast[j].f6[sd].u[c][b];
+                                f6_put(tab, c / kF6Cols, row, c % kF6Cols, b, f6_code(u));
+                            }
+                        continue;
+                    }
                     if (plan->engine == 2) {
                         // bias = 64 * a_hi + a_lo in the spare bytes of k-block 0; an empty slot or dead strand: bias -1, no coefficients
                         const int32_t bias = j < fast.size() ? fast[j].w2[sd].bias : -1;
@@ -500,7 +557,7 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
                 }
             }
         }
-        plan->lds_bytes_per_position += (int64_t) rt_kb[t] * kMfmaRowTileBytesPerKb / 64;     // A-operand bytes per window start (2 x 32 windows share a read)
+        plan->lds_bytes_per_position += (int64_t) rt_kb[t] * (int64_t) kb_bytes / 64;     // A-operand bytes per window start (2 x 32 windows share a read)
     }
     for (const FastMotifI8 &fm : fast) plan->fast_motifs.push_back(fm.id);
     plan->tables.resize(bytes.size() / 4);
@@ -509,7 +566,7 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
     // LDS tiles (whole row tiles; work ~ bytes), classes = runs of equal k-block count
     if (n_rt > 0) {
         const size_t total = rt_off[n_rt];
-        const size_t budget = std::max<size_t>(lds_budget, (size_t) 4 * kMfmaRowTileBytesPerKb);
+        const size_t budget = std::max<size_t>(lds_budget, (size_t) 4 * kb_bytes);
         const size_t n_tiles = (total + budget - 1) / budget;
         const size_t target = (total + n_tiles - 1) / n_tiles;
         size_t q = 0;
@@ -520,7 +577,7 @@ int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t 
             t.first_group = (int32_t) (2 * q);
             size_t used = 0;
             while (q < n_rt) {
-                const size_t need = (size_t) rt_kb[q] * kMfmaRowTileBytesPerKb;
+                const size_t need = (size_t) rt_kb[q] * kb_bytes;
                 if (used > 0 && (used + need > budget || used >= target)) break;
                 if (t.n_classes == 0 || t.cls[t.n_classes - 1].G != rt_kb[q]) {
                     ClassDesc &cd = t.cls[t.n_classes++];

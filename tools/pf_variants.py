@@ -26,7 +26,7 @@ for rep in range(2):
     for noemit in (0, 1):
         for v, b in combos:
             os.environ["MS_PF_VARIANT"] = str(v)
-            os.environ["MS_PF_ENGINE"] = "2" if v in (24, 25) else "1" if v >= 16 else "0"       # variants >= 16: int8 matrix-core engines
+            os.environ["MS_PF_ENGINE"] = "3" if v >= 28 else "2" if v in (24, 25) else "1" if v >= 16 else "0"       # variants >= 16: int8 matrix-core engines
             os.environ["MS_PF_BLOCKS_PER_CU"] = str(b)
             os.environ["MS_PF_NOEMIT"] = str(noemit)
             ms = []
