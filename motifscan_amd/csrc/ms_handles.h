@@ -41,7 +41,7 @@ struct DeviceCtx {
     hipStream_t stream_up = nullptr;         // sequence upload + packing (runs beside a scan of the previous batch)
     hipStream_t stream_down = nullptr;       // copy-out of hit arrays (runs beside a scan of the next batch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     int n_cu = 0;
     size_t lds_max = 0;
     size_t lds_set[64] = {};                // dynamic-LDS attribute already raised to this, per kernel variant (+32: measurement instantiation)

@@ -104,9 +104,9 @@ struct PfArgs {
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
 int prefilter_set_lds(int variant, bool meas, size_t bytes);
 int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
-int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
-                   int strand_mask, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
-                   hipStream_t st);
+int launch_nlist(const DevSeq &S, int max_w, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H, hipStream_t st);
+int launch_neval(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask, const NPos *list,
+                 const unsigned long long *n_list, uint64_t list_cap, const HitOut &H, int n_blocks_max, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,

@@ -25,6 +25,9 @@
 //   dedup / compact / site_tables kernels   scanner.py:156-193 and io/__init__.py:23-33 on the sorted hits
 //   extract_kernel    regions cut out of a genome that is resident as 2-bit codes (scanner.py:71-87)
 //   blk2reg_kernel    region of every 64th position, so later position -> region lookups are O(1)
+#include <algorithm>
+#include <cstdlib>
+
 #include "ms_device.h"
 
 namespace ms {
@@ -930,28 +933,64 @@ __global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm
         }
     }
     __syncthreads();
-    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long) gridDim.x * blockDim.x) {
-        const NPos q = list[i];
-        const uint32_t nw = q.nw;
-        const uint64_t cw = q.cw;
-        const int64_t gk = q.coord;
-        for (int m = 0; m < cnt; m++) {
-            const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
-            const uint32_t nm = nw & low_mask(W);
-            if (nm == 0) continue;
-            if (W > q.room) continue;                           // window runs past its region (cscore.c:340)
-            const int a = __ffs((int) nm) - 1, b = 32 - __clz((int) nm);
-            if (__popc(nm) == b - a) {                           // one contiguous run (the usual case): bound by the columns outside it
-                const double fl = s_floor[m];
-                const bool dead_f = !(strand_mask & 1) || s_pre[m][0][a] + s_suf[m][0][b] < fl;
-                const bool dead_r = !(strand_mask & 2) || s_pre[m][1][a] + s_suf[m][1][b] < fl;
-                if (dead_f && dead_r) continue;
-            }
-            double fwd, rev;
-            score_window32(s_tab + s_off[m], W, cw, nw, fwd, rev);
-            test_and_emit(H, Pw, (uint32_t) s_motif[m], gk, fwd, rev, strand_mask);
+    // Two phases per round of 256 positions, so that the fp64 scoring runs DENSE: (1) every lane checks its position against the
+    // block's 8 motifs (does the window reach an N, does it fit its region, can its non-N columns reach the cutoff) and queues
+    // the few (position, motif) pairs that survive; (2) the lanes take one queued pair each.  Scoring inline would make every wave
+    // execute the scoring path for every motif as soon as ONE of its 64 positions needs it (measured: 0.35 -> see DESIGN.md).
+    constexpr int U = 1;                                  // positions per lane and round (4 with a quarter of the blocks measured 20-70 % slower: the kernel wants many small blocks)
+    constexpr unsigned int kWorkCap = 4096;
+    __shared__ uint16_t s_work[kWorkCap];                 // (position slot in the round: 10 bits) << 3 | motif of the block
+    __shared__ unsigned int s_nwork;
+    const unsigned long long per_sub = (unsigned long long) gridDim.x * blockDim.x;
+    const unsigned long long per_round = per_sub * U;
+    const unsigned long long rounds = (n + per_round - 1) / per_round;
+    for (unsigned long long rd = 0; rd < rounds; rd++) {
+        if (threadIdx.x == 0) s_nwork = 0;
+        __syncthreads();
+        const unsigned long long i0 = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+        NPos q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            q[u].nw = 0;                                    // no N: no motif's window reaches one
+            if (i0 + u * per_sub < n) q[u] = list[i0 + u * per_sub];
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (q[u].nw == 0) continue;
+            for (int m = 0; m < cnt; m++) {
+                const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
+                const uint32_t nm = q[u].nw & low_mask(W);
+                if (nm == 0) continue;
+                if (W > q[u].room) continue;                        // window runs past its region (cscore.c:340)
+                const int a = __ffs((int) nm) - 1, b = 32 - __clz((int) nm);
+                if (__popc(nm) == b - a) {                           // one contiguous run (the usual case): bound by the columns outside it
+                    const double fl = s_floor[m];
+                    const bool dead_f = !(strand_mask & 1) || s_pre[m][0][a] + s_suf[m][0][b] < fl;
+                    const bool dead_r = !(strand_mask & 2) || s_pre[m][1][a] + s_suf[m][1][b] < fl;
+                    if (dead_f && dead_r) continue;
+                }
+                const unsigned int slot = atomicAdd(&s_nwork, 1u);
+                if (slot < kWorkCap) {
+                    s_work[slot] = (uint16_t) (((uint32_t) (u * 256 + (int) threadIdx.x) << 3) | (uint32_t) m);
+                } else {                                             // queue full (dense N): score here
+                    double fwd, rev;
+                    score_window32(s_tab + s_off[m], W, q[u].cw, q[u].nw, fwd, rev);
+                    test_and_emit(H, Pw, (uint32_t) s_motif[m], q[u].coord, fwd, rev, strand_mask);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned int nw_items = s_nwork < kWorkCap ? s_nwork : kWorkCap;
+        for (unsigned int k = threadIdx.x; k < nw_items; k += blockDim.x) {
+            const uint32_t item = s_work[k];
+            const int m = (int) (item & 7u);
+            const uint32_t slot = item >> 3;                         // u * 256 + thread
+            const NPos p = list[rd * per_round + (unsigned long long) (slot >> 8) * per_sub + (unsigned long long) blockIdx.x * blockDim.x + (slot & 255u)];
+            double fwd, rev;
+            score_window32(s_tab + s_off[m], s_width[m], p.cw, p.nw, fwd, rev);
+            test_and_emit(H, Pw, (uint32_t) s_motif[m], p.coord, fwd, rev, strand_mask);
+        }
+        __syncthreads();
     }
 }
 
@@ -1554,17 +1593,27 @@ int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_til
     return MS_OK;
 }
 
-int launch_nwindow(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int max_w,
-                   int strand_mask, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H,
-                   hipStream_t st) {
-    if (S.n_bases == 0 || n_motifs == 0) return MS_OK;
+// The positions whose window may hold a non-ACGT base, each with its motif-independent data (needs only the sequence: it is
+// launched BEFORE the pre-filter, so that the fp64 scoring of these windows can start the moment the pre-filter is done).
+int launch_nlist(const DevSeq &S, int max_w, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H, hipStream_t st) {
+    if (S.n_bases == 0) return MS_OK;
     const int64_t want = ((S.n_bases + 31) / 32 + 255) / 256;
     hipLaunchKernelGGL(nlist_kernel, dim3((unsigned) (want < 4096 ? want : 4096)), dim3(256), 0, st, S.nmask, S.n_bases,
                        max_w, list, n_list, list_cap);
     MS_HIP(hipGetLastError());
     hipLaunchKernelGGL(nprep_kernel, dim3(1024), dim3(256), 0, st, S, list, n_list, list_cap, H);
     MS_HIP(hipGetLastError());
-    dim3 grid(64, (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk));      // few, fat blocks: block dispatch, not work, bounds this kernel
+    return MS_OK;
+}
+
+int launch_neval(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask, const NPos *list,
+                 const unsigned long long *n_list, uint64_t list_cap, const HitOut &H, int n_blocks_max, hipStream_t st) {
+    if (S.n_bases == 0 || n_motifs == 0) return MS_OK;
+    const unsigned rows = (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk);
+    (void) n_blocks_max;
+    unsigned gx = 64;                                     // many small blocks (measured against one wave of fat blocks: profiles/r02_n_fraction.log)
+    if (const char *e = measure_env("MS_NEVAL_GX")) gx = (unsigned) std::max(1, atoi(e));
+    dim3 grid(gx, rows);
     hipLaunchKernelGGL(neval_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, list, n_list, list_cap, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
