@@ -729,6 +729,13 @@ __device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const 
         f32x16 c0[ILP], c1[ILP];
 #pragma unroll
         for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
+        // keep BOTH tiles' matrix instructions ahead of the first reduction (left alone, hipcc sinks the second tile's below
+        // the first tile's test and the wave sits out its own result latency once per tile)
+        if constexpr (ILP > 1) {
+#pragma unroll
+            for (int u = 0; u < ILP; u++) asm volatile("" : "+v"(c0[u]), "+v"(c1[u]));      // (an empty asm "uses" the results here: the IR-level sinking cannot pass it)
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
     }
