@@ -923,6 +923,15 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
             const int bpt = std::max(1, c->n_cu * pf_blocks_per_cu / n_tiles);
+            if ((size_t) n_tiles > sc.chunk_counters_cap) {
+                dev_free(sc.chunk_counters);
+                sc.chunk_counters_cap = 0;
+                if ((rc = dev_alloc(&sc.chunk_counters, (size_t) n_tiles + 16))) return fail(rc);
+                sc.chunk_counters_cap = (size_t) n_tiles + 16;
+            }
+            he = hipMemsetAsync(sc.chunk_counters, 0, sizeof(unsigned int) * (size_t) n_tiles, c->stream);
+            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+            A.chunk_counter = sc.chunk_counters;
             A.clk = nullptr;
             if (pf_clock) {
                 clk_blocks = bpt * n_tiles;
@@ -1722,9 +1731,10 @@ int ms_debug_release_scratch(void) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     Scratch &sc = c->sc;
-    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.nlist); dev_free(sc.tile_state);
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.nlist); dev_free(sc.tile_state); dev_free(sc.chunk_counters);
     sc.nlist_cap = 0;
     sc.tile_cap = 0;
+    sc.chunk_counters_cap = 0;
     if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
     sc.sort_tmp = nullptr;
     sc.cand_cap = sc.hit_cap = sc.sort_tmp_bytes = 0;

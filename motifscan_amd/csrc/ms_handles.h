@@ -20,6 +20,7 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
     NPos *nlist = nullptr;        size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
     unsigned long long *tile_state = nullptr;  size_t tile_cap = 0;   // look-back states of the ordered re-scoring
+    unsigned int *chunk_counters = nullptr;    size_t chunk_counters_cap = 0;   // per LDS tile: the pre-filter's chunk dispenser
     unsigned long long *counters = nullptr;      // 8 words, see scan_locked
     unsigned long long *h_counters = nullptr;    // pinned
 };

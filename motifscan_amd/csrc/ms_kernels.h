@@ -99,6 +99,7 @@ struct PfArgs {
     uint64_t cand_cap;
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
+    unsigned int *chunk_counter;   // [LDS tiles], zeroed: the matrix-core kernels hand their position chunks out dynamically
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);

@@ -798,7 +798,19 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // Chunks are handed out DYNAMICALLY, kSuper at a time per block: the kernel wants every CU whole (all its LDS and registers),
+    // so a block whose CU is still busy with another stream's kernel (an upload's pack, a copy-out's blit: the batch stream runs
+    // them beside the scan) starts late -- with a static partition the whole launch then waits for that block's full share
+    // (measured: 3.7x on the streamed sweep with copy-out, profiles/r02_stream_coexistence.log); now it simply takes fewer chunks.
+    constexpr int kSuper = 4;
+    __shared__ unsigned int s_super;
+    for (;;) {
+        __syncthreads();                                                   // every wave is done with the previous hand-out
+        if (threadIdx.x == 0) s_super = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
+        __syncthreads();
+        const int64_t first = (int64_t) s_super * kSuper;
+        if (first >= n_chunks) break;
+    for (int64_t chunk = first; chunk < first + kSuper && chunk < n_chunks; chunk++) {
         const int64_t g0 = chunk * NT + (threadIdx.x & ~63u) + r;          // window start of N-tile 0; N-tile 1: + 32
         const bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
         const uint64_t cw0 = code_window(A.codes, live0 ? g0 : 0);
@@ -819,6 +831,7 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
                 default: break;
             }
         }
+    }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
     if constexpr (MEAS) {

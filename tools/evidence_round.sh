@@ -13,8 +13,9 @@ python bench.py --workload c5shard --steps 4 --warmup 1 > $OUT/bench_c5shard.jso
 python bench.py --workload c5 --genome-mbp 3000 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_3000mbp.json 2> $OUT/bench_c5.err
 python tools/pf_clock.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_clock.log
 python tools/pf_uniform.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_uniform_width.log
-python tools/pf_variants.py c4shard 16:1 19:1 18:1 17:2 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
+python tools/pf_variants.py c4shard 31:1 28:1 29:1 30:2 16:1 18:1 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
 python tools/once_overlap.py 2>&1 | grep -v amdgpu.ids > $OUT/scan_once_overlap.log
+python tools/n_fraction.py 2>&1 | grep -v amdgpu.ids > $OUT/n_fraction.log
 ./tools/ubench/mfma_i8_rate > $OUT/mfma_i8_rate.log 2>&1
 ./tools/ubench/mfma_f6_probe > $OUT/mfma_f6_probe.log 2>&1
 python tests/fuzz_parity.py --cases 1500 --seed 20000 > $OUT/fuzz.log 2>&1
@@ -26,7 +27,7 @@ mkdir -p $P
 B="python3 bench.py --no-cpu-baseline --no-end-to-end"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $B --steps 5 --warmup 2 > $P/bench_under_rocprof.json 2> $P/stats.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $P/sq1 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq1.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $P/sq2 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq2.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F8 SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $P/sq2 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq2.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/write.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/lds -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/lds.err
