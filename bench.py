@@ -523,8 +523,10 @@ def main_sweep(a, world, rank, local_rank):
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            pool0 = _lib.pool_stats()
             for _ in range(a.steps):
                 sites, st = one_pass(flags, packed)
+            pool1 = _lib.pool_stats()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -535,7 +537,8 @@ def main_sweep(a, world, rank, local_rank):
                 dist.all_reduce(un, op=dist.ReduceOp.SUM)
             out[mode] = {"value": float(un.item()) * a.steps / float(el.item()), "ms_per_step": float(el.item()) / a.steps * 1e3,
                          "sites_per_step_per_gpu": int(sites), "spans_per_gpu": len(mine),
-                         "prefilter_ms_per_step": st["ms_prefilter"], "device_ms_per_step": st["ms_total"]}
+                         "prefilter_ms_per_step": st["ms_prefilter"], "device_ms_per_step": st["ms_total"],
+                         "hbm_pool_timed": {k: pool1[k] - pool0[k] for k in ("hits", "misses", "driver_frees", "driver_ms")}}
         if rank == 0:
             line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
                     "value": out["counts_only"]["value"], "unit": "bp*motifs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -109,6 +109,11 @@ int ms_version(void);
 int ms_device_count(int *count);
 int ms_set_device(int device);
 int ms_device_name(char *buf, int buflen);
+/* The calling thread's device keeps freed HBM blocks for reuse (hipMalloc / hipFree stall every stream of the device).
+ * out[0] requests served from the cache, out[1] requests that went to the driver, out[2] blocks returned to the driver,
+ * out[3] nanoseconds spent inside the driver for [1] and [2], out[4] bytes cached now, out[5] blocks cached now.
+ * No reference counterpart (numpy owns the reference's memory). */
+int ms_device_pool_stats(uint64_t out[6]);
 
 /* ---- PWM set -------------------------------------------------------------------------- */
 /* values: the P matrices concatenated, each row-major [4][width] (rows A,C,G,T).

@@ -113,6 +113,7 @@ def lib():
         "ms_result_hits_host": (c_int, [vp, ctypes.POINTER(pi64), ctypes.POINTER(pi64), ctypes.POINTER(pd), ctypes.POINTER(pi8)]),
         "ms_result_hits_packed_host": (c_int, [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64)), ctypes.POINTER(pd)]),
         "ms_host_alloc": (c_int, [ctypes.c_size_t, pvp]),
+        "ms_device_pool_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64)]),
         "ms_host_free": (None, [vp]),
         "ms_stream_create": (c_int, [vp, c_int, c_u32, c_int, pvp]),
         "ms_stream_submit": (c_int, [vp, vp, pi64, c_i64]),
@@ -479,6 +480,14 @@ class ScanResult:
             self.h = None
 
     __del__ = close
+
+
+def pool_stats():
+    """HBM block cache of the calling thread's device (ms_device_pool_stats)."""
+    out = (ctypes.c_uint64 * 6)()
+    check(lib().ms_device_pool_stats(out))
+    return {"hits": int(out[0]), "misses": int(out[1]), "driver_frees": int(out[2]), "driver_ms": out[3] / 1e6,
+            "cached_bytes": int(out[4]), "cached_blocks": int(out[5])}
 
 
 def scan(pwms, seqs, strand_mask=3, flags=MS_SCAN_DEFAULT):

@@ -14,6 +14,8 @@
 #include <string>
 #include <thread>
 
+#include <chrono>
+
 #include "ms_handles.h"
 
 namespace ms {
@@ -74,34 +76,55 @@ int get_ctx(int device, DeviceCtx **out) {
     return MS_OK;
 }
 
+// Size class of a request: the next of {8..15} x 2^k at or above it (at most 12.5 % over), 64 KB at least.
+static size_t pool_class(size_t bytes) {
+    size_t b = std::max<size_t>(bytes, 1u << 16);
+    int k = 63 - __builtin_clzll((unsigned long long) b);          // 2^k <= b
+    const size_t step = (size_t) 1 << (k - 3);
+    return (b + step - 1) & ~(step - 1);
+}
+
+static uint64_t now_ns() {
+    return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
+    const size_t want = pool_class(bytes);
     {
         std::lock_guard<std::mutex> lk(c->pool.mu);
         size_t best = (size_t) -1;
         for (size_t i = 0; i < c->pool.free_.size(); i++) {
             const size_t sz = c->pool.free_[i].second;
-            if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && (best == (size_t) -1 || sz < c->pool.free_[best].second)) best = i;
+            if (sz >= want && sz <= want + want / 4 && (best == (size_t) -1 || sz < c->pool.free_[best].second)) best = i;
         }
         if (best != (size_t) -1) {
             *out = c->pool.free_[best].first;
             *got = c->pool.free_[best].second;
             c->pool.bytes -= *got;
             c->pool.free_.erase(c->pool.free_.begin() + (long) best);
+            c->pool.n_hit++;
             return MS_OK;
         }
     }
+    const uint64_t t0 = now_ns();
     char *p = nullptr;
-    int rc = dev_alloc(&p, bytes);
+    int rc = dev_alloc(&p, want);
     if (rc) {                                   // drop the cache and retry once
         std::lock_guard<std::mutex> lk(c->pool.mu);
         for (auto &b : c->pool.free_) (void) hipFree(b.first);
+        c->pool.n_driver_free += c->pool.free_.size();
         c->pool.free_.clear();
         c->pool.bytes = 0;
-        rc = dev_alloc(&p, bytes);
+        rc = dev_alloc(&p, want);
         if (rc) return rc;
     }
+    {
+        std::lock_guard<std::mutex> lk(c->pool.mu);
+        c->pool.n_miss++;
+        c->pool.ns_driver += now_ns() - t0;
+    }
     *out = p;
-    *got = bytes;
+    *got = want;
     return MS_OK;
 }
 
@@ -141,10 +164,28 @@ void pinned_free(void *p, size_t bytes) {
 
 void pool_free(DeviceCtx *c, void *p, size_t bytes) {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(c->pool.mu);
-    if (c->pool.bytes + bytes > BlockPool::kMaxBytes || c->pool.free_.size() >= 16) { (void) hipFree(p); return; }
-    c->pool.free_.emplace_back(p, bytes);
-    c->pool.bytes += bytes;
+    std::unique_lock<std::mutex> lk(c->pool.mu);
+    if (c->pool.bytes + bytes <= BlockPool::kMaxBytes && c->pool.free_.size() < BlockPool::kMaxBlocks) {
+        c->pool.free_.emplace_back(p, bytes);
+        c->pool.bytes += bytes;
+        return;
+    }
+    // full: give the driver the SMALLEST cached block (or this one), the large ones are the dear ones to make again
+    size_t small = (size_t) -1;
+    for (size_t i = 0; i < c->pool.free_.size(); i++)
+        if (c->pool.free_[i].second < bytes && (small == (size_t) -1 || c->pool.free_[i].second < c->pool.free_[small].second)) small = i;
+    void *victim = p;
+    if (small != (size_t) -1 && c->pool.bytes - c->pool.free_[small].second + bytes <= BlockPool::kMaxBytes) {
+        victim = c->pool.free_[small].first;
+        c->pool.bytes += bytes - c->pool.free_[small].second;
+        c->pool.free_[small] = {p, bytes};
+    }
+    c->pool.n_driver_free++;
+    lk.unlock();
+    const uint64_t t0 = now_ns();
+    (void) hipFree(victim);
+    lk.lock();
+    c->pool.ns_driver += now_ns() - t0;
 }
 
 }  // namespace ms
@@ -922,7 +963,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
-            const int bpt = std::max(1, c->n_cu * pf_blocks_per_cu / n_tiles);
+            // While a batch stream is live, 1/32 of the CUs is left to its upload / pack / copy-out kernels: the pre-filter's blocks
+            // are persistent and fill their CUs completely, so a copy kernel that arrives after them would otherwise wait for the
+            // whole launch and the next batch with it (the chunks are handed out dynamically: fewer blocks just take more each)
+            const int reserve = c->n_streams.load() > 0 ? std::max(2, c->n_cu / 32) : 0;
+            const int bpt = std::max(1, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles);
             if ((size_t) n_tiles > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
                 sc.chunk_counters_cap = 0;
@@ -1236,6 +1281,17 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
     char *b = static_cast<char *>(r->h_pinned);
     if (coord) *coord = reinterpret_cast<const uint64_t *>(b);
     if (score) *score = reinterpret_cast<const double *>(b + 8 * n_round);
+    return MS_OK;
+}
+
+int ms_device_pool_stats(uint64_t out[6]) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    int rc = get_ctx(g_device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->pool.mu);
+    out[0] = c->pool.n_hit; out[1] = c->pool.n_miss; out[2] = c->pool.n_driver_free; out[3] = c->pool.ns_driver;
+    out[4] = c->pool.bytes; out[5] = c->pool.free_.size();
     return MS_OK;
 }
 

@@ -1,6 +1,7 @@
 // ms_handles.h -- private to libmotifscan_amd: per-device state and the structs behind the opaque handles of
 // include/motifscan_amd.h, shared by ms_api.hip (scan pipeline) and ms_stream.hip (batch streams, host-streamed sweeps).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -31,7 +32,12 @@ struct BlockPool {
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> free_;
     size_t bytes = 0;
-    static constexpr size_t kMaxBytes = 8ull << 30;
+    // Blocks are handed out in size classes (pool_class: eight per octave), so that batches of similar but unequal size -- the
+    // chromosomes of a sweep, the batches of a region stream -- reuse each other's blocks instead of going to the driver:
+    // hipMalloc maps pages for milliseconds and hipFree waits for the whole device, either stalls every stage of a stream.
+    static constexpr size_t kMaxBytes = 48ull << 30;       // cached at most (of 288 GB)
+    static constexpr size_t kMaxBlocks = 64;
+    uint64_t n_hit = 0, n_miss = 0, n_driver_free = 0, ns_driver = 0;
 };
 
 struct DeviceCtx {
@@ -44,6 +50,7 @@ struct DeviceCtx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev[8] = {};
     int n_cu = 0;
+    std::atomic<int> n_streams{0};          // live batch streams on this device: their copy / pack kernels need a few CUs beside the scan
     size_t lds_max = 0;
     size_t lds_set[64] = {};                // dynamic-LDS attribute already raised to this, per kernel variant (+32: measurement instantiation)
     Scratch sc;

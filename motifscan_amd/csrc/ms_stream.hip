@@ -171,6 +171,7 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
         if (st->th_down.joinable()) st->th_down.join();
         return MS_ERR_RUNTIME;
     }
+    c->n_streams.fetch_add(1);
     *out = st.release();
     return MS_OK;
 }
@@ -253,6 +254,8 @@ void ms_stream_free(ms_stream *st) {
         if (j->res) ms_result_free(j->res);
         delete j;
     }
+    DeviceCtx *c = nullptr;
+    if (get_ctx(st->device, &c) == MS_OK) c->n_streams.fetch_sub(1);
     delete st;
 }
 
