@@ -403,12 +403,22 @@ def end_to_end(a, wl, pw, world, dev, torch, dist):
             dist.all_reduce(u, op=dist.ReduceOp.SUM)
         return float(u.item()) / float(t.item()), float(t.item()) / passes * 1e3, hits // passes
 
+    stages = {}
+
     def pipelined(packed):
         def run():
             n = 0
-            for res in _lib.scan_stream(pw, iter(batches), 3, 0, depth=2, packed=packed):
+            st = stages.setdefault("pipelined" if packed else "pipelined_25B", {})
+            dev_ms = {"prefilter": 0.0, "fp64_stage": 0.0, "sort": 0.0, "finalize": 0.0, "scan_total": 0.0, "clock_mhz_sum": 0.0}
+            for res in _lib.scan_stream(pw, iter(batches), 3, 0, depth=2, packed=packed, stage_stats=st):
                 n += res.n_hits                         # the arrays are already in pinned host memory at this point
+                s_ = res.stats()
+                for k_, f_ in (("prefilter", "ms_prefilter"), ("fp64_stage", "ms_exact"), ("sort", "ms_sort"), ("finalize", "ms_finalize"),
+                               ("scan_total", "ms_total")):
+                    dev_ms[k_] += s_[f_]
+                dev_ms["clock_mhz_sum"] += s_["pf_clock_mhz"]          # 0 unless MS_MEASURE=1 MS_PF_CLOCK=1
                 res.close()
+            st["scan_device_ms"] = {k_: round(v_, 2) for k_, v_ in dev_ms.items()}
             return n
         return run
 
@@ -431,6 +441,8 @@ def end_to_end(a, wl, pw, world, dev, torch, dist):
     return {"pipelined": v_p16, "pipelined_25B": v_p25, "serial": v_s, "unit": "bp*motifs/s",
             "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s},
             "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "hits_per_pass_per_gpu": int(hits),
+            "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
+            "cu_partition": "while a stream is live the copy / pack kernels own 1 CU of every 32 (CU masks), the scan the other 31",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "
                           "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 16 bytes per hit "
                           "(coord word + fp64 score), 'pipelined_25B' the four plain arrays, 'serial' runs the stages of one batch after another"}
@@ -501,8 +513,9 @@ def main_sweep(a, world, rank, local_rank):
         def one_pass(flags, packed):
             c = np.zeros(P, dtype=np.int64)
             sites = 0
-            st = {"ms_prefilter": 0.0, "ms_total": 0.0, "n": 0}
-            for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, flags, depth=2, spans=mine, packed=packed):
+            st = {"ms_prefilter": 0.0, "ms_total": 0.0, "n": 0, "stages": {}}
+            for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, flags, depth=2, spans=mine, packed=packed,
+                                             stage_stats=st["stages"]):
                 c += res.region_counts()
                 sites += res.n_hits
                 s = res.stats()
@@ -538,7 +551,8 @@ def main_sweep(a, world, rank, local_rank):
             out[mode] = {"value": float(un.item()) * a.steps / float(el.item()), "ms_per_step": float(el.item()) / a.steps * 1e3,
                          "sites_per_step_per_gpu": int(sites), "spans_per_gpu": len(mine),
                          "prefilter_ms_per_step": st["ms_prefilter"], "device_ms_per_step": st["ms_total"],
-                         "hbm_pool_timed": {k: pool1[k] - pool0[k] for k in ("hits", "misses", "driver_frees", "driver_ms")}}
+                         "hbm_pool_timed": {k: pool1[k] - pool0[k] for k in ("hits", "misses", "driver_frees", "driver_ms")},
+                         "stage_ms_last_pass": {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in st["stages"].items()}}
         if rank == 0:
             line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
                     "value": out["counts_only"]["value"], "unit": "bp*motifs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -215,6 +215,10 @@ int ms_stream_submit_span(ms_stream *st, const char *bases, int64_t n_bases, int
  * ms_result_hits_packed_host return at once).  *out = NULL when nothing is in flight.  The caller frees the result. */
 int ms_stream_next(ms_stream *st, ms_result **out);
 int ms_stream_in_flight(const ms_stream *st, int *n);
+/* Where the stream's three stages spent their time so far, for stage k = 0 uploader, 1 scanner, 2 downloader:
+ * out[4k] batches done, out[4k+1] ms working, out[4k+2] ms waiting for input, out[4k+3] ms waiting for room downstream.
+ * The stage with the least waiting is the one that bounds the stream. */
+int ms_stream_stats(const ms_stream *stream, double out[12]);
 int ms_stream_capacity(const ms_stream *st, int *n);
 void ms_stream_free(ms_stream *st);          /* drains and discards whatever is still in flight */
 

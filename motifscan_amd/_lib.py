@@ -121,6 +121,7 @@ def lib():
         "ms_stream_next": (c_int, [vp, pvp]),
         "ms_stream_in_flight": (c_int, [vp, ctypes.POINTER(c_int)]),
         "ms_stream_capacity": (c_int, [vp, ctypes.POINTER(c_int)]),
+        "ms_stream_stats": (c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
         "ms_stream_free": (None, [vp]),
         "ms_sweep_spans": (c_int, [pi64, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(Span), c_i64, pi64]),
         "ms_result_region_counts": (c_int, [vp, pi64]),
@@ -572,6 +573,13 @@ class Stream:
                 self._keep.pop(0)                      # returned or failed: either way the batch no longer borrows its buffer
         return ScanResult(h, self.pwms.n) if h.value else None
 
+    def stats(self):
+        """ms_stream_stats: per stage {batches, ms_work, ms_wait_in, ms_wait_out}; the stage that waits least bounds the stream."""
+        out = (ctypes.c_double * 12)()
+        check(lib().ms_stream_stats(self.h, out))
+        return {name: {"batches": int(out[4 * k]), "ms_work": out[4 * k + 1], "ms_wait_in": out[4 * k + 2], "ms_wait_out": out[4 * k + 3]}
+                for k, name in enumerate(("upload", "scan", "copy_out"))}
+
     def close(self):
         if getattr(self, "h", None):
             lib().ms_stream_free(self.h)
@@ -608,9 +616,9 @@ def merge_hits(parts, n_pwms):
     return out
 
 
-def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False):
+def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None):
     """Generator: push (bases, offsets) batches through a Stream, yield each batch's ScanResult in order (the caller
-    closes them).  Keeps the stream as full as its capacity allows."""
+    closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end."""
     st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
     try:
         for bases, offsets in batches:
@@ -619,11 +627,14 @@ def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False):
             st.submit(bases, offsets)
         while st.in_flight:
             yield st.next()
+        if stage_stats is not None:
+            stage_stats.update(st.stats())
     finally:
         st.close()
 
 
-def sweep_stream(pwms, chroms, window, stride, max_span_bases, strand_mask=3, flags=0, depth=2, spans=None, packed=False):
+def sweep_stream(pwms, chroms, window, stride, max_span_bases, strand_mask=3, flags=0, depth=2, spans=None, packed=False,
+                 stage_stats=None):
     """Host-streamed window sweep over a whole genome (BASELINE configs[4]): chroms = list of uint8 arrays (host memory,
     ideally pinned); the windows [k*stride, k*stride + window) of every chromosome are cut into spans of at most
     max_span_bases bases (ms_sweep_spans), and the spans flow through a Stream (upload + pack | scan-once + hand-out |
@@ -642,6 +653,8 @@ def sweep_stream(pwms, chroms, window, stride, max_span_bases, strand_mask=3, fl
             pending.append(sp)
         while st.in_flight:
             yield pending.pop(0), st.next()
+        if stage_stats is not None:
+            stage_stats.update(st.stats())
     finally:
         st.close()
 

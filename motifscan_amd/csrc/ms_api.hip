@@ -62,10 +62,34 @@ int get_ctx(int device, DeviceCtx **out) {
     c->lds_max = std::max<size_t>((size_t) lds_attr, prop.sharedMemPerBlock);
     if (c->lds_max < 65536) c->lds_max = 65536;
     if (c->lds_max > 163840) c->lds_max = 163840;
-    MS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    MS_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    MS_HIP(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
-    MS_HIP(hipStreamCreateWithFlags(&c->stream_down, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream.whole, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream2.whole, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream_up.whole, hipStreamNonBlocking));
+    MS_HIP(hipStreamCreateWithFlags(&c->stream_down.whole, hipStreamNonBlocking));
+    for (StreamSel *s : {&c->stream, &c->stream2, &c->stream_up, &c->stream_down}) s->n_streams = &c->n_streams;
+    if (measure_env("MS_CU_PARTITION")) {
+        // A/B switch (MS_MEASURE=1 MS_CU_PARTITION=1); off by default, see StreamSel.
+        // CU mask bit i = CU (i / n_xcc) of XCC (i % n_xcc) (measured, tools/ubench/cumask_probe.hip: the first 8 bits select one
+        // CU on each of the 8 XCCs; an XCC without a bit is left unmasked, so the copy share must cover every XCC): the first
+        // n_cu / 32 bits go to the copy streams, the rest to the scan.
+        const int k = std::max(1, c->n_cu / 32);
+        std::vector<uint32_t> m_copy((size_t) (c->n_cu + 31) / 32, 0u), m_scan((size_t) (c->n_cu + 31) / 32, 0u);
+        for (int i = 0; i < c->n_cu; i++) (i < k ? m_copy : m_scan)[(size_t) i / 32] |= 1u << (i % 32);
+        bool ok = c->n_cu >= 64;
+        ok = ok && hipExtStreamCreateWithCUMask(&c->stream.part, (uint32_t) m_scan.size(), m_scan.data()) == hipSuccess;
+        ok = ok && hipExtStreamCreateWithCUMask(&c->stream2.part, (uint32_t) m_scan.size(), m_scan.data()) == hipSuccess;
+        ok = ok && hipExtStreamCreateWithCUMask(&c->stream_up.part, (uint32_t) m_copy.size(), m_copy.data()) == hipSuccess;
+        ok = ok && hipExtStreamCreateWithCUMask(&c->stream_down.part, (uint32_t) m_copy.size(), m_copy.data()) == hipSuccess;
+        if (ok) {
+            c->n_cu_copy = k;
+        } else {                                   // no masks on this device / runtime: everything stays on the whole-device streams
+            (void) hipGetLastError();
+            for (StreamSel *s : {&c->stream, &c->stream2, &c->stream_up, &c->stream_down}) {
+                if (s->part) (void) hipStreamDestroy(s->part);
+                s->part = nullptr;
+            }
+        }
+    }
     MS_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     MS_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (auto &ev : c->ev) MS_HIP(hipEventCreate(&ev));
@@ -605,9 +629,10 @@ static int seqset_alloc_packed(ms_seqset *s) {
     s->d_blk2reg = reinterpret_cast<int32_t *>(b + up(b_codes) + up(b_nmask) + up(b_off));
     // only the pad words behind the packed data need clearing: the kernels write everything else
     // sequence sets are built on the upload stream: a batch can be packed while the previous one is being scanned
-    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), c->stream_up));
-    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), c->stream_up));
-    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, c->stream_up));
+    s->up = c->stream_up;                                 // read once: every step of building this set stays on one stream
+    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));
     return MS_OK;
 }
 
@@ -629,12 +654,12 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
         raw->d_ascii = static_cast<uint8_t *>(blk);
     }
     if (raw->n_bases > 0) {
-        hipError_t e = hipMemcpyAsync(raw->d_ascii, bases, (size_t) raw->n_bases, hipMemcpyHostToDevice, c->stream_up);
+        hipError_t e = hipMemcpyAsync(raw->d_ascii, bases, (size_t) raw->n_bases, hipMemcpyHostToDevice, raw->up);
         if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     }
-    if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream_up))) return fail(rc);
-    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream_up))) return fail(rc);
-    hipError_t e = hipStreamSynchronize(c->stream_up);
+    if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, raw->up))) return fail(rc);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up))) return fail(rc);
+    hipError_t e = hipStreamSynchronize(raw->up);
     if (e != hipSuccess) { set_error("upload / pack failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     if (!keep_ascii) { pool_free(c, raw->d_ascii, raw->ascii_bytes); raw->d_ascii = nullptr; raw->ascii_bytes = 0; }
     *out = raw;
@@ -653,10 +678,10 @@ int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n
     ms_seqset *raw = s.release();
     auto fail = [&](int code) { ms_seqset_free(raw); return code; };
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
-    if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, c->stream_up)))
+    if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, raw->up)))
         return fail(rc);
-    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream_up))) return fail(rc);
-    hipError_t e = hipStreamSynchronize(c->stream_up);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up))) return fail(rc);
+    hipError_t e = hipStreamSynchronize(raw->up);
     if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     *out = raw;
     return MS_OK;
@@ -668,9 +693,10 @@ int ms_seqset_repack(ms_seqset *s) {
     DeviceCtx *c;
     int rc = get_ctx(s->device, &c);
     if (rc) return rc;
-    if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, c->stream_up))) return rc;
-    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, c->stream_up))) return rc;
-    MS_HIP(hipStreamSynchronize(c->stream_up));
+    const hipStream_t up = c->stream_up;
+    if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, up))) return rc;
+    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, up))) return rc;
+    MS_HIP(hipStreamSynchronize(up));
     return MS_OK;
 }
 
@@ -777,11 +803,11 @@ int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
     int64_t *d_src = nullptr;
     if ((rc = dev_alloc(&d_src, (size_t) n_regions + 1))) return fail(rc);
-    hipError_t he = hipMemcpyAsync(d_src, src.data(), ((size_t) n_regions + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream_up);
+    hipError_t he = hipMemcpyAsync(d_src, src.data(), ((size_t) n_regions + 1) * sizeof(int64_t), hipMemcpyHostToDevice, raw->up);
     if (he == hipSuccess) {
-        rc = launch_extract(G->d_codes, G->d_nmask, d_src, raw->d_offsets, raw->R, raw->n_bases, raw->d_codes, raw->d_nmask, c->stream_up);
-        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, c->stream_up);
-        if (!rc) he = hipStreamSynchronize(c->stream_up);
+        rc = launch_extract(G->d_codes, G->d_nmask, d_src, raw->d_offsets, raw->R, raw->n_bases, raw->d_codes, raw->d_nmask, raw->up);
+        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up);
+        if (!rc) he = hipStreamSynchronize(raw->up);
     }
     dev_free(d_src);
     if (rc) return fail(rc);
@@ -963,10 +989,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
-            // While a batch stream is live, 1/32 of the CUs is left to its upload / pack / copy-out kernels: the pre-filter's blocks
-            // are persistent and fill their CUs completely, so a copy kernel that arrives after them would otherwise wait for the
-            // whole launch and the next batch with it (the chunks are handed out dynamically: fewer blocks just take more each)
-            const int reserve = c->n_streams.load() > 0 ? std::max(2, c->n_cu / 32) : 0;
+            // While a batch stream is live the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs, one
+            // persistent block each (the chunks are handed out dynamically: fewer blocks just take more each)
+            const int reserve = c->n_streams.load() > 0 ? c->n_cu_copy : 0;
             const int bpt = std::max(1, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles);
             if ((size_t) n_tiles > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
@@ -1222,11 +1247,12 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
             // the device block may have been carved for more hits than there are (the ordered re-scoring sizes it by a bound):
             // four copies, packed n_round elements apart on the host
             char *hb = static_cast<char *>(r->h_pinned);
-            MS_HIP(hipMemcpyAsync(hb, r->d_seq_idx, 8 * n, hipMemcpyDeviceToHost, c->stream_down));
-            MS_HIP(hipMemcpyAsync(hb + 8 * n_round, r->d_pos, 8 * n, hipMemcpyDeviceToHost, c->stream_down));
-            MS_HIP(hipMemcpyAsync(hb + 16 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, c->stream_down));
-            MS_HIP(hipMemcpyAsync(hb + 24 * n_round, r->d_strand, n, hipMemcpyDeviceToHost, c->stream_down));
-            MS_HIP(hipStreamSynchronize(c->stream_down));
+            const hipStream_t down = c->stream_down;
+            MS_HIP(hipMemcpyAsync(hb, r->d_seq_idx, 8 * n, hipMemcpyDeviceToHost, down));
+            MS_HIP(hipMemcpyAsync(hb + 8 * n_round, r->d_pos, 8 * n, hipMemcpyDeviceToHost, down));
+            MS_HIP(hipMemcpyAsync(hb + 16 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, down));
+            MS_HIP(hipMemcpyAsync(hb + 24 * n_round, r->d_strand, n, hipMemcpyDeviceToHost, down));
+            MS_HIP(hipStreamSynchronize(down));
         }
         r->h_pinned_hits = r->n_hits;
         r->h_packed = false;
@@ -1263,13 +1289,14 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
             uint64_t *d_coord = static_cast<uint64_t *>(blk);
             unsigned int *d_bad = reinterpret_cast<unsigned int *>(d_coord + n_round);
             unsigned int bad = 0;
-            hipError_t he = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), c->stream_down);
-            if (he == hipSuccess) rc = launch_pack_hits((int64_t) n, r->d_seq_idx, r->d_pos, r->d_strand, d_coord, d_bad, c->stream_down);
+            const hipStream_t down = c->stream_down;
+            hipError_t he = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), down);
+            if (he == hipSuccess) rc = launch_pack_hits((int64_t) n, r->d_seq_idx, r->d_pos, r->d_strand, d_coord, d_bad, down);
             char *hb = static_cast<char *>(r->h_pinned);
-            if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb, d_coord, 8 * n, hipMemcpyDeviceToHost, c->stream_down);
-            if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb + 8 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, c->stream_down);
-            if (he == hipSuccess && !rc) he = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream_down);
-            const hipError_t hs = hipStreamSynchronize(c->stream_down);
+            if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb, d_coord, 8 * n, hipMemcpyDeviceToHost, down);
+            if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb + 8 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, down);
+            if (he == hipSuccess && !rc) he = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, down);
+            const hipError_t hs = hipStreamSynchronize(down);
             pool_free(c, blk, got);
             if (rc) return rc;
             if (he != hipSuccess || hs != hipSuccess) { set_error("compact copy-out failed: %s", hipGetErrorString(he != hipSuccess ? he : hs)); return MS_ERR_RUNTIME; }

@@ -40,17 +40,37 @@ struct BlockPool {
     uint64_t n_hit = 0, n_miss = 0, n_driver_free = 0, ns_driver = 0;
 };
 
+// A stream in two editions: `whole` may use every CU; `part` is confined by a CU mask (hipExtStreamCreateWithCUMask).
+// With MS_MEASURE=1 MS_CU_PARTITION=1 the CUs are partitioned while a batch stream is live (DeviceCtx::n_streams > 0): the
+// scan's two streams keep all but 1 of every 32 CUs, the upload / copy-out streams get those.  What it is for
+// (tools/ubench/cu_share_probe.hip): the pre-filter's blocks are persistent and each fills a CU, and a second kernel's
+// workgroups are handed to the shader engines in order -- one full engine stalls the whole hand-out, so a pack or copy kernel
+// launched beside the pre-filter ends only when the pre-filter does, even when whole CUs elsewhere are idle (248 or 240 hog
+// blocks still hold a side kernel back for their whole run; 224, one free CU per engine, do not).  With the masks the 62 MB
+// upload + pack takes 2.4 ms beside a scan, not 4.  It is OFF by default because it buys nothing end to end
+// (profiles/r02_cu_partition_ab.log): the pre-filter runs power-limited, and copy kernels that really run beside it lower its
+// clock (2236 vs 2343 MHz) on top of the 3 % of CUs they take -- 76.5 vs 75.2 ms per configs[3] pass, and the sweep's
+// copy-out of every site drops to 41 GB/s on 8 CUs.  Starved copies that wait for the pre-filter cost less than concurrent ones.
+struct StreamSel {
+    hipStream_t whole = nullptr, part = nullptr;
+    const std::atomic<int> *n_streams = nullptr;
+    operator hipStream_t() const { return (part && n_streams && n_streams->load(std::memory_order_relaxed) > 0) ? part : whole; }
+};
+
 struct DeviceCtx {
     int device = -1;
     BlockPool pool;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;           // side stream: the N-window kernels run beside the candidate re-scoring
-    hipStream_t stream_up = nullptr;         // sequence upload + packing (runs beside a scan of the previous batch)
-    hipStream_t stream_down = nullptr;       // copy-out of hit arrays (runs beside a scan of the next batch)
+    // stream / stream2 are only used under `mu`, and n_streams only changes under `mu`: one scan sees one edition throughout.
+    // stream_up / stream_down are used without `mu`: every function reads them ONCE into a local hipStream_t.
+    StreamSel stream;
+    StreamSel stream2;                       // side stream: the N-window kernels run beside the candidate re-scoring
+    StreamSel stream_up;                     // sequence upload + packing (runs beside a scan of the previous batch)
+    StreamSel stream_down;                   // copy-out of hit arrays (runs beside a scan of the next batch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev[8] = {};
     int n_cu = 0;
-    std::atomic<int> n_streams{0};          // live batch streams on this device: their copy / pack kernels need a few CUs beside the scan
+    int n_cu_copy = 0;                       // CUs the copy streams own while the device is partitioned (0: masks unavailable)
+    std::atomic<int> n_streams{0};           // live batch streams on this device
     size_t lds_max = 0;
     size_t lds_set[64] = {};                // dynamic-LDS attribute already raised to this, per kernel variant (+32: measurement instantiation)
     Scratch sc;
@@ -141,6 +161,7 @@ struct ms_seqset {
     uint32_t *d_nmask = nullptr;
     int64_t *d_offsets = nullptr;
     int32_t *d_blk2reg = nullptr;         // region of position 64*b
+    hipStream_t up = nullptr;             // the upload stream this set is being built on (DeviceCtx::stream_up, read once)
 };
 
 struct ms_result {

@@ -10,6 +10,7 @@
 // The reference has no counterpart (its Scanner holds every sequence as a Python str and makes one c_scan_motif call,
 // scanner.py:71-87, 125); the batches' concatenation is what that one call returns.
 #include <atomic>
+#include <chrono>
 
 #include "ms_handles.h"
 
@@ -62,6 +63,16 @@ private:
     bool closed_ = false;
 };
 
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Where a stage's thread spends its time: working, waiting for input, waiting for room downstream
+struct StageClock {
+    std::atomic<uint64_t> work_us{0}, wait_in_us{0}, wait_out_us{0}, jobs{0};
+    static void add(std::atomic<uint64_t> &a, double s) { a.fetch_add((uint64_t) (s * 1e6)); }
+};
+
 void fail_job(Job *j, int rc) {
     j->rc = rc;
     j->err = ms_last_error();         // the failing call left its message on THIS worker thread
@@ -79,24 +90,40 @@ struct ms_stream {
     std::atomic<int> in_flight{0};
     std::unique_ptr<JobQueue> q_in, q_up, q_scan, q_done;
     std::thread th_up, th_scan, th_down;
+    StageClock clk[3];                // uploader, scanner, downloader
 
-    void uploader() {
+    // one stage: pop -> work -> push, each leg timed
+    template <class F>
+    void run_stage(int k, JobQueue &in, JobQueue &out, F &&work) {
         set_current_device(device);
         (void) hipSetDevice(device);
-        while (Job *j = q_in->pop()) {
-            if (j->rc == MS_OK) {
-                const int rc = ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
-                if (rc) fail_job(j, rc);
-            }
-            q_up->push(j);
+        for (;;) {
+            const double t0 = now_s();
+            Job *j = in.pop();
+            const double t1 = now_s();
+            if (!j) break;
+            work(j);
+            const double t2 = now_s();
+            out.push(j);
+            const double t3 = now_s();
+            StageClock::add(clk[k].wait_in_us, t1 - t0);
+            StageClock::add(clk[k].work_us, t2 - t1);
+            StageClock::add(clk[k].wait_out_us, t3 - t2);
+            clk[k].jobs.fetch_add(1);
         }
-        q_up->close();
+        out.close();
+    }
+
+    void uploader() {
+        run_stage(0, *q_in, *q_up, [](Job *j) {
+            if (j->rc != MS_OK) return;
+            const int rc = ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+            if (rc) fail_job(j, rc);
+        });
     }
 
     void scanner() {
-        set_current_device(device);
-        (void) hipSetDevice(device);
-        while (Job *j = q_up->pop()) {
+        run_stage(1, *q_up, *q_scan, [this](Job *j) {
             if (j->rc == MS_OK) {
                 DeviceCtx *c = nullptr;
                 int rc = get_ctx(device, &c);
@@ -114,23 +141,16 @@ struct ms_stream {
                 if (rc) fail_job(j, rc);
             }
             if (j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
-            q_scan->push(j);
-        }
-        q_scan->close();
+        });
     }
 
     void downloader() {
-        set_current_device(device);
-        (void) hipSetDevice(device);
-        while (Job *j = q_scan->pop()) {
-            if (j->rc == MS_OK && !(flags & MS_STREAM_NO_HITS)) {
-                const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
-                                                          : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
-                if (rc) fail_job(j, rc);
-            }
-            q_done->push(j);
-        }
-        q_done->close();
+        run_stage(2, *q_scan, *q_done, [this](Job *j) {
+            if (j->rc != MS_OK || (flags & MS_STREAM_NO_HITS)) return;
+            const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
+                                                      : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
+            if (rc) fail_job(j, rc);
+        });
     }
 };
 
@@ -171,7 +191,10 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
         if (st->th_down.joinable()) st->th_down.join();
         return MS_ERR_RUNTIME;
     }
-    c->n_streams.fetch_add(1);
+    {
+        std::lock_guard<std::mutex> lk_dev(c->mu);       // between scans: a scan sees one edition of its streams throughout
+        c->n_streams.fetch_add(1);
+    }
     *out = st.release();
     return MS_OK;
 }
@@ -238,6 +261,17 @@ int ms_stream_in_flight(const ms_stream *st, int *n) {
     return MS_OK;
 }
 
+int ms_stream_stats(const ms_stream *st, double out[12]) {
+    if (!st || !out) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    for (int k = 0; k < 3; k++) {
+        out[4 * k + 0] = (double) st->clk[k].jobs.load();
+        out[4 * k + 1] = st->clk[k].work_us.load() * 1e-3;
+        out[4 * k + 2] = st->clk[k].wait_in_us.load() * 1e-3;
+        out[4 * k + 3] = st->clk[k].wait_out_us.load() * 1e-3;
+    }
+    return MS_OK;
+}
+
 int ms_stream_capacity(const ms_stream *st, int *n) {
     if (!st || !n) { set_error("NULL argument"); return MS_ERR_INVALID; }
     *n = st->capacity;
@@ -255,7 +289,10 @@ void ms_stream_free(ms_stream *st) {
         delete j;
     }
     DeviceCtx *c = nullptr;
-    if (get_ctx(st->device, &c) == MS_OK) c->n_streams.fetch_sub(1);
+    if (get_ctx(st->device, &c) == MS_OK) {
+        std::lock_guard<std::mutex> lk_dev(c->mu);
+        c->n_streams.fetch_sub(1);
+    }
     delete st;
 }
 
