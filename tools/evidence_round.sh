@@ -18,6 +18,13 @@ python tools/once_overlap.py 2>&1 | grep -v amdgpu.ids > $OUT/scan_once_overlap.
 python tools/n_fraction.py 2>&1 | grep -v amdgpu.ids > $OUT/n_fraction.log
 ./tools/ubench/mfma_i8_rate > $OUT/mfma_i8_rate.log 2>&1
 ./tools/ubench/mfma_f6_probe > $OUT/mfma_f6_probe.log 2>&1
+timeout 60 ./tools/ubench/valu_rate.bin > $OUT/valu_rate.log 2>&1
+timeout 60 ./tools/ubench/issue_model.bin > $OUT/issue_model.log 2>&1
+timeout 100 ./tools/ubench/cumask_probe.bin > $OUT/cumask_probe.log 2>&1
+timeout 60 ./tools/ubench/cu_share_probe.bin > $OUT/cu_share_probe.log 2>&1
+python tools/h2d_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/h2d_probe.log
+python tools/c2_scaling.py 2>&1 | grep -v amdgpu.ids > $OUT/c2_scaling.log
+python bench.py --workload c5 --genome-mbp 3000 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_3000mbp_again.json 2> /dev/null
 python tests/fuzz_parity.py --cases 1500 --seed 20000 > $OUT/fuzz.log 2>&1
 python tests/fuzz_parity.py --cases 300 --seed 30000 --sweep >> $OUT/fuzz.log 2>&1
 fi
