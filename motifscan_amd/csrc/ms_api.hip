@@ -119,7 +119,7 @@ int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
         size_t best = (size_t) -1;
         for (size_t i = 0; i < c->pool.free_.size(); i++) {
             const size_t sz = c->pool.free_[i].second;
-            if (sz >= want && sz <= want + want / 4 && (best == (size_t) -1 || sz < c->pool.free_[best].second)) best = i;
+            if (sz >= want && sz <= want + want / 2 && (best == (size_t) -1 || sz < c->pool.free_[best].second)) best = i;
         }
         if (best != (size_t) -1) {
             *out = c->pool.free_[best].first;

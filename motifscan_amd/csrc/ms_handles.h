@@ -35,7 +35,7 @@ struct BlockPool {
     // Blocks are handed out in size classes (pool_class: eight per octave), so that batches of similar but unequal size -- the
     // chromosomes of a sweep, the batches of a region stream -- reuse each other's blocks instead of going to the driver:
     // hipMalloc maps pages for milliseconds and hipFree waits for the whole device, either stalls every stage of a stream.
-    static constexpr size_t kMaxBytes = 48ull << 30;       // cached at most (of 288 GB)
+    static constexpr size_t kMaxBytes = 96ull << 30;       // cached at most (of 288 GB)
     static constexpr size_t kMaxBlocks = 64;
     uint64_t n_hit = 0, n_miss = 0, n_driver_free = 0, ns_driver = 0;
 };

@@ -1585,10 +1585,6 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
         case 28: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 3, true>;       // engine 3 (fp6 x fp4, 16 columns per k-block), two row tiles in flight
         case 29: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true>;       // engine 3, one row tile in flight
         case 30: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 2, 6>;   // engine 3, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
-        case 32: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 4, 6>;   // engine 3, 2 x 12 waves per CU, any row tile depth
-        case 33: *threads = 768; return prefilter_mfma_kernel<768, 2, 3, true, 4, 6>;   // the same with per-half maxima kept
-        case 34: *threads = 768; return prefilter_mfma_kernel<768, 3, 3, true, 4, 6>;   // the same, two row tiles in flight
-        case 35: *threads = 896; return prefilter_mfma_kernel<896, 0, 3, true, 4, 7>;   // 2 x 14 waves per CU (<= 72 VGPRs)
         case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path: the default
             return meas ? prefilter_mfma_kernel<1024, 3, 3, true> : prefilter_mfma_kernel<1024, 3, 3, false>;
         case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default
