@@ -129,6 +129,13 @@ int main(void) {
         ms_result *none = (ms_result *) 1;
         CHECK(ms_stream_next(st, &none));
         if (none != NULL) return 1;
+        double stage[12];
+        uint64_t pool[6];
+        CHECK(ms_stream_stats(st, stage));
+        CHECK(ms_device_pool_stats(pool));
+        for (int k = 0; k < 3; k++)
+            if (stage[4 * k] != 3.0 || stage[4 * k + 1] < 0.0) { fprintf(stderr, "stream: stage %d saw %.0f batches\n", k, stage[4 * k]); return 1; }
+        if (pool[0] + pool[1] == 0) { fprintf(stderr, "block pool saw no request\n"); return 1; }
         ms_stream_free(st);
         ms_host_free(pin);
         oracle_free(w_off); oracle_free(w_seq); oracle_free(w_pos); oracle_free(w_score); oracle_free(w_sd);

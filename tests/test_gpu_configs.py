@@ -223,6 +223,66 @@ def test_stream_counts_only_errors_and_pinned_input(oracle):
         _lib.Stream(pw, 3, 0, depth=0)
 
 
+def test_stream_stage_clocks_and_block_pool_statistics():
+    """ms_stream_stats counts every batch once per stage and its clocks are sane; ms_device_pool_stats: a second pass over the
+    same batches is served from the block cache (size classes), not by the driver."""
+    vals, widths, cutoffs = synth.load_motif_set(40)
+    bases, offsets = synth.make_regions(4000, 300, seed=23, ragged=True)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    bounds = [(0, 700), (700, 1900), (1900, 2000), (2000, 4000)]
+
+    def one_pass():
+        st = {}
+        n = 0
+        for res in _lib.scan_stream(pw, (dist.take_shard(bases, offsets, a, b) for a, b in bounds), 3, 0, depth=2, packed=True,
+                                    stage_stats=st):
+            n += res.n_hits
+            res.close()
+        return n, st
+
+    n1, _ = one_pass()
+    p0 = _lib.pool_stats()
+    n2, st = one_pass()
+    p1 = _lib.pool_stats()
+    assert n1 == n2 == _lib.scan(pw, _lib.SeqSet(bases, offsets), 3).n_hits
+    assert set(st) == {"upload", "scan", "copy_out"}
+    for stage in st.values():
+        assert stage["batches"] == len(bounds)
+        assert stage["ms_work"] >= 0 and stage["ms_wait_in"] >= 0 and stage["ms_wait_out"] >= 0
+    assert st["upload"]["ms_work"] > 0 and st["scan"]["ms_work"] > 0 and st["copy_out"]["ms_work"] > 0
+    assert p1["hits"] > p0["hits"]
+    assert p1["misses"] == p0["misses"], "the second pass went to hipMalloc: %r -> %r" % (p0, p1)
+    assert p1["cached_bytes"] > 0 and p1["cached_blocks"] > 0
+
+
+def test_cu_partitioned_streams_give_the_same_result():
+    """MS_MEASURE=1 MS_CU_PARTITION=1 (CU-masked copy / scan streams while a batch stream is live; read once per process, hence
+    the child process): batched results == the single call, and the resident path of the same process is untouched."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from motifscan_amd import _lib, synth, dist
+vals, widths, cutoffs = synth.load_motif_set(64)
+bases, offsets = synth.make_regions(6000, 400, seed=29, frac_n=0.03, ragged=True)
+pw = _lib.PwmSet(vals, widths, cutoffs)
+want = _lib.scan(pw, _lib.SeqSet(bases, offsets), 3).hits()
+bounds = [(0, 1000), (1000, 1001), (1001, 3500), (3500, 6000)]
+parts = []
+for (a, b), res in zip(bounds, _lib.scan_stream(pw, (dist.take_shard(bases, offsets, a, b) for a, b in bounds), 3, 0, depth=2)):
+    parts.append((res.hits(), a)); res.close()
+got = _lib.merge_hits(parts, len(widths))
+again = _lib.scan(pw, _lib.SeqSet(bases, offsets), 3).hits()          # after the stream is gone: whole-device streams again
+for k in ("motif_offsets", "seq_idx", "pos", "strand"):
+    assert np.array_equal(got[k], want[k]) and np.array_equal(again[k], want[k]), k
+assert np.array_equal(got["score"].view(np.uint64), want["score"].view(np.uint64))
+print("OK", int(want["motif_offsets"][-1]))
+""" % ROOT
+    env = dict(os.environ, MS_MEASURE="1", MS_CU_PARTITION="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("OK ")
+
+
 def test_owned_views_keep_the_result_alive():
     """views of the library's pinned buffers must not dangle when the caller drops the result object."""
     import gc
