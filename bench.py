@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=list(WORKLOAD_TEXT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-batch-ramp", action="store_true", help="end-to-end passes: equal batches (default: small first and last batches)")
     ap.add_argument("--min-warm-seconds", type=float, default=2.0, help="untimed warm-up steps continue until this much wall time has passed (DVFS steady state)")
     ap.add_argument("--regions-per-set", type=int, default=None, help="c4 only: shrink the workload (development aid; the line then says so)")
     ap.add_argument("--genome-mbp", type=int, default=3000, help="c5 only: synthetic genome size in Mbp")
@@ -376,16 +377,26 @@ def end_to_end(a, wl, pw, world, dev, torch, dist):
        serial     one batch at a time: upload + pack, scan, copy-out.
     Whole-job rates (max time over ranks)."""
     from motifscan_amd import _lib, dist as msdist
-    pins, batches = [], []
+    pins, batches, cuts = [], [], []
     for bases, offsets in wl["sets"]:
         pin = _lib.PinnedBuffer(max(bases.size, 1))
         pin.array[:bases.size] = bases
         pins.append(pin)
         n = len(offsets) - 1
         for r0 in range(0, n, a.batch_regions):
-            r1 = min(n, r0 + a.batch_regions)
-            lo, hi = int(offsets[r0]), int(offsets[r1])
-            batches.append((pin.array[lo:hi], np.ascontiguousarray(offsets[r0:r1 + 1] - lo)))
+            cuts.append((len(pins) - 1, r0, min(n, r0 + a.batch_regions)))
+    if not a.no_batch_ramp and len(cuts) >= 4:
+        # the pass begins with an upload nothing overlaps and ends with a copy-out nothing overlaps: make those two batches small
+        # (first batch cut 1/4 + 1/4 + 1/2, last 1/2 + 1/4 + 1/4); what the pipeline does per region is unchanged
+        def split(c, fr):
+            k, r0, r1 = c
+            pts = [r0 + int((r1 - r0) * f) for f in fr] + [r1]
+            return [(k, x, y) for x, y in zip(pts[:-1], pts[1:]) if y > x]
+        cuts = split(cuts[0], (0.0, 0.25, 0.5)) + cuts[1:-1] + split(cuts[-1], (0.0, 0.5, 0.75))
+    for k, r0, r1 in cuts:
+        offsets = wl["sets"][k][1]
+        lo, hi = int(offsets[r0]), int(offsets[r1])
+        batches.append((pins[k].array[lo:hi], np.ascontiguousarray(offsets[r0:r1 + 1] - lo)))
     units = float(wl["units"])
 
     def timed(fn, passes):
@@ -440,7 +451,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist):
         pin.close()
     return {"pipelined": v_p16, "pipelined_25B": v_p25, "serial": v_s, "unit": "bp*motifs/s",
             "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s},
-            "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "hits_per_pass_per_gpu": int(hits),
+            "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
             "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
             "cu_partition": "while a stream is live the copy / pack kernels own 1 CU of every 32 (CU masks), the scan the other 31",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "

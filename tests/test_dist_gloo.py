@@ -113,3 +113,18 @@ def test_sweep_shards_cover_every_window_once():
                     assert b == begin + k0 * stride and e == begin + (k1 - 1) * stride + window and e <= end
                     assert (e - b - window) // stride + 1 == k1 - k0          # the span holds exactly the rank's windows
             assert seen == list(range(n))
+
+
+def test_batch_bounds_cover_every_region_once_with_and_without_ramp():
+    from motifscan_amd import dist as msdist
+    for n in (0, 1, 5, 999, 1000, 1001, 4000, 125_000 * 8 + 17):
+        for step in (1, 7, 250, 125_000):
+            if n / step > 5000:
+                continue
+            for ramp in (False, True):
+                b = msdist.batch_bounds(n, step, ramp=ramp)
+                assert b[0][0] == 0 and b[-1][1] == max(n, 0) or (n == 0 and b == [(0, 0)])
+                assert all(x[1] == y[0] for x, y in zip(b[:-1], b[1:])), (n, step, ramp)
+                assert all(0 < r1 - r0 <= step for r0, r1 in b) or n == 0
+    b = msdist.batch_bounds(1000, 100, ramp=True)
+    assert b[:3] == [(0, 25), (25, 50), (50, 100)] and b[-3:] == [(900, 950), (950, 975), (975, 1000)] and len(b) == 14
