@@ -853,12 +853,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
     const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : pf_engine() == 3 ? kF6LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
-    size_t lds_budget = c->lds_max - lds_fixed;
-    int pf_blocks_per_cu = 1;
-    if (const char *e = measure_env("MS_PF_BLOCKS_PER_CU")) {          // measurement: smaller tiles, several blocks per CU
-        pf_blocks_per_cu = std::max(1, atoi(e));
-        lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - lds_fixed;
-    }
+    // engine 3 runs as TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile): the same 16 waves per CU as one
+    // 1024-thread block, 10 % faster -- the chunk loop's block-wide barriers hold 8 waves instead of 16 (profiles/r02_wave_occupancy_ab.log)
+    int pf_blocks_per_cu = pf_engine() == 3 ? 2 : 1;
+    if (const char *e = measure_env("MS_PF_BLOCKS_PER_CU")) pf_blocks_per_cu = std::max(1, atoi(e));       // measurement: smaller tiles, several blocks per CU
+    const size_t lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - lds_fixed;
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
     const PrefilterPlan &plan = pwms->plan;
@@ -951,10 +950,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
     // kernel variant: engine 1 queues records without flags for the second tail form (expand_kernel decodes them)
-    int pf_variant = plan.engine == 3 ? 31 : plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
+    int pf_variant = plan.engine == 3 ? (pf_blocks_per_cu == 2 ? 44 : 31) : plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_VARIANT")) {
-        const int v = atoi(e) & 31;
-        const int v_engine = (v >= 28 && v <= 31) ? 3 : (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;
+        const int v = atoi(e) & 63;
+        const int v_engine = v >= 28 ? 3 : (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;
         if (v_engine == plan.engine && !(v == 20 && tail != 2)) pf_variant = v;     // a variant of another engine cannot read this plan
     }
     if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
@@ -963,9 +962,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     int clk_blocks = 0;
     const bool pf_meas = pf_no_emit != 0 || pf_clock;              // the measurement instantiation of the kernel
     raw->invalid = pf_no_emit != 0;                                // stage times only: the hit accessors refuse such a result
-    if (lds_bytes > c->lds_set[pf_variant + (pf_meas ? 32 : 0)]) {
+    if (lds_bytes > c->lds_set[pf_variant + (pf_meas ? 64 : 0)]) {
         if ((rc = prefilter_set_lds(pf_variant, pf_meas, lds_bytes))) return fail(rc);
-        c->lds_set[pf_variant + (pf_meas ? 32 : 0)] = lds_bytes;
+        c->lds_set[pf_variant + (pf_meas ? 64 : 0)] = lds_bytes;
     }
 
     // counters: [0] candidate records, [1] hits (tail 1) / entries (tail 2), [2] N-window positions, [3] hits written by the

@@ -1585,7 +1585,19 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
         case 28: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 3, true>;       // engine 3 (fp6 x fp4, 16 columns per k-block), two row tiles in flight
         case 29: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true>;       // engine 3, one row tile in flight
         case 30: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 2, 6>;   // engine 3, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
-        case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path: the default
+        case 32: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 4, 6>;   // A/B (r02_wave_occupancy_ab.log): 30 with the 3-k-block class compiled in
+        case 33: *threads = 768; return prefilter_mfma_kernel<768, 2, 3, true, 2, 6>;   // 30 + per-half maxima kept
+        case 34: *threads = 768; return prefilter_mfma_kernel<768, 3, 3, true, 2, 6>;   // 30 + two row tiles in flight
+        case 35: *threads = 896; return prefilter_mfma_kernel<896, 0, 3, true, 2, 7>;   // 2 x 14 waves per CU (<= 72 VGPRs)
+        case 36: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 3, true, 2, 4>;  // 31 without the 3-k-block class
+        case 37: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true, 2, 8>;  // 2 x 16 waves per CU (<= 64 VGPRs)
+        case 38: *threads = 640; return prefilter_mfma_kernel<640, 0, 3, true, 2, 5>;    // 2 x 10 waves per CU
+        case 39: *threads = 512; return prefilter_mfma_kernel<512, 0, 3, true, 2, 4>;    // 2 x 8 waves per CU (= 16, as 31, in two blocks)
+        case 43: *threads = 512; return prefilter_mfma_kernel<512, 2, 3, true, 2, 4>;    // 2 x 8 waves, per-half maxima kept
+        case 44: *threads = 512;                                           // engine 3 as shipped: 31's code in two 512-thread blocks per CU (no 3-k-block class: W <= 32 is <= 2 k-blocks of 16 columns)
+            return meas ? prefilter_mfma_kernel<512, 3, 3, true, 2, 4> : prefilter_mfma_kernel<512, 3, 3, false, 2, 4>;
+        case 45: *threads = 512; return prefilter_mfma_kernel<512, 1, 3, true, 2, 4>;    // 2 x 8 waves, two row tiles in flight
+        case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path, one 1024-thread block per CU (the default until 44)
             return meas ? prefilter_mfma_kernel<1024, 3, 3, true> : prefilter_mfma_kernel<1024, 3, 3, false>;
         case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default
             return meas ? prefilter_mfma_kernel<1024, 5, 1, true> : prefilter_mfma_kernel<1024, 5, 1, false>;
