@@ -853,8 +853,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
     const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : pf_engine() == 3 ? kF6LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
-    // engine 3 runs as TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile): the same 16 waves per CU as one
-    // 1024-thread block, 10 % faster -- the chunk loop's block-wide barriers hold 8 waves instead of 16 (profiles/r02_wave_occupancy_ab.log)
+    // engine 3 runs as TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by
+    // one: the same 16 waves per CU as one 1024-thread block with a block-wide hand-out, 12 % faster -- the chunk loop's barriers made
+    // every wave wait for the block's slowest, the one that met the rare path most often (profiles/r02_wave_occupancy_ab.log)
     int pf_blocks_per_cu = pf_engine() == 3 ? 2 : 1;
     if (const char *e = measure_env("MS_PF_BLOCKS_PER_CU")) pf_blocks_per_cu = std::max(1, atoi(e));       // measurement: smaller tiles, several blocks per CU
     const size_t lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - lds_fixed;
@@ -950,7 +951,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
     // kernel variant: engine 1 queues records without flags for the second tail form (expand_kernel decodes them)
-    int pf_variant = plan.engine == 3 ? (pf_blocks_per_cu == 2 ? 44 : 31) : plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
+    int pf_variant = plan.engine == 3 ? (pf_blocks_per_cu == 2 ? 46 : 31) : plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_VARIANT")) {
         const int v = atoi(e) & 63;
         const int v_engine = v >= 28 ? 3 : (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;

@@ -761,7 +761,7 @@ __device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const 
 // MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
 // MAXNK / WPS (A/B): a kernel that only knows row tiles of <= MAXNK k-blocks needs fewer registers (B operands: 8 per k-block),
 // WPS = waves per SIMD the register allocation must leave room for (two 768-thread blocks per CU = 6).
-template <int NT, int V, int ENG, bool MEAS, int MAXNK = 4, int WPS = NT / 256>
+template <int NT, int V, int ENG, bool MEAS, int MAXNK = 4, int WPS = NT / 256, int HANDOUT = 0>
 __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -802,16 +802,7 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
     // so a block whose CU is still busy with another stream's kernel (an upload's pack, a copy-out's blit: the batch stream runs
     // them beside the scan) starts late -- with a static partition the whole launch then waits for that block's full share
     // (measured: 3.7x on the streamed sweep with copy-out, profiles/r02_stream_coexistence.log); now it simply takes fewer chunks.
-    constexpr int kSuper = 4;
-    __shared__ unsigned int s_super;
-    for (;;) {
-        __syncthreads();                                                   // every wave is done with the previous hand-out
-        if (threadIdx.x == 0) s_super = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
-        __syncthreads();
-        const int64_t first = (int64_t) s_super * kSuper;
-        if (first >= n_chunks) break;
-    for (int64_t chunk = first; chunk < first + kSuper && chunk < n_chunks; chunk++) {
-        const int64_t g0 = chunk * NT + (threadIdx.x & ~63u) + r;          // window start of N-tile 0; N-tile 1: + 32
+    auto scan_pass = [&](int64_t g0) {                                       // 64 window starts of this wave against every class
         const bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
         const uint64_t cw0 = code_window(A.codes, live0 ? g0 : 0);
         const uint64_t cw1 = code_window(A.codes, live1 ? g0 + 32 : 0);
@@ -831,6 +822,35 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
                 default: break;
             }
         }
+    };
+    if constexpr (HANDOUT == 1) {
+        // Per-WAVE hand-out: a wave takes kWavePasses x 64 consecutive window starts per atomic (the next unit is requested before the
+        // current one is scanned, so the atomic's latency is hidden) and never meets the block's other waves again: no barrier in the
+        // loop, a wave that ran into the rare path more often than its neighbours delays nobody.
+        constexpr int kWavePasses = 8;
+        const int64_t n_units = (A.n_bases + 64 * kWavePasses - 1) / (64 * kWavePasses);
+        auto take = [&]() {
+            unsigned int u = 0;
+            if (lane == 0) u = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
+            return (int64_t) __builtin_amdgcn_readfirstlane((int) u);
+        };
+        int64_t unit = take();
+        while (unit < n_units) {
+            const int64_t next = take();
+            for (int j = 0; j < kWavePasses; j++) scan_pass((unit * kWavePasses + j) * 64 + r);
+            unit = next;
+        }
+    } else {
+    constexpr int kSuper = 4;
+    __shared__ unsigned int s_super;
+    for (;;) {
+        __syncthreads();                                                   // every wave is done with the previous hand-out
+        if (threadIdx.x == 0) s_super = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
+        __syncthreads();
+        const int64_t first = (int64_t) s_super * kSuper;
+        if (first >= n_chunks) break;
+        for (int64_t chunk = first; chunk < first + kSuper && chunk < n_chunks; chunk++)
+            scan_pass(chunk * NT + (threadIdx.x & ~63u) + r);              // window start of N-tile 0; N-tile 1: + 32
     }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
@@ -1594,9 +1614,11 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
         case 38: *threads = 640; return prefilter_mfma_kernel<640, 0, 3, true, 2, 5>;    // 2 x 10 waves per CU
         case 39: *threads = 512; return prefilter_mfma_kernel<512, 0, 3, true, 2, 4>;    // 2 x 8 waves per CU (= 16, as 31, in two blocks)
         case 43: *threads = 512; return prefilter_mfma_kernel<512, 2, 3, true, 2, 4>;    // 2 x 8 waves, per-half maxima kept
-        case 44: *threads = 512;                                           // engine 3 as shipped: 31's code in two 512-thread blocks per CU (no 3-k-block class: W <= 32 is <= 2 k-blocks of 16 columns)
-            return meas ? prefilter_mfma_kernel<512, 3, 3, true, 2, 4> : prefilter_mfma_kernel<512, 3, 3, false, 2, 4>;
+        case 44: *threads = 512; return prefilter_mfma_kernel<512, 3, 3, true, 2, 4>;    // 31's code in two 512-thread blocks per CU (no 3-k-block class: W <= 32 is <= 2 k-blocks of 16 columns)
         case 45: *threads = 512; return prefilter_mfma_kernel<512, 1, 3, true, 2, 4>;    // 2 x 8 waves, two row tiles in flight
+        case 46: *threads = 512;                                           // engine 3 as shipped: 44 with per-WAVE hand-out (no barrier in the loop)
+            return meas ? prefilter_mfma_kernel<512, 3, 3, true, 2, 4, 1> : prefilter_mfma_kernel<512, 3, 3, false, 2, 4, 1>;
+        case 47: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 3, true, 2, 4, 1>; // 31 with per-wave hand-out
         case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path, one 1024-thread block per CU (the default until 44)
             return meas ? prefilter_mfma_kernel<1024, 3, 3, true> : prefilter_mfma_kernel<1024, 3, 3, false>;
         case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default
