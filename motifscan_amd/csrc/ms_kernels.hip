@@ -823,11 +823,11 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
             }
         }
     };
-    if constexpr (HANDOUT == 1) {
-        // Per-WAVE hand-out: a wave takes kWavePasses x 64 consecutive window starts per atomic (the next unit is requested before the
+    if constexpr (HANDOUT >= 1) {
+        // Per-WAVE hand-out (HANDOUT = passes per atomic): a wave takes kWavePasses x 64 consecutive window starts per atomic (the next unit is requested before the
         // current one is scanned, so the atomic's latency is hidden) and never meets the block's other waves again: no barrier in the
         // loop, a wave that ran into the rare path more often than its neighbours delays nobody.
-        constexpr int kWavePasses = 8;
+        constexpr int kWavePasses = HANDOUT;
         const int64_t n_units = (A.n_bases + 64 * kWavePasses - 1) / (64 * kWavePasses);
         auto take = [&]() {
             unsigned int u = 0;
@@ -1605,20 +1605,11 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
         case 28: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 3, true>;       // engine 3 (fp6 x fp4, 16 columns per k-block), two row tiles in flight
         case 29: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true>;       // engine 3, one row tile in flight
         case 30: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 2, 6>;   // engine 3, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
-        case 32: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 4, 6>;   // A/B (r02_wave_occupancy_ab.log): 30 with the 3-k-block class compiled in
-        case 33: *threads = 768; return prefilter_mfma_kernel<768, 2, 3, true, 2, 6>;   // 30 + per-half maxima kept
-        case 34: *threads = 768; return prefilter_mfma_kernel<768, 3, 3, true, 2, 6>;   // 30 + two row tiles in flight
-        case 35: *threads = 896; return prefilter_mfma_kernel<896, 0, 3, true, 2, 7>;   // 2 x 14 waves per CU (<= 72 VGPRs)
-        case 36: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 3, true, 2, 4>;  // 31 without the 3-k-block class
-        case 37: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true, 2, 8>;  // 2 x 16 waves per CU (<= 64 VGPRs)
-        case 38: *threads = 640; return prefilter_mfma_kernel<640, 0, 3, true, 2, 5>;    // 2 x 10 waves per CU
-        case 39: *threads = 512; return prefilter_mfma_kernel<512, 0, 3, true, 2, 4>;    // 2 x 8 waves per CU (= 16, as 31, in two blocks)
-        case 43: *threads = 512; return prefilter_mfma_kernel<512, 2, 3, true, 2, 4>;    // 2 x 8 waves, per-half maxima kept
+        case 33: *threads = 768; return prefilter_mfma_kernel<768, 2, 3, true, 2, 6>;   // A/B: 30 + per-half maxima kept (2 x 12 waves, 16 registers spilled)
         case 44: *threads = 512; return prefilter_mfma_kernel<512, 3, 3, true, 2, 4>;    // 31's code in two 512-thread blocks per CU (no 3-k-block class: W <= 32 is <= 2 k-blocks of 16 columns)
-        case 45: *threads = 512; return prefilter_mfma_kernel<512, 1, 3, true, 2, 4>;    // 2 x 8 waves, two row tiles in flight
         case 46: *threads = 512;                                           // engine 3 as shipped: 44 with per-WAVE hand-out (no barrier in the loop)
-            return meas ? prefilter_mfma_kernel<512, 3, 3, true, 2, 4, 1> : prefilter_mfma_kernel<512, 3, 3, false, 2, 4, 1>;
-        case 47: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 3, true, 2, 4, 1>; // 31 with per-wave hand-out
+            return meas ? prefilter_mfma_kernel<512, 3, 3, true, 2, 4, 8> : prefilter_mfma_kernel<512, 3, 3, false, 2, 4, 8>;
+        case 47: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 3, true, 2, 4, 8>; // 31 with per-wave hand-out
         case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path, one 1024-thread block per CU (the default until 44)
             return meas ? prefilter_mfma_kernel<1024, 3, 3, true> : prefilter_mfma_kernel<1024, 3, 3, false>;
         case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default

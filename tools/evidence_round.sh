@@ -13,7 +13,7 @@ python bench.py --workload c5shard --steps 4 --warmup 1 > $OUT/bench_c5shard.jso
 python bench.py --workload c5 --genome-mbp 3000 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_3000mbp.json 2> $OUT/bench_c5.err
 python tools/pf_clock.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_clock.log
 python tools/pf_uniform.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_uniform_width.log
-python tools/pf_variants.py c4shard 31:1 28:1 29:1 30:2 16:1 18:1 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
+python tools/pf_variants.py c4shard 46:2 44:2 47:1 31:1 28:1 29:1 30:2 33:2 16:1 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
 python tools/once_overlap.py 2>&1 | grep -v amdgpu.ids > $OUT/scan_once_overlap.log
 python tools/n_fraction.py 2>&1 | grep -v amdgpu.ids > $OUT/n_fraction.log
 ./tools/ubench/mfma_i8_rate > $OUT/mfma_i8_rate.log 2>&1
