@@ -992,16 +992,34 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             // While a batch stream is live the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs, one
             // persistent block each (the chunks are handed out dynamically: fewer blocks just take more each)
             const int reserve = c->n_streams.load() > 0 ? c->n_cu_copy : 0;
-            const int bpt = std::max(1, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles);
+            const int pf_threads = prefilter_threads(pf_variant);
+            const int64_t pf_chunks = (S.n_bases + pf_threads - 1) / pf_threads;
+            const int bpt = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles));
             if ((size_t) n_tiles > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
                 sc.chunk_counters_cap = 0;
                 if ((rc = dev_alloc(&sc.chunk_counters, (size_t) n_tiles + 16))) return fail(rc);
                 sc.chunk_counters_cap = (size_t) n_tiles + 16;
             }
-            he = hipMemsetAsync(sc.chunk_counters, 0, sizeof(unsigned int) * (size_t) n_tiles, c->stream);
+            // block hand-out: the counter counts chunks from 0; per-wave hand-out: units 0 .. waves-1 are the waves' own first units
+            const unsigned int first_free = (pf_variant == 46 || pf_variant == 47) ? (unsigned int) (bpt * (pf_threads / 64)) : 0u;
+            he = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc.chunk_counters), (int) first_free, (size_t) n_tiles, c->stream);
             if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             A.chunk_counter = sc.chunk_counters;
+            {
+                // unit of the per-wave hand-out: a pass (64 window starts against a tile's k-blocks) takes ~0.25 us per k-block with 16
+                // waves per CU, and the launch's waves should not exceed ~47 atomics per microsecond on a tile's counter word
+                int64_t kb_tile = 0;
+                for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_tile += plan.group_G[q];
+                kb_tile = std::max<int64_t>(1, kb_tile / std::max(1, n_tiles));
+                const double waves = (double) bpt * (prefilter_threads(pf_variant) / 64);       // per tile
+                const int64_t need = (int64_t) std::ceil(waves / (47.0 * 0.25 * (double) kb_tile));
+                int64_t wp = 8;                                               // a power of two: units start on 512-position boundaries
+                while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;
+                const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
+                if (passes_total <= wp * n_waves) wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);   // small input: one unit per wave
+                A.wave_passes = (int) wp;
+            }
             A.clk = nullptr;
             if (pf_clock) {
                 clk_blocks = bpt * n_tiles;

@@ -100,10 +100,12 @@ struct PfArgs {
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
     unsigned int *chunk_counter;   // [LDS tiles], zeroed: the matrix-core kernels hand their position chunks out dynamically
+    int wave_passes;               // per-wave hand-out: passes of 64 window starts a wave takes per atomic (scan_locked sizes it)
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
 int prefilter_set_lds(int variant, bool meas, size_t bytes);
+int prefilter_threads(int variant);           // block size of a kernel variant
 int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_nlist(const DevSeq &S, int max_w, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H, hipStream_t st);
 int launch_neval(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask, const NPos *list,

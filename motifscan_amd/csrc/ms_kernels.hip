@@ -824,20 +824,27 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
         }
     };
     if constexpr (HANDOUT >= 1) {
-        // Per-WAVE hand-out (HANDOUT = passes per atomic): a wave takes kWavePasses x 64 consecutive window starts per atomic (the next unit is requested before the
-        // current one is scanned, so the atomic's latency is hidden) and never meets the block's other waves again: no barrier in the
-        // loop, a wave that ran into the rare path more often than its neighbours delays nobody.
-        constexpr int kWavePasses = HANDOUT;
-        const int64_t n_units = (A.n_bases + 64 * kWavePasses - 1) / (64 * kWavePasses);
+        // Per-WAVE hand-out: a wave takes A.wave_passes x 64 consecutive window starts per atomic (the next unit is requested
+        // before the current one is scanned, so the atomic's latency is hidden) and never meets the block's other waves again: no
+        // barrier in the loop, a wave that ran into the rare path more often than its neighbours delays nobody.  The host sizes
+        // the unit so that the launch's waves together stay below ~50 atomics per microsecond on the one counter word (it saturates
+        // near 90: 4 passes per atomic on the 579-motif set cost +13 %); an input with fewer passes than that per wave is split evenly.
+        const int wave_passes = A.wave_passes < 1 ? HANDOUT : A.wave_passes;
+        const int64_t n_passes_total = (A.n_bases + 63) / 64;
+        const int64_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
         auto take = [&]() {
             unsigned int u = 0;
             if (lane == 0) u = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
             return (int64_t) __builtin_amdgcn_readfirstlane((int) u);
         };
-        int64_t unit = take();
+        // the first unit is the wave's own number (the counter starts at the number of waves): the launch does not begin with every
+        // wave queueing on one word
+        int64_t unit = (int64_t) blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+        const bool more = n_units > (int64_t) gridDim.x * (NT / 64);          // a small input is one unit per wave: no atomic at all
         while (unit < n_units) {
-            const int64_t next = take();
-            for (int j = 0; j < kWavePasses; j++) scan_pass((unit * kWavePasses + j) * 64 + r);
+            const int64_t next = more ? take() : n_units;
+            const int64_t p0 = unit * wave_passes, p1 = p0 + wave_passes < n_passes_total ? p0 + wave_passes : n_passes_total;
+            for (int64_t ps = p0; ps < p1; ps++) scan_pass(ps * 64 + r);
             unit = next;
         }
     } else {
@@ -1619,6 +1626,12 @@ static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
         case 25: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 2, true>;  // engine 2, one row tile in flight per wave
         default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
     }
+}
+
+int prefilter_threads(int variant) {
+    int threads = 0;
+    (void) pf_kernel_for(variant, true, &threads);
+    return threads;
 }
 
 int prefilter_set_lds(int variant, bool meas, size_t bytes) {

@@ -102,12 +102,21 @@ def _c4_block(args):
 
 def _pool_map(fn, jobs, workers):
     """Generate blocks in worker processes (plain numpy work; started before anything touches the GPU)."""
+    if os.environ.get("MS_SYNTH_WORKERS"):                  # e.g. 1 under a profiler that follows forked children
+        workers = int(os.environ["MS_SYNTH_WORKERS"])
     workers = max(1, min(workers, len(jobs)))
     if workers == 1:
         return [fn(j) for j in jobs]
     import multiprocessing as mp
-    with mp.get_context("fork").Pool(workers) as pool:
-        return pool.map(fn, jobs, chunksize=1)
+    pool = mp.get_context("fork").Pool(workers)
+    try:
+        out = pool.map(fn, jobs, chunksize=1)
+        pool.close()                                        # workers leave through their normal exit path, not SIGTERM
+        pool.join()
+        return out
+    except BaseException:
+        pool.terminate()
+        raise
 
 
 def c4_shard(rank=0, world=1, workers=None, regions_per_set=None):
