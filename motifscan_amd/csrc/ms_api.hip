@@ -1017,7 +1017,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 int64_t wp = 8;                                               // a power of two: units start on 512-position boundaries
                 while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;
                 const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
-                if (passes_total <= wp * n_waves) wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);   // small input: one unit per wave
+                if (passes_total <= 8 * wp * n_waves) wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);   // fewer than 8 units per wave: one even unit each, no atomics (a second round of a few units would leave most waves idle)
                 A.wave_passes = (int) wp;
             }
             A.clk = nullptr;

@@ -829,22 +829,23 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
         // barrier in the loop, a wave that ran into the rare path more often than its neighbours delays nobody.  The host sizes
         // the unit so that the launch's waves together stay below ~50 atomics per microsecond on the one counter word (it saturates
         // near 90: 4 passes per atomic on the 579-motif set cost +13 %); an input with fewer passes than that per wave is split evenly.
-        const int wave_passes = A.wave_passes < 1 ? HANDOUT : A.wave_passes;
-        const int64_t n_passes_total = (A.n_bases + 63) / 64;
-        const int64_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
+        const uint32_t wave_passes = A.wave_passes < 1 ? (uint32_t) HANDOUT : (uint32_t) A.wave_passes;
+        const uint32_t n_passes_total = (uint32_t) ((A.n_bases + 63) / 64);           // <= 2^28: a set holds <= 2^34 bases
+        const uint32_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
         auto take = [&]() {
             unsigned int u = 0;
             if (lane == 0) u = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
-            return (int64_t) __builtin_amdgcn_readfirstlane((int) u);
+            return (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
         };
         // the first unit is the wave's own number (the counter starts at the number of waves): the launch does not begin with every
         // wave queueing on one word
-        int64_t unit = (int64_t) blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-        const bool more = n_units > (int64_t) gridDim.x * (NT / 64);          // a small input is one unit per wave: no atomic at all
+        uint32_t unit = blockIdx.x * (uint32_t) (NT / 64) + (threadIdx.x >> 6);
+        const bool more = n_units > gridDim.x * (uint32_t) (NT / 64);                 // a small input is one unit per wave: no atomic at all
         while (unit < n_units) {
-            const int64_t next = more ? take() : n_units;
-            const int64_t p0 = unit * wave_passes, p1 = p0 + wave_passes < n_passes_total ? p0 + wave_passes : n_passes_total;
-            for (int64_t ps = p0; ps < p1; ps++) scan_pass(ps * 64 + r);
+            const uint32_t next = more ? take() : n_units;
+            const uint32_t p0 = unit * wave_passes;
+            for (uint32_t j = 0; j < wave_passes; j++)                                // passes past the end scan dead lanes (last unit only)
+                scan_pass((int64_t) (p0 + j) * 64 + r);
             unit = next;
         }
     } else {
