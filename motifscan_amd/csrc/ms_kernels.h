@@ -4,7 +4,7 @@
 
 namespace ms {
 
-constexpr int kPfThreads = 1024;      // largest pre-filter block: 16 waves, one block per CU
+constexpr int kPfThreads = 1024;      // largest pre-filter block (16 waves; engine 3 runs two 512-thread blocks per CU): sizes the wave queues
 constexpr int kNwMotifChunk = 8;      // motifs per neval_kernel block (their fp64 tables sit in LDS: 16 KB; 16 per block measured 20 % slower)
 constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spilled to HBM when the next append would not fit
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);

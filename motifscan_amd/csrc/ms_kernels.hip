@@ -761,6 +761,9 @@ __device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const 
 // MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
 // MAXNK / WPS (A/B): a kernel that only knows row tiles of <= MAXNK k-blocks needs fewer registers (B operands: 8 per k-block),
 // WPS = waves per SIMD the register allocation must leave room for (two 768-thread blocks per CU = 6).
+// HANDOUT: 0 = a BLOCK takes 4 chunks of NT positions per atomic behind two __syncthreads (every wave then waits for the block's
+// slowest: -10 % with 16 waves per block, -2 % with 8); >= 1 = every WAVE takes its own units, no barrier in the loop -- the shipped
+// engine-3 form (two 512-thread blocks per CU, variant 46; profiles/r02_wave_occupancy_ab.log).
 template <int NT, int V, int ENG, bool MEAS, int MAXNK = 4, int WPS = NT / 256, int HANDOUT = 0>
 __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
@@ -798,10 +801,10 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
-    // Chunks are handed out DYNAMICALLY, kSuper at a time per block: the kernel wants every CU whole (all its LDS and registers),
+    // Work is handed out DYNAMICALLY (per wave or per block, HANDOUT): the kernel wants every CU whole (all its LDS and registers),
     // so a block whose CU is still busy with another stream's kernel (an upload's pack, a copy-out's blit: the batch stream runs
     // them beside the scan) starts late -- with a static partition the whole launch then waits for that block's full share
-    // (measured: 3.7x on the streamed sweep with copy-out, profiles/r02_stream_coexistence.log); now it simply takes fewer chunks.
+    // (measured: 3.7x on the streamed sweep with copy-out, profiles/r02_stream_coexistence.log); now it simply takes less.
     auto scan_pass = [&](int64_t g0) {                                       // 64 window starts of this wave against every class
         const bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
         const uint64_t cw0 = code_window(A.codes, live0 ? g0 : 0);
