@@ -283,6 +283,27 @@ print("OK", int(want["motif_offsets"][-1]))
     assert out.stdout.strip().splitlines()[-1].startswith("OK ")
 
 
+@pytest.mark.parametrize("n_regions", [43_500, 44_800, 46_500])
+def test_work_handout_regimes_agree_with_the_all_fp64_kernel(n_regions):
+    """The pre-filter hands its work out per wave: an input worth fewer than 8 units per wave is split evenly with no atomics, a
+    larger one goes through the tile's counter word (8 passes of 64 window starts per unit on the 579-motif set, i.e. the
+    switch sits near 16.8 Mbase = 44 700 ragged regions of 250-500 bp).  Sizes either side of it, ragged region lengths and a last region that ends mid-pass:
+    the result must equal the all-fp64 kernel's (MS_SCAN_EXACT_ONLY: no pre-filter at all), hit for hit and bit for bit."""
+    vals, widths, cutoffs = synth.load_motif_set(579)
+    bases, offsets = synth.make_regions(n_regions, 500, seed=31, frac_n=0.01, ragged=True)
+    cut = int(offsets[-1]) - 37                                # drop 37 bases: the last region ends inside a pass
+    offsets = offsets.copy(); offsets[-1] = cut
+    bases = bases[:cut]
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    sq = _lib.SeqSet(bases, offsets)
+    got = _lib.scan(pw, sq, 3)
+    st = got.stats()
+    assert st["pf_engine"] == 3 and st["n_tiles"] == 1
+    want = _lib.scan(pw, sq, 3, _lib.MS_SCAN_EXACT_ONLY)
+    assert_same_hits(got.hits(), want.hits())
+    assert np.array_equal(got.region_counts(), want.region_counts())
+
+
 def test_owned_views_keep_the_result_alive():
     """views of the library's pinned buffers must not dangle when the caller drops the result object."""
     import gc
