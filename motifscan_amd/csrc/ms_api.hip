@@ -1001,24 +1001,33 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 if ((rc = dev_alloc(&sc.chunk_counters, (size_t) n_tiles + 16))) return fail(rc);
                 sc.chunk_counters_cap = (size_t) n_tiles + 16;
             }
-            // block hand-out: the counter counts chunks from 0; per-wave hand-out: units 0 .. waves-1 are the waves' own first units
-            const unsigned int first_free = (pf_variant == 46 || pf_variant == 47) ? (unsigned int) (bpt * (pf_threads / 64)) : 0u;
-            he = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc.chunk_counters), (int) first_free, (size_t) n_tiles, c->stream);
-            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             A.chunk_counter = sc.chunk_counters;
+            const bool per_wave = pf_variant == 46 || pf_variant == 47;
+            bool counter_used = true;
             {
                 // unit of the per-wave hand-out: a pass (64 window starts against a tile's k-blocks) takes ~0.25 us per k-block with 16
                 // waves per CU, and the launch's waves should not exceed ~47 atomics per microsecond on a tile's counter word
                 int64_t kb_tile = 0;
                 for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_tile += plan.group_G[q];
                 kb_tile = std::max<int64_t>(1, kb_tile / std::max(1, n_tiles));
-                const double waves = (double) bpt * (prefilter_threads(pf_variant) / 64);       // per tile
+                const double waves = (double) bpt * (pf_threads / 64);                          // per tile
                 const int64_t need = (int64_t) std::ceil(waves / (47.0 * 0.25 * (double) kb_tile));
                 int64_t wp = 8;                                               // a power of two: units start on 512-position boundaries
                 while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;
                 const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
-                if (passes_total <= 8 * wp * n_waves) wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);   // fewer than 8 units per wave: one even unit each, no atomics (a second round of a few units would leave most waves idle)
+                if (passes_total <= 8 * wp * n_waves) {
+                    // fewer than 8 units per wave: one even unit each and no atomics (a second round of a few units would leave
+                    // most waves idle); the kernel then never touches the counter word
+                    wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);
+                    counter_used = !per_wave;
+                }
                 A.wave_passes = (int) wp;
+            }
+            if (counter_used) {
+                // block hand-out: the counter counts chunks from 0; per-wave hand-out: units 0 .. waves-1 are the waves' own first units
+                const unsigned int first_free = per_wave ? (unsigned int) (bpt * (pf_threads / 64)) : 0u;
+                he = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc.chunk_counters), (int) first_free, (size_t) n_tiles, c->stream);
+                if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             }
             A.clk = nullptr;
             if (pf_clock) {
