@@ -995,11 +995,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             const int pf_threads = prefilter_threads(pf_variant);
             const int64_t pf_chunks = (S.n_bases + pf_threads - 1) / pf_threads;
             const int bpt = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles));
-            if ((size_t) n_tiles > sc.chunk_counters_cap) {
+            const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // per-wave hand-out: kPfCounters words per tile, 64 bytes apart
+            if (counter_words > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
                 sc.chunk_counters_cap = 0;
-                if ((rc = dev_alloc(&sc.chunk_counters, (size_t) n_tiles + 16))) return fail(rc);
-                sc.chunk_counters_cap = (size_t) n_tiles + 16;
+                if ((rc = dev_alloc(&sc.chunk_counters, counter_words + 16))) return fail(rc);
+                sc.chunk_counters_cap = counter_words + 16;
             }
             A.chunk_counter = sc.chunk_counters;
             const bool per_wave = pf_variant == 46 || pf_variant == 47;
@@ -1011,22 +1012,23 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_tile += plan.group_G[q];
                 kb_tile = std::max<int64_t>(1, kb_tile / std::max(1, n_tiles));
                 const double waves = (double) bpt * (pf_threads / 64);                          // per tile
-                const int64_t need = (int64_t) std::ceil(waves / (47.0 * 0.25 * (double) kb_tile));
-                int64_t wp = 8;                                               // a power of two: units start on 512-position boundaries
-                while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;
+                const double waves_word = per_wave ? waves / kPfCounters : waves;               // ... and per counter word
+                const int64_t need = (int64_t) std::ceil(waves_word / (47.0 * 0.25 * (double) kb_tile));
                 const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
-                if (passes_total <= 8 * wp * n_waves) {
-                    // fewer than 8 units per wave: one even unit each and no atomics (a second round of a few units would leave
-                    // most waves idle); the kernel then never touches the counter word
+                int64_t wp = per_wave ? 2 : 8;                                // a power of two: units start on 128-position boundaries at least
+                while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;            // the words' rate limit
+                while (wp < 8 && 128 * wp <= passes_total / n_waves) wp *= 2;             // a long launch: the tail (one unit) stays below 1 % anyway, fewer atomics
+                if (passes_total <= 8 * std::max<int64_t>(wp, 8) * n_waves) {
+                    // fewer than 8 units (of 8 passes at least) per wave: one even unit each and no atomics (a second round of a few
+                    // units would leave most waves idle); the kernel then never touches the counter words
                     wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);
                     counter_used = !per_wave;
                 }
                 A.wave_passes = (int) wp;
             }
             if (counter_used) {
-                // block hand-out: the counter counts chunks from 0; per-wave hand-out: units 0 .. waves-1 are the waves' own first units
-                const unsigned int first_free = per_wave ? (unsigned int) (bpt * (pf_threads / 64)) : 0u;
-                he = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc.chunk_counters), (int) first_free, (size_t) n_tiles, c->stream);
+                // block hand-out: the counter counts chunks from 0; per-wave hand-out: the words count the units behind the waves' own first ones
+                he = hipMemsetAsync(sc.chunk_counters, 0, sizeof(unsigned int) * (per_wave ? counter_words : (size_t) n_tiles), c->stream);
                 if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             }
             A.clk = nullptr;

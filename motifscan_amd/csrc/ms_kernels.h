@@ -6,6 +6,7 @@ namespace ms {
 
 constexpr int kPfThreads = 1024;      // largest pre-filter block (16 waves; engine 3 runs two 512-thread blocks per CU): sizes the wave queues
 constexpr int kNwMotifChunk = 8;      // motifs per neval_kernel block (their fp64 tables sit in LDS: 16 KB; 16 per block measured 20 % slower)
+constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spilled to HBM when the next append would not fit
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
 constexpr size_t kMfmaLutBytes = 256 * 16;   // engine 1: byte of four 2-bit codes -> 16 one-hot operand bytes, after the wave queues

@@ -830,26 +830,38 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
         // Per-WAVE hand-out: a wave takes A.wave_passes x 64 consecutive window starts per atomic (the next unit is requested
         // before the current one is scanned, so the atomic's latency is hidden) and never meets the block's other waves again: no
         // barrier in the loop, a wave that ran into the rare path more often than its neighbours delays nobody.  The host sizes
-        // the unit so that the launch's waves together stay below ~50 atomics per microsecond on the one counter word (it saturates
-        // near 90: 4 passes per atomic on the 579-motif set cost +13 %); an input with fewer passes than that per wave is split evenly.
+        // the unit so that the waves of a counter word stay below ~50 atomics per microsecond on it (a word saturates near 90: with ONE
+        // word per tile, 4 passes per atomic on the 579-motif set cost +13 %); an input worth few units per wave is split evenly.
         const uint32_t wave_passes = A.wave_passes < 1 ? (uint32_t) HANDOUT : (uint32_t) A.wave_passes;
         const uint32_t n_passes_total = (uint32_t) ((A.n_bases + 63) / 64);           // <= 2^28: a set holds <= 2^34 bases
         const uint32_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
-        auto take = [&]() {
-            unsigned int u = 0;
-            if (lane == 0) u = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
-            return (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
-        };
-        // the first unit is the wave's own number (the counter starts at the number of waves): the launch does not begin with every
-        // wave queueing on one word
-        uint32_t unit = blockIdx.x * (uint32_t) (NT / 64) + (threadIdx.x >> 6);
-        const bool more = n_units > gridDim.x * (uint32_t) (NT / 64);                 // a small input is one unit per wave: no atomic at all
-        while (unit < n_units) {
-            const uint32_t next = more ? take() : n_units;
-            const uint32_t p0 = unit * wave_passes;
-            for (uint32_t j = 0; j < wave_passes; j++)                                // passes past the end scan dead lanes (last unit only)
-                scan_pass((int64_t) (p0 + j) * 64 + r);
-            unit = next;
+        constexpr uint32_t wpb = NT / 64;
+        if (n_units <= gridDim.x * wpb) {                                             // a small input: one unit per wave, no atomic at all
+            const uint32_t unit = blockIdx.x * wpb + (threadIdx.x >> 6);
+            if (unit < n_units)
+                for (uint32_t j = 0; j < wave_passes; j++) scan_pass((int64_t) (unit * wave_passes + j) * 64 + r);
+        } else {
+            // kPfCounters counter words per tile, 64 bytes apart: the blocks are dealt round-robin onto them and a word hands out every
+            // kPfCounters-th unit, so that the units can be small (a short tail: the launch ends one unit after its last wave starts
+            // one) without the words saturating (~90 atomics per microsecond each).  A wave's first unit in its group is its own
+            // number there; the words start at 0 and the waves add their group's size themselves.
+            const uint32_t g = blockIdx.x % (uint32_t) kPfCounters;
+            const uint32_t waves_g = ((gridDim.x - g + (uint32_t) kPfCounters - 1) / (uint32_t) kPfCounters) * wpb;
+            const uint32_t units_g = n_units > g ? (n_units - g + (uint32_t) kPfCounters - 1) / (uint32_t) kPfCounters : 0u;
+            unsigned int *word = A.chunk_counter + ((size_t) blockIdx.y * kPfCounters + g) * 16;
+            auto take = [&]() {
+                unsigned int u = 0;
+                if (lane == 0) u = atomicAdd(word, 1u);
+                return waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+            };
+            uint32_t v = (blockIdx.x / (uint32_t) kPfCounters) * wpb + (threadIdx.x >> 6);
+            while (v < units_g) {
+                const uint32_t next = take();                                         // asked for before this unit is scanned
+                const uint32_t p0 = (v * (uint32_t) kPfCounters + g) * wave_passes;
+                for (uint32_t j = 0; j < wave_passes; j++)                            // passes past the end scan dead lanes (last unit only)
+                    scan_pass((int64_t) (p0 + j) * 64 + r);
+                v = next;
+            }
         }
     } else {
     constexpr int kSuper = 4;
