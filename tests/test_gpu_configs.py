@@ -304,6 +304,28 @@ def test_work_handout_regimes_agree_with_the_all_fp64_kernel(n_regions):
     assert np.array_equal(got.region_counts(), want.region_counts())
 
 
+@pytest.mark.parametrize("n_motifs,strand", [(50, 3), (579, 1), (1300, 2)])
+def test_work_handout_over_sizes_and_tiles_against_the_all_fp64_kernel(n_motifs, strand):
+    """The hand-out's unit size and regime depend on the motif set (k-blocks per tile, number of LDS tiles) and on the input size;
+    a sweep over both, single strands included, against the kernel that uses no pre-filter at all."""
+    vals, widths, cutoffs = synth.load_motif_set(min(n_motifs, 579))
+    if n_motifs > 579:                                         # the set repeated: several LDS tiles
+        mats = synth.matrices_of(vals, widths)
+        pick = [i % 579 for i in range(n_motifs)]
+        vals = np.concatenate([mats[i].ravel() for i in pick]); widths = widths[pick]; cutoffs = cutoffs[pick]
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    for n_regions, length in ((1, 37), (3, 64), (700, 300), (9_000, 500), (40_000, 450)):
+        bases, offsets = synth.make_regions(n_regions, length, seed=100 + n_regions, frac_n=0.02, ragged=n_regions > 3)
+        sq = _lib.SeqSet(bases, offsets)
+        got = _lib.scan(pw, sq, strand)
+        want = _lib.scan(pw, sq, strand, _lib.MS_SCAN_EXACT_ONLY)
+        assert_same_hits(got.hits(), want.hits())
+        assert np.array_equal(got.region_counts(), want.region_counts())
+        if n_motifs == 1300:
+            assert got.stats()["n_tiles"] >= 2
+        got.close(); want.close(); sq.close()
+
+
 def test_owned_views_keep_the_result_alive():
     """views of the library's pinned buffers must not dangle when the caller drops the result object."""
     import gc
