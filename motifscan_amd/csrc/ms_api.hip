@@ -994,7 +994,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             const int reserve = c->n_streams.load() > 0 ? c->n_cu_copy : 0;
             const int pf_threads = prefilter_threads(pf_variant);
             const int64_t pf_chunks = (S.n_bases + pf_threads - 1) / pf_threads;
-            const int bpt = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles));
+            int bpt_ = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles));
+            if (const char *e = measure_env("MS_PF_MAX_BLOCKS")) bpt_ = std::max(1, std::min(bpt_, atoi(e)));    // test aid: few blocks per tile, as a very large motif set would have
+            const int bpt = bpt_;
             const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // per-wave hand-out: kPfCounters words per tile, 64 bytes apart
             if (counter_words > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
@@ -1012,7 +1014,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_tile += plan.group_G[q];
                 kb_tile = std::max<int64_t>(1, kb_tile / std::max(1, n_tiles));
                 const double waves = (double) bpt * (pf_threads / 64);                          // per tile
-                const double waves_word = per_wave ? waves / kPfCounters : waves;               // ... and per counter word
+                const double waves_word = per_wave ? waves / std::min(kPfCounters, bpt) : waves;   // ... and per counter word
                 const int64_t need = (int64_t) std::ceil(waves_word / (47.0 * 0.25 * (double) kb_tile));
                 const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
                 int64_t wp = per_wave ? 2 : 8;                                // a power of two: units start on 128-position boundaries at least

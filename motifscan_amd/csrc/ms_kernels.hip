@@ -845,19 +845,20 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
             // kPfCounters-th unit, so that the units can be small (a short tail: the launch ends one unit after its last wave starts
             // one) without the words saturating (~90 atomics per microsecond each).  A wave's first unit in its group is its own
             // number there; the words start at 0 and the waves add their group's size themselves.
-            const uint32_t g = blockIdx.x % (uint32_t) kPfCounters;
-            const uint32_t waves_g = ((gridDim.x - g + (uint32_t) kPfCounters - 1) / (uint32_t) kPfCounters) * wpb;
-            const uint32_t units_g = n_units > g ? (n_units - g + (uint32_t) kPfCounters - 1) / (uint32_t) kPfCounters : 0u;
+            const uint32_t K = gridDim.x < (uint32_t) kPfCounters ? gridDim.x : (uint32_t) kPfCounters;     // every word needs a block
+            const uint32_t g = blockIdx.x % K;
+            const uint32_t waves_g = ((gridDim.x - g + K - 1) / K) * wpb;
+            const uint32_t units_g = n_units > g ? (n_units - g + K - 1) / K : 0u;
             unsigned int *word = A.chunk_counter + ((size_t) blockIdx.y * kPfCounters + g) * 16;
             auto take = [&]() {
                 unsigned int u = 0;
                 if (lane == 0) u = atomicAdd(word, 1u);
                 return waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
             };
-            uint32_t v = (blockIdx.x / (uint32_t) kPfCounters) * wpb + (threadIdx.x >> 6);
+            uint32_t v = (blockIdx.x / K) * wpb + (threadIdx.x >> 6);
             while (v < units_g) {
                 const uint32_t next = take();                                         // asked for before this unit is scanned
-                const uint32_t p0 = (v * (uint32_t) kPfCounters + g) * wave_passes;
+                const uint32_t p0 = (v * K + g) * wave_passes;
                 for (uint32_t j = 0; j < wave_passes; j++)                            // passes past the end scan dead lanes (last unit only)
                     scan_pass((int64_t) (p0 + j) * 64 + r);
                 v = next;

@@ -326,6 +326,22 @@ def test_work_handout_over_sizes_and_tiles_against_the_all_fp64_kernel(n_motifs,
         got.close(); want.close(); sq.close()
 
 
+@pytest.mark.parametrize("max_blocks", [1, 3, 5, 8, 13])
+def test_work_handout_with_fewer_blocks_than_counter_words(monkeypatch, max_blocks):
+    """A very large motif set leaves a tile only a few blocks; the hand-out deals the blocks onto min(8, blocks) counter words --
+    a word without a block would never hand its units out.  MS_PF_MAX_BLOCKS (a measurement switch) caps the blocks per tile."""
+    monkeypatch.setenv("MS_MEASURE", "1")
+    monkeypatch.setenv("MS_PF_MAX_BLOCKS", str(max_blocks))
+    vals, widths, cutoffs = synth.load_motif_set(120)
+    bases, offsets = synth.make_regions(6000, 500, seed=77, frac_n=0.01, ragged=True)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    sq = _lib.SeqSet(bases, offsets)
+    got = _lib.scan(pw, sq, 3)
+    want = _lib.scan(pw, sq, 3, _lib.MS_SCAN_EXACT_ONLY)
+    assert got.n_hits > 1000
+    assert_same_hits(got.hits(), want.hits())
+
+
 def test_owned_views_keep_the_result_alive():
     """views of the library's pinned buffers must not dangle when the caller drops the result object."""
     import gc
