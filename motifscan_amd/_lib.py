@@ -134,8 +134,7 @@ def lib():
         "ms_score_ranks": (c_int, [vp, vp, c_int, pi64, c_i32, pd]),
         "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
         "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
-        "ms_debug_plan_tables": (c_int, [vp, pi32, pi32, pi32, pu32, pi32, pi32]),
-        "ms_debug_plan_mfma_rows": (c_int, [vp, ctypes.POINTER(ctypes.c_int16), pi32, pi32]),
+        "ms_debug_plan_rows": (c_int, [vp, pi32, ctypes.POINTER(ctypes.c_int16), pi32, pi32, pi32, pi32]),
         "ms_debug_release_scratch": (c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -222,41 +221,25 @@ class PwmSet:
         check(lib().ms_pwmset_max_raw(self.h, ptr(out, ctypes.c_double)))
         return out
 
-    def plan(self, strand_mask=3, lds_budget=143 * 1024):
-        """Host-side view of the integer pre-filter plan (tests only)."""
+    def plan(self, strand_mask=3, lds_budget=70 * 1024):
+        """Host-side view of the pre-filter plan, decoded from the operand image the kernel reads (tests only):
+        group_fields [groups][16] motif of the field (-1 empty; both strands: field n = slot n >> 1, even forward, odd reverse;
+        one strand: field n = slot n), rows [groups][16][64 columns][4 bases] and bias [groups][16] in units of 1/8,
+        group_kb [groups] k-blocks of 16 columns."""
         L = lib()
         nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
         check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
                                    ctypes.byref(nq), ctypes.byref(nt)))
-        gm = np.full((nq.value, 8), -1, dtype=np.int32)
-        gg = np.zeros(nq.value, dtype=np.int32)
-        gf = np.zeros(nq.value, dtype=np.int32)
-        tb = np.zeros((nq.value, 16, 16, 4), dtype=np.uint32)
+        gf = np.full((nq.value, 16), -1, dtype=np.int32)
         ex = np.zeros(max(ne.value, 1), dtype=np.int32)
         tf = np.zeros(nt.value + 1, dtype=np.int32)
-        check(L.ms_debug_plan_tables(self.h, ptr(gm, ctypes.c_int32), ptr(gg, ctypes.c_int32), ptr(gf, ctypes.c_int32),
-                                     ptr(tb, ctypes.c_uint32), ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
-        return {"n_fast": nf.value, "n_exact": ne.value, "group_motifs": gm, "group_G": gg, "group_fb": gf,
-                "tables": tb, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
-
-    def plan_mfma(self, strand_mask=3, lds_budget=143 * 1024):
-        """Host-side view of the int8 / matrix-core plan (tests only; MS_PF_ENGINE = 1 or 2 in the environment picks the form)."""
-        L = lib()
-        nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
-        check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
-                                   ctypes.byref(nq), ctypes.byref(nt)))
-        gm = np.full((nq.value, 8), -1, dtype=np.int32)
-        ex = np.zeros(max(ne.value, 1), dtype=np.int32)
-        tf = np.zeros(nt.value + 1, dtype=np.int32)
-        check(L.ms_debug_plan_tables(self.h, ptr(gm, ctypes.c_int32), None, None, None, ptr(ex, ctypes.c_int32),
-                                     ptr(tf, ctypes.c_int32)))
-        rows = np.zeros((nq.value, 16, 32, 4), dtype=np.int16)
+        rows = np.zeros((nq.value, 16, 64, 4), dtype=np.int16)
         bias = np.zeros((nq.value, 16), dtype=np.int32)
         kb = np.zeros(nq.value, dtype=np.int32)
-        check(L.ms_debug_plan_mfma_rows(self.h, ptr(rows, ctypes.c_int16), ptr(bias, ctypes.c_int32), ptr(kb, ctypes.c_int32)))
-        cols = {"2": 10, "3": 16}.get(os.environ.get("MS_PF_ENGINE"), 8)
-        return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "group_motifs": gm, "rows": rows, "bias": bias,
-                "group_kb": kb, "cols_per_kb": cols, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
+        check(L.ms_debug_plan_rows(self.h, ptr(gf, ctypes.c_int32), ptr(rows, ctypes.c_int16), ptr(bias, ctypes.c_int32),
+                                   ptr(kb, ctypes.c_int32), ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
+        return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "strand_mask": strand_mask, "group_fields": gf,
+                "rows": rows, "bias": bias, "group_kb": kb, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 
     def close(self):
         if getattr(self, "h", None):

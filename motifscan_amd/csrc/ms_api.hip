@@ -63,10 +63,9 @@ int get_ctx(int device, DeviceCtx **out) {
     if (c->lds_max < 65536) c->lds_max = 65536;
     if (c->lds_max > 163840) c->lds_max = 163840;
     MS_HIP(hipStreamCreateWithFlags(&c->stream.whole, hipStreamNonBlocking));
-    MS_HIP(hipStreamCreateWithFlags(&c->stream2.whole, hipStreamNonBlocking));
     MS_HIP(hipStreamCreateWithFlags(&c->stream_up.whole, hipStreamNonBlocking));
     MS_HIP(hipStreamCreateWithFlags(&c->stream_down.whole, hipStreamNonBlocking));
-    for (StreamSel *s : {&c->stream, &c->stream2, &c->stream_up, &c->stream_down}) s->n_streams = &c->n_streams;
+    for (StreamSel *s : {&c->stream, &c->stream_up, &c->stream_down}) s->n_streams = &c->n_streams;
     if (measure_env("MS_CU_PARTITION")) {
         // A/B switch (MS_MEASURE=1 MS_CU_PARTITION=1); off by default, see StreamSel.
         // CU mask bit i = CU (i / n_xcc) of XCC (i % n_xcc) (measured, tools/ubench/cumask_probe.hip: the first 8 bits select one
@@ -77,14 +76,13 @@ int get_ctx(int device, DeviceCtx **out) {
         for (int i = 0; i < c->n_cu; i++) (i < k ? m_copy : m_scan)[(size_t) i / 32] |= 1u << (i % 32);
         bool ok = c->n_cu >= 64;
         ok = ok && hipExtStreamCreateWithCUMask(&c->stream.part, (uint32_t) m_scan.size(), m_scan.data()) == hipSuccess;
-        ok = ok && hipExtStreamCreateWithCUMask(&c->stream2.part, (uint32_t) m_scan.size(), m_scan.data()) == hipSuccess;
         ok = ok && hipExtStreamCreateWithCUMask(&c->stream_up.part, (uint32_t) m_copy.size(), m_copy.data()) == hipSuccess;
         ok = ok && hipExtStreamCreateWithCUMask(&c->stream_down.part, (uint32_t) m_copy.size(), m_copy.data()) == hipSuccess;
         if (ok) {
             c->n_cu_copy = k;
         } else {                                   // no masks on this device / runtime: everything stays on the whole-device streams
             (void) hipGetLastError();
-            for (StreamSel *s : {&c->stream, &c->stream2, &c->stream_up, &c->stream_down}) {
+            for (StreamSel *s : {&c->stream, &c->stream_up, &c->stream_down}) {
                 if (s->part) (void) hipStreamDestroy(s->part);
                 s->part = nullptr;
             }
@@ -266,8 +264,7 @@ static double c_max_raw(const double *m, int W) {
 static void pwmset_free_device(ms_pwmset *p) {
     if (p->device >= 0 || p->plan_device >= 0) (void) hipSetDevice(p->device >= 0 ? p->device : p->plan_device);
     dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff); dev_free(p->d_raw_floor);
-    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
-    dev_free(p->d_exact_motifs); dev_free(p->d_rt_off16); dev_free(p->d_rt_nk);
+    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_fields); dev_free(p->d_exact_motifs);
     p->device = -1;
     p->plan_device = -1;
     p->dev_cutoff_version = 0;
@@ -341,45 +338,27 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
     return MS_OK;
 }
 
-// Pre-filter engine: 3 (default) = fp6 x fp4 one-hot product on the matrix cores (16 motif columns per instruction);
-// A/B (MS_MEASURE=1 MS_PF_ENGINE=n): 1 = int8 one-hot product (8 columns), 2 = int8 Walsh form (10 columns),
-// 0 = packed 2-mer tables read per lane from LDS.  All four are rigorous upper bounds: the result never depends on the choice.
-static int pf_engine() {
-    if (const char *e = measure_env("MS_PF_ENGINE")) { const int v = atoi(e); return v == 0 ? 0 : (v == 2 ? 2 : (v == 1 ? 1 : 3)); }
-    return 3;
-}
-
 static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
                        int device) {
-    const int engine = pf_engine();
-    int min_fb = 10;                                   // measurement switch: MS_PF_FIELD_BITS=16 forces 16-bit fields
-    if (const char *e = measure_env("MS_PF_FIELD_BITS")) min_fb = atoi(e) >= 16 ? 16 : 10;
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
-                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_min_fb != min_fb ||
-                       p->plan_engine != engine;
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only;
     if (stale) {
         if (exact_only) {
             p->plan = PrefilterPlan();
             p->plan.strand_mask = strand_mask;
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
-            int rc = engine >= 1
-                         ? build_plan_mfma(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
-                                           p->max_raw.data(), p->P, strand_mask, lds_budget, engine, &p->plan)
-                         : build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(),
-                                      p->max_raw.data(), p->P, strand_mask, lds_budget, min_fb, &p->plan);
+            int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(), p->max_raw.data(),
+                                p->P, strand_mask, lds_budget, &p->plan);
             if (rc) return rc;
         }
         p->plan_strand = strand_mask;
         p->plan_cutoff_version = p->cutoff_version;
         p->plan_lds = lds_budget;
         p->plan_exact_only = exact_only;
-        p->plan_min_fb = min_fb;
-        p->plan_engine = engine;
         if (p->plan_device >= 0) {
             (void) hipSetDevice(p->plan_device);
-            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_motifs); dev_free(p->d_fast_motifs);
-            dev_free(p->d_exact_motifs); dev_free(p->d_rt_off16); dev_free(p->d_rt_nk);
+            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_fields); dev_free(p->d_exact_motifs);
             p->plan_device = -1;
         }
     }
@@ -389,35 +368,18 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         int rc;
         if ((rc = dev_alloc(&p->d_tables, pl.tables.size() / 4))) return rc;
         if ((rc = dev_alloc(&p->d_tiles, pl.tiles.size()))) return rc;
-        if ((rc = dev_alloc(&p->d_group_motifs, pl.group_motifs.size()))) return rc;
-        if ((rc = dev_alloc(&p->d_fast_motifs, pl.fast_motifs.size()))) return rc;
+        if ((rc = dev_alloc(&p->d_group_fields, pl.group_fields.size()))) return rc;
         if ((rc = dev_alloc(&p->d_exact_motifs, pl.exact_motifs.size()))) return rc;
         if (!pl.tables.empty())
             MS_HIP(hipMemcpy(p->d_tables, pl.tables.data(), pl.tables.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!pl.tiles.empty())
             MS_HIP(hipMemcpy(p->d_tiles, pl.tiles.data(), pl.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-        if (!pl.group_motifs.empty())
-            MS_HIP(hipMemcpy(p->d_group_motifs, pl.group_motifs.data(), pl.group_motifs.size() * sizeof(int32_t),
-                             hipMemcpyHostToDevice));
-        if (!pl.fast_motifs.empty())
-            MS_HIP(hipMemcpy(p->d_fast_motifs, pl.fast_motifs.data(), pl.fast_motifs.size() * sizeof(int32_t),
+        if (!pl.group_fields.empty())
+            MS_HIP(hipMemcpy(p->d_group_fields, pl.group_fields.data(), pl.group_fields.size() * sizeof(int32_t),
                              hipMemcpyHostToDevice));
         if (!pl.exact_motifs.empty())
             MS_HIP(hipMemcpy(p->d_exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t),
                              hipMemcpyHostToDevice));
-        if (pl.engine >= 1) {                                   // row tiles of the matrix-core tables, for expand_kernel
-            const size_t n_rt = pl.group_G.size() / 2;
-            std::vector<uint32_t> off16(n_rt + 1, 0);
-            std::vector<int32_t> nk(n_rt + 1, 0);
-            for (size_t t = 0; t < n_rt; t++) {
-                nk[t] = pl.group_G[2 * t];
-                off16[t + 1] = off16[t] + (uint32_t) nk[t] * ((pl.engine == 3 ? kF6BytesPerKb : kMfmaRowTileBytesPerKb) / 16);
-            }
-            if ((rc = dev_alloc(&p->d_rt_off16, n_rt + 1))) return rc;
-            if ((rc = dev_alloc(&p->d_rt_nk, n_rt + 1))) return rc;
-            MS_HIP(hipMemcpy(p->d_rt_off16, off16.data(), off16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            MS_HIP(hipMemcpy(p->d_rt_nk, nk.data(), nk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        }
         p->plan_device = device;
     }
     return MS_OK;
@@ -818,14 +780,8 @@ int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_
 
 // ---------------------------------------------------------------------------- scan --
 
-static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap, size_t nlist_cap) {
+static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap) {
     int rc;
-    if (nlist_cap > sc.nlist_cap) {
-        dev_free(sc.nlist);
-        sc.nlist_cap = 0;
-        if ((rc = dev_alloc(&sc.nlist, nlist_cap))) return rc;
-        sc.nlist_cap = nlist_cap;
-    }
     if (cand_cap > sc.cand_cap) {
         dev_free(sc.cand);
         sc.cand_cap = 0;
@@ -847,18 +803,16 @@ static int scratch_reserve(Scratch &sc, size_t cand_cap, size_t hit_cap, size_t 
 
 namespace ms {
 
-// The scan pipeline: pre-filter -> fp64 re-score (+ N windows, + motifs the filter cannot take) -> order -> coordinates.
+// The scan pipeline: pre-filter -> fp64 re-score of the candidates (+ motifs the filter cannot take) -> order -> coordinates.
 // The caller holds c->mu (one scan at a time per device: shared scratch) and pwms->mu (lazily cached device copies / plan).
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kWqBytes + (pf_engine() == 1 ? kMfmaLutBytes : pf_engine() == 2 ? kMfma2LutBytes : pf_engine() == 3 ? kF6LutBytes : 0);   // wave queues (+ B-operand table) follow the tables
-    // engine 3 runs as TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by
-    // one: the same 16 waves per CU as one 1024-thread block with a block-wide hand-out, 12 % faster -- the chunk loop's barriers made
-    // every wave wait for the block's slowest, the one that met the rare path most often (profiles/r02_wave_occupancy_ab.log)
-    int pf_blocks_per_cu = pf_engine() == 3 ? 2 : 1;
-    if (const char *e = measure_env("MS_PF_BLOCKS_PER_CU")) pf_blocks_per_cu = std::max(1, atoi(e));       // measurement: smaller tiles, several blocks per CU
-    const size_t lds_budget = c->lds_max / (size_t) pf_blocks_per_cu - lds_fixed;
+    const size_t lds_fixed = kWqBytes + kF6LutBytes;                 // wave queues + B-operand table follow the tables
+    // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
+    // (profiles/r02_wave_occupancy_ab.log)
+    size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
+    if (const char *e = measure_env("MS_PF_LDS_BUDGET")) lds_budget = std::min(lds_budget, (size_t) std::max(1, atoi(e)));   // test aid: several LDS tiles, as a very large motif set would have
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
     const PrefilterPlan &plan = pwms->plan;
@@ -878,18 +832,14 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     int64_t fast_windows = 0;
     for (int32_t p = 0; p < pwms->P; p++) stt.n_windows += windows_for_width(seqs, pwms->widths[p]);
     for (int32_t p : plan.fast_motifs) fast_windows += windows_for_width(seqs, pwms->widths[p]);
-    stt.lds_bytes_read = plan.lds_bytes_per_position * (((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads);
-    stt.pf_engine = plan.engine;
+    const int64_t padded = ((seqs->n_bases + 63) / 64) * 64;
+    stt.lds_bytes_read = plan.lds_bytes_per_position * padded;
+    stt.pf_engine = 3;
     {
         int64_t cells = 0;                                                          // (window, column) pairs of one strand
         for (int32_t p : plan.fast_motifs) cells += windows_for_width(seqs, pwms->widths[p]) * pwms->widths[p];
         stt.mfma_ops_algorithmic = 2 * (strand_mask == 3 ? 2 : 1) * cells;           // one multiply-add per cell and strand
-        if (plan.engine >= 1) {
-            int64_t kb_sum = 0;                                                     // k-blocks over all row tiles (2 groups each)
-            for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_sum += plan.group_G[q];
-            const int64_t padded = ((seqs->n_bases + kPfThreads - 1) / kPfThreads) * kPfThreads;
-            stt.mfma_ops = padded / 32 * kb_sum * (2LL * 32 * 32 * (plan.engine == 3 ? 64 : 32));     // one 32x32x32 (engine 3: 32x32x64) instruction per (32 windows, row tile, k-block)
-        }
+        stt.mfma_ops = padded / 32 * plan.kb_total * (2LL * 32 * 32 * 64);           // one 32x32x64 instruction per (32 windows, row tile, k-block)
     }
 
     ms_result *raw = res.release();
@@ -927,22 +877,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     }
 
     Scratch &sc = c->sc;
-    // tail form: 1 (default) = re-score the candidates unordered -> sort (key, score) pairs -> unpack;
-    // 2 (A/B, MS_MEASURE=1 MS_TAIL=2) = expand -> key-only sort -> ordered fp64 re-scoring that writes the final arrays
-    // (ms_tail.hip): measured slower on the benchmark set (profiles/r02_tail_forms.log), kept as the comparison
-    int tail = 1;
-    if (const char *e = measure_env("MS_TAIL")) tail = atoi(e) == 2 ? 2 : 1;
-    if (flags & MS_SCAN_RAW_INTERNAL) tail = 1;
     // expected density at the CLI default p = 1e-4 is ~1.5e-4 candidates per window and strand; 4x head room
     size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
     size_t want_hits = want_cand;
     if (!plan.exact_motifs.empty()) want_hits = std::max<size_t>(want_hits, 1 << 22);
-    size_t want_nlist = std::max<size_t>(1 << 20, (size_t) seqs->n_bases / 64);
     want_cand = std::max(want_cand, sc.cand_cap);
     want_hits = std::max(want_hits, sc.hit_cap);
-    want_nlist = std::max(want_nlist, sc.nlist_cap);
-    int fast_max_w = 1;
-    for (int32_t p : plan.fast_motifs) fast_max_w = std::max(fast_max_w, (int) pwms->widths[p]);
 
     const DevSeq S = dev_seq(seqs);
     const DevPwm Pw = dev_pwm(pwms);
@@ -950,54 +890,42 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
     const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
-    // kernel variant: engine 1 queues records without flags for the second tail form (expand_kernel decodes them)
-    int pf_variant = plan.engine == 3 ? (pf_blocks_per_cu == 2 ? 46 : 31) : plan.engine == 2 ? 24 : plan.engine == 1 ? (tail == 2 ? 20 : 16) : 4, pf_no_emit = 0;
-    if (const char *e = measure_env("MS_PF_VARIANT")) {
-        const int v = atoi(e) & 63;
-        const int v_engine = v >= 28 ? 3 : (v == 24 || v == 25) ? 2 : v >= 16 ? 1 : 0;
-        if (v_engine == plan.engine && !(v == 20 && tail != 2)) pf_variant = v;     // a variant of another engine cannot read this plan
-    }
+    int pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
     const bool pf_clock = measure_env("MS_PF_CLOCK") && atoi(measure_env("MS_PF_CLOCK")) != 0;
     unsigned long long *d_clk = nullptr;
     int clk_blocks = 0;
     const bool pf_meas = pf_no_emit != 0 || pf_clock;              // the measurement instantiation of the kernel
     raw->invalid = pf_no_emit != 0;                                // stage times only: the hit accessors refuse such a result
-    if (lds_bytes > c->lds_set[pf_variant + (pf_meas ? 64 : 0)]) {
-        if ((rc = prefilter_set_lds(pf_variant, pf_meas, lds_bytes))) return fail(rc);
-        c->lds_set[pf_variant + (pf_meas ? 64 : 0)] = lds_bytes;
+    if (lds_bytes > c->lds_set[pf_meas ? 1 : 0]) {
+        if ((rc = prefilter_set_lds(pf_meas, lds_bytes))) return fail(rc);
+        c->lds_set[pf_meas ? 1 : 0] = lds_bytes;
     }
 
-    // counters: [0] candidate records, [1] hits (tail 1) / entries (tail 2), [2] N-window positions, [3] hits written by the
-    // ordered re-scoring, [4] its tile dispenser (32-bit), [5] its error flag (32-bit)
+    // counters: [0] candidate records, [1] hits
     unsigned long long n_cand = 0, n_hits = 0;
     for (int pass = 1;; pass++) {
-        if ((rc = scratch_reserve(sc, want_cand, want_hits, want_nlist))) return fail(rc);
+        if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
         stt.n_passes = pass;
         HitOut H;
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
-        H.entries = tail == 2 ? 1 : 0;
         he = hipMemsetAsync(sc.counters, 0, 8 * sizeof(unsigned long long), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
-        (void) hipEventRecord(c->ev[6], c->stream);
-        if (!plan.fast_motifs.empty())                 // the N-window list needs only the sequence: ready before the pre-filter ends
-            if ((rc = launch_nlist(S, fast_max_w, sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->stream))) return fail(rc);
         (void) hipEventRecord(c->ev[0], c->stream);
         if (!plan.tiles.empty()) {
             PfArgs A;
-            A.codes = S.codes; A.n_bases = S.n_bases; A.no_emit = pf_no_emit;
+            A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
             const int n_tiles = (int) plan.tiles.size();
-            // While a batch stream is live the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs, one
-            // persistent block each (the chunks are handed out dynamically: fewer blocks just take more each)
+            // While a batch stream is live and the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs (the
+            // units are handed out dynamically: fewer blocks just take more each)
             const int reserve = c->n_streams.load() > 0 ? c->n_cu_copy : 0;
-            const int pf_threads = prefilter_threads(pf_variant);
-            const int64_t pf_chunks = (S.n_bases + pf_threads - 1) / pf_threads;
-            int bpt_ = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * pf_blocks_per_cu / n_tiles));
+            const int64_t pf_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
+            int bpt_ = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * kPfBlocksPerCu / n_tiles));
             if (const char *e = measure_env("MS_PF_MAX_BLOCKS")) bpt_ = std::max(1, std::min(bpt_, atoi(e)));    // test aid: few blocks per tile, as a very large motif set would have
             const int bpt = bpt_;
-            const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // per-wave hand-out: kPfCounters words per tile, 64 bytes apart
+            const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
             if (counter_words > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
                 sc.chunk_counters_cap = 0;
@@ -1005,32 +933,28 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 sc.chunk_counters_cap = counter_words + 16;
             }
             A.chunk_counter = sc.chunk_counters;
-            const bool per_wave = pf_variant == 46 || pf_variant == 47;
             bool counter_used = true;
             {
                 // unit of the per-wave hand-out: a pass (64 window starts against a tile's k-blocks) takes ~0.25 us per k-block with 16
                 // waves per CU, and the launch's waves should not exceed ~47 atomics per microsecond on a tile's counter word
-                int64_t kb_tile = 0;
-                for (size_t q = 0; q < plan.group_G.size(); q += 2) kb_tile += plan.group_G[q];
-                kb_tile = std::max<int64_t>(1, kb_tile / std::max(1, n_tiles));
-                const double waves = (double) bpt * (pf_threads / 64);                          // per tile
-                const double waves_word = per_wave ? waves / std::min(kPfCounters, bpt) : waves;   // ... and per counter word
+                const int64_t kb_tile = std::max<int64_t>(1, plan.kb_total / std::max(1, n_tiles));
+                const double waves = (double) bpt * (kPfThreads / 64);                          // per tile
+                const double waves_word = waves / std::min(kPfCounters, bpt);                   // ... and per counter word
                 const int64_t need = (int64_t) std::ceil(waves_word / (47.0 * 0.25 * (double) kb_tile));
                 const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
-                int64_t wp = per_wave ? 2 : 8;                                // a power of two: units start on 128-position boundaries at least
+                int64_t wp = 2;                                               // a power of two: units start on 128-position boundaries at least
                 while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;            // the words' rate limit
                 while (wp < 8 && 128 * wp <= passes_total / n_waves) wp *= 2;             // a long launch: the tail (one unit) stays below 1 % anyway, fewer atomics
                 if (passes_total <= 8 * std::max<int64_t>(wp, 8) * n_waves) {
                     // fewer than 8 units (of 8 passes at least) per wave: one even unit each and no atomics (a second round of a few
                     // units would leave most waves idle); the kernel then never touches the counter words
                     wp = std::max<int64_t>(1, (passes_total + n_waves - 1) / n_waves);
-                    counter_used = !per_wave;
+                    counter_used = false;
                 }
                 A.wave_passes = (int) wp;
             }
             if (counter_used) {
-                // block hand-out: the counter counts chunks from 0; per-wave hand-out: the words count the units behind the waves' own first ones
-                he = hipMemsetAsync(sc.chunk_counters, 0, sizeof(unsigned int) * (per_wave ? counter_words : (size_t) n_tiles), c->stream);
+                he = hipMemsetAsync(sc.chunk_counters, 0, sizeof(unsigned int) * counter_words, c->stream);
                 if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             }
             A.clk = nullptr;
@@ -1040,29 +964,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * 2 * clk_blocks, c->stream);
                 A.clk = d_clk;
             }
-            if ((rc = launch_prefilter(A, pf_variant, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
+            if ((rc = launch_prefilter(A, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
         }
         (void) hipEventRecord(c->ev[1], c->stream);
-        if (!plan.fast_motifs.empty()) {
-            // two independent latency-bound jobs, both appending to the same list: run them side by side
-            // (forked AFTER the pre-filter, whose blocks need whole CUs to themselves)
-            (void) hipEventRecord(c->ev_fork, c->stream);
-            (void) hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-            if ((rc = launch_neval(S, Pw, pwms->d_fast_motifs, (int32_t) plan.fast_motifs.size(), strand_mask,
-                                   sc.nlist, sc.counters + 2, sc.nlist_cap, H, c->n_cu * 4, c->stream2))) return fail(rc);
-            (void) hipEventRecord(c->ev_join, c->stream2);
-            if (tail == 2) {
-                ExpandArgs E;
-                E.cand = sc.cand; E.n_cand = sc.counters; E.cand_cap = sc.cand_cap;
-                E.tables = pwms->d_tables; E.rt_off16 = pwms->d_rt_off16; E.rt_nk = pwms->d_rt_nk;
-                E.group_motifs = pwms->d_group_motifs; E.width = pwms->d_width; E.S = S;
-                E.entries = sc.keys; E.n_entries = sc.counters + 1; E.entry_cap = sc.hit_cap; E.cbits = gbits; E.pbits = pbits;
-                if ((rc = launch_expand(E, c->n_cu * 8, c->stream))) return fail(rc);
-            } else {
-                if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_motifs, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
-            }
-            (void) hipStreamWaitEvent(c->stream, c->ev_join, 0);
-        }
+        if (!plan.fast_motifs.empty())
+            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_fields, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
         if (!plan.exact_motifs.empty())
             if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
         (void) hipEventRecord(c->ev[2], c->stream);
@@ -1070,17 +976,14 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         n_cand = sc.h_counters[0];
-        n_hits = sc.h_counters[1];                                 // tail 2: entries
-        const unsigned long long n_nlist = sc.h_counters[2];
-        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap && n_nlist <= sc.nlist_cap) break;
+        n_hits = sc.h_counters[1];
+        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap) break;
         if (pass >= 5) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
         // a buffer was too small: the counters hold the exact need (a truncated candidate list
         // under-reports hits, so leave head room there) -- grow and run the pass again
         want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
         const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
         want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
-        want_nlist = std::max<size_t>(sc.nlist_cap, (size_t) (n_nlist + 1024));
-        if (n_nlist > sc.nlist_cap) want_hits = std::max<size_t>(want_hits, 2 * sc.hit_cap);   // its hits were not all counted
     }
     stt.n_candidates = (int64_t) n_cand;
     if (d_clk) {                                             // median over blocks of cycles per 10 ns tick
@@ -1093,103 +996,61 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         }
         dev_free(d_clk);
     }
+    int64_t pwm_bytes = 0;
+    for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
+    // SURVEY.md 8(d): compulsory HBM bytes of one call
+    stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
 
     if (flags & MS_SCAN_RAW_INTERNAL) {                      // the caller takes the unordered hits from the scratch
         float ms01 = 0, ms12 = 0;
         (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
         (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
-        float ms60 = 0;
-        (void) hipEventElapsedTime(&ms60, c->ev[6], c->ev[0]);
-        stt.ms_prefilter = ms01; stt.ms_exact = ms12 + ms60; stt.ms_total = ms60 + ms01 + ms12;
+        stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_total = ms01 + ms12;
         stt.n_hits = (int64_t) n_hits;
         raw->n_hits = (int64_t) n_hits;
         raw->raw_gbits = gbits;
         raw->raw_pbits = pbits;
-        int64_t pwm_bytes = 0;
-        for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
-        stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
         *out = raw;
         return MS_OK;
     }
 
-    // one pooled block for everything the result owns.  Tail 2 learns the number of hits only at the very end: the block
-    // is sized by the bound "every entry hits on every scanned strand"
-    const unsigned long long n_entries = n_hits;
-    const size_t res_cap = tail == 2 ? (size_t) n_entries * (strand_mask == 3 ? 2 : 1) : (size_t) n_hits;
+    // one pooled block for everything the result owns
     {
         void *blk = nullptr;
         size_t got = 0;
-        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, res_cap), &blk, &got))) return fail(rc);
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, (size_t) n_hits), &blk, &got))) return fail(rc);
         raw->block = blk;
         raw->block_bytes = got;
-        result_carve(raw, blk, res_cap);
+        result_carve(raw, blk, (size_t) n_hits);
         const size_t P1 = (size_t) pwms->P + 1;
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
     }
     int64_t *d_motif_first = raw->d_motif_first;
-    auto fail2 = [&](int code) { return fail(code); };
 
     (void) hipEventRecord(c->ev[3], c->stream);
     if (n_hits > 0) {
-        const int end_bit = tail == 2 ? gbits + mbits : gbits + 1 + mbits;
+        const int end_bit = gbits + 1 + mbits;
         size_t need = 0;
-        if (tail == 2) rc = sort_keys(nullptr, &need, sc.keys, sc.keys_sorted, (size_t) n_hits, end_bit, c->stream);
-        else rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream);
-        if (rc) return fail2(rc);
+        if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream))) return fail(rc);
         if (need > sc.sort_tmp_bytes) {
             if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
             sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
             he = hipMalloc(&sc.sort_tmp, need);
-            if (he != hipSuccess) { set_error("hipMalloc of %zu bytes (sort) failed: %s", need, hipGetErrorString(he)); return fail2(MS_ERR_NOMEM); }
+            if (he != hipSuccess) { set_error("hipMalloc of %zu bytes (sort) failed: %s", need, hipGetErrorString(he)); return fail(MS_ERR_NOMEM); }
             sc.sort_tmp_bytes = need;
         }
         size_t have = sc.sort_tmp_bytes;
-        if (tail == 2) rc = sort_keys(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, (size_t) n_hits, end_bit, c->stream);
-        else rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream);
-        if (rc) return fail2(rc);
+        if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream))) return fail(rc);
     }
     (void) hipEventRecord(c->ev[4], c->stream);
-    if (tail == 2) {
-        if (n_entries == 0) {
-            he = hipMemsetAsync(d_motif_first, 0, 8 * ((size_t) pwms->P + 1), c->stream);       // no hits: every per-motif offset is 0
-            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
-        } else {
-            const size_t n_tiles_r = ordered_tiles(n_entries);
-            if (n_tiles_r > sc.tile_cap) {
-                dev_free(sc.tile_state);
-                sc.tile_cap = 0;
-                if ((rc = dev_alloc(&sc.tile_state, n_tiles_r + n_tiles_r / 4 + 64))) return fail2(rc);
-                sc.tile_cap = n_tiles_r + n_tiles_r / 4 + 64;
-            }
-            he = hipMemsetAsync(sc.tile_state, 0, n_tiles_r * sizeof(unsigned long long), c->stream);
-            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
-            OrderedArgs O;
-            O.S = S; O.Pw = Pw; O.keys = sc.keys_sorted; O.n = n_entries; O.cbits = gbits; O.pbits = pbits; O.strand_mask = strand_mask;
-            O.P = pwms->P; O.tile_state = sc.tile_state;
-            O.tile_counter = reinterpret_cast<unsigned int *>(sc.counters + 4);
-            O.error = reinterpret_cast<unsigned int *>(sc.counters + 5);
-            O.seq_idx = raw->d_seq_idx; O.pos = raw->d_pos; O.score = raw->d_score; O.strand = raw->d_strand;
-            O.motif_first = d_motif_first; O.n_hits = sc.counters + 3; O.cap = res_cap;
-            if ((rc = launch_rescore_ordered(O, c->stream))) return fail2(rc);
-            if ((rc = launch_pair_counts(sc.counters + 3, res_cap, d_motif_first, pwms->P, raw->d_seq_idx, raw->d_region_counts,
-                                         c->n_cu * 8, c->stream))) return fail2(rc);
-        }
-    } else {
-        if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
-                                  raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail2(rc);
-    }
+    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
+                              raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail(rc);
     (void) hipEventRecord(c->ev[5], c->stream);
-    // the complete per-motif offsets (and, tail 2, the number of hits) are on the device; one copy brings them to the host
+    // the complete per-motif offsets are on the device; one copy brings them to the host
     he = hipMemcpyAsync(raw->motif_offsets.data(), d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess && tail == 2) he = hipMemcpyAsync(sc.h_counters, sc.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-    if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
-    if (tail == 2) {
-        n_hits = n_entries ? sc.h_counters[3] : 0;
-        if (reinterpret_cast<const unsigned int *>(sc.h_counters + 5)[0] != 0) { set_error("ordered re-scoring: a block waited too long for its predecessors"); return fail2(MS_ERR_RUNTIME); }
-        if (n_hits > res_cap) { set_error("ordered re-scoring produced more hits than its bound (%llu > %zu)", n_hits, res_cap); return fail2(MS_ERR_RUNTIME); }
-    }
+    if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
     stt.n_hits = (int64_t) n_hits;
     raw->n_hits = (int64_t) n_hits;
 
@@ -1198,15 +1059,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
     (void) hipEventElapsedTime(&ms34, c->ev[3], c->ev[4]);
     (void) hipEventElapsedTime(&ms45, c->ev[4], c->ev[5]);
-    (void) hipEventElapsedTime(&ms05, c->ev[6], c->ev[5]);
-    float ms60 = 0;
-    (void) hipEventElapsedTime(&ms60, c->ev[6], c->ev[0]);        // the N-window list, built ahead of the pre-filter: booked with the fp64 stage
-    stt.ms_prefilter = ms01; stt.ms_exact = ms12 + ms60; stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
-    // SURVEY.md 8(d): compulsory HBM bytes of one call
-    int64_t pwm_bytes = 0;
-    for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
-    stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes +
-                                16 * (int64_t) n_hits + 8LL * pwms->P;
+    (void) hipEventElapsedTime(&ms05, c->ev[0], c->ev[5]);
+    stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
     *out = raw;
     return MS_OK;
 }
@@ -1744,95 +1598,63 @@ int ms_dedup_hits(const int64_t *motif_offsets, int32_t n_pwms, const int32_t *w
 int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_budget, int32_t *n_fast,
                        int32_t *n_exact, int32_t *n_groups, int32_t *n_tiles) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d", strand_mask); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     std::lock_guard<std::mutex> lk(pwms->mu);
     int rc = pwmset_plan(pwms, strand_mask, (size_t) lds_budget, false, false, -1);
     if (rc) return rc;
     if (n_fast) *n_fast = (int32_t) pwms->plan.fast_motifs.size();
     if (n_exact) *n_exact = (int32_t) pwms->plan.exact_motifs.size();
-    if (n_groups) *n_groups = (int32_t) pwms->plan.group_G.size();
+    if (n_groups) *n_groups = (int32_t) pwms->plan.group_kb.size();
     if (n_tiles) *n_tiles = (int32_t) pwms->plan.tiles.size();
     return MS_OK;
 }
 
-// group_motifs [n_groups][8], group_G [n_groups], group_fb [n_groups],
-// tables [n_groups][16 positions][16 codes][4 words] (zero padded), exact_motifs [n_exact], tile_first_group [n_tiles+1]
-int ms_debug_plan_tables(const ms_pwmset *pwms_c, int32_t *group_motifs, int32_t *group_G, int32_t *group_fb,
-                         uint32_t *tables, int32_t *exact_motifs, int32_t *tile_first_group) {
+// The plan built by the last ms_debug_plan_dims call, decoded from the PHYSICAL operand image the kernel reads (any pointer
+// may be NULL): group_fields [n_groups][16] motif of the field (-1 = empty), rows [n_groups][16 fields][64 columns][4 bases]
+// int16 = what the product adds for that base at that column, units of 1/8 (the bias column reads 0 here), bias [n_groups][16]
+// = the entry of the row tile's last column (MS_ERR_RUNTIME if its four bases disagree), group_kb [n_groups] k-blocks,
+// exact_motifs [n_exact], tile_first_group [n_tiles + 1].
+int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *rows, int32_t *bias, int32_t *group_kb,
+                       int32_t *exact_motifs, int32_t *tile_first_group) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     std::lock_guard<std::mutex> lk(pwms->mu);
     const PrefilterPlan &pl = pwms->plan;
     if (pwms->plan_strand < 0) { set_error("call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
-    const size_t nq = pl.group_G.size();
-    if (group_motifs && nq) std::memcpy(group_motifs, pl.group_motifs.data(), pl.group_motifs.size() * sizeof(int32_t));
-    if (group_G && nq) std::memcpy(group_G, pl.group_G.data(), nq * sizeof(int32_t));
-    if (group_fb && nq) std::memcpy(group_fb, pl.group_fb.data(), nq * sizeof(int32_t));
-    if (tables) {
-        std::memset(tables, 0, nq * 16 * 16 * 4 * sizeof(uint32_t));
-        size_t off16 = 0;
-        for (size_t q = 0; q < nq; q++) {
-            const int G = pl.group_G[q];
-            for (int g = 0; g < G; g++)
-                for (int x = 0; x < 16; x++)
-                    for (int k = 0; k < 4; k++)
-                        tables[((q * 16 + g) * 16 + x) * 4 + k] = pl.tables[(off16 + (size_t) g * 16 + x) * 4 + k];
-            off16 += (size_t) G * 16;
-        }
-    }
+    const size_t nq = pl.group_kb.size();
+    if (group_fields && nq) std::memcpy(group_fields, pl.group_fields.data(), pl.group_fields.size() * sizeof(int32_t));
     if (exact_motifs && !pl.exact_motifs.empty())
         std::memcpy(exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t));
     if (tile_first_group) {
         for (size_t t = 0; t < pl.tiles.size(); t++) tile_first_group[t] = pl.tiles[t].first_group;
         tile_first_group[pl.tiles.size()] = (int32_t) nq;
     }
-    return MS_OK;
-}
-
-// Matrix-core plan (MS_PF_ENGINE=1 or 2 at ms_debug_plan_dims time), decoded from the PHYSICAL operand image the
-// kernel reads: rows [n_groups][16 fields][32 columns][4 bases] int16 (what the product adds for that base at that
-// column), bias [n_groups][16] (engine 2: the spare k-slots; engine 1: 0), group_kb [n_groups] k-blocks.
-int ms_debug_plan_mfma_rows(const ms_pwmset *pwms_c, int16_t *rows, int32_t *bias, int32_t *group_kb) {
-    if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
-    ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
-    std::lock_guard<std::mutex> lk(pwms->mu);
-    const PrefilterPlan &pl = pwms->plan;
-    if (pwms->plan_strand < 0 || pl.engine < 1) { set_error("no matrix-core plan: set MS_PF_ENGINE=1 or 2 and call ms_debug_plan_dims first"); return MS_ERR_INVALID; }
-    const size_t nq = pl.group_G.size();
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(pl.tables.data());
-    const int cols = pl.engine == 2 ? kW2Cols : pl.engine == 3 ? kF6Cols : 8;
-    const size_t kb_bytes = pl.engine == 3 ? (size_t) kF6BytesPerKb : (size_t) kMfmaRowTileBytesPerKb;
     size_t off = 0;
     for (size_t q = 0; q < nq; q++) {
-        const int kb_n = pl.group_G[q];
+        const int kb_n = pl.group_kb[q];
         const int h = (int) (q & 1);
+        const int n_cols = kF6Cols * kb_n;
         if (group_kb) group_kb[q] = kb_n;
-        for (int f = 0; f < 16; f++) {
+        for (int f = 0; f < kGroupFields; f++) {
             const int row = mfma_row_of(h, f);
-            int32_t bs = 0;
-            if (pl.engine == 2)                                       // spare k-slots of k-block 0: 64 * a_hi + a_lo
-                bs = 64 * (int8_t) bytes[off + mfma2_spare_index(row, 0)] + (int8_t) bytes[off + mfma2_spare_index(row, 1)];
-            if (bias) bias[q * 16 + f] = bs;
-            for (int c = 0; c < 32; c++)
-                for (int b = 0; b < 4; b++) {
-                    int v = 0;
-                    if (c < cols * kb_n) {
-                        if (pl.engine == 3) {
-                            v = f6_value(f6_get(bytes + off, c / cols, row, c % cols, b));       // units of 1/8
-                        } else if (pl.engine == 2) {
-                            const int s1 = (b & 1) ? -1 : 1, s2 = (b & 2) ? -1 : 1;
-                            const int c1 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 0)];
-                            const int c2 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 1)];
-                            const int c3 = (int8_t) bytes[off + mfma2_byte_index(c / cols, row, c % cols, 2)];
-                            v = c1 * s1 + c2 * s2 + c3 * s1 * s2;
-                        } else {
-                            v = (int8_t) bytes[off + mfma_byte_index(c >> 3, row, c & 7, b)];
-                        }
-                    }
-                    rows[((q * 16 + f) * 32 + c) * 4 + b] = (int16_t) v;
+            const int b0 = f6_value(f6_get(bytes + off, (n_cols - 1) / kF6Cols, row, (n_cols - 1) % kF6Cols, 0));
+            for (int b = 1; b < 4; b++)
+                if (f6_value(f6_get(bytes + off, (n_cols - 1) / kF6Cols, row, (n_cols - 1) % kF6Cols, b)) != b0) {
+                    set_error("bias column of group %zu field %d differs between bases", q, f);
+                    return MS_ERR_RUNTIME;
                 }
+            if (bias) bias[q * kGroupFields + f] = b0;
+            if (rows)
+                for (int c = 0; c < kF6Cols * kF6MaxKb; c++)
+                    for (int b = 0; b < 4; b++) {
+                        int v = 0;
+                        if (c < n_cols - 1) v = f6_value(f6_get(bytes + off, c / kF6Cols, row, c % kF6Cols, b));       // units of 1/8
+                        rows[((q * kGroupFields + f) * (kF6Cols * kF6MaxKb) + c) * 4 + b] = (int16_t) v;
+                    }
         }
-        if (h == 1) off += (size_t) kb_n * kb_bytes;
+        if (h == 1) off += (size_t) kb_n * kF6BytesPerKb;
     }
     return MS_OK;
 }
@@ -1845,9 +1667,7 @@ int ms_debug_release_scratch(void) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     Scratch &sc = c->sc;
-    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.nlist); dev_free(sc.tile_state); dev_free(sc.chunk_counters);
-    sc.nlist_cap = 0;
-    sc.tile_cap = 0;
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.chunk_counters);
     sc.chunk_counters_cap = 0;
     if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
     sc.sort_tmp = nullptr;

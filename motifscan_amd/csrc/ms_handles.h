@@ -19,8 +19,6 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     uint64_t *cand = nullptr;     size_t cand_cap = 0;
     uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
-    NPos *nlist = nullptr;        size_t nlist_cap = 0;      // positions whose window may hold a non-ACGT base
-    unsigned long long *tile_state = nullptr;  size_t tile_cap = 0;   // look-back states of the ordered re-scoring
     unsigned int *chunk_counters = nullptr;    size_t chunk_counters_cap = 0;   // per LDS tile: the pre-filter's chunk dispenser
     unsigned long long *counters = nullptr;      // 8 words, see scan_locked
     unsigned long long *h_counters = nullptr;    // pinned
@@ -42,7 +40,7 @@ struct BlockPool {
 
 // A stream in two editions: `whole` may use every CU; `part` is confined by a CU mask (hipExtStreamCreateWithCUMask).
 // With MS_MEASURE=1 MS_CU_PARTITION=1 the CUs are partitioned while a batch stream is live (DeviceCtx::n_streams > 0): the
-// scan's two streams keep all but 1 of every 32 CUs, the upload / copy-out streams get those.  What it is for
+// scan's stream keeps all but 1 of every 32 CUs, the upload / copy-out streams get those.  What it is for
 // (tools/ubench/cu_share_probe.hip): the pre-filter's blocks are persistent and each fills a CU, and a second kernel's
 // workgroups are handed to the shader engines in order -- one full engine stalls the whole hand-out, so a pack or copy kernel
 // launched beside the pre-filter ends only when the pre-filter does, even when whole CUs elsewhere are idle (248 or 240 hog
@@ -60,10 +58,9 @@ struct StreamSel {
 struct DeviceCtx {
     int device = -1;
     BlockPool pool;
-    // stream / stream2 are only used under `mu`, and n_streams only changes under `mu`: one scan sees one edition throughout.
+    // stream is only used under `mu`, and n_streams only changes under `mu`: one scan sees one edition throughout.
     // stream_up / stream_down are used without `mu`: every function reads them ONCE into a local hipStream_t.
     StreamSel stream;
-    StreamSel stream2;                       // side stream: the N-window kernels run beside the candidate re-scoring
     StreamSel stream_up;                     // sequence upload + packing (runs beside a scan of the previous batch)
     StreamSel stream_down;                   // copy-out of hit arrays (runs beside a scan of the next batch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -132,16 +129,11 @@ struct ms_pwmset {
     uint64_t plan_cutoff_version = 0;
     size_t plan_lds = 0;
     bool plan_exact_only = false;
-    int plan_min_fb = 0;
-    int plan_engine = -1;
     int plan_device = -1;
     uint4 *d_tables = nullptr;
     ms::TileDesc *d_tiles = nullptr;
-    int32_t *d_group_motifs = nullptr;
-    int32_t *d_fast_motifs = nullptr;
+    int32_t *d_group_fields = nullptr;            // [table groups][kGroupFields] motif of the field, -1 = empty
     int32_t *d_exact_motifs = nullptr;
-    uint32_t *d_rt_off16 = nullptr;               // matrix-core plans: start of every row tile in d_tables (16-byte units) ...
-    int32_t *d_rt_nk = nullptr;                   // ... and its k-blocks (expand_kernel)
     std::mutex mu;
 };
 

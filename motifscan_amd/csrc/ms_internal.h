@@ -23,8 +23,9 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
         }                                                                                   \
     } while (0)
 
-// Measurement / A-B switches (MS_PF_*, MS_HIT_COORD) are honoured only when MS_MEASURE=1 is set as well: a stray
-// variable in the environment must never change what the product does (tests/ and tools/ opt in explicitly).
+// Measurement switches (MS_PF_NOEMIT, MS_PF_CLOCK, MS_PF_MAX_BLOCKS, MS_HIT_COORD, MS_CU_PARTITION) are honoured only when
+// MS_MEASURE=1 is set as well: a stray variable in the environment must never change what the product does (tests/ and tools/
+// opt in explicitly).
 inline const char *measure_env(const char *name) {
     const char *g = getenv("MS_MEASURE");
     if (!g || g[0] != '1' || g[1] != 0) return nullptr;
@@ -32,28 +33,60 @@ inline const char *measure_env(const char *name) {
 }
 
 // ------------------------------------------------------------------ limits / packing --
-constexpr int kMaxFastWidth = 32;      // one lane holds 32 bases (64 bits of 2-bit codes)
-constexpr int kMaxGroups = 16;         // 2-mer groups per motif (ceil(32 / 2))
-constexpr int kMaxMotifs = 65000;      // 14-bit table-group id in a candidate record, >= 4 motifs per group
+constexpr int kMaxFastWidth = 63;      // widest motif the pre-filter takes: 4 k-blocks of 16 columns, the last column carries the row bias
+constexpr int kMaxMotifs = 65000;      // 14-bit table-group id in a candidate record, >= 8 motifs per group
 constexpr int kPadWords = 8;           // zero words after the packed codes (window reads run past the end)
 
-constexpr int64_t kMaxBases = (1LL << 34) - 64;   // 34-bit position field of a candidate record
+constexpr int64_t kMaxBases = (1LL << 34) - 128;   // 34-bit position field of a candidate record
 
 // candidate record (one per lane and table group): [63:30] global base position, [29:16] table group,
-// [15:0] flags: bit n = field n flagged (motif slot n >> 1; even n forward, odd n reverse)
+// [15:0] flags: bit n = field n of the group flagged (PrefilterPlan::group_fields)
 __host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t group, uint32_t flags) {
     return (g << 30) | ((uint64_t) group << 16) | flags;
 }
 
 // ------------------------------------------------------------------ pre-filter plan --
-constexpr int kGroupSlots = 8;         // motif slots per table group (4 at 16-bit fields, 6 at 10-bit)
-constexpr int kMaxClasses = 2 * kMaxGroups;
+//
+// The pre-filter is a rigorous UPPER bound of both strand scores of every window, evaluated as a matrix product on the matrix
+// cores: v_mfma_scale_f32_32x32x64_f8f6f4 with A = the quantised PWM entries in fp6 (e2m3), B = the one-hot image of the
+// sequence in fp4 (e2m1, 1.0 = code 0x2), both block scales 2^0; K = 64 per instruction = SIXTEEN motif columns x 4 bases
+// ("k-block").  The f32 result is exact (entries are multiples of 1/8 of magnitude <= 7.5, at most 64 of them add up).
+//
+// Rows are (motif, strand) "fields", columns are 32 consecutive window starts.  A ROW TILE = the 32 rows of one instruction =
+// two TABLE GROUPS of 16 fields (the unit a candidate record names): with both strands scanned a group holds 8 motifs x
+// {fwd, rev} (field n: motif slot n >> 1, even n forward, odd n reverse), with one strand 16 motifs (field n: slot n).
+// Result register j of lane (r, khalf = h) is row (j & 3) + 8 * (j >> 2) + 4 * h, so lane half h of row tile t owns table group
+// 2t + h, and register j is that group's field 15 - j: shifting the 16 sign bits together in register order yields the flag
+// word of a candidate record.
+//
+// Operand layout (probed with exact data, profiles/r02_mfma_f6_probe.log): lane l = 32 * khalf + r holds row (A) / window (B) r
+// and the 32 consecutive k = 32 * khalf + j, value j at bits [6j, 6j + 6) of the lane's 192 bits (A) / bits [4j, 4j + 4) of its
+// 128 bits (B); k-slot j of lane half khalf = motif column 8 * khalf + (j >> 2), base j & 3.  A row tile is stored per k-block as
+// [plane 0..2][lane 0..63][8 bytes] (plane p = bits [64p, 64p + 64) of the lane's field): three conflict-free ds_read_b64.
+//
+// Entries, in units of 1/8 (ms_plan.cpp): v_c(b) = t_c - dq_c(b), dq = the column's deficit against its best base, quantised
+// DOWN onto the e2m3 grid {0..16, 18..32 step 2, 36..60 step 4}; 56 budget levels; deficits of 60 and more are stored as 60.
+// The offsets t_c (multiples of 4, <= 16, and never more than the column's own best contribution) sit on the columns themselves;
+// what is left of the budget, b0 = 56 - sum t_c, is the ROW BIAS, stored for all four bases in the LAST column of the row tile's
+// last k-block (column 16 * kb - 1: a motif of width W takes kb = W / 16 + 1 k-blocks).  acc = b0 + sum_c (t_c - dq_c) =
+// (56 - sum dq) / 8 >= 0  <=>  candidate: the sign bit of the f32 result.
+// Non-ACGT bases are all-zero one-hot columns (the kernel clears them in the B operand; the bias column is exempt), exactly the
+// reference's "adds nothing" (cscore.c:345-353): because t_c never exceeds the column's best contribution, dropping a column
+// can only lower acc by less than the true score loses, so windows with N go through the same filter -- no separate N path.
+constexpr int kF6Cols = 16;                     // motif columns per k-block (the last one of a row tile is the bias column)
+constexpr int kF6MaxKb = 4;
+constexpr int kF6BytesPerKb = 3 * 64 * 8;       // 1536
+constexpr int kF6Levels = 56;
+constexpr int kGroupFields = 16;                // fields per table group = result registers per lane
+constexpr int kMaxClasses = kF6MaxKb;
+
+inline int f6_kb_of_width(int W) { return W / kF6Cols + 1; }
+inline int mfma_row_of(int h, int field) { const int j = 15 - field; return (j & 3) + 8 * (j >> 2) + 4 * h; }
 
 struct ClassDesc {
-    int32_t G;          // 2-mer groups of every table group in the class
-    int32_t n_groups;
-    int32_t fb;         // field bits: 16 (4 motifs per 16-byte entry) or 10 (6 motifs)
-    uint32_t base16;    // offset of the class's tables inside the tile, 16-byte units
+    int32_t nk;            // k-blocks of every row tile in the class
+    int32_t n_row_tiles;
+    uint32_t base16;       // offset of the class's tables inside the LDS tile, 16-byte units
     int32_t first_group;   // global index of the class's first table group
 };
 
@@ -62,80 +95,24 @@ struct TileDesc {
     uint32_t table_len16;   // tile size in 16-byte units
     int32_t first_group;    // global index of the tile's first table group
     int32_t n_classes;
+    int32_t max_nk;         // widest class of the tile
     ClassDesc cls[kMaxClasses];
 };
 
-// Host-side result of planning: which motifs take the integer pre-filter, their quantised
-// 2-mer tables in groups that share 16-byte entries, and how groups are cut into LDS tiles.
+// Host-side result of planning: which motifs take the pre-filter, their operand tables, and how row tiles are cut into LDS tiles.
 struct PrefilterPlan {
     int strand_mask = 0;
-    int engine = 0;                      // 0: packed 2-mer tables read per lane from LDS; 1: int8 one-hot MFMA; 2: int8 Walsh-form MFMA; 3: fp6 x fp4 one-hot MFMA (below)
     std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in group order
     std::vector<int32_t> exact_motifs;   // motif ids scored in fp64 at every window
-    std::vector<int32_t> group_motifs;   // [n_groups][kGroupSlots], -1 = empty slot
-    std::vector<int32_t> group_G;        // [n_groups]
-    std::vector<int32_t> group_fb;       // [n_groups]
-    std::vector<uint32_t> tables;        // per group: [G][16 codes][4 words]; field n of motif slot j: n = 2j (fwd), 2j+1 (rev)
+    std::vector<int32_t> group_fields;   // [n_groups][kGroupFields] motif id of the field, -1 = empty
+    std::vector<int32_t> group_kb;       // [n_groups] k-blocks of the group's row tile
+    std::vector<uint32_t> tables;        // the operand image, row tile after row tile
     std::vector<TileDesc> tiles;
-    int64_t lds_bytes_per_position = 0;  // sum over groups of G * 16 bytes (per lane, per position)
+    int64_t lds_bytes_per_position = 0;  // A-operand bytes read per window start
+    int64_t kb_total = 0;                // k-blocks over all row tiles
+    bool alln_can_hit = false;           // some pre-filter motif reports windows made of non-ACGT bases only (threshold <= 0)
 };
 
-// ---- engine 1: the pre-filter as an int8 matrix product on the matrix cores -------------------
-// v_mfma_i32_32x32x32_i8: D[row][col] += sum_k A[row][k] * B[k][col].  Rows are (motif, strand)
-// fields, columns are 32 consecutive window starts, and k runs over (column of the motif, base):
-// B is the one-hot image of the sequence (1 where the base at window start + column is that base),
-// A holds the quantised PWM entries.  One instruction covers 8 motif columns ("k-block"); a row
-// tile (32 rows = 2 table groups of 8 motifs x {fwd, rev}) needs ceil(W_max / 8) of them.
-//
-// Operand bytes: lane l = 32 * khalf + r holds 16 bytes; byte i of k-block kb is motif column
-// 8 * kb + 4 * khalf + (i >> 2), base i & 3 -- for A (r = row) and for B (r = window) alike, so the
-// hardware's own k order never matters.  A row tile is stored as [kb][lane][16 bytes]: a wave reads
-// its A operand with one conflict-free ds_read_b128 at lane * 16.
-//
-// Result register j of lane (r, khalf = h) is row (j & 3) + 8 * (j >> 2) + 4 * h.  Lane half h of
-// row tile t therefore owns table group 2t + h, and register j is that group's field 15 - j
-// (field n: motif slot n >> 1, even n forward, odd n reverse), so that shifting the 16 sign bits
-// together in register order yields the flag word of a candidate record directly.
-constexpr int kMfmaRowTileBytesPerKb = 1024;
-inline int mfma_row_of(int h, int field) { const int j = 15 - field; return (j & 3) + 8 * (j >> 2) + 4 * h; }
-inline size_t mfma_byte_index(int kb, int row, int col_in_kb, int base) {     // inside a row tile
-    const int khalf = col_in_kb >> 2;
-    return (size_t) kb * kMfmaRowTileBytesPerKb + (size_t) (khalf * 32 + row) * 16 + (size_t) (col_in_kb & 3) * 4 + base;
-}
-
-// ---- engine 2: the same product with THREE k-slots per base instead of four ---------------------
-// A base has four states, so any per-column score table is  c0 + c1*s1 + c2*s2 + c3*s1*s2  with
-// s1 = +1/-1 by bit 0 of the base code and s2 = +1/-1 by bit 1 (Walsh form): three k-slots per column, the
-// constants c0 summed into a per-row bias.  32 k-slots = 10 columns (5 per lane half: bytes 3j..3j+2 of the
-// half hold c1, c2, c3 of its j-th column) + one spare byte per half; the B operand carries (s1, s2, s1*s2) per
-// base and the constants 64 (half 0) / 1 (half 1) in the spare bytes, so the A-side spare bytes of k-block 0
-// give the row bias 64 * a_hi + a_lo.  Rows tiles need ceil(W / 10) k-blocks: 18 % fewer matrix instructions on
-// the JASPAR width distribution than engine 1's 8 columns per k-block.
-constexpr int kW2Cols = 10;            // motif columns per k-block
-constexpr int kW2MaxWidth = 30;        // 3 k-blocks
-inline size_t mfma2_byte_index(int kb, int row, int col_in_kb, int slot) {      // slot 0..2 = c1, c2, c3; inside a row tile
-    const int khalf = col_in_kb / 5;
-    return (size_t) kb * kMfmaRowTileBytesPerKb + (size_t) (khalf * 32 + row) * 16 + (size_t) (col_in_kb % 5) * 3 + slot;
-}
-inline size_t mfma2_spare_index(int row, int khalf) {                           // k-block 0
-    return (size_t) (khalf * 32 + row) * 16 + 15;
-}
-
-// ---- engine 3: the product on the FP6 x FP4 block-scaled matrix instruction ---------------------------------------------
-// v_mfma_scale_f32_32x32x64_f8f6f4 takes K = 64 per instruction in the time the int8 instruction takes for K = 32 (measured:
-// profiles/r02_mfma_f6_probe.log), i.e. SIXTEEN motif columns per k-block.  A (PWM side) is fp6 e2m3, B (sequence side) the
-// one-hot image in fp4 e2m1 (1.0 = code 0x2), both with block scale 127 = 2^0; the f32 result is exact (entries are multiples
-// of 1/8 of magnitude <= 7.5, at most 32 of them add up).  Operand layout, probed with exact data: lane l = 32 * khalf + r
-// holds row (A) / window (B) r and the 32 consecutive k = 32 * khalf + j, value j at bits [6j, 6j + 6) of the lane's 192 bits
-// (A) / bits [4j, 4j + 4) of its 128 bits (B); here k-slot j of lane half khalf = motif column 8 * khalf + (j >> 2), base j & 3.
-// A row tile is stored per k-block as [plane 0..2][lane 0..63][8 bytes] (plane p = bits [64p, 64p + 64) of the lane's field):
-// three conflict-free ds_read_b64 at lane * 8.
-// Entries are in units of 1/8: v_c(b) = t_c - dq_c(b) with dq on the e2m3 grid {0..16, 18..32 step 2, 36..60 step 4}, 56 budget
-// levels, a clamped deficit = 60, and the offsets t = 16, 16, 16, 8 on the first four columns (multiples of 4 keep every
-// difference on the grid), so that acc = (56 - sum dq) / 8 >= 0  <=>  candidate: the sign bit of the f32 result.
-constexpr int kF6Cols = 16;                     // motif columns per k-block
-constexpr int kF6BytesPerKb = 3 * 64 * 8;       // 1536
-constexpr int kF6Levels = 56;
 inline bool f6_representable(int u) {           // |u| in units of 1/8
     const int m = u < 0 ? -u : u;
     return m <= 16 || (m <= 32 && (m & 1) == 0) || (m <= 60 && (m & 3) == 0);
@@ -180,22 +157,13 @@ inline uint32_t f6_get(const uint8_t *tile, int kb, int row, int col_in_kb, int 
     return code;
 }
 
-// Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes; min_field_bits 10 or 16.
-// engine 1 (build_plan_mfma): ClassDesc.G = k-blocks per row tile, .n_groups = ROW TILES in the class,
-// .first_group = table group of its first row tile; group_G = k-blocks, group_fb = 8.
-int build_plan_mfma(const double *values, const int64_t *val_off, const int32_t *widths,
-                    const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
-                    size_t lds_budget, int engine, PrefilterPlan *plan);
-int build_plan(const double *values, const int64_t *val_off, const int32_t *widths,
-               const double *cutoffs, const double *max_raw, int32_t n_pwms, int strand_mask,
-               size_t lds_budget, int min_field_bits, PrefilterPlan *plan);
+// Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes.
+int build_plan(const double *values, const int64_t *val_off, const int32_t *widths, const double *cutoffs,
+               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, PrefilterPlan *plan);
 
 // Sort (ms_sort.hip): keys ascending over bits [0, end_bit).  Query temp size with temp == nullptr.
 int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                    const double *vals_in, double *vals_out, size_t n, int end_bit, hipStream_t stream);
-
-// Keys-only sort of the candidate entries (motif | coordinate) over bits [0, end_bit).
-int sort_keys(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, size_t n, int end_bit, hipStream_t stream);
 
 // Descending sort of one row of fp64 scores (cutoff builder).  Query temp size with temp == nullptr.
 int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream);

@@ -4,14 +4,12 @@
 
 namespace ms {
 
-constexpr int kPfThreads = 1024;      // largest pre-filter block (16 waves; engine 3 runs two 512-thread blocks per CU): sizes the wave queues
-constexpr int kNwMotifChunk = 8;      // motifs per neval_kernel block (their fp64 tables sit in LDS: 16 KB; 16 per block measured 20 % slower)
+constexpr int kPfThreads = 512;       // pre-filter block: 8 waves, two blocks per CU
+constexpr int kPfBlocksPerCu = 2;
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spilled to HBM when the next append would not fit
 constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
-constexpr size_t kMfmaLutBytes = 256 * 16;   // engine 1: byte of four 2-bit codes -> 16 one-hot operand bytes, after the wave queues
-constexpr size_t kMfma2LutBytes = 1024 * 16; // engine 2: ten bits of five 2-bit codes -> 15 Walsh operand bytes + the spare
-constexpr size_t kF6LutBytes = 256 * 8;      // engine 3: byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes)
+constexpr size_t kF6LutBytes = 256 * 8;      // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the wave queues
 
 struct DevSeq {
     const uint32_t *codes;
@@ -20,16 +18,6 @@ struct DevSeq {
     const int32_t *blk2reg;   // [n_bases/64 + 2] region of position 64*b
     int64_t R;
     int64_t n_bases;
-};
-
-// One position whose window may overlap a non-ACGT base, prepared once (nprep_kernel) for the 73 motif-chunk rows of
-// neval_kernel blocks that all visit it: 32 bytes, read with two 16-byte loads.
-struct NPos {
-    int64_t g;                // global base position
-    uint64_t cw;              // the next 32 bases (2-bit codes)
-    int64_t coord;            // hit coordinate (HitOut: region << pbits | position, or the global position)
-    uint32_t nw;              // the next 32 bases' non-ACGT bits
-    int32_t room;             // bases left in the position's region (capped at 64)
 };
 
 struct DevPwm {
@@ -50,47 +38,11 @@ struct HitOut {
     uint64_t cap;
     int gbits;                // bits of the coordinate field
     int pbits;                // > 0: bits of the position inside a region (see keys)
-    int entries;              // != 0: emit ENTRIES instead of hits -- motif << gbits | coordinate, once per window that passes on
-                              // either strand, no score (ms_tail.hip re-scores the entries in order); vals is unused
-};
-
-// ms_tail.hip
-struct ExpandArgs {
-    const uint64_t *cand;              // candidate records of the pre-filter
-    const unsigned long long *n_cand;
-    uint64_t cand_cap;
-    const uint4 *tables;               // int8 operand tables of the matrix-core pre-filter (global memory)
-    const uint32_t *rt_off16;          // [row tiles] start of the row tile in `tables`, 16-byte units
-    const int32_t *rt_nk;              // [row tiles] k-blocks
-    const int32_t *group_motifs;       // [table groups][kGroupSlots]
-    const int32_t *width;              // [P]
-    DevSeq S;
-    uint64_t *entries;                 // motif << cbits | coordinate
-    unsigned long long *n_entries;
-    uint64_t entry_cap;
-    int cbits, pbits;
-};
-
-struct OrderedArgs {
-    DevSeq S;
-    DevPwm Pw;
-    const uint64_t *keys;              // sorted entries
-    uint64_t n;
-    int cbits, pbits, strand_mask;
-    int32_t P;
-    unsigned long long *tile_state;    // [tiles], zeroed
-    unsigned int *tile_counter;        // zeroed
-    unsigned int *error;               // set if a look-back spin ran out (never expected)
-    int64_t *seq_idx, *pos;
-    double *score;
-    int8_t *strand;
-    int64_t *motif_first;              // [P+1] per-motif offsets, complete after the kernel
-    unsigned long long *n_hits;
-    uint64_t cap;
 };
 
 struct PfArgs {
     const uint32_t *codes;
+    const uint32_t *nmask;
     int64_t n_bases;
     const uint4 *tables;
     const TileDesc *tiles;
@@ -98,23 +50,20 @@ struct PfArgs {
     uint64_t *cand;
     unsigned long long *n_cand;
     uint64_t cand_cap;
+    int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
-    unsigned int *chunk_counter;   // [LDS tiles], zeroed: the matrix-core kernels hand their position chunks out dynamically
+    unsigned int *chunk_counter;   // [LDS tiles][kPfCounters] words 64 bytes apart, zeroed: the units behind the waves' own first ones
     int wave_passes;               // per-wave hand-out: passes of 64 window starts a wave takes per atomic (scan_locked sizes it)
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int prefilter_set_lds(int variant, bool meas, size_t bytes);
-int prefilter_threads(int variant);           // block size of a kernel variant
-int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
-int launch_nlist(const DevSeq &S, int max_w, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H, hipStream_t st);
-int launch_neval(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask, const NPos *list,
-                 const unsigned long long *n_list, uint64_t list_cap, const HitOut &H, int n_blocks_max, hipStream_t st);
+int prefilter_set_lds(bool meas, size_t bytes);
+int launch_prefilter(const PfArgs &A, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
-                   uint64_t cand_cap, const int32_t *group_motifs, int strand_mask, const HitOut &H, int n_blocks,
+                   uint64_t cand_cap, const int32_t *group_fields, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
 int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S, int64_t *seq_idx,
                     int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
@@ -139,11 +88,6 @@ int launch_site_tables(int64_t n, const int64_t *motif_off, int32_t P, int64_t R
                        const double *score, int32_t *n_sites, double *max_score, hipStream_t st);
 int launch_pack_hits(int64_t n, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord, unsigned int *bad,
                      hipStream_t st);
-int launch_expand(const ExpandArgs &A, int n_blocks, hipStream_t st);
-size_t ordered_tiles(uint64_t n_entries);
-int launch_rescore_ordered(const OrderedArgs &A, hipStream_t st);
-int launch_pair_counts(const unsigned long long *n_hits, uint64_t cap, const int64_t *motif_first, int32_t P, const int64_t *seq_idx,
-                       unsigned long long *region_counts, int n_blocks, hipStream_t st);
 int launch_gather_ranks(const double *sorted, int64_t n, const int64_t *ranks, int32_t n_ranks, double *out, hipStream_t st);
 
 }  // namespace ms

@@ -11,11 +11,8 @@
 //
 // Kernels:
 //   pack_kernel       ASCII -> codes + nmask                     (cscore.c:81-114)
-//   prefilter_mfma_kernel  rigorous integer upper bound of both strand scores for EVERY window as an int8
-//                     one-hot product on the matrix cores (v_mfma_i32_32x32x32_i8); emits candidates
-//   prefilter_kernel  the same bound from packed 10/16-bit 2-mer fields read per lane from LDS
-//                     (engine 0, MS_PF_ENGINE=0: A/B reference)
-//   nlist/neval       fp64 scoring of the windows that overlap a non-ACGT base
+//   prefilter_f6_kernel  rigorous upper bound of both strand scores for EVERY window (with or without non-ACGT bases) as an
+//                     fp6 x fp4 one-hot product on the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4); emits candidates
 //   exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take
 //   rescore_kernel    fp64 scoring of the candidates, in the reference's order of operations,
 //                     and the reference's hit test (cscore.c:356-358, 373-375)
@@ -60,13 +57,6 @@ __device__ __forceinline__ void test_and_emit(const HitOut &H, const DevPwm &Pw,
     const double cutoff = Pw.cutoff[motif];
     const double s_f = try_f ? fwd / max_raw : 0.0, s_r = try_r ? rev / max_raw : 0.0;
     const bool hit_f = try_f && s_f - cutoff >= -1e-10, hit_r = try_r && s_r - cutoff >= -1e-10;
-    if (H.entries) {                                     // one entry per window: rescore_ordered_kernel repeats this very test
-        if (hit_f || hit_r) {
-            const unsigned long long i = atomicAdd(H.n_hits, 1ULL);
-            if (i < H.cap) H.keys[i] = ((uint64_t) motif << H.gbits) | (uint64_t) g;
-        }
-        return;
-    }
     if (hit_f) emit_hit(H, motif, g, 0u, s_f);
     if (hit_r) emit_hit(H, motif, g, 1u, s_r);
 }
@@ -172,19 +162,22 @@ __global__ void __launch_bounds__(256) pack_kernel(const uint8_t *__restrict__ a
 }
 
 // ---------------------------------------------------------------------- pre-filter --
-
-__device__ __forceinline__ void add4(uint4 &a, const uint4 &b) {
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-}
-
-// ---- candidate hand-off --------------------------------------------------------------------
-// Candidates are ~2e-4 of the (window, motif) pairs, i.e. about one wave in ten finds one in a
-// pair of table groups.  One global atomic per find would put every wave of the chip on ONE address
-// (measured: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  So each
-// wave appends to its own queue in LDS with ballot/mbcnt ranks (no atomics at all) and spills it
-// to the global list with a single atomicAdd per >= 64 entries.  A record is per LANE and per
-// table group: position, group, and one flag bit per field (motif slot, strand) -- rescore_kernel
+//
+// The pre-filter on the matrix cores (operand layout, quantisation and the proof that it never loses a hit: ms_internal.h,
+// ms_plan.cpp).  Per wave and pass: 64 consecutive window starts = two 32-column B operands per k-block (the one-hot image of the
+// lane's bases in fp4, built once per class and reused by every row tile), and per row tile of 32 (motif, strand) rows
+// NK x 3 ds_read_b64 for the A operand (fp6) and 2 NK matrix instructions.  acc >= +0 (sign bit clear) in any of the 16 result
+// registers of a lane marks a candidate.
+//
+// ---- candidate hand-off ----
+// Candidates are ~2e-4 of the (window, motif) pairs.  One global atomic per find would put every wave of the chip on ONE address
+// (measured in round 1: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  So each wave appends to its
+// own queue in LDS with ballot/mbcnt ranks (no atomics at all) and spills it to the global list with a single atomicAdd per
+// <= 64 entries.  A record is per LANE and per table group: position, group, and one flag bit per field -- rescore_kernel
 // expands the flags.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __noinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
                                       unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
@@ -196,333 +189,28 @@ __device__ __noinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, u
         if (base + i < cand_cap) cand[base + i] = wbuf[i];
 }
 
-// Field geometry of a 32-bit table word at FB bits per field.
-template <int FB> struct Fields {
-    static constexpr int NF = 32 / FB;                                   // fields per word
-    static constexpr uint32_t low() { uint32_t m = 0; for (int f = 0; f < NF; f++) m |= 1u << (f * FB); return m; }
-    static constexpr uint32_t kLow = low();                              // bit 0 of every field
-    static constexpr uint32_t kTop = kLow << (FB - 1);                   // top (flag) bit of every field
-};
-
-// 16-byte entry -> flags: bit n = field n reached its top bit (field n: word n & 3, field n >> 2)
-template <int FB>
-__device__ __forceinline__ uint32_t group_flags(const uint4 &a) {
-    uint32_t f = (a.x >> (FB - 1)) & Fields<FB>::kLow;
-    f |= ((a.y >> (FB - 1)) & Fields<FB>::kLow) << 1;
-    f |= ((a.z >> (FB - 1)) & Fields<FB>::kLow) << 2;
-    f |= ((a.w >> (FB - 1)) & Fields<FB>::kLow) << 3;
-    uint32_t out = f & 0xFu;
-#pragma unroll
-    for (int k = 1; k < Fields<FB>::NF; k++) out |= ((f >> (k * FB)) & 0xFu) << (4 * k);
-    return out;
-}
-
-struct PfWave {
+struct MfWave {
     uint64_t *wbuf;      // this wave's queue in LDS (kWqCap entries)
     uint32_t n;          // entries queued (wave-uniform)
-    int64_t g;           // this lane's window start
-    bool live;           // g < n_bases
 };
 
-// Entered by the WHOLE wave (uniform branch); appends one record per lane that flagged anything in
-// this table group.
-__device__ __forceinline__ void emit_flags(const PfArgs &A, PfWave &W, uint32_t flags, int32_t group) {
-    const bool flagged = W.live && flags != 0;
-    const unsigned long long mask = __ballot(flagged);
-    if (mask == 0) return;
-    const uint32_t n_new = (uint32_t) __popcll(mask);
-    if (W.n + n_new > (uint32_t) kWqCap) {
-        wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
-        W.n = 0;
-    }
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    if (flagged) W.wbuf[W.n + rank] = cand_pack((uint64_t) W.g, (uint32_t) group, flags);
-    W.n += n_new;
-}
-
-// One loop trip: NG consecutive table groups of a class for the lane's window start.  All NG*G
-// reads are issued as one batch (at most 8 rows at a time when that is more than 16 reads), then
-// added, then ONE test decides whether any of the 64 lanes flagged any field of the NG groups.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// ds_read_b128 issued by hand: hipcc's scheduler otherwise splits a trip's reads into per-group
-// batches of G with a full lgkmcnt(0) drain between them (kernel .s), i.e. keeps only ~6 reads in
-// flight per wave.  The loads below are issued back to back; ONE s_waitcnt lgkmcnt(0) +
-// sched_barrier follows (hipcc tracks neither inline-asm loads nor their waits).  lgkmcnt(0) also
-// covers any scalar load in flight, so no counted wait has to reason about SMEM's out-of-order
-// returns.
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read128_asm(uint32_t byte_addr) {
-    u32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(byte_addr), "n"(OFF));
-    return r;
-}
-
-// s_waitcnt lgkmcnt(rows_left * NG), as an immediate
-template <int NG>
-__device__ __forceinline__ void wait_lgkm(int rows_left) {
-    switch (rows_left * NG) {
-        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;   // 15 cannot be relied on (4-bit counter): a stricter wait is never wrong
-    }
-}
-
-template <int G, int NG, int FB, bool ASM, bool PROG>
-__device__ __forceinline__ void prefilter_trip(const PfArgs &A, PfWave &W, const uint4 *__restrict__ lds4,
-                                               const uint32_t (&a)[G], int32_t group) {
-    uint4 acc[NG];
-    constexpr int B = (NG * G <= 16) ? G : (16 / NG < 1 ? 1 : 16 / NG);      // rows per batch
-    if constexpr (ASM) {
-        // a[] holds BYTE addresses here
-#pragma unroll
-        for (int k0 = 0; k0 < G; k0 += B) {
-            u32x4 r[NG][B];
-#pragma unroll
-            for (int k = 0; k < B; k++)
-                if (k0 + k < G) {
-                    if constexpr (NG >= 1) r[0][k] = lds_read128_asm<0>(a[k0 + k]);
-                    if constexpr (NG >= 2) r[1][k] = lds_read128_asm<1 * G * 256>(a[k0 + k]);
-                    if constexpr (NG >= 3) r[2][k] = lds_read128_asm<2 * G * 256>(a[k0 + k]);
-                    if constexpr (NG >= 4) r[3][k] = lds_read128_asm<3 * G * 256>(a[k0 + k]);
-                }
-            if constexpr (!PROG) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int k = 0; k < B; k++)
-                if (k0 + k < G) {
-                    if constexpr (PROG) {
-                        // LDS returns in order and nothing else is on lgkmcnt inside the trip loop: row k of
-                        // all NG groups is back once at most (rows still behind it) x NG reads are outstanding
-                        const int rows_in_batch = (G - k0) < B ? (G - k0) : B;       // folds after unrolling
-                        wait_lgkm<NG>(rows_in_batch - 1 - k);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < NG; u++) {
-                        if (k0 + k == 0) { acc[u].x = r[u][k].x; acc[u].y = r[u][k].y; acc[u].z = r[u][k].z; acc[u].w = r[u][k].w; }
-                        else { acc[u].x += r[u][k].x; acc[u].y += r[u][k].y; acc[u].z += r[u][k].z; acc[u].w += r[u][k].w; }
-                    }
-                }
-        }
-    } else {
-#pragma unroll
-        for (int k0 = 0; k0 < G; k0 += B) {
-            uint4 r[NG][B];
-#pragma unroll
-            for (int k = 0; k < B; k++)
-                if (k0 + k < G) {
-#pragma unroll
-                    for (int u = 0; u < NG; u++) r[u][k] = lds4[a[k0 + k] + u * G * 16];
-                }
-#pragma unroll
-            for (int k = 0; k < B; k++)
-                if (k0 + k < G) {
-#pragma unroll
-                    for (int u = 0; u < NG; u++) {
-                        if (k0 + k == 0) acc[u] = r[u][k];
-                        else add4(acc[u], r[u][k]);
-                    }
-                }
-        }
-    }
-    uint32_t any[NG], all = 0;
-#pragma unroll
-    for (int u = 0; u < NG; u++) {
-        any[u] = (acc[u].x | acc[u].y | acc[u].z | acc[u].w) & Fields<FB>::kTop;
-        all |= any[u];
-    }
-    if (__any(all != 0) && !A.no_emit) {
-        // usually only one of the groups has a flagged lane: decode flags only for that one
-#pragma unroll
-        for (int u = 0; u < NG; u++)
-            if (NG == 1 || __any(any[u] != 0)) emit_flags(A, W, group_flags<FB>(acc[u]), group + u);
-    }
-}
-
-// All table groups of one class (same 2-mer count G, same field width FB): per group G LDS reads
-// of 16 bytes (2 * 32/FB motifs x {fwd,rev} fields) and (G-1) x 4 packed adds.  A table row of
-// one (group, 2-mer position) is 16 codes x 16 B = 256 B = every LDS bank exactly once, so the
-// read is conflict-free whatever the codes are (SQ_LDS_BANK_CONFLICT = 0, profiles/).
-//
-// The kernel is bound by LDS bandwidth, so a trip covers as many groups as give 12-16 reads in
-// flight per wave (4 groups of narrow motifs, 2 of wide ones); the few groups left over at the
-// end of a class take one smaller trip.  Variants (A/B runs, tools/pf_variants.py): V = 0 two groups
-// per trip; V = 1 trips sized by width, reads left to hipcc; V = 3 reads issued by hand, one wait;
-// V = 4 (default) reads issued by hand, counted waits so the adds start as rows arrive.  (A fully
-// double-buffered form -- next trip's reads queued behind the current one's -- measured 6 % slower:
-// one group per trip costs more test instructions than the shorter LDS queue gaps win.)
-template <int G, int V, int FB>
-__device__ __forceinline__ void prefilter_class(const PfArgs &A, const uint4 *__restrict__ lds4, uint32_t base16,
-                                                int n_groups, int32_t first_group, const uint64_t cw, PfWave &W) {
-    constexpr bool ASM = V == 3 || V == 4;
-    constexpr bool PROG = V == 4;
-    constexpr uint32_t unit = ASM ? 16u : 1u;          // a[] in bytes (hand-issued reads) or in 16-byte entries
-    uint32_t a[G];
-#pragma unroll
-    for (int k = 0; k < G; k++) a[k] = (base16 + (uint32_t) k * 16u + ((uint32_t) (cw >> (4 * k)) & 15u)) * unit;
-    constexpr int NG = V == 0 ? 2 : (G <= 4 ? 4 : (G == 5 ? 3 : 2));
-    int q = 0;
-    for (; q + NG <= n_groups; q += NG) {
-        prefilter_trip<G, NG, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
-#pragma unroll
-        for (int k = 0; k < G; k++) a[k] += NG * G * 16 * unit;
-    }
-    const int rem = n_groups - q;                       // wave-uniform
-    if (NG > 3 && rem == 3) prefilter_trip<G, 3, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
-    else if (NG > 2 && rem == 2) prefilter_trip<G, 2, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
-    else if (rem == 1) prefilter_trip<G, 1, FB, ASM, PROG>(A, W, lds4, a, first_group + q);
-}
-
-#define MS_PF_CASE(GG)                                                                                      \
-    case GG:                                                                                                \
-        if (fb == 10) prefilter_class<GG, V, 10>(A, lds4, base16, nq, first_group, cw, W);                  \
-        else prefilter_class<GG, V, 16>(A, lds4, base16, nq, first_group, cw, W);                           \
-        break;
-
-// grid = (blocks per tile, tiles).  One block per CU (the tile's tables fill the LDS), NT/64 waves,
-// each wave takes 64 consecutive window starts per iteration.  Dynamic LDS = tables of the
-// largest tile, then one queue of kWqCap candidates per wave.
-template <int NT, int V, int MW>
-__global__ void __launch_bounds__(NT, MW) prefilter_kernel(const PfArgs A) {
-    extern __shared__ uint4 lds4[];
-    const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
-    const uint32_t len16 = T->table_len16;
-    const uint4 *__restrict__ src = A.tables + T->table_off16;
-    for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
-    __syncthreads();
-    const int n_classes = T->n_classes;
-    PfWave W;
-    W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
-    W.n = 0;
-    const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
-    // optional clock stamps (measurement runs only; written to a buffer nothing else reads):
-    // shader cycles (s_memtime) against the 100 MHz constant clock (s_memrealtime)
-    unsigned long long t0 = 0, r0 = 0;
-    if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-
-    // the sequence words of the NEXT chunk are fetched while the current one is scanned
-    uint64_t cw_next = 0;
-    {
-        const int64_t g0 = (int64_t) blockIdx.x * NT + threadIdx.x;
-        if (blockIdx.x < n_chunks) cw_next = code_window(A.codes, g0 < A.n_bases ? g0 : 0);
-    }
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        W.g = chunk * NT + threadIdx.x;
-        W.live = W.g < A.n_bases;
-        const uint64_t cw = cw_next;
-        {
-            const int64_t gn = W.g + (int64_t) gridDim.x * NT;
-            if (chunk + gridDim.x < n_chunks) cw_next = code_window(A.codes, gn < A.n_bases ? gn : 0);
-        }
-
-        // (walking the classes in a per-wave rotated order, so that the waves do not reach the class
-        // boundaries together, measured 5 % SLOWER: the waves then execute 11 different loops at once)
-        int c = 0;
-        ClassDesc cur = T->cls[c];
-        for (int i = 0; i < n_classes; i++) {
-            c = c + 1 < n_classes ? c + 1 : 0;
-            const ClassDesc nxt = T->cls[c];                      // scalar loads land while this class runs
-            const int G = cur.G;
-            const int nq = cur.n_groups;
-            const int fb = cur.fb;
-            const uint32_t base16 = cur.base16;
-            const int32_t first_group = cur.first_group;
-            switch (G) {
-                MS_PF_CASE(1) MS_PF_CASE(2) MS_PF_CASE(3) MS_PF_CASE(4)
-                MS_PF_CASE(5) MS_PF_CASE(6) MS_PF_CASE(7) MS_PF_CASE(8)
-                MS_PF_CASE(9) MS_PF_CASE(10) MS_PF_CASE(11) MS_PF_CASE(12)
-                MS_PF_CASE(13) MS_PF_CASE(14) MS_PF_CASE(15) MS_PF_CASE(16)
-                default: break;
-            }
-            cur = nxt;
-        }
-    }
-    if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
-    if (A.clk && threadIdx.x == 0) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        const size_t b = (size_t) blockIdx.y * gridDim.x + blockIdx.x;
-        A.clk[2 * b] = t1 - t0;
-        A.clk[2 * b + 1] = r1 - r0;
-    }
-}
-
-// ------------------------------------------------------- pre-filter on the matrix cores --
-//
-// Engine 1 (ms_internal.h, "engine 1"): the same rigorous upper-bound test as above, evaluated as an
-// int8 matrix product.  Per wave and iteration: 64 consecutive window starts = two 32-column
-// B operands per k-block (the one-hot image of the lane's bases, built once in registers and reused
-// by every row tile), and per row tile of 16 motifs x {fwd, rev} one ds_read_b128 per k-block for the
-// A operand.  acc >= 0 (sign bit clear) in any of the 16 result registers of a lane marks a candidate.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-
-// 4 bases (8 bits of 2-bit codes) -> 4 words, byte `code` of each word = 1
-__device__ __forceinline__ i32x4 onehot4(uint32_t codes8) {
-    i32x4 r;
-    r.x = (int) (1u << ((codes8 & 3u) << 3));
-    r.y = (int) (1u << (((codes8 >> 2) & 3u) << 3));
-    r.z = (int) (1u << (((codes8 >> 4) & 3u) << 3));
-    r.w = (int) (1u << (((codes8 >> 6) & 3u) << 3));
-    return r;
-}
-
-// engine 2: 5 bases (10 bits of 2-bit codes) -> bytes 3j, 3j+1, 3j+2 = s1, s2, s1*s2 of base j (s1 = -1 if bit 0 of the
-// code is set, s2 = -1 if bit 1 is); byte 15 (the spare k-slot) is filled in by the reader
-__device__ __forceinline__ uint4 walsh5(uint32_t codes10) {
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const uint32_t code = (codes10 >> (2 * j)) & 3u;
-        const int s1 = (code & 1u) ? -1 : 1, s2 = (code & 2u) ? -1 : 1;
-        const int v[3] = {s1, s2, s1 * s2};
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int byte = 3 * j + t;
-            w[byte >> 2] |= ((uint32_t) v[t] & 0xFFu) << (8 * (byte & 3));
-        }
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__device__ __forceinline__ int max16(const i32x16 &c) {
-    int a = max(max(c[0], c[1]), c[2]);             // v_max3_i32
-    int b = max(max(c[3], c[4]), c[5]);
-    int d = max(max(c[6], c[7]), c[8]);
-    int e = max(max(c[9], c[10]), c[11]);
-    int f = max(max(c[12], c[13]), c[14]);
-    a = max(max(a, b), d);
-    e = max(max(e, f), c[15]);
-    return max(a, e);
-}
-
 // bit n of the result = result register 15 - n is non-negative (field n of the lane's table group)
-__device__ __forceinline__ uint32_t nonneg_flags(const i32x16 &c) {
+__device__ __forceinline__ uint32_t nonneg_flags(const f32x16 &c) {
     uint32_t m = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) m = __builtin_amdgcn_alignbit(m, (uint32_t) c[j], 31);   // (m << 1) | sign
+    for (int j = 0; j < 16; j++) m = __builtin_amdgcn_alignbit(m, (uint32_t) __float_as_int(c[j]), 31);   // (m << 1) | sign
     return ~m & 0xFFFFu;
 }
 
-struct MfWave {
-    uint64_t *wbuf;
-    uint32_t n;
-};
+// AND of the 16 sign bits (bit 31 of the result): clear <=> some result register is >= +0.  Eight 3-input ANDs (v_bitop3_b32)
+// through one accumulator: the forwarded operand keeps the instruction at two fresh register reads
+// (profiles/r03_insp_probe.log: 95 cycles per row tile against 108 for the tree of v_max3_i32 round 2 used).
+__device__ __forceinline__ uint32_t all_negative(const f32x16 &c) {
+    uint32_t x = (uint32_t) __float_as_int(c[0]) & (uint32_t) __float_as_int(c[1]) & (uint32_t) __float_as_int(c[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) x = x & (uint32_t) __float_as_int(c[i]) & (uint32_t) __float_as_int(c[i + 1]);
+    return x & (uint32_t) __float_as_int(c[15]);
+}
 
 __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, int64_t g, uint32_t flags, int32_t group) {
     const bool flagged = live && flags != 0;
@@ -538,158 +226,52 @@ __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, 
     W.n += n_new;
 }
 
-// the record without flags (flags = 0): expand_kernel recomputes the group's 16 row sums for the flagged lanes
-__device__ __forceinline__ void emit_rec_noflags(const PfArgs &A, MfWave &W, bool flagged, uint64_t gkey, int32_t group) {
-    const unsigned long long mask = __ballot(flagged);
-    if (mask == 0) return;
-    const uint32_t n_new = (uint32_t) __popcll(mask);
-    if (W.n + n_new > (uint32_t) kWqCap) {
-        wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
-        W.n = 0;
-    }
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    if (flagged) W.wbuf[W.n + rank] = gkey | ((uint64_t) (uint32_t) group << 16);
-    W.n += n_new;
+// The lane's 8 bases of one k-block half as 32 fp4 one-hot k-slots: two reads of the 256-entry table (byte of four 2-bit codes ->
+// 16 k-slots = 8 bytes).  n8 = the 8 bases' non-ACGT bits: such a base is an all-zero column (cscore.c:345-353 "adds nothing").
+__device__ __forceinline__ i32x8 onehot_f4(const char *__restrict__ lut, uint32_t c16) {
+    const int2 lo = *reinterpret_cast<const int2 *>(lut + ((c16 & 0xFFu) << 3)), hi = *reinterpret_cast<const int2 *>(lut + ((c16 >> 8) << 3));
+    return i32x8{lo.x, lo.y, hi.x, hi.y, 0, 0, 0, 0};
 }
-
-// any of the 32 result registers of the two 32-window operands non-negative?  (16 x v_max3_i32)
-__device__ __forceinline__ int max32(const i32x16 &c, const i32x16 &d) {
-    int m[11];
+__device__ __forceinline__ void clear_n(i32x8 &b, uint32_t n8) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        m[i] = max(max(c[3 * i], c[3 * i + 1]), c[3 * i + 2]);
-        m[5 + i] = max(max(d[3 * i], d[3 * i + 1]), d[3 * i + 2]);
-    }
-    m[10] = max(max(c[15], d[15]), m[0]);
-    const int x = max(max(m[1], m[2]), m[3]), y = max(max(m[4], m[5]), m[6]), z = max(max(m[7], m[8]), m[9]);
-    return max(max(x, y), max(z, m[10]));
-}
-
-// Rare path (about one tile in five has a candidate in some lane): which of the two 32-window operands, which
-// fields; queue the records.  (Inlined: a real call would pass the 32 result registers and the argument block
-// through scratch memory.)
-__device__ __forceinline__ void mfma_emit(const PfArgs &A, MfWave &W, const i32x16 &c0, const i32x16 &c1, int32_t group,
-                                          int64_t g0, bool live0, bool live1) {
-    if (__any(max16(c0) >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
-    if (__any(max16(c1) >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
-}
-
-// All row tiles of one class (NK k-blocks each): per tile NK ds_read_b128 (A operand), 2 * NK matrix
-// instructions, 16 v_max3 and one compare.  The B operands (one-hot image of the lane's bases) come from a
-// 256-entry table in LDS: 4 bases (one byte of 2-bit codes) -> 16 operand bytes.
-template <int NK, int V, int ENG, bool MEAS>
-__device__ __forceinline__ void mfma_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
-                                           uint32_t byte_off, int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
-                                           int64_t g0, bool live0, bool live1) {
-    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
-    const char *p = lds + byte_off + lane * 16u;
-    constexpr int kStep = NK * kMfmaRowTileBytesPerKb;
-    i32x4 b0[NK], b1[NK];
-#pragma unroll
-    for (int kb = 0; kb < NK; kb++) {
-        if constexpr (ENG == 2) {
-            // 5 bases per lane half; the spare k-slot (byte 15) carries the bias scale: 64 in half 0, 1 in half 1
-            const int spare = h ? (1 << 24) : (64 << 24);
-            b0[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw0 >> (20 * kb + 10 * h)) & 0x3FFu) << 4));
-            b1[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw1 >> (20 * kb + 10 * h)) & 0x3FFu) << 4));
-            b0[kb].w |= spare;
-            b1[kb].w |= spare;
-        } else {
-            b0[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw0 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
-            b1[kb] = *reinterpret_cast<const i32x4 *>(lut + (((uint32_t) (cw1 >> (16 * kb + 8 * h)) & 0xFFu) << 4));
-        }
-    }
-    const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto product = [&](const char *q, i32x16 &c0, i32x16 &c1) {
-        i32x4 a[NK];
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) a[kb] = *reinterpret_cast<const i32x4 *>(q + kb * kMfmaRowTileBytesPerKb);
-        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b0[0], z, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b1[0], z, 0, 0, 0);
-#pragma unroll
-        for (int kb = 1; kb < NK; kb++) {
-            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b0[kb], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b1[kb], c1, 0, 0, 0);
-        }
-    };
-    auto test = [&](const i32x16 &c0, const i32x16 &c1, int t) {
-        if constexpr (V & 4) {
-            // default: the rare path only queues (position, table group) of the lanes that flagged anything; which of the group's
-            // 16 fields it was is recomputed by expand_kernel from the same int8 tables (ms_tail.hip)
-            const int m0 = max16(c0), m1 = max16(c1);
-            if (__builtin_expect(__any(max(m0, m1) >= 0) && !(MEAS && A.no_emit), 0)) {
-                const int32_t group = first_group + 2 * t + (int32_t) h;
-                emit_rec_noflags(A, W, live0 && m0 >= 0, (uint64_t) g0 << 30, group);
-                emit_rec_noflags(A, W, live1 && m1 >= 0, (uint64_t) (g0 + 32) << 30, group);
-            }
-        } else if constexpr (V & 2) {
-            // A/B: the two halves' maxima are kept (17 instead of 16 max instructions per tile), so the rare path does not
-            // recompute them (2 x 8 fewer there)
-            const int m0 = max16(c0), m1 = max16(c1);
-            if (__builtin_expect(__any(max(m0, m1) >= 0) && !(MEAS && A.no_emit), 0)) {
-                const int32_t group = first_group + 2 * t + (int32_t) h;
-                if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
-                if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
-            }
-        } else {
-            if (__builtin_expect(__any(max32(c0, c1) >= 0) && !(MEAS && A.no_emit), 0))
-                mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
-        }
-    };
-    // ILP tiles' products are issued back to back (independent accumulators), then reduced: a wave that
-    // spends more of its time issuing matrix instructions leaves the pipe idle less often (4 waves per SIMD)
-    constexpr int ILP = (V & 1) && NK <= 2 ? 2 : 1;      // V: bit 0 two tiles in flight, bit 1 per-half maxima (A/B), bit 2 flag-free records
-    int t = 0;
-    for (; t + ILP <= n_row_tiles; t += ILP, p += ILP * kStep) {
-        i32x16 c0[ILP], c1[ILP];
-#pragma unroll
-        for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
-        if constexpr ((V & 8) && ILP == 2) {
-            // A/B: ONE branch for the pair of tiles (the vector -> scalar -> branch chain is paid once per two tiles)
-            const int ma = max32(c0[0], c1[0]), mb = max32(c0[1], c1[1]);
-            if (__builtin_expect(__any(max(ma, mb) >= 0) && !(MEAS && A.no_emit), 0)) {
-                if (__any(ma >= 0)) mfma_emit(A, W, c0[0], c1[0], first_group + 2 * t + (int32_t) h, g0, live0, live1);
-                if (__any(mb >= 0)) mfma_emit(A, W, c0[1], c1[1], first_group + 2 * (t + 1) + (int32_t) h, g0, live0, live1);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
-        }
-    }
-    for (; t < n_row_tiles; t++, p += kStep) {
-        i32x16 c0, c1;
-        product(p, c0, c1);
-        test(c0, c1, t);
+    for (int r = 0; r < 4; r++) {                                   // word r = bases 2r (low half) and 2r + 1 (high half)
+        const uint32_t two = (n8 >> (2 * r)) & 3u;
+        b[r] &= (int) (((two & 1u) ? 0u : 0xFFFFu) | ((two & 2u) ? 0u : 0xFFFF0000u));
     }
 }
 
-// ---- engine 3: the same tiles on v_mfma_scale_f32_32x32x64_f8f6f4 (A fp6 e2m3, B fp4 one-hot), 16 motif columns per k-block
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// The 64 bases (2-bit codes) / their 64 non-ACGT bits from window start g + 32 * which on: cw[which], cw[which + 1]
+struct PassSeq {
+    uint64_t cw[3];      // code windows at g, g + 32, g + 64 (the last only when the tile has classes of 3 or 4 k-blocks)
+    uint32_t nw[3];      // non-ACGT bits of the same bases, 32 per word
+    bool any_n;          // wave-uniform: some lane sees a non-ACGT base
+};
 
-__device__ __forceinline__ i32x16 as_bits(const f32x16 &c) {           // the f32 results as bit patterns: sign bit clear <=> value >= +0
-    i32x16 r;
-#pragma unroll
-    for (int j = 0; j < 16; j++) r[j] = __float_as_int(c[j]);
-    return r;
-}
-
-template <int NK, int V, bool MEAS>
-__device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
-                                              uint32_t byte_off, int n_row_tiles, int32_t first_group, uint64_t cw0, uint64_t cw1,
-                                              int64_t g0, bool live0, bool live1) {
+// All row tiles of one class (NK k-blocks each).  ILP row tiles' products are issued back to back (independent accumulators), then
+// inspected: a wave that spends more of its time issuing matrix instructions leaves the pipe idle less often (4 waves per SIMD).
+template <int NK, bool MEAS>
+__device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
+                                         uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
+                                         int64_t g0, bool live0, bool live1) {
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     const char *p = lds + byte_off + lane * 8u;
     constexpr int kStep = NK * kF6BytesPerKb;
-    // B operands: the lane's 8 bases of k-block kb (columns 16 kb + 8 h ...) as 32 fp4 one-hot k-slots = two table reads of 8 bytes
+    // B operands: k-block kb of the window at g0 covers bases 16 kb + 8 h ... + 7 from g0; of the window at g0 + 32 the same from there
     i32x8 b0[NK], b1[NK];
 #pragma unroll
     for (int kb = 0; kb < NK; kb++) {
-        const uint32_t c0 = (uint32_t) (cw0 >> (32 * kb + 16 * h)) & 0xFFFFu, c1 = (uint32_t) (cw1 >> (32 * kb + 16 * h)) & 0xFFFFu;
-        const int2 l0 = *reinterpret_cast<const int2 *>(lut + ((c0 & 0xFFu) << 3)), h0 = *reinterpret_cast<const int2 *>(lut + ((c0 >> 8) << 3));
-        const int2 l1 = *reinterpret_cast<const int2 *>(lut + ((c1 & 0xFFu) << 3)), h1 = *reinterpret_cast<const int2 *>(lut + ((c1 >> 8) << 3));
-        b0[kb] = i32x8{l0.x, l0.y, h0.x, h0.y, 0, 0, 0, 0};
-        b1[kb] = i32x8{l1.x, l1.y, h1.x, h1.y, 0, 0, 0, 0};
+        const int w = kb >> 1, sh = 32 * (kb & 1);
+        b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[w] >> (sh + 16 * h)) & 0xFFFFu);
+        b1[kb] = onehot_f4(lut, (uint32_t) (Q.cw[w + 1] >> (sh + 16 * h)) & 0xFFFFu);
+    }
+    if (Q.any_n) {                                                                // rare, wave-uniform
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) {
+            const int w = kb >> 1, sh = 16 * (kb & 1);
+            const uint32_t keep = (kb == NK - 1 && h) ? 0x7Fu : 0xFFu;            // the row tile's last column carries the bias: never cleared
+            clear_n(b0[kb], (Q.nw[w] >> (sh + 8 * h)) & keep);
+            clear_n(b1[kb], (Q.nw[w + 1] >> (sh + 8 * h)) & keep);
+        }
     }
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
@@ -709,27 +291,22 @@ __device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const 
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, 127, 0, 127);
         }
     };
-    auto test = [&](const f32x16 &f0, const f32x16 &f1, int t) {
-        const i32x16 c0 = as_bits(f0), c1 = as_bits(f1);
-        if constexpr (V & 2) {                                // the two halves' maxima are kept for the rare path (this engine is VALU-issue bound)
-            const int m0 = max16(c0), m1 = max16(c1);
-            if (__builtin_expect(__any(max(m0, m1) >= 0) && !(MEAS && A.no_emit), 0)) {
-                const int32_t group = first_group + 2 * t + (int32_t) h;
-                if (__any(m0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
-                if (__any(m1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
-            }
-        } else {
-            if (__builtin_expect(__any(max32(c0, c1) >= 0) && !(MEAS && A.no_emit), 0))
-                mfma_emit(A, W, c0, c1, first_group + 2 * t + (int32_t) h, g0, live0, live1);
+    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) {
+        const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
+        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
+            // rare path (about one row tile in four holds a candidate in some lane): which of the two 32-window operands, which fields
+            const int32_t group = first_group + 2 * t + (int32_t) h;
+            if (__any((int) x0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
+            if (__any((int) x1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
         }
     };
-    constexpr int ILP = (V & 1) ? 2 : 1;
+    constexpr int ILP = NK <= 2 ? 2 : 1;
     int t = 0;
     for (; t + ILP <= n_row_tiles; t += ILP, p += ILP * kStep) {
         f32x16 c0[ILP], c1[ILP];
 #pragma unroll
         for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
-        // keep BOTH tiles' matrix instructions ahead of the first reduction (left alone, hipcc sinks the second tile's below
+        // keep BOTH tiles' matrix instructions ahead of the first inspection (left alone, hipcc sinks the second tile's below
         // the first tile's test and the wave sits out its own result latency once per tile)
         if constexpr (ILP > 1) {
 #pragma unroll
@@ -746,33 +323,28 @@ __device__ __forceinline__ void mfma_class_f6(const PfArgs &A, MfWave &W, const 
     }
 }
 
-// grid = (blocks per tile, tiles); NT / 64 waves per block, each takes 64 consecutive window starts
-// per iteration (lanes l and l + 32 share window l & 31 and hold the two halves of every k-block).
-// Dynamic LDS: operand tables of the tile | wave queues | B-operand table (kMfmaLutBytes / kMfma2LutBytes).
-// V (A/B measurement): 1 = two row tiles' products in flight per wave in the narrow classes.
-// (Measured and dropped, tools/pf_variants.py: fetching the next chunk's sequence words early, class descriptors
-// in registers, waves walking the classes in rotated order, tiles software-pipelined in pairs -- each within noise;
-// 5 waves per SIMD (two 640-thread blocks per CU at <= 96 VGPRs) spills and is 35 % slower; software-pipelining the
-// one-k-block class alone: 66 -> 63 cycles per matrix instruction on an all-W=8 set, < 1 % on the benchmark set;
-// s_setprio raised around the matrix instructions: within noise; 12 waves per CU: +7 % time at +3 % clock;
-// A operands fetched one row tile ahead (first fetch before the class's B operands are waited for): +4 % time;
-// 128 windows per wave in the narrow classes (each A operand serves four B operands): 64 + 32 + 8 registers of tiles
-// do not fit 128 VGPRs, 80 spills, +70 % time.)
+// grid = (blocks per tile, tiles); two 512-thread blocks per CU (16 waves per CU, <= 128 VGPRs), each with its own copy of the
+// LDS tile.  Dynamic LDS: operand tables of the tile | wave queues | B-operand table (kF6LutBytes).
+// Work is handed out per WAVE, without a barrier in the loop: a wave's first unit is its own number, every further unit one
+// atomicAdd on one of the tile's kPfCounters counter words (64 bytes apart; the blocks are dealt round-robin onto them and a word
+// hands out every kPfCounters-th unit), requested before the current unit is scanned (the atomic's latency hides behind the unit);
+// a unit = wave_passes x 64 consecutive window starts, sized on the host (scan_locked).  A block whose CU is still busy with another
+// stream's kernel starts late and simply takes fewer units (profiles/r02_stream_coexistence.log, r02_wave_occupancy_ab.log).
 // MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
-// MAXNK / WPS (A/B): a kernel that only knows row tiles of <= MAXNK k-blocks needs fewer registers (B operands: 8 per k-block),
-// WPS = waves per SIMD the register allocation must leave room for (two 768-thread blocks per CU = 6).
-// HANDOUT: 0 = a BLOCK takes 4 chunks of NT positions per atomic behind two __syncthreads (every wave then waits for the block's
-// slowest: -10 % with 16 waves per block, -2 % with 8); >= 1 = every WAVE takes its own units, no barrier in the loop -- the shipped
-// engine-3 form (two 512-thread blocks per CU, variant 46; profiles/r02_wave_occupancy_ab.log).
-template <int NT, int V, int ENG, bool MEAS, int MAXNK = 4, int WPS = NT / 256, int HANDOUT = 0>
-__global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A) {
+// (Measured and dropped in rounds 1-2, tools/pf_variants.py history: fetching the next pass's sequence words early, class
+// descriptors in registers, waves walking the classes in rotated order, A operands fetched one row tile ahead, s_setprio around the
+// matrix instructions, 12 / 20 / 24 waves per CU, 128 windows per wave, a block-wide hand-out behind barriers, one branch per pair
+// of row tiles, a real function call for the rare path.)
+template <bool MEAS>
+__global__ void __launch_bounds__(kPfThreads, kPfThreads / 256) prefilter_f6_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
+    constexpr int NT = kPfThreads;
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
     const uint32_t len16 = T->table_len16;
     const uint4 *__restrict__ src = A.tables + T->table_off16;
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     uint4 *lut4 = lds4 + A.wq_off16 + kWqBytes / 16;
-    if constexpr (ENG == 3) {
+    {
         // byte of four 2-bit codes -> 16 fp4 k-slots (8 bytes): slot 4 c + code_c = 1.0 (e2m1 code 0x2)
         uint2 *lut2 = reinterpret_cast<uint2 *>(lut4);
         for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
@@ -781,58 +353,59 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
             for (int c = 0; c < 4; c++) w |= 2ULL << (4 * (4 * c + (int) ((i >> (2 * c)) & 3u)));
             lut2[i] = make_uint2((uint32_t) w, (uint32_t) (w >> 32));
         }
-    } else if constexpr (ENG == 2) {
-        for (uint32_t i = threadIdx.x; i < 1024u; i += NT) lut4[i] = walsh5(i);
-    } else {
-        for (uint32_t i = threadIdx.x; i < 256u; i += NT) {
-            const i32x4 v = onehot4(i);
-            lut4[i] = make_uint4((uint32_t) v.x, (uint32_t) v.y, (uint32_t) v.z, (uint32_t) v.w);
-        }
     }
     __syncthreads();
     const char *lds = reinterpret_cast<const char *>(lds4);
     const char *lut = reinterpret_cast<const char *>(lut4);
     const int n_classes = T->n_classes;
+    const bool wide = T->max_nk > 2;
     MfWave W;
     W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
     W.n = 0;
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
-    const int64_t n_chunks = (A.n_bases + NT - 1) / NT;
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
-    // Work is handed out DYNAMICALLY (per wave or per block, HANDOUT): the kernel wants every CU whole (all its LDS and registers),
-    // so a block whose CU is still busy with another stream's kernel (an upload's pack, a copy-out's blit: the batch stream runs
-    // them beside the scan) starts late -- with a static partition the whole launch then waits for that block's full share
-    // (measured: 3.7x on the streamed sweep with copy-out, profiles/r02_stream_coexistence.log); now it simply takes less.
     auto scan_pass = [&](int64_t g0) {                                       // 64 window starts of this wave against every class
-        const bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
-        const uint64_t cw0 = code_window(A.codes, live0 ? g0 : 0);
-        const uint64_t cw1 = code_window(A.codes, live1 ? g0 + 32 : 0);
+        bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
+        const int64_t ga = live0 ? g0 : 0, gb = live1 ? g0 + 32 : 0;
+        PassSeq Q;
+        Q.cw[0] = code_window(A.codes, ga);
+        Q.cw[1] = code_window(A.codes, gb);
+        Q.nw[0] = n_window(A.nmask, ga);
+        Q.nw[1] = n_window(A.nmask, gb);
+        Q.cw[2] = 0;
+        Q.nw[2] = 0;
+        if (wide) {                                                          // bases 64 .. 95 from g0: only classes of 3 or 4 k-blocks read them
+            const int64_t gc = g0 + 64 < A.n_bases ? g0 + 64 : 0;
+            Q.cw[2] = code_window(A.codes, gc);
+            Q.nw[2] = n_window(A.nmask, gc);
+        }
+        Q.any_n = __any((Q.nw[0] | Q.nw[1] | Q.nw[2]) != 0u);
+        if (Q.any_n && A.skip_alln) {
+            // a window whose bases are ALL non-ACGT (the tile's motifs span <= 32 bases, <= 64 with wide classes) scores 0 on every
+            // motif and none reports that (plan: every threshold > 0): such lanes queue nothing, and a pass made of them only --
+            // the inside of an assembly gap -- is skipped whole
+            const bool dead0 = Q.nw[0] == 0xFFFFFFFFu && (!wide || Q.nw[1] == 0xFFFFFFFFu);
+            const bool dead1 = Q.nw[1] == 0xFFFFFFFFu && (!wide || Q.nw[2] == 0xFFFFFFFFu);
+            live0 = live0 && !dead0;
+            live1 = live1 && !dead1;
+            if (!__any(live0 || live1)) return;
+        }
         for (int i = 0; i < n_classes; i++) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
-            if constexpr (ENG == 3) {
-                if (cd.G == 1) mfma_class_f6<1, V, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1);
-                else if (cd.G == 2) mfma_class_f6<2, V, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1);
-                continue;
-            }
-            switch (cd.G) {
-                case 1: mfma_class<1, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 2: mfma_class<2, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 3: if constexpr (MAXNK >= 3) mfma_class<3, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
-                case 4: if constexpr (ENG == 1 && MAXNK >= 4) mfma_class<4, V, ENG, MEAS>(A, W, lds, lut, off, cd.n_groups, cd.first_group, cw0, cw1, g0, live0, live1); break;
+            switch (cd.nk) {
+                case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
+                case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
+                case 3: f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
+                case 4: f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
                 default: break;
             }
         }
     };
-    if constexpr (HANDOUT >= 1) {
-        // Per-WAVE hand-out: a wave takes A.wave_passes x 64 consecutive window starts per atomic (the next unit is requested
-        // before the current one is scanned, so the atomic's latency is hidden) and never meets the block's other waves again: no
-        // barrier in the loop, a wave that ran into the rare path more often than its neighbours delays nobody.  The host sizes
-        // the unit so that the waves of a counter word stay below ~50 atomics per microsecond on it (a word saturates near 90: with ONE
-        // word per tile, 4 passes per atomic on the 579-motif set cost +13 %); an input worth few units per wave is split evenly.
-        const uint32_t wave_passes = A.wave_passes < 1 ? (uint32_t) HANDOUT : (uint32_t) A.wave_passes;
+    {
+        const uint32_t wave_passes = A.wave_passes < 1 ? 8u : (uint32_t) A.wave_passes;
         const uint32_t n_passes_total = (uint32_t) ((A.n_bases + 63) / 64);           // <= 2^28: a set holds <= 2^34 bases
         const uint32_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
         constexpr uint32_t wpb = NT / 64;
@@ -841,10 +414,8 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
             if (unit < n_units)
                 for (uint32_t j = 0; j < wave_passes; j++) scan_pass((int64_t) (unit * wave_passes + j) * 64 + r);
         } else {
-            // kPfCounters counter words per tile, 64 bytes apart: the blocks are dealt round-robin onto them and a word hands out every
-            // kPfCounters-th unit, so that the units can be small (a short tail: the launch ends one unit after its last wave starts
-            // one) without the words saturating (~90 atomics per microsecond each).  A wave's first unit in its group is its own
-            // number there; the words start at 0 and the waves add their group's size themselves.
+            // kPfCounters counter words per tile: a wave's first unit in its word's group is its own number there; the words start
+            // at 0 and the waves add their group's size themselves.
             const uint32_t K = gridDim.x < (uint32_t) kPfCounters ? gridDim.x : (uint32_t) kPfCounters;     // every word needs a block
             const uint32_t g = blockIdx.x % K;
             const uint32_t waves_g = ((gridDim.x - g + K - 1) / K) * wpb;
@@ -864,18 +435,6 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
                 v = next;
             }
         }
-    } else {
-    constexpr int kSuper = 4;
-    __shared__ unsigned int s_super;
-    for (;;) {
-        __syncthreads();                                                   // every wave is done with the previous hand-out
-        if (threadIdx.x == 0) s_super = atomicAdd(A.chunk_counter + blockIdx.y, 1u);
-        __syncthreads();
-        const int64_t first = (int64_t) s_super * kSuper;
-        if (first >= n_chunks) break;
-        for (int64_t chunk = first; chunk < first + kSuper && chunk < n_chunks; chunk++)
-            scan_pass(chunk * NT + (threadIdx.x & ~63u) + r);              // window start of N-tile 0; N-tile 1: + 32
-    }
     }
     if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
     if constexpr (MEAS) {
@@ -890,176 +449,8 @@ __global__ void __launch_bounds__(NT, WPS) prefilter_mfma_kernel(const PfArgs A)
 
 // -------------------------------------------------------------------- fp64 kernels --
 
-// Windows that overlap a non-ACGT base are scored in fp64 outright: the pre-filter packs such
-// bases as 'A', so its answer for these windows means nothing (and rescore_kernel skips them).
-// Two steps so that the rare work is spread over the whole chip instead of a few waves:
-//   nlist_kernel  one thread per 32 positions: list the positions whose next max_w bases hold an N
-//   neval_kernel  one thread per (listed position, chunk of kNwMotifChunk motifs)
-__global__ void __launch_bounds__(256) nlist_kernel(const uint32_t *__restrict__ nmask, int64_t n_bases, int max_w,
-                                                    NPos *__restrict__ list, unsigned long long *__restrict__ n_list,
-                                                    uint64_t cap) {
-    const int64_t n_words = (n_bases + 31) / 32;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    const uint32_t wm = low_mask(max_w);
-    for (int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; j < n_words; j += stride) {
-        const uint32_t w0 = nmask[j], w1 = nmask[j + 1];
-        if ((w0 | w1) == 0) continue;
-        const uint64_t comb = ((uint64_t) w1 << 32) | w0;
-        uint32_t qual = 0;                                   // positions of this word whose window holds an N
-        for (int b = 0; b < 32; b++)
-            if (j * 32 + b < n_bases && ((uint32_t) (comb >> b) & wm) != 0) qual |= 1u << b;
-        if (qual == 0) continue;
-        unsigned long long i = atomicAdd(n_list, (unsigned long long) __popc(qual));
-        while (qual) {
-            const int b = __ffs((int) qual) - 1;
-            qual &= qual - 1u;
-            if (i < cap) list[i].g = j * 32 + b;
-            i++;
-        }
-    }
-}
-
-// everything about a listed position that does not depend on the motif, computed once
-__global__ void __launch_bounds__(256) nprep_kernel(const DevSeq S, NPos *__restrict__ list, const unsigned long long *__restrict__ n_list,
-                                                    uint64_t cap, const HitOut H) {
-    unsigned long long n = *n_list;
-    if (n > cap) n = cap;
-    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long) gridDim.x * blockDim.x) {
-        const int64_t g = list[i].g;
-        const int64_t r = find_region(S, g);
-        const int64_t room = S.offsets[r + 1] - g;
-        NPos q;
-        q.g = g;
-        q.cw = code_window(S.codes, g);
-        q.nw = n_window(S.nmask, g);
-        q.coord = hit_coord(H, S, r, g);
-        q.room = (int32_t) (room < 64 ? room : 64);
-        list[i] = q;
-    }
-}
-
-__global__ void __launch_bounds__(256) neval_kernel(const DevSeq S, const DevPwm Pw, const int32_t *__restrict__ motifs,
-                                                    int32_t n_motifs, int strand_mask, const NPos *__restrict__ list,
-                                                    const unsigned long long *__restrict__ n_list, uint64_t cap,
-                                                    const HitOut H) {
-    // the block's motifs never change: their fp64 tables are read from LDS, not through L1/L2
-    __shared__ double2 s_tab[kNwMotifChunk * kMaxFastWidth * 4];
-    __shared__ int32_t s_motif[kNwMotifChunk], s_width[kNwMotifChunk], s_off[kNwMotifChunk];
-    unsigned long long n = *n_list;
-    if (n > cap) n = cap;
-    const int m0 = blockIdx.y * kNwMotifChunk;
-    const int cnt = min(kNwMotifChunk, n_motifs - m0);
-    __shared__ int64_t s_src[kNwMotifChunk];
-    if ((int) threadIdx.x < cnt) {
-        const int32_t p = motifs[m0 + threadIdx.x];
-        s_motif[threadIdx.x] = p;
-        s_width[threadIdx.x] = Pw.width[p];
-        s_src[threadIdx.x] = Pw.tab_off[p];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int off = 0;
-        for (int m = 0; m < cnt; m++) { s_off[m] = off; off += s_width[m] * 4; }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < cnt * kMaxFastWidth * 4; j += blockDim.x) {       // all motifs' loads in flight together
-        const int m = j / (kMaxFastWidth * 4), i = j % (kMaxFastWidth * 4);
-        if (i < s_width[m] * 4) s_tab[s_off[m] + i] = Pw.tab2[s_src[m] + i];
-    }
-    __syncthreads();
-    // Upper bound of a window's raw score when one contiguous run of columns [a, b) is non-ACGT (adds nothing, cscore.c:345-353):
-    // the best base of every other column = pre[a] + suf[b].  Most windows that overlap a run of N lose too many columns to
-    // reach the cutoff; they are dismissed by two table reads instead of 2 W fp64 adds.
-    __shared__ double s_pre[kNwMotifChunk][2][kMaxFastWidth + 1], s_suf[kNwMotifChunk][2][kMaxFastWidth + 1];
-    __shared__ double s_floor[kNwMotifChunk];
-    if ((int) threadIdx.x < 2 * cnt) {
-        const int m = threadIdx.x >> 1, sd = threadIdx.x & 1, W = s_width[m];
-        const double2 *t = s_tab + s_off[m];
-        double acc = 0.0;
-        s_pre[m][sd][0] = 0.0;
-        for (int c = 0; c < W; c++) {
-            double hi = -INFINITY;
-            for (int b = 0; b < 4; b++) hi = fmax(hi, sd ? t[c * 4 + b].y : t[c * 4 + b].x);
-            acc += hi;
-            s_pre[m][sd][c + 1] = acc;
-        }
-        acc = 0.0;
-        s_suf[m][sd][W] = 0.0;
-        for (int c = W - 1; c >= 0; c--) {
-            double hi = -INFINITY;
-            for (int b = 0; b < 4; b++) hi = fmax(hi, sd ? t[c * 4 + b].y : t[c * 4 + b].x);
-            acc += hi;
-            s_suf[m][sd][c] = acc;
-        }
-        if (sd == 0) {                                          // the raw-sum floor of the hit test (ms_api.hip), minus room for this bound's own rounding
-            const double fl = Pw.raw_floor[s_motif[m]];
-            s_floor[m] = fl - 1e-9 * (1.0 + fabs(fl));
-        }
-    }
-    __syncthreads();
-    // Two phases per round of 256 positions, so that the fp64 scoring runs DENSE: (1) every lane checks its position against the
-    // block's 8 motifs (does the window reach an N, does it fit its region, can its non-N columns reach the cutoff) and queues
-    // the few (position, motif) pairs that survive; (2) the lanes take one queued pair each.  Scoring inline would make every wave
-    // execute the scoring path for every motif as soon as ONE of its 64 positions needs it (measured: 0.35 -> see DESIGN.md).
-    constexpr int U = 1;                                  // positions per lane and round (4 with a quarter of the blocks measured 20-70 % slower: the kernel wants many small blocks)
-    constexpr unsigned int kWorkCap = 4096;
-    __shared__ uint16_t s_work[kWorkCap];                 // (position slot in the round: 10 bits) << 3 | motif of the block
-    __shared__ unsigned int s_nwork;
-    const unsigned long long per_sub = (unsigned long long) gridDim.x * blockDim.x;
-    const unsigned long long per_round = per_sub * U;
-    const unsigned long long rounds = (n + per_round - 1) / per_round;
-    for (unsigned long long rd = 0; rd < rounds; rd++) {
-        if (threadIdx.x == 0) s_nwork = 0;
-        __syncthreads();
-        const unsigned long long i0 = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
-        NPos q[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            q[u].nw = 0;                                    // no N: no motif's window reaches one
-            if (i0 + u * per_sub < n) q[u] = list[i0 + u * per_sub];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (q[u].nw == 0) continue;
-            for (int m = 0; m < cnt; m++) {
-                const int W = s_width[m];                           // <= 32: only pre-filter motifs come here
-                const uint32_t nm = q[u].nw & low_mask(W);
-                if (nm == 0) continue;
-                if (W > q[u].room) continue;                        // window runs past its region (cscore.c:340)
-                const int a = __ffs((int) nm) - 1, b = 32 - __clz((int) nm);
-                if (__popc(nm) == b - a) {                           // one contiguous run (the usual case): bound by the columns outside it
-                    const double fl = s_floor[m];
-                    const bool dead_f = !(strand_mask & 1) || s_pre[m][0][a] + s_suf[m][0][b] < fl;
-                    const bool dead_r = !(strand_mask & 2) || s_pre[m][1][a] + s_suf[m][1][b] < fl;
-                    if (dead_f && dead_r) continue;
-                }
-                const unsigned int slot = atomicAdd(&s_nwork, 1u);
-                if (slot < kWorkCap) {
-                    s_work[slot] = (uint16_t) (((uint32_t) (u * 256 + (int) threadIdx.x) << 3) | (uint32_t) m);
-                } else {                                             // queue full (dense N): score here
-                    double fwd, rev;
-                    score_window32(s_tab + s_off[m], W, q[u].cw, q[u].nw, fwd, rev);
-                    test_and_emit(H, Pw, (uint32_t) s_motif[m], q[u].coord, fwd, rev, strand_mask);
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned int nw_items = s_nwork < kWorkCap ? s_nwork : kWorkCap;
-        for (unsigned int k = threadIdx.x; k < nw_items; k += blockDim.x) {
-            const uint32_t item = s_work[k];
-            const int m = (int) (item & 7u);
-            const uint32_t slot = item >> 3;                         // u * 256 + thread
-            const NPos p = list[rd * per_round + (unsigned long long) (slot >> 8) * per_sub + (unsigned long long) blockIdx.x * blockDim.x + (slot & 255u)];
-            double fwd, rev;
-            score_window32(s_tab + s_off[m], s_width[m], p.cw, p.nw, fwd, rev);
-            test_and_emit(H, Pw, (uint32_t) s_motif[m], p.coord, fwd, rev, strand_mask);
-        }
-        __syncthreads();
-    }
-}
-
 // grid = (ceil(n_bases/256), n_exact motifs).  Fallback for motifs the pre-filter cannot take
-// (W > 32, max_raw <= 0, non-finite values, cutoff below the quantiser's floor).
+// (W > 63, max_raw <= 0, non-finite values, a cutoff so low that (almost) every window passes).
 __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const DevPwm Pw, const int32_t *__restrict__ motifs,
                                                         int strand_mask, const HitOut H) {
     const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1080,7 +471,7 @@ constexpr int kRescoreU = 4;
 
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
                                                       const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
-                                                      const int32_t *__restrict__ group_motifs, int strand_mask,
+                                                      const int32_t *__restrict__ group_fields, int strand_mask,
                                                       const HitOut H) {
     __shared__ HitStage st;
     if (threadIdx.x == 0) st.n = 0;
@@ -1088,6 +479,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
     unsigned long long n = *n_cand;
     if (n > cand_cap) n = cand_cap;
     constexpr int U = kRescoreU;
+    const bool both = strand_mask == 3;                  // both strands: fields 2k, 2k + 1 = motif slot k forward, reverse; one strand: field n = slot n
     const unsigned long long per_sub = (unsigned long long) gridDim.x * blockDim.x;
     const unsigned long long per_round = per_sub * U;
     const unsigned long long rounds = (n + per_round - 1) / per_round;
@@ -1109,12 +501,12 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
         for (int u = 0; u < U; u++) {
             g[u] = (int64_t) (c[u] >> 30);
             group[u] = (int32_t) ((c[u] >> 16) & 0x3FFFu);
-            uint32_t f = (uint32_t) c[u] & 0xFFFFu;                    // bit n = field n; motif slot n >> 1
-            flags[u] = (f | (f >> 1)) & 0x5555u;                        // both strands are re-scored anyway
+            const uint32_t f = (uint32_t) c[u] & 0xFFFFu;              // bit n = field n
+            flags[u] = both ? (f | (f >> 1)) & 0x5555u : f;             // a motif's two strands are re-scored together anyway
             lo[u] = S.blk2reg[g[u] >> 6];
             cw[u] = code_window(S.codes, g[u]);
             nw[u] = n_window(S.nmask, g[u]);
-            pm[u] = flags[u] ? group_motifs[group[u] * kGroupSlots + ((__ffs((int) flags[u]) - 1) >> 1)] : -1;
+            pm[u] = flags[u] ? group_fields[group[u] * kGroupFields + (__ffs((int) flags[u]) - 1)] : -1;
         }
         // second hop: the region's bounds, the first motif's width / table offset
         int64_t r[U], beg[U], end[U];
@@ -1136,21 +528,21 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             const int64_t gk = H.pbits ? (int64_t) (((uint64_t) r[u] << H.pbits) | (uint64_t) (g[u] - beg[u])) : g[u];
             bool first = true;
             while (flags[u]) {
-                const int slot = (__ffs((int) flags[u]) - 1) >> 1;
+                const int field = __ffs((int) flags[u]) - 1;
                 flags[u] &= flags[u] - 1u;
                 int32_t m = pm[u];
                 int w = W[u];
                 int64_t to = toff[u];
                 if (!first) {                                            // further motifs of the group: rare
-                    m = group_motifs[group[u] * kGroupSlots + slot];
+                    m = group_fields[group[u] * kGroupFields + field];
                     if (m >= 0) { w = Pw.width[m]; to = Pw.tab_off[m]; }
                 }
                 first = false;
                 if (m < 0) continue;
                 if (g[u] + w > end[u]) continue;                         // window runs past its region (cscore.c:340)
-                if (nw[u] & low_mask(w)) continue;                       // scored by neval_kernel
                 double fwd, rev;
-                score_window32(Pw.tab2 + to, w, cw[u], 0u, fwd, rev);    // no N in the window (checked above)
+                if (w <= 32) score_window32(Pw.tab2 + to, w, cw[u], nw[u], fwd, rev);     // non-ACGT bases add nothing (cscore.c:345-353)
+                else score_window(S, Pw.tab2 + to, w, g[u], fwd, rev);
                 test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask);
             }
         }
@@ -1607,89 +999,17 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
     return MS_OK;
 }
 
-typedef void (*PfKernel)(const PfArgs);
-
-static PfKernel pf_kernel_for(int variant, bool meas, int *threads) {
-    switch (variant) {                                                    // A/B switch MS_PF_VARIANT (MS_MEASURE=1)
-        case 0: *threads = 1024; return prefilter_kernel<1024, 0, 4>;     // two groups per trip, compiler-ordered reads
-        case 1: *threads = 1024; return prefilter_kernel<1024, 1, 4>;     // 2-4 groups per trip, compiler-ordered reads
-        case 3: *threads = 1024; return prefilter_kernel<1024, 3, 4>;     // hand-issued reads, one full wait
-        case 5: *threads = 1024; return prefilter_kernel<1024, 0, 8>;     // <= 64 VGPRs: two blocks per CU
-        case 8: *threads = 768; return prefilter_kernel<768, 4, 3>;       // default form with 12 waves per CU
-        case 16: *threads = 1024;                                          // engine 1 (int8 one-hot product on the matrix cores), 16 waves per CU
-            return meas ? prefilter_mfma_kernel<1024, 1, 1, true> : prefilter_mfma_kernel<1024, 1, 1, false>;
-        case 17: *threads = 512; return prefilter_mfma_kernel<512, 1, 1, true>;    // engine 1, 8 waves per block
-        case 18: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 1, true>;  // A/B: one row tile in flight per wave
-        case 19: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 1, true>;  // A/B: per-half maxima kept for the rare path
-        case 21: *threads = 768; return prefilter_mfma_kernel<768, 2, 1, true, 2, 6>;    // A/B: row tiles of <= 2 k-blocks only, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
-        case 22: *threads = 1024; return prefilter_mfma_kernel<1024, 2, 1, true, 2, 4>;  // A/B: the same code at 16 waves per CU
-        case 23: *threads = 512; return prefilter_mfma_kernel<512, 2, 1, true, 2, 6>;    // A/B: <= 2 k-blocks, 3 x 8 waves per CU (MS_PF_BLOCKS_PER_CU=3)
-        case 26: *threads = 640; return prefilter_mfma_kernel<640, 2, 1, true, 2, 5>;    // A/B: <= 2 k-blocks, 2 x 10 waves per CU (MS_PF_BLOCKS_PER_CU=2), <= 96 VGPRs
-        case 27: *threads = 1024; return prefilter_mfma_kernel<1024, 9, 1, true>;  // A/B: one branch per pair of tiles
-        case 28: *threads = 1024; return prefilter_mfma_kernel<1024, 1, 3, true>;       // engine 3 (fp6 x fp4, 16 columns per k-block), two row tiles in flight
-        case 29: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 3, true>;       // engine 3, one row tile in flight
-        case 30: *threads = 768; return prefilter_mfma_kernel<768, 0, 3, true, 2, 6>;   // engine 3, 2 x 12 waves per CU (MS_PF_BLOCKS_PER_CU=2)
-        case 33: *threads = 768; return prefilter_mfma_kernel<768, 2, 3, true, 2, 6>;   // A/B: 30 + per-half maxima kept (2 x 12 waves, 16 registers spilled)
-        case 44: *threads = 512; return prefilter_mfma_kernel<512, 3, 3, true, 2, 4>;    // 31's code in two 512-thread blocks per CU (no 3-k-block class: W <= 32 is <= 2 k-blocks of 16 columns)
-        case 46: *threads = 512;                                           // engine 3 as shipped: 44 with per-WAVE hand-out (no barrier in the loop)
-            return meas ? prefilter_mfma_kernel<512, 3, 3, true, 2, 4, 8> : prefilter_mfma_kernel<512, 3, 3, false, 2, 4, 8>;
-        case 47: *threads = 1024; return prefilter_mfma_kernel<1024, 3, 3, true, 2, 4, 8>; // 31 with per-wave hand-out
-        case 31: *threads = 1024;                                          // engine 3, two row tiles in flight, per-half maxima kept for the rare path, one 1024-thread block per CU (the default until 44)
-            return meas ? prefilter_mfma_kernel<1024, 3, 3, true> : prefilter_mfma_kernel<1024, 3, 3, false>;
-        case 20: *threads = 1024;                                          // engine 1, records without flags (expand_kernel decodes): the default
-            return meas ? prefilter_mfma_kernel<1024, 5, 1, true> : prefilter_mfma_kernel<1024, 5, 1, false>;
-        case 24: *threads = 1024;                                          // engine 2 (Walsh form: 10 columns per k-block)
-            return meas ? prefilter_mfma_kernel<1024, 1, 2, true> : prefilter_mfma_kernel<1024, 1, 2, false>;
-        case 25: *threads = 1024; return prefilter_mfma_kernel<1024, 0, 2, true>;  // engine 2, one row tile in flight per wave
-        default: *threads = 1024; return prefilter_kernel<1024, 4, 4>;    // hand-issued reads, counted waits (default)
-    }
-}
-
-int prefilter_threads(int variant) {
-    int threads = 0;
-    (void) pf_kernel_for(variant, true, &threads);
-    return threads;
-}
-
-int prefilter_set_lds(int variant, bool meas, size_t bytes) {
-    int threads;
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel_for(variant, meas, &threads)),
+int prefilter_set_lds(bool meas, size_t bytes) {
+    MS_HIP(hipFuncSetAttribute(meas ? reinterpret_cast<const void *>(prefilter_f6_kernel<true>) : reinterpret_cast<const void *>(prefilter_f6_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
-int launch_prefilter(const PfArgs &A, int variant, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
-    int threads;
-    PfKernel k = pf_kernel_for(variant, meas, &threads);
-    const int64_t n_chunks = (A.n_bases + threads - 1) / threads;
+int launch_prefilter(const PfArgs &A, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+    const int64_t n_chunks = (A.n_bases + kPfThreads - 1) / kPfThreads;
     if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
-    hipLaunchKernelGGL(k, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(threads), lds_bytes, st, A);
-    MS_HIP(hipGetLastError());
-    return MS_OK;
-}
-
-// The positions whose window may hold a non-ACGT base, each with its motif-independent data (needs only the sequence: it is
-// launched BEFORE the pre-filter, so that the fp64 scoring of these windows can start the moment the pre-filter is done).
-int launch_nlist(const DevSeq &S, int max_w, NPos *list, unsigned long long *n_list, uint64_t list_cap, const HitOut &H, hipStream_t st) {
-    if (S.n_bases == 0) return MS_OK;
-    const int64_t want = ((S.n_bases + 31) / 32 + 255) / 256;
-    hipLaunchKernelGGL(nlist_kernel, dim3((unsigned) (want < 4096 ? want : 4096)), dim3(256), 0, st, S.nmask, S.n_bases,
-                       max_w, list, n_list, list_cap);
-    MS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nprep_kernel, dim3(1024), dim3(256), 0, st, S, list, n_list, list_cap, H);
-    MS_HIP(hipGetLastError());
-    return MS_OK;
-}
-
-int launch_neval(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask, const NPos *list,
-                 const unsigned long long *n_list, uint64_t list_cap, const HitOut &H, int n_blocks_max, hipStream_t st) {
-    if (S.n_bases == 0 || n_motifs == 0) return MS_OK;
-    const unsigned rows = (unsigned) ((n_motifs + kNwMotifChunk - 1) / kNwMotifChunk);
-    (void) n_blocks_max;
-    unsigned gx = 64;                                     // many small blocks (measured against one wave of fat blocks: profiles/r02_n_fraction.log)
-    if (const char *e = measure_env("MS_NEVAL_GX")) gx = (unsigned) std::max(1, atoi(e));
-    dim3 grid(gx, rows);
-    hipLaunchKernelGGL(neval_kernel, grid, dim3(256), 0, st, S, Pw, motifs, n_motifs, strand_mask, list, n_list, list_cap, H);
+    if (meas) hipLaunchKernelGGL(prefilter_f6_kernel<true>, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
+    else hipLaunchKernelGGL(prefilter_f6_kernel<false>, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
@@ -1707,10 +1027,10 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 }
 
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
-                   uint64_t cand_cap, const int32_t *group_motifs, int strand_mask, const HitOut &H, int n_blocks,
+                   uint64_t cand_cap, const int32_t *group_fields, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st) {
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned) n_blocks), dim3(256), 0, st, S, Pw, cand, n_cand, cand_cap,
-                       group_motifs, strand_mask, H);
+                       group_fields, strand_mask, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -304,7 +304,7 @@ def test_work_handout_regimes_agree_with_the_all_fp64_kernel(n_regions):
     assert np.array_equal(got.region_counts(), want.region_counts())
 
 
-@pytest.mark.parametrize("n_motifs,strand", [(50, 3), (579, 1), (1300, 2)])
+@pytest.mark.parametrize("n_motifs,strand", [(50, 3), (579, 1), (1300, 3), (2400, 2)])
 def test_work_handout_over_sizes_and_tiles_against_the_all_fp64_kernel(n_motifs, strand):
     """The hand-out's unit size and regime depend on the motif set (k-blocks per tile, number of LDS tiles) and on the input size;
     a sweep over both, single strands included, against the kernel that uses no pre-filter at all."""

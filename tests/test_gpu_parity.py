@@ -294,44 +294,57 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
     assert_same_hits(res.hits(), want)
 
 
-@pytest.mark.parametrize("env", [{"MS_PF_ENGINE": "0"},
-                                 {"MS_PF_ENGINE": "0", "MS_PF_FIELD_BITS": "16"},
-                                 {"MS_PF_ENGINE": "0", "MS_PF_BLOCKS_PER_CU": "3"},
-                                 {"MS_PF_ENGINE": "0", "MS_PF_FIELD_BITS": "16", "MS_PF_BLOCKS_PER_CU": "2", "MS_PF_VARIANT": "0"},
-                                 {"MS_PF_ENGINE": "1", "MS_PF_VARIANT": "17"},
-                                 {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4"},
-                                 {"MS_PF_ENGINE": "1", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "17"},
-                                 {"MS_PF_ENGINE": "1", "MS_HIT_COORD": "global"},
-                                 {"MS_PF_ENGINE": "2"},
-                                 {"MS_PF_ENGINE": "2", "MS_PF_BLOCKS_PER_CU": "4", "MS_PF_VARIANT": "25"},
-                                 {"MS_PF_ENGINE": "3"},                                         # fp6 x fp4 matrix instruction, 16 columns per k-block
-                                 {"MS_PF_ENGINE": "3", "MS_PF_VARIANT": "29"},
-                                 {"MS_PF_ENGINE": "3", "MS_PF_VARIANT": "31"},
-                                 {"MS_PF_ENGINE": "3", "MS_PF_BLOCKS_PER_CU": "2", "MS_PF_VARIANT": "30"},
-                                 {"MS_PF_ENGINE": "3", "MS_PF_BLOCKS_PER_CU": "4", "MS_TAIL": "2"},
-                                 {"MS_PF_ENGINE": "1", "MS_TAIL": "2"},                       # second tail form (ms_tail.hip)
-                                 {"MS_PF_ENGINE": "0", "MS_TAIL": "2"},
-                                 {"MS_PF_ENGINE": "1", "MS_TAIL": "2", "MS_PF_BLOCKS_PER_CU": "4", "MS_HIT_COORD": "global"}])
+@pytest.mark.parametrize("env", [{},
+                                 {"MS_PF_LDS_BUDGET": "24576"},                                 # several LDS tiles (grid.y), as a very large motif set has
+                                 {"MS_PF_LDS_BUDGET": "12288", "MS_HIT_COORD": "global"},
+                                 {"MS_HIT_COORD": "global"},
+                                 {"MS_PF_MAX_BLOCKS": "3"},
+                                 {"MS_PF_LDS_BUDGET": "24576", "MS_PF_MAX_BLOCKS": "5"}])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
-    """Pre-filter engine (matrix-core product / packed LDS lookups), field width, number of LDS tiles
-    and kernel variant are tuning knobs: every setting must give the same (bit-exact) hits.  Small
-    LDS budgets force several tiles."""
-    monkeypatch.setenv("MS_MEASURE", "1")                       # the A/B switches are only honoured with the explicit opt-in
+    """Number of LDS tiles, blocks per tile and the hit-key form are tuning knobs: every setting must give the same (bit-exact)
+    hits on every strand mask (one strand: 32 motifs per row tile)."""
+    monkeypatch.setenv("MS_MEASURE", "1")                       # measurement switches are only honoured with the explicit opt-in
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     vals, widths = jaspar579["pwm_values"], jaspar579["widths"]
     cutoffs = jaspar579["cutoffs"]["1e-4"]
     bases, offsets = synth.make_regions(150, 600, seed=5, frac_n=0.05, ragged=True)
-    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
     for strand in (3, 1, 2):
-        if strand != 3:
-            want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, strand, 8)
+        want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, strand, 8)
         res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), strand)
         assert_same_hits(res.hits(), want)
         st = res.stats()
-        assert st["pf_engine"] == int(env["MS_PF_ENGINE"])
-        if ("MS_PF_BLOCKS_PER_CU" in env and not (env["MS_PF_ENGINE"] == "3" and env["MS_PF_BLOCKS_PER_CU"] == "2")) or "MS_PF_FIELD_BITS" in env:
-            assert st["n_tiles"] >= 2                    # (the fp6 tables, 66 KB, still fit half of the LDS)
+        assert st["pf_engine"] == 3 and st["n_pwms_exact"] == 0
+        assert (st["n_tiles"] >= 2) == ("MS_PF_LDS_BUDGET" in env)
+
+
+@pytest.mark.parametrize("env", [{}, {"MS_PF_LDS_BUDGET": "16384"}])
+def test_wide_motif_classes_vs_oracle(oracle, monkeypatch, env):
+    """Row tiles of 1 ... 4 k-blocks (motifs of up to 63 columns take the pre-filter: W // 16 + 1 k-blocks, the last column
+    of a row tile carries the bias), wider ones the all-fp64 kernel; sequences with runs of N long enough to blank whole
+    windows; every strand mask.  cscore.c:336-353 has no width limit."""
+    monkeypatch.setenv("MS_MEASURE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(77)
+    ws = list(range(1, 64)) + [15, 16, 31, 32, 47, 48, 63, 64, 70] + [int(w) for w in rng.integers(30, 64, size=30)]
+    mats = []
+    for w in ws:
+        p = rng.dirichlet(np.full(4, 0.4), size=w).T
+        mats.append(np.round(np.log(np.maximum(p, 1e-3) / 0.25), 5))
+    ml = [m.tolist() for m in mats]
+    bases, offsets = synth.make_regions(60, 900, seed=9, frac_n=0.3, ragged=True)
+    raw = bases.tobytes()
+    seqs = [raw[offsets[i]:offsets[i + 1]].decode() for i in range(len(offsets) - 1)]
+    seqs += ["N" * 150 + "ACGT" * 40, "ACGTTGCA" * 30 + "N" * 70 + "TTGACA" * 20, "N" * 64, "A" * 62 + "N", ""]
+    for strand, cut in ((3, 0.55), (1, 0.5), (2, 0.6), (3, -0.1)):
+        cuts = [cut] * len(mats)
+        want = oracle.c_scan_motif(ml, cuts, seqs, strand, 8)
+        got = cscore.c_scan_motif(ml, cuts, seqs, strand, 1)
+        assert got == want, (strand, cut)
+    pw = _lib.PwmSet.from_matrices(mats, [0.55] * len(mats))
+    res = _lib.scan(pw, _lib.SeqSet.from_strings(seqs), 3)
+    assert res.stats()["n_pwms_exact"] == 2                      # only the 64- and 70-column motifs leave the pre-filter
 
 
 def test_edge_shapes_vs_oracle(oracle):

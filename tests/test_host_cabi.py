@@ -73,120 +73,97 @@ def test_max_raw_is_the_c_definition(oracle, rnd):
 
 # ---------------------------------------------------------------- pre-filter plan --
 
-def emulate_prefilter(plan, seq_codes_2bit):
-    """numpy model of prefilter_kernel: for every window start of one N-free sequence return the
-    set of (motif, pos, strand) whose field reaches its top bit."""
-    L = len(seq_codes_2bit)
-    padded = np.concatenate([seq_codes_2bit, np.zeros(40, dtype=np.int64)])
-    code = padded[:-1] | (padded[1:] << 2)                    # 2-mer code at every position
-    flagged = set()
-    for q in range(plan["group_motifs"].shape[0]):
-        G, fb = int(plan["group_G"][q]), int(plan["group_fb"][q])
-        nf = 32 // fb
-        acc = np.zeros((L, 4), dtype=np.uint64)
-        for g in range(G):
-            acc += plan["tables"][q, g][code[2 * g:2 * g + L]]
-        assert (acc < (1 << 32)).all()                        # the kernel adds in 32 bits
-        for n in range(4 * nf):                               # field n: word n & 3, field n >> 2
-            field = (acc[:, n & 3] >> np.uint64((n >> 2) * fb)) & np.uint64((1 << fb) - 1)
-            m = int(plan["group_motifs"][q, n >> 1])
-            hot = np.nonzero(field >= (1 << (fb - 1)))[0]
-            if m < 0:
-                assert len(hot) == 0
-                continue
-            for j in hot:
-                flagged.add((m, int(j), 1 + (n & 1)))
-        if nf * fb < 32:                                      # unused high bits of every word stay clear
-            assert not (acc >> np.uint64(nf * fb)).any()
-    return flagged
+LUT = {c: i for i, c in enumerate("ACGT")}
 
 
-def fields_never_overflow(plan):
-    """Worst case of every field (sum over 2-mer positions of the largest entry) fits its width, so
-    no carry can ever cross into the neighbouring field."""
-    t = plan["tables"].astype(np.uint64)
-    for q in range(t.shape[0]):
-        fb = int(plan["group_fb"][q])
-        for n in range(4 * (32 // fb)):
-            field = (t[q, :, :, n & 3] >> np.uint64((n >> 2) * fb)) & np.uint64((1 << fb) - 1)
-            assert int(field.max(axis=1).sum()) <= (1 << fb) - 1
+def encode(seq):
+    """2-bit codes and the non-ACGT mask of a sequence, as convert_seq sees it (cscore.c:92-111: case folded, the rest 'adds nothing')."""
+    up = seq.upper()
+    codes = np.array([LUT.get(c, 0) for c in up], dtype=np.int64)
+    isn = np.array([c not in LUT for c in up], dtype=bool)
+    return codes, isn
 
 
-@pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
-@pytest.mark.parametrize("strand", [1, 2, 3])
-def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch):
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", "0")
-    mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
-    pw = _lib.PwmSet.from_matrices(mats, cut)
-    plan = pw.plan(strand)
-    fields_never_overflow(plan)
-    assert plan["n_fast"] + plan["n_exact"] == len(mats)
-    fast = set(plan["group_motifs"].ravel().tolist()) - {-1}
-    assert fast | set(plan["exact_motifs"].tolist()) == set(range(len(mats)))
-    rng = np.random.default_rng(5)
-    seqs = ["".join(rng.choice(list("ACGT"), p=[.295, .205, .205, .295], size=3000)) for _ in range(3)]
-    lut = {c: i for i, c in enumerate("ACGT")}
-    n_flag = n_hit = 0
-    for s in seqs:
-        codes = np.array([lut[c] for c in s], dtype=np.int64)
-        flagged = emulate_prefilter(plan, codes)
-        sites = oracle.c_scan_motif([m.tolist() for m in mats], cut.tolist(), [s], strand, 2)
-        for m, hits in enumerate(sites):
-            if m not in fast:
-                continue
-            for _, pos, _, sd in hits:
-                assert (m, pos, sd) in flagged, (m, pos, sd)
-                n_hit += 1
-        n_flag += sum(1 for (m, j, sd) in flagged if j + mats[m].shape[1] <= len(s))
-    # the filter must stay selective: allow 2.5x the true hits plus slack
-    assert n_flag <= 2.5 * n_hit + 200, (n_flag, n_hit)
+def field_strand(plan, n):
+    return 1 + (n & 1) if plan["strand_mask"] == 3 else plan["strand_mask"]
 
 
-def emulate_mfma_prefilter(plan, seq_codes_2bit):
-    """numpy model of prefilter_mfma_kernel: i32 sums of int8 rows over the one-hot sequence image;
-    a (field, window) is a candidate iff the sum is >= 0."""
-    L = len(seq_codes_2bit)
-    padded = np.concatenate([seq_codes_2bit, np.zeros(40, dtype=np.int64)])
+def emulate_prefilter(plan, codes, isn):
+    """numpy model of prefilter_f6_kernel, from the decoded PHYSICAL operand image: acc = bias + sum over the window's ACGT
+    columns of rows[column][base] in units of 1/8 (a non-ACGT base is an all-zero one-hot column; the bias column is never
+    cleared); a (field, window) is a candidate iff acc >= 0.  Returns {(motif, pos, strand)}."""
+    L = len(codes)
+    pc = np.concatenate([codes, np.zeros(70, dtype=np.int64)])
+    pn = np.concatenate([isn, np.zeros(70, dtype=bool)])
     flagged = set()
     rows = plan["rows"].astype(np.int64)
     for q in range(rows.shape[0]):
-        ncol = min(32, plan["cols_per_kb"] * int(plan["group_kb"][q]))
+        ncol = 16 * int(plan["group_kb"][q]) - 1                # the last column of the row tile carries the bias
         assert not rows[q, :, ncol:, :].any()
         for n in range(16):
-            m = int(plan["group_motifs"][q, n >> 1])
+            m = int(plan["group_fields"][q, n])
             acc = np.full(L, int(plan["bias"][q, n]), dtype=np.int64)
             for c in range(ncol):
-                acc += rows[q, n, c][padded[c:c + L]]
+                acc += np.where(pn[c:c + L], 0, rows[q, n, c][pc[c:c + L]])
             hot = np.nonzero(acc >= 0)[0]
             if m < 0:
-                assert len(hot) == 0                          # empty slots never flag
+                assert len(hot) == 0                          # empty fields never flag
                 continue
+            sd = field_strand(plan, n)
             for j in hot:
-                flagged.add((m, int(j), 1 + (n & 1)))
+                flagged.add((m, int(j), sd))
     return flagged
 
 
-@pytest.mark.parametrize("engine", ["1", "2", "3"])
+def check_plan_shape(plan, n_motifs, widths):
+    assert plan["n_fast"] + plan["n_exact"] == n_motifs
+    gf = plan["group_fields"]
+    fast = set(gf.ravel().tolist()) - {-1}
+    assert fast | set(plan["exact_motifs"].tolist()) == set(range(n_motifs)) and not (fast & set(plan["exact_motifs"].tolist()))
+    assert gf.shape[0] % 2 == 0                                 # two table groups per 32-row operand tile
+    assert (plan["group_kb"][0::2] == plan["group_kb"][1::2]).all()
+    for q in range(gf.shape[0]):
+        for n in range(16):
+            m = int(gf[q, n])
+            if m >= 0:
+                assert widths[m] <= 16 * plan["group_kb"][q] - 1   # the motif's columns stay clear of the bias column
+                if plan["strand_mask"] == 3:
+                    assert gf[q, n ^ 1] == m                    # forward and reverse of a motif share a slot
+    mag = np.abs(plan["rows"].astype(np.int64))                 # fp6 e2m3: every entry is on the grid (units of 1/8): sums are exact in f32
+    assert ((mag <= 16) | ((mag <= 32) & (mag % 2 == 0)) | ((mag <= 60) & (mag % 4 == 0))).all()
+    bm = np.abs(plan["bias"].astype(np.int64))
+    assert ((bm <= 16) | ((bm <= 32) & (bm % 2 == 0)) | ((bm <= 60) & (bm % 4 == 0))).all()
+    return fast
+
+
+def random_seqs(rng, n, length, n_frac):
+    """iid background sequences, some with runs of N (1 ... 40), some lower case."""
+    out = []
+    for i in range(n):
+        s = rng.choice(list("ACGT"), p=[.295, .205, .205, .295], size=length)
+        if n_frac and i % 2 == 0:
+            for _ in range(max(1, int(n_frac * length / 12))):
+                st = int(rng.integers(0, length - 1))
+                s[st:st + int(rng.integers(1, 41))] = "N"
+        s = "".join(s)
+        out.append(s.lower() if i % 3 == 2 else s)
+    return out
+
+
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-4"])
 @pytest.mark.parametrize("strand", [1, 2, 3])
-def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, monkeypatch, engine):
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", engine)
+def test_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand):
     mats, cut = rnd["mats"], rnd["cutoff_by_key"][pkey]
+    widths = [m.shape[1] for m in mats]
     pw = _lib.PwmSet.from_matrices(mats, cut)
-    plan = pw.plan_mfma(strand)
-    assert plan["n_fast"] + plan["n_exact"] == len(mats)
-    fast = set(plan["group_motifs"].ravel().tolist()) - {-1}
-    assert fast | set(plan["exact_motifs"].tolist()) == set(range(len(mats)))
-    assert plan["rows"].shape[0] % 2 == 0                     # two table groups per 32-row operand tile
+    plan = pw.plan(strand)
+    fast = check_plan_shape(plan, len(mats), widths)
     rng = np.random.default_rng(5)
-    seqs = ["".join(rng.choice(list("ACGT"), p=[.295, .205, .205, .295], size=3000)) for _ in range(3)]
-    lut = {c: i for i, c in enumerate("ACGT")}
-    n_flag = n_hit = 0
+    seqs = random_seqs(rng, 3, 3000, 0.0) + random_seqs(rng, 2, 2000, 0.03)       # N-free and with runs of N
+    n_flag = n_hit = n_hit_n = 0
     for s in seqs:
-        codes = np.array([lut[c] for c in s], dtype=np.int64)
-        flagged = emulate_mfma_prefilter(plan, codes)
+        codes, isn = encode(s)
+        flagged = emulate_prefilter(plan, codes, isn)
         assert all((strand >> (sd - 1)) & 1 for (_, _, sd) in flagged)      # a strand not asked for never flags
         sites = oracle.c_scan_motif([m.tolist() for m in mats], cut.tolist(), [s], strand, 2)
         for m, hits in enumerate(sites):
@@ -195,125 +172,126 @@ def test_mfma_prefilter_never_loses_a_reference_hit(oracle, rnd, pkey, strand, m
             for _, pos, _, sd in hits:
                 assert (m, pos, sd) in flagged, (m, pos, sd)
                 n_hit += 1
-        n_flag += sum(1 for (m, j, sd) in flagged if j + mats[m].shape[1] <= len(s))
-    # the filter must stay selective (the fp6 grid of engine 3 is coarser: ~56 levels against 127-254, which shows at p = 1e-2)
-    assert n_flag <= (3.0 if engine == "3" else 2.0) * n_hit + 200, (n_flag, n_hit)
-    if engine == "3":                                         # fp6 e2m3: every entry is on the grid (units of 1/8), rows are exact in f32
-        mag = np.abs(plan["rows"].astype(np.int64))
-        assert ((mag <= 16) | ((mag <= 32) & (mag % 2 == 0)) | ((mag <= 60) & (mag % 4 == 0))).all()
+                n_hit_n += bool(isn[pos:pos + widths[m]].any())
+        if not isn.any():
+            n_flag += sum(1 for (m, j, sd) in flagged if j + widths[m] <= len(s))
+            n_hit_clean = n_hit
+    assert n_hit_n > 0 or pkey == "1e-4"                        # windows with N do hit at the loose cutoffs
+    # the filter must stay selective on N-free sequence (56 levels on the fp6 grid: coarse at p = 1e-2)
+    assert n_flag <= 3.0 * n_hit_clean + 200, (n_flag, n_hit_clean)
 
 
-@pytest.mark.parametrize("engine", ["1", "2", "3"])
-def test_mfma_plan_on_decision_boundary_cases(oracle, monkeypatch, engine):
-    """The fuzzer's tie-heavy cases (cutoffs exactly on attainable scores): the int8 plans keep every hit."""
+def test_prefilter_keeps_hits_in_windows_with_non_acgt_bases(oracle, jaspar579):
+    """N-aware operand: non-ACGT bases are all-zero one-hot columns, so windows with N go through the same filter.  Dense N
+    (every window overlaps some) at the loosest cutoffs, where an all-N window can be a hit."""
+    n = 60
+    widths = jaspar579["widths"][:n]
+    vals = jaspar579["pwm_values"][:4 * int(widths.sum())]
+    mats, o = [], 0
+    for w in widths:
+        mats.append(vals[o:o + 4 * w].reshape(4, w))
+        o += 4 * w
+    rng = np.random.default_rng(11)
+    for pkey, strand in (("1e-2", 3), ("1e-3", 1), ("1e-4", 2)):
+        cut = jaspar579["cutoffs"][pkey][:n]
+        pw = _lib.PwmSet(vals, widths, cut)
+        plan = pw.plan(strand)
+        fast = check_plan_shape(plan, n, widths)
+        seqs = random_seqs(rng, 4, 1500, 0.08) + ["N" * 200, "ACGT" * 10 + "N" * 50 + "TTGACA" * 8, "NNNNNA" * 40]
+        checked = 0
+        for s in seqs:
+            codes, isn = encode(s)
+            flagged = emulate_prefilter(plan, codes, isn)
+            sites = oracle.c_scan_motif([m.tolist() for m in mats], cut.tolist(), [s], strand, 2)
+            for m, hits in enumerate(sites):
+                if m in fast:
+                    for _, pos, _, sd in hits:
+                        assert (m, pos, sd) in flagged, (pkey, m, pos, sd)
+                        checked += bool(isn[pos:pos + widths[m]].any())
+            if set(s) == {"N"}:                                 # an all-N window flags only where the row bias alone is >= 0
+                for q in range(plan["bias"].shape[0]):
+                    for f in range(16):
+                        m = int(plan["group_fields"][q, f])
+                        if m >= 0 and plan["bias"][q, f] < 0:
+                            assert not any((m, j, field_strand(plan, f)) in flagged for j in range(len(s) - 70))
+        assert checked > 0 or pkey == "1e-4", pkey
+    # at the CLI default the bias of most JASPAR-like motifs is negative: runs of N do not flood the candidate list
+    pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
+    plan = pw.plan(3)
+    live = plan["group_fields"] >= 0
+    assert (plan["bias"][live] < 0).mean() > 0.85
+
+
+def test_plan_on_decision_boundary_cases(oracle):
+    """The fuzzer's tie-heavy cases (cutoffs exactly on attainable scores, arbitrary matrices incl. columns whose best base
+    is negative, sequences with non-ACGT bases): the plan keeps every hit."""
     import fuzz_parity
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", engine)
-    lut = {c: i for i, c in enumerate("ACGT")}
-    checked = 0
-    for seed in range(40):
+    checked = checked_n = 0
+    for seed in range(60):
         mats, cutoffs, seqs, strand = fuzz_parity.make_case(seed)
         if len(mats) > 40:
             continue
-        seqs = [s.upper() for s in seqs if len(s) >= 8 and set(s.upper()) <= set("ACGT")][:6]
+        seqs = [s for s in seqs if len(s) >= 8][:6]
         if not seqs:
             continue
+        widths = [m.shape[1] for m in mats]
         pw = _lib.PwmSet.from_matrices(mats, cutoffs)
-        plan = pw.plan_mfma(strand)
-        fast = set(plan["group_motifs"].ravel().tolist()) - {-1}
+        plan = pw.plan(strand)
+        fast = check_plan_shape(plan, len(mats), widths)
         sites = oracle.c_scan_motif([m.tolist() for m in mats], cutoffs.tolist(), seqs, strand, 2)
-        flagged = [emulate_mfma_prefilter(plan, np.array([lut[c] for c in s], dtype=np.int64)) for s in seqs]
+        enc = [encode(s) for s in seqs]
+        flagged = [emulate_prefilter(plan, c, n) for c, n in enc]
         for m, hits in enumerate(sites):
             if m in fast:
                 for si, pos, _, sd in hits:
                     assert (m, pos, sd) in flagged[si], (seed, m, pos, sd)
                     checked += 1
-    assert checked > 2000
+                    checked_n += bool(enc[si][1][pos:pos + widths[m]].any())
+    assert checked > 2000 and checked_n > 20, (checked, checked_n)
 
 
-@pytest.mark.parametrize("engine", ["0", "1"])
-def test_prefilter_routes_degenerate_pwms_to_exact_path(monkeypatch, engine):
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", engine)
-    wide = np.zeros((4, 40))
+def test_prefilter_routes_degenerate_pwms_to_exact_path():
+    wide = np.zeros((4, 70))
     wide[0] = 1.0
     allneg = -np.ones((4, 5))
     nonfinite = np.ones((4, 6))
     nonfinite[2, 3] = -np.inf
     ok = np.array([[1.0, -2, 0.5], [-1, 1.2, -0.3], [0.2, -0.4, 0.9], [-3, 0.1, -1.0]])
     low_cut = ok.copy()
-    pw = _lib.PwmSet.from_matrices([wide, allneg, nonfinite, ok, low_cut], [0.5, 0.5, 0.5, 0.6, -50.0])
-    plan = pw.plan(3) if engine == "0" else pw.plan_mfma(3)
-    assert sorted(plan["exact_motifs"].tolist()) == [0, 1, 2, 4]
-    assert plan["n_fast"] == 1
+    w40 = np.zeros((4, 40))
+    w40[1] = 1.0
+    pw = _lib.PwmSet.from_matrices([wide, allneg, nonfinite, ok, low_cut, w40], [0.5, 0.5, 0.5, 0.6, -50.0, 0.9])
+    plan = pw.plan(3)
+    assert sorted(plan["exact_motifs"].tolist()) == [0, 1, 2, 4]      # W > 63, max_raw = 0, -inf entry, every window passes
+    assert plan["n_fast"] == 2                                     # a 3-column and a 40-column motif (3 k-blocks)
+    kb_of = {int(plan["group_fields"][q, n]): int(plan["group_kb"][q]) for q in range(plan["group_fields"].shape[0]) for n in range(16)}
+    assert kb_of[5] == 3 and kb_of[3] in (1, 3)
 
 
-def test_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", "0")
-    pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
-    for budget in (64 * 1024, 143 * 1024):
-        plan = pw.plan(3, budget)
-        assert plan["n_exact"] == 0 and plan["n_fast"] == 579
-        tf = plan["tile_first_group"]
-        for t in range(len(tf) - 1):
-            tile_bytes = int(plan["group_G"][tf[t]:tf[t + 1]].sum()) * 256
-            assert 0 < tile_bytes <= budget
-        assert tf[-1] == len(plan["group_G"])
-        per_group = np.where(plan["group_fb"] == 10, 6, 4)
-        assert (plan["group_motifs"] >= 0).sum() == 579 and ((plan["group_motifs"] >= 0).sum(axis=1) <= per_group).all()
-        key = plan["group_fb"].astype(np.int64) * 100 + plan["group_G"]
-        assert (np.diff(key) >= 0).all()                      # same field width together, narrow to wide
-        assert (plan["group_fb"] == 10).sum() > 0.8 * len(key)   # JASPAR-like motifs mostly take 10-bit fields
-
-
-def test_mfma_plan_tiles_respect_lds_budget(jaspar579, monkeypatch):
-    """Engine 1: 16 motifs x {fwd, rev} per 32-row operand tile, ceil(W_max / 8) KiB each, narrow to wide;
+def test_plan_tiles_respect_lds_budget(jaspar579):
+    """16 motifs x {fwd, rev} (one strand: 32 motifs) per 32-row operand tile, W // 16 + 1 k-blocks of 1.5 KiB, narrow to wide;
     LDS tiles hold whole row tiles and stay inside the budget."""
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", "1")
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     widths = jaspar579["widths"]
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", "2")                    # Walsh form: 10 columns per k-block, fewer k-blocks in total
-    p2 = pw.plan_mfma(3, 143 * 1024)
-    assert p2["n_fast"] == 579 and int(p2["group_kb"][0::2].sum()) == 62 and p2["group_kb"].max() == 3
-    for q in range(len(p2["group_kb"])):
-        ws = widths[p2["group_motifs"][q][p2["group_motifs"][q] >= 0]]
-        assert len(ws) == 0 or (ws <= 10 * p2["group_kb"][q]).all()
-    monkeypatch.setenv("MS_PF_ENGINE", "3")                    # fp6 x fp4: 16 columns per k-block of 1.5 KiB
-    p3 = pw.plan_mfma(3, 143 * 1024)
-    assert p3["n_fast"] == 579 and int(p3["group_kb"][0::2].sum()) == 43 and p3["group_kb"].max() == 2 and p3["n_tiles"] == 1
-    for q in range(len(p3["group_kb"])):
-        ws = widths[p3["group_motifs"][q][p3["group_motifs"][q] >= 0]]
-        assert len(ws) == 0 or (ws <= 16 * p3["group_kb"][q]).all()
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", "1")
-    for budget in (32 * 1024, 143 * 1024):
-        plan = pw.plan_mfma(3, budget)
-        assert plan["n_exact"] == 0 and plan["n_fast"] == 579
-        gm, kb, tf = plan["group_motifs"], plan["group_kb"], plan["tile_first_group"]
-        assert len(kb) == 2 * ((579 + 15) // 16) and (kb[0::2] == kb[1::2]).all()
-        assert (np.diff(kb) >= 0).all()
-        for q in range(len(kb)):
-            ws = widths[gm[q][gm[q] >= 0]]
-            assert len(ws) == 0 or (ws <= 8 * kb[q]).all()
-        assert sorted(gm[gm >= 0].tolist()) == list(range(579))
-        assert plan["n_tiles"] == len(tf) - 1 and tf[-1] == len(kb) and (np.array(tf) % 2 == 0).all()
-        for t in range(len(tf) - 1):
-            tile_bytes = int(kb[tf[t]:tf[t + 1]:2].sum()) * 1024
-            assert 0 < tile_bytes <= budget
-        assert (plan["n_tiles"] == 1) == (budget > 100 * 1024)
-
-
-def test_field_width_switch(jaspar579, monkeypatch):
-    monkeypatch.setenv("MS_MEASURE", "1")            # measurement / A-B switches need the explicit opt-in
-    monkeypatch.setenv("MS_PF_ENGINE", "0")
-    pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
-    monkeypatch.setenv("MS_PF_FIELD_BITS", "16")
+    for strand, per_rt in ((3, 16), (1, 32), (2, 32)):
+        for budget in (24 * 1024, 70 * 1024):
+            plan = pw.plan(strand, budget)
+            assert plan["n_exact"] == 0 and plan["n_fast"] == 579
+            check_plan_shape(plan, 579, widths)
+            gf, kb, tf = plan["group_fields"], plan["group_kb"], plan["tile_first_group"]
+            assert len(kb) == 2 * ((579 + per_rt - 1) // per_rt)
+            assert (np.diff(kb) >= 0).all() and kb.max() == 2 and kb.min() == 1
+            assert sorted(set(gf[gf >= 0].tolist())) == list(range(579))
+            assert (gf >= 0).sum() == 579 * (2 if strand == 3 else 1)
+            assert plan["n_tiles"] == len(tf) - 1 and tf[-1] == len(kb) and (np.array(tf) % 2 == 0).all()
+            for t in range(len(tf) - 1):
+                tile_bytes = int(kb[tf[t]:tf[t + 1]:2].sum()) * 1536
+                assert 0 < tile_bytes <= budget
+            assert (plan["n_tiles"] == 1) == (budget > 64 * 1024)
+    # the benchmark set at both strands: 37 row tiles, one k-block up to W = 15, two up to W = 31
     plan = pw.plan(3)
-    assert (plan["group_fb"] == 16).all() and len(plan["group_G"]) == (579 + 3) // 4
-    fields_never_overflow(plan)
+    want = sum(sorted(int(w) // 16 + 1 for w in widths)[15::16]) + (0 if 579 % 16 == 0 else int(max(widths)) // 16 + 1)
+    assert int(plan["group_kb"][0::2].sum()) == want
 
 
 # --------------------------------------------------------------------------- dedup --
@@ -480,14 +458,17 @@ def test_streams_and_pinned_memory_fail_loudly_without_a_gpu():
 
 
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
-    """MS_PF_* variables alone must not change what the library does (host-visible part: the plan)."""
+    """measurement variables alone must not change what the library does; the retired engine / variant / tail switches
+    of rounds 1-2 change nothing at all (host-visible part: the plan)."""
     vals, widths, cutoffs = (np.load(os.path.join(ROOT, "tests", "golden", "synth_jaspar579.npz"))[k] for k in ("pwm_values", "widths", "cutoffs"))
     n = 40
     pw = _lib.PwmSet(vals[:4 * int(widths[:n].sum())], widths[:n], cutoffs[:n, 2])
     monkeypatch.delenv("MS_MEASURE", raising=False)
-    monkeypatch.setenv("MS_PF_ENGINE", "0")
-    base = pw.plan_mfma(3)                                       # engine 0 requested without the opt-in: still the matrix-core plan
-    assert base["group_kb"].size > 0
-    monkeypatch.setenv("MS_MEASURE", "1")
-    with pytest.raises(ValueError):
-        pw.plan_mfma(3)                                          # now engine 0 is really selected: no matrix-core plan to show
+    base = pw.plan(3)
+    for var, val in (("MS_PF_ENGINE", "0"), ("MS_PF_VARIANT", "16"), ("MS_TAIL", "2"), ("MS_PF_FIELD_BITS", "16"), ("MS_PF_BQ_MAX", "100")):
+        monkeypatch.setenv(var, val)
+    for measure in (None, "1"):
+        if measure:
+            monkeypatch.setenv("MS_MEASURE", measure)
+        other = _lib.PwmSet(vals[:4 * int(widths[:n].sum())], widths[:n], cutoffs[:n, 2]).plan(3)
+        assert all(np.array_equal(base[k], other[k]) for k in ("group_fields", "rows", "bias", "group_kb"))

@@ -1,8 +1,10 @@
 // issue_model.hip -- what one SIMD sustains for the pre-filter's instruction mix (gfx950).
 // Per loop trip a wave issues 1 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, fp6 x fp4: 32 cycles of the matrix pipe) and K plain VALU
 // instructions (v_max3_f32 on independent registers), optionally S SALU instructions and L ds_read_b64.  Blocks of 256 / 512 / 1024
-// threads put 1 / 2 / 4 waves on each SIMD.  Reported: cycles per trip PER SIMD (wall clock x shader clock / trips / waves-per-SIMD
-// serialised), so that "32" = matrix pipe saturated, and K x 2 or K x 4 tells what a VALU instruction costs beside it.
+// threads put 1 / 2 / 4 waves on each SIMD.  Reported: cycles per trip PER SIMD = wall time x shader clock / (trips x waves per SIMD),
+// so that "32" = matrix pipe saturated, and K x 2 or K x 4 tells what a VALU instruction costs beside it.  The shader clock is
+// s_memtime against the 100 MHz s_memrealtime inside the kernel.  (Round 2 divided ONE wave's own cycle count by the waves per SIMD:
+// the oldest wave of a SIMD wins the arbitration and finishes early, so that column fell below the matrix pipe's 32-cycle floor.)
 // Build: hipcc -O2 --offload-arch=gfx950 issue_model.hip -o issue_model.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,7 +28,7 @@ __global__ void __launch_bounds__(1024) mix_kernel(float *out, int trips, long l
     unsigned int s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3;
     unsigned long long l0 = 0, l1 = 0;
     const unsigned int laddr = (unsigned int) (size_t) (lds + (threadIdx.x & 63));
-    const long long t0 = clock64();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < trips; t += 2) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {                   // two trips per pass, one accumulator each: no copies, no branch on t
@@ -52,13 +54,13 @@ __global__ void __launch_bounds__(1024) mix_kernel(float *out, int trips, long l
             if (L) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    const long long t1 = clock64();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += v[i] + acc0[i] + acc1[i];
     s += (float) (s0 + s1 + s2 + s3) + (float) (l0 + l1);
     if (s == 1234.5f) out[0] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cycles[0] = (long long) (t1 - t0); cycles[1] = (long long) (r1 - r0); }
 }
 
 template <int K, int S, int L, bool MFMA>
@@ -75,11 +77,11 @@ static void run(const char *what, float *d_out, long long *d_cyc) {
         CK(hipDeviceSynchronize());
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        long long cyc = 0;
-        CK(hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost));
+        long long cyc[2] = {0, 0};
+        CK(hipMemcpy(cyc, d_cyc, 16, hipMemcpyDeviceToHost));
         const int wps = threads / 256;
-        // clock64 = shader clock cycles for the wave; per-SIMD cycles per (trip of one wave) = cyc / trips / wps
-        printf("  %dw/SIMD: %6.1f cyc/trip/wave = %5.1f per SIMD-trip (%.3f ms)", wps, (double) cyc / trips, (double) cyc / trips / wps, ms);
+        const double mhz = cyc[1] ? 100.0 * (double) cyc[0] / (double) cyc[1] : 0.0;
+        printf("  %dw/SIMD: %5.1f cycles per SIMD-trip (%.3f ms at %4.0f MHz)", wps, ms * 1e-3 * mhz * 1e6 / ((double) trips * wps), ms, mhz);
     }
     printf("\n");
 }
