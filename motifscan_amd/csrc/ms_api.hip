@@ -808,7 +808,7 @@ namespace ms {
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kWqBytes + kF6LutBytes;                 // wave queues + B-operand table follow the tables
+    const size_t lds_fixed = kF6LutBytes;                            // the B-operand table follows the tables
     // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
     // (profiles/r02_wave_occupancy_ab.log)
     size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
@@ -881,6 +881,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
     size_t want_hits = want_cand;
     if (!plan.exact_motifs.empty()) want_hits = std::max<size_t>(want_hits, 1 << 22);
+    // a wave reserves candidate slots in blocks (ms_kernels.hip, "candidate hand-off"): about an eighth of what it is expected to
+    // need, 64 ... 2048; the slots a wave leaves unused in its last block are head room on top
+    const int64_t pf_waves_max = (int64_t) c->n_cu * kPfBlocksPerCu * (kPfThreads / 64);
+    uint32_t cand_block = 64;
+    while (cand_block < 2048 && (double) cand_block * 8.0 * (double) pf_waves_max < 1.5e-4 * (double) fast_windows) cand_block *= 2;
+    want_cand += (size_t) pf_waves_max * cand_block * (plan.tiles.size() > 1 ? 2 : 1);
     want_cand = std::max(want_cand, sc.cand_cap);
     want_hits = std::max(want_hits, sc.hit_cap);
 
@@ -888,7 +894,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     const DevPwm Pw = dev_pwm(pwms);
     size_t lds_bytes = 0;
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
-    const uint32_t wq_off16 = (uint32_t) (lds_bytes / 16);
+    const uint32_t lut_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
     int pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
@@ -897,10 +903,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     int clk_blocks = 0;
     const bool pf_meas = pf_no_emit != 0 || pf_clock;              // the measurement instantiation of the kernel
     raw->invalid = pf_no_emit != 0;                                // stage times only: the hit accessors refuse such a result
-    if (lds_bytes > c->lds_set[pf_meas ? 1 : 0]) {
-        if ((rc = prefilter_set_lds(pf_meas, lds_bytes))) return fail(rc);
-        c->lds_set[pf_meas ? 1 : 0] = lds_bytes;
-    }
 
     // counters: [0] candidate records, [1] hits
     unsigned long long n_cand = 0, n_hits = 0;
@@ -913,11 +915,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         (void) hipEventRecord(c->ev[0], c->stream);
         if (!plan.tiles.empty()) {
+            const int n_tiles = (int) plan.tiles.size();
             PfArgs A;
             A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
-            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.wq_off16 = wq_off16;
-            A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap;
-            const int n_tiles = (int) plan.tiles.size();
+            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16;
+            A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
             // While a batch stream is live and the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs (the
             // units are handed out dynamically: fewer blocks just take more each)
             const int reserve = c->n_streams.load() > 0 ? c->n_cu_copy : 0;
@@ -925,7 +927,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             int bpt_ = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * kPfBlocksPerCu / n_tiles));
             if (const char *e = measure_env("MS_PF_MAX_BLOCKS")) bpt_ = std::max(1, std::min(bpt_, atoi(e)));    // test aid: few blocks per tile, as a very large motif set would have
             const int bpt = bpt_;
-            const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
+            const size_t counter_words = plan.tiles.size() * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
             if (counter_words > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
                 sc.chunk_counters_cap = 0;
@@ -937,7 +939,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             {
                 // unit of the per-wave hand-out: a pass (64 window starts against a tile's k-blocks) takes ~0.25 us per k-block with 16
                 // waves per CU, and the launch's waves should not exceed ~47 atomics per microsecond on a tile's counter word
-                const int64_t kb_tile = std::max<int64_t>(1, plan.kb_total / std::max(1, n_tiles));
+                const int64_t kb_tile = std::max<int64_t>(1, plan.kb_total / n_tiles);
                 const double waves = (double) bpt * (kPfThreads / 64);                          // per tile
                 const double waves_word = waves / std::min(kPfCounters, bpt);                   // ... and per counter word
                 const int64_t need = (int64_t) std::ceil(waves_word / (47.0 * 0.25 * (double) kb_tile));
@@ -952,9 +954,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                     counter_used = false;
                 }
                 A.wave_passes = (int) wp;
+                A.use_counters = counter_used ? 1 : 0;
             }
             if (counter_used) {
-                he = hipMemsetAsync(sc.chunk_counters, 0, sizeof(unsigned int) * counter_words, c->stream);
+                he = hipMemsetAsync(A.chunk_counter, 0, sizeof(unsigned int) * (size_t) n_tiles * kPfCounters * 16, c->stream);
                 if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             }
             A.clk = nullptr;
@@ -964,7 +967,14 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * 2 * clk_blocks, c->stream);
                 A.clk = d_clk;
             }
-            if ((rc = launch_prefilter(A, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
+            bool wide = false;
+            for (const TileDesc &t : plan.tiles) wide = wide || t.max_nk > 2;
+            const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0);
+            if (lds_bytes > c->lds_set[li]) {
+                if ((rc = prefilter_set_lds(wide, pf_meas, lds_bytes))) return fail(rc);
+                c->lds_set[li] = lds_bytes;
+            }
+            if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
         }
         (void) hipEventRecord(c->ev[1], c->stream);
         if (!plan.fast_motifs.empty())

@@ -7,9 +7,7 @@ namespace ms {
 constexpr int kPfThreads = 512;       // pre-filter block: 8 waves, two blocks per CU
 constexpr int kPfBlocksPerCu = 2;
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
-constexpr int kWqCap = 64;            // candidates per wave queue (LDS); spilled to HBM when the next append would not fit
-constexpr size_t kWqBytes = (size_t) (kPfThreads / 64) * kWqCap * sizeof(uint64_t);
-constexpr size_t kF6LutBytes = 256 * 8;      // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the wave queues
+constexpr size_t kF6LutBytes = 256 * 8;      // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables
 
 struct DevSeq {
     const uint32_t *codes;
@@ -46,20 +44,22 @@ struct PfArgs {
     int64_t n_bases;
     const uint4 *tables;
     const TileDesc *tiles;
-    uint32_t wq_off16;        // start of the wave queues in dynamic LDS (16-byte units)
-    uint64_t *cand;
-    unsigned long long *n_cand;
+    uint32_t lut_off16;       // start of the B-operand table in dynamic LDS (16-byte units)
+    uint64_t *cand;           // candidate records; a wave reserves blocks of cand_block slots (unused slots are written as 0 = empty)
+    unsigned long long *n_cand;   // slots reserved so far
     uint64_t cand_cap;
+    uint32_t cand_block;      // >= 64
     int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
     unsigned int *chunk_counter;   // [LDS tiles][kPfCounters] words 64 bytes apart, zeroed: the units behind the waves' own first ones
+    int use_counters;              // 0: a small input, one even unit per wave and no atomics
     int wave_passes;               // per-wave hand-out: passes of 64 window starts a wave takes per atomic (scan_locked sizes it)
 };
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int prefilter_set_lds(bool meas, size_t bytes);
-int launch_prefilter(const PfArgs &A, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
+int prefilter_set_lds(bool wide, bool meas, size_t bytes);
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,

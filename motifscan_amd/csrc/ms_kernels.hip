@@ -171,27 +171,19 @@ __global__ void __launch_bounds__(256) pack_kernel(const uint8_t *__restrict__ a
 //
 // ---- candidate hand-off ----
 // Candidates are ~2e-4 of the (window, motif) pairs.  One global atomic per find would put every wave of the chip on ONE address
-// (measured in round 1: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  So each wave appends to its
-// own queue in LDS with ballot/mbcnt ranks (no atomics at all) and spills it to the global list with a single atomicAdd per
-// <= 64 entries.  A record is per LANE and per table group: position, group, and one flag bit per field -- rescore_kernel
-// expands the flags.
+// (measured in round 1: the whole kernel then runs at the ~90 M atomics/s a single word sustains).  Each wave therefore reserves
+// BLOCKS of A.cand_block record slots of the global list (one atomicAdd per block) and stores its records straight into its block
+// with ballot/mbcnt ranks; slots it leaves unused (fewer than 64 when a block is abandoned, the rest of the last block at the end)
+// are written as empty records (flags 0), which rescore_kernel skips.  (Rounds 1-2 staged 64 records per wave in LDS and spilled
+// them through a called function: at p = 1e-3, ten times the records, that flush was most of the kernel's time.)
+// A record is per LANE and per table group: position, group, and one flag bit per field -- rescore_kernel expands the flags.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __noinline__ void wq_flush(uint64_t *__restrict__ wbuf, uint32_t n, uint64_t *__restrict__ cand,
-                                      unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(n_cand, (unsigned long long) n);
-    base = __shfl(base, 0);
-    for (uint32_t i = lane; i < n; i += 64)
-        if (base + i < cand_cap) cand[base + i] = wbuf[i];
-}
-
 struct MfWave {
-    uint64_t *wbuf;      // this wave's queue in LDS (kWqCap entries)
-    uint32_t n;          // entries queued (wave-uniform)
+    unsigned long long base;   // next free slot of this wave's block in the global candidate list (wave-uniform)
+    uint32_t left;             // slots left in the block (wave-uniform)
 };
 
 // bit n of the result = result register 15 - n is non-negative (field n of the lane's table group)
@@ -212,18 +204,29 @@ __device__ __forceinline__ uint32_t all_negative(const f32x16 &c) {
     return x & (uint32_t) __float_as_int(c[15]);
 }
 
+// empty records into the `n` (< 64) slots at W.base
+__device__ __forceinline__ void pad_block(const PfArgs &A, const MfWave &W, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane < n && W.base + lane < A.cand_cap) A.cand[W.base + lane] = 0ULL;
+}
+
 __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, int64_t g, uint32_t flags, int32_t group) {
     const bool flagged = live && flags != 0;
     const unsigned long long mask = __ballot(flagged);
     if (mask == 0) return;
     const uint32_t n_new = (uint32_t) __popcll(mask);
-    if (W.n + n_new > (uint32_t) kWqCap) {
-        wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
-        W.n = 0;
+    if (n_new > W.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
+        pad_block(A, W, W.left);
+        unsigned long long b = 0;
+        if ((threadIdx.x & 63u) == 0) b = atomicAdd(A.n_cand, (unsigned long long) A.cand_block);
+        W.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b >> 32)) << 32) |
+                 (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) b);          // wave-uniform: scalar registers
+        W.left = A.cand_block;
     }
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    if (flagged) W.wbuf[W.n + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
-    W.n += n_new;
+    if (flagged && W.base + rank < A.cand_cap) A.cand[W.base + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
+    W.base += n_new;
+    W.left -= n_new;
 }
 
 // The lane's 8 bases of one k-block half as 32 fp4 one-hot k-slots: two reads of the 256-entry table (byte of four 2-bit codes ->
@@ -240,11 +243,12 @@ __device__ __forceinline__ void clear_n(i32x8 &b, uint32_t n8) {
     }
 }
 
-// The 64 bases (2-bit codes) / their 64 non-ACGT bits from window start g + 32 * which on: cw[which], cw[which + 1]
+// What a pass keeps per lane for all its classes: the 64 bases (2-bit codes) from its two window starts g0 and g0 + 32.  Classes of 3
+// or 4 k-blocks (motifs of 32 ... 63 columns: rare) read the 32 bases behind them themselves, and every class re-reads the
+// non-ACGT bits where it needs them (rare): the narrow classes' hot loops own every register they can get.
 struct PassSeq {
-    uint64_t cw[3];      // code windows at g, g + 32, g + 64 (the last only when the tile has classes of 3 or 4 k-blocks)
-    uint32_t nw[3];      // non-ACGT bits of the same bases, 32 per word
-    bool any_n;          // wave-uniform: some lane sees a non-ACGT base
+    uint64_t cw[2];
+    bool any_n;          // wave-uniform: some lane sees a non-ACGT base in the 96 bases from g0
 };
 
 // All row tiles of one class (NK k-blocks each).  ILP row tiles' products are issued back to back (independent accumulators), then
@@ -252,25 +256,36 @@ struct PassSeq {
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                          uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
-                                         int64_t g0, bool live0, bool live1) {
+                                         int64_t pass0, bool live0, bool live1) {
+    // pass0 = the pass's first window start (wave-uniform: scalar registers); this lane's two window starts are pass0 + r and
+    // pass0 + r + 32 with r = lane & 31 -- recomputed where needed (rare paths), not carried
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     const char *p = lds + byte_off + lane * 8u;
     constexpr int kStep = NK * kF6BytesPerKb;
+    constexpr int NW = NK > 2 ? 3 : 2;
+    auto start = [&](int i) { const int64_t g = pass0 + (lane & 31u) + 32 * i; return g < A.n_bases ? g : (int64_t) 0; };
+    uint64_t cw[NW];
+    cw[0] = Q.cw[0];
+    cw[1] = Q.cw[1];
+    if constexpr (NW == 3) cw[2] = code_window(A.codes, start(2));
     // B operands: k-block kb of the window at g0 covers bases 16 kb + 8 h ... + 7 from g0; of the window at g0 + 32 the same from there
     i32x8 b0[NK], b1[NK];
 #pragma unroll
     for (int kb = 0; kb < NK; kb++) {
         const int w = kb >> 1, sh = 32 * (kb & 1);
-        b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[w] >> (sh + 16 * h)) & 0xFFFFu);
-        b1[kb] = onehot_f4(lut, (uint32_t) (Q.cw[w + 1] >> (sh + 16 * h)) & 0xFFFFu);
+        b0[kb] = onehot_f4(lut, (uint32_t) (cw[w] >> (sh + 16 * h)) & 0xFFFFu);
+        b1[kb] = onehot_f4(lut, (uint32_t) (cw[w + 1] >> (sh + 16 * h)) & 0xFFFFu);
     }
     if (Q.any_n) {                                                                // rare, wave-uniform
+        uint32_t nw[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) nw[i] = n_window(A.nmask, start(i));
 #pragma unroll
         for (int kb = 0; kb < NK; kb++) {
             const int w = kb >> 1, sh = 16 * (kb & 1);
             const uint32_t keep = (kb == NK - 1 && h) ? 0x7Fu : 0xFFu;            // the row tile's last column carries the bias: never cleared
-            clear_n(b0[kb], (Q.nw[w] >> (sh + 8 * h)) & keep);
-            clear_n(b1[kb], (Q.nw[w + 1] >> (sh + 8 * h)) & keep);
+            clear_n(b0[kb], (nw[w] >> (sh + 8 * h)) & keep);
+            clear_n(b1[kb], (nw[w + 1] >> (sh + 8 * h)) & keep);
         }
     }
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -296,8 +311,8 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
         if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
             // rare path (about one row tile in four holds a candidate in some lane): which of the two 32-window operands, which fields
             const int32_t group = first_group + 2 * t + (int32_t) h;
-            if (__any((int) x0 >= 0)) emit_rec(A, W, live0, g0, nonneg_flags(c0), group);
-            if (__any((int) x1 >= 0)) emit_rec(A, W, live1, g0 + 32, nonneg_flags(c1), group);
+            if (__any((int) x0 >= 0)) emit_rec(A, W, live0, pass0 + (lane & 31u), nonneg_flags(c0), group);
+            if (__any((int) x1 >= 0)) emit_rec(A, W, live1, pass0 + (lane & 31u) + 32, nonneg_flags(c1), group);
         }
     };
     constexpr int ILP = NK <= 2 ? 2 : 1;
@@ -324,26 +339,29 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 }
 
 // grid = (blocks per tile, tiles); two 512-thread blocks per CU (16 waves per CU, <= 128 VGPRs), each with its own copy of the
-// LDS tile.  Dynamic LDS: operand tables of the tile | wave queues | B-operand table (kF6LutBytes).
+// LDS tile.  Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes).
 // Work is handed out per WAVE, without a barrier in the loop: a wave's first unit is its own number, every further unit one
 // atomicAdd on one of the tile's kPfCounters counter words (64 bytes apart; the blocks are dealt round-robin onto them and a word
 // hands out every kPfCounters-th unit), requested before the current unit is scanned (the atomic's latency hides behind the unit);
 // a unit = wave_passes x 64 consecutive window starts, sized on the host (scan_locked).  A block whose CU is still busy with another
 // stream's kernel starts late and simply takes fewer units (profiles/r02_stream_coexistence.log, r02_wave_occupancy_ab.log).
+// MAXNK: 2 = the kernel for plans whose row tiles all have 1 or 2 k-blocks (motifs of up to 31 columns: every JASPAR-like set);
+// 4 = the kernel that also knows row tiles of 3 and 4 k-blocks (its register allocation spills in rare paths).
 // MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
 // (Measured and dropped in rounds 1-2, tools/pf_variants.py history: fetching the next pass's sequence words early, class
 // descriptors in registers, waves walking the classes in rotated order, A operands fetched one row tile ahead, s_setprio around the
 // matrix instructions, 12 / 20 / 24 waves per CU, 128 windows per wave, a block-wide hand-out behind barriers, one branch per pair
 // of row tiles, a real function call for the rare path.)
-template <bool MEAS>
-__global__ void __launch_bounds__(kPfThreads, kPfThreads / 256) prefilter_f6_kernel(const PfArgs A) {
+template <int MAXNK, bool MEAS>
+__global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     constexpr int NT = kPfThreads;
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
+    const bool wide = MAXNK > 2 && T->max_nk > 2;
     const uint32_t len16 = T->table_len16;
     const uint4 *__restrict__ src = A.tables + T->table_off16;
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
-    uint4 *lut4 = lds4 + A.wq_off16 + kWqBytes / 16;
+    uint4 *lut4 = lds4 + A.lut_off16;
     {
         // byte of four 2-bit codes -> 16 fp4 k-slots (8 bytes): slot 4 c + code_c = 1.0 (e2m1 code 0x2)
         uint2 *lut2 = reinterpret_cast<uint2 *>(lut4);
@@ -358,36 +376,29 @@ __global__ void __launch_bounds__(kPfThreads, kPfThreads / 256) prefilter_f6_ker
     const char *lds = reinterpret_cast<const char *>(lds4);
     const char *lut = reinterpret_cast<const char *>(lut4);
     const int n_classes = T->n_classes;
-    const bool wide = T->max_nk > 2;
     MfWave W;
-    W.wbuf = reinterpret_cast<uint64_t *>(lds4 + A.wq_off16) + (threadIdx.x >> 6) * kWqCap;
-    W.n = 0;
+    W.base = 0;
+    W.left = 0;
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
-    auto scan_pass = [&](int64_t g0) {                                       // 64 window starts of this wave against every class
+    auto scan_pass = [&](int64_t pass0) {                                    // 64 window starts of this wave (pass0 ... + 63, wave-uniform) against every class
+        const int64_t g0 = pass0 + r;
         bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
-        const int64_t ga = live0 ? g0 : 0, gb = live1 ? g0 + 32 : 0;
+        auto start = [&](int i) { return g0 + 32 * i < A.n_bases ? g0 + 32 * i : (int64_t) 0; };
         PassSeq Q;
-        Q.cw[0] = code_window(A.codes, ga);
-        Q.cw[1] = code_window(A.codes, gb);
-        Q.nw[0] = n_window(A.nmask, ga);
-        Q.nw[1] = n_window(A.nmask, gb);
-        Q.cw[2] = 0;
-        Q.nw[2] = 0;
-        if (wide) {                                                          // bases 64 .. 95 from g0: only classes of 3 or 4 k-blocks read them
-            const int64_t gc = g0 + 64 < A.n_bases ? g0 + 64 : 0;
-            Q.cw[2] = code_window(A.codes, gc);
-            Q.nw[2] = n_window(A.nmask, gc);
-        }
-        Q.any_n = __any((Q.nw[0] | Q.nw[1] | Q.nw[2]) != 0u);
+        Q.cw[0] = code_window(A.codes, start(0));
+        Q.cw[1] = code_window(A.codes, start(1));
+        const uint32_t nw0 = n_window(A.nmask, start(0)), nw1 = n_window(A.nmask, start(1));
+        const uint32_t nw2 = wide ? n_window(A.nmask, start(2)) : 0u;              // only classes of 3 or 4 k-blocks reach bases 64 ... 95
+        Q.any_n = __any((nw0 | nw1 | nw2) != 0u);
         if (Q.any_n && A.skip_alln) {
             // a window whose bases are ALL non-ACGT (the tile's motifs span <= 32 bases, <= 64 with wide classes) scores 0 on every
             // motif and none reports that (plan: every threshold > 0): such lanes queue nothing, and a pass made of them only --
             // the inside of an assembly gap -- is skipped whole
-            const bool dead0 = Q.nw[0] == 0xFFFFFFFFu && (!wide || Q.nw[1] == 0xFFFFFFFFu);
-            const bool dead1 = Q.nw[1] == 0xFFFFFFFFu && (!wide || Q.nw[2] == 0xFFFFFFFFu);
+            const bool dead0 = nw0 == 0xFFFFFFFFu && (!wide || nw1 == 0xFFFFFFFFu);
+            const bool dead1 = nw1 == 0xFFFFFFFFu && (!wide || nw2 == 0xFFFFFFFFu);
             live0 = live0 && !dead0;
             live1 = live1 && !dead1;
             if (!__any(live0 || live1)) return;
@@ -396,10 +407,10 @@ __global__ void __launch_bounds__(kPfThreads, kPfThreads / 256) prefilter_f6_ker
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
             switch (cd.nk) {
-                case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
-                case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
-                case 3: f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
-                case 4: f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, g0, live0, live1); break;
+                case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
+                case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
+                case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
+                case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
                 default: break;
             }
         }
@@ -409,34 +420,33 @@ __global__ void __launch_bounds__(kPfThreads, kPfThreads / 256) prefilter_f6_ker
         const uint32_t n_passes_total = (uint32_t) ((A.n_bases + 63) / 64);           // <= 2^28: a set holds <= 2^34 bases
         const uint32_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
         constexpr uint32_t wpb = NT / 64;
-        if (n_units <= gridDim.x * wpb) {                                             // a small input: one unit per wave, no atomic at all
-            const uint32_t unit = blockIdx.x * wpb + (threadIdx.x >> 6);
-            if (unit < n_units)
-                for (uint32_t j = 0; j < wave_passes; j++) scan_pass((int64_t) (unit * wave_passes + j) * 64 + r);
-        } else {
-            // kPfCounters counter words per tile: a wave's first unit in its word's group is its own number there; the words start
-            // at 0 and the waves add their group's size themselves.
-            const uint32_t K = gridDim.x < (uint32_t) kPfCounters ? gridDim.x : (uint32_t) kPfCounters;     // every word needs a block
-            const uint32_t g = blockIdx.x % K;
-            const uint32_t waves_g = ((gridDim.x - g + K - 1) / K) * wpb;
-            const uint32_t units_g = n_units > g ? (n_units - g + K - 1) / K : 0u;
-            unsigned int *word = A.chunk_counter + ((size_t) blockIdx.y * kPfCounters + g) * 16;
-            auto take = [&]() {
+        // A small input (A.use_counters == 0): one unit per wave, no atomic at all.  Else kPfCounters counter words per tile: a
+        // wave's first unit in its word's group is its own number there; the words start at 0 and the waves add their group's
+        // size themselves.
+        const bool dyn = A.use_counters != 0;
+        const uint32_t K = !dyn ? 1u : (gridDim.x < (uint32_t) kPfCounters ? gridDim.x : (uint32_t) kPfCounters);     // every word needs a block
+        const uint32_t g = blockIdx.x % K;
+        const uint32_t waves_g = ((gridDim.x - g + K - 1) / K) * wpb;
+        const uint32_t units_g = n_units > g ? (n_units - g + K - 1) / K : 0u;
+        unsigned int *word = A.chunk_counter + ((size_t) blockIdx.y * kPfCounters + g) * 16;
+        uint32_t v = (blockIdx.x / K) * wpb + (threadIdx.x >> 6);
+        while (v < units_g) {
+            uint32_t next = 0xFFFFFFFFu;
+            if (dyn) {                                                            // asked for before this unit is scanned
                 unsigned int u = 0;
                 if (lane == 0) u = atomicAdd(word, 1u);
-                return waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
-            };
-            uint32_t v = (blockIdx.x / K) * wpb + (threadIdx.x >> 6);
-            while (v < units_g) {
-                const uint32_t next = take();                                         // asked for before this unit is scanned
-                const uint32_t p0 = (v * K + g) * wave_passes;
-                for (uint32_t j = 0; j < wave_passes; j++)                            // passes past the end scan dead lanes (last unit only)
-                    scan_pass((int64_t) (p0 + j) * 64 + r);
-                v = next;
+                next = waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
             }
+            const uint32_t p0 = (v * K + g) * wave_passes;
+            for (uint32_t j = 0; j < wave_passes; j++)                            // passes past the end scan dead lanes (last unit only)
+                scan_pass((int64_t) (p0 + j) * 64);
+            v = next;
         }
     }
-    if (W.n > 0) wq_flush(W.wbuf, W.n, A.cand, A.n_cand, A.cand_cap);
+    for (uint32_t i = 0; i < W.left; i += 64) {                                   // the unused rest of the last block: empty records
+        const unsigned long long j = W.base + i + lane;
+        if (i + lane < W.left && j < A.cand_cap) A.cand[j] = 0ULL;
+    }
     if constexpr (MEAS) {
         if (A.clk && threadIdx.x == 0) {
             const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -999,17 +1009,22 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
     return MS_OK;
 }
 
-int prefilter_set_lds(bool meas, size_t bytes) {
-    MS_HIP(hipFuncSetAttribute(meas ? reinterpret_cast<const void *>(prefilter_f6_kernel<true>) : reinterpret_cast<const void *>(prefilter_f6_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+typedef void (*PfKernel)(const PfArgs);
+static PfKernel pf_kernel(bool wide, bool meas) {
+    if (wide) return meas ? prefilter_f6_kernel<4, true> : prefilter_f6_kernel<4, false>;
+    return meas ? prefilter_f6_kernel<2, true> : prefilter_f6_kernel<2, false>;
+}
+
+int prefilter_set_lds(bool wide, bool meas, size_t bytes) {
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
-int launch_prefilter(const PfArgs &A, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+// wide: the plan holds row tiles of 3 or 4 k-blocks
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
     const int64_t n_chunks = (A.n_bases + kPfThreads - 1) / kPfThreads;
     if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
-    if (meas) hipLaunchKernelGGL(prefilter_f6_kernel<true>, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
-    else hipLaunchKernelGGL(prefilter_f6_kernel<false>, dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
+    hipLaunchKernelGGL(pf_kernel(wide, meas), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -2,7 +2,7 @@
 motifscan_amd.synth -- seeded synthetic workloads: there is no network, so no
 real JASPAR file and no real genome exist on either box.
 
-  * the motif set is a committed fixture (tests/golden/synth_jaspar579.npz): 579 JASPAR-width
+  * the motif set is package data (motifscan_amd/data/synth_jaspar579.npz): 579 JASPAR-width
     PFMs pushed through the REFERENCE's own build pipeline in the build container
     (to_ppm().to_pwm(bg), cutoffs from 10^6 background k-mers scored by the reference's c_score,
     get_score_cutoffs, around(,8)) by tests/golden/make_golden.py;
@@ -15,7 +15,8 @@ import os
 
 import numpy as np
 
-_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+MOTIF_SET = os.path.join(_DATA, "synth_jaspar579.npz")
 
 BG = np.array([0.295, 0.205, 0.205, 0.295])
 
@@ -33,12 +34,33 @@ C5_SHARD = {"genome_bp": 375_000_000, "window": 200, "stride": 50, "n_pwms": 579
 
 def load_motif_set(n_pwms=579, p_value="1e-4"):
     """(pwm_values, widths, cutoffs) of the first n_pwms synthetic JASPAR-like motifs."""
-    d = np.load(os.path.join(_GOLDEN, "synth_jaspar579.npz"))
+    d = np.load(MOTIF_SET)
     widths = d["widths"][:n_pwms].astype(np.int32)
     n_vals = 4 * int(widths.sum())
     keys = [str(k) for k in d["cutoff_keys"]]
     cutoffs = d["cutoffs"][:n_pwms, keys.index(p_value)].astype(np.float64)
     return d["pwm_values"][:n_vals].astype(np.float64), widths, cutoffs
+
+
+def random_motif(width, seed, p_value=1e-4, n_kmers=200_000):
+    """(matrix 4 x width, cutoff): one more synthetic motif made the way the fixture's were (Dirichlet(0.3) columns x depth ->
+    counts -> PPM with the reference's pseudo-count -> log-odds against BG, 5 decimals; matrix.py:125-171), its cutoff the
+    reference's rank pick (motif/__init__.py:393-399) over n_kmers background k-mers scored on both strands by plain numpy --
+    for timing motifs wider than the fixture holds (bench workloads), not a parity vector."""
+    from . import matrix
+    rng = np.random.default_rng(seed)
+    depth = int(rng.integers(20, 3001))
+    counts = np.rint(rng.dirichlet(0.3 * np.ones(4), size=width).T * depth).astype(np.int64)
+    counts[:, counts.sum(axis=0) == 0] = 1
+    bg = dict(zip("ACGT", BG))
+    m = matrix.PositionFrequencyMatrix(counts).to_ppm().to_pwm(bg).matrix
+    codes = rng.choice(4, size=(n_kmers, width), p=BG)
+    cols = np.arange(width)
+    fwd = m[codes, cols].sum(axis=1)
+    rev = m[3 - codes, width - 1 - cols].sum(axis=1)
+    max_raw = float(np.maximum(m.max(axis=0), 0.0).sum())
+    sc = np.sort(np.maximum(fwd, rev) / max_raw)[::-1]
+    return m, float(np.around(sc[max(int(n_kmers * p_value) - 1, 0)], 8))
 
 
 def matrices_of(pwm_values, widths):

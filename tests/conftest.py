@@ -44,7 +44,7 @@ def rnd():
 
 @pytest.fixture(scope="session")
 def jaspar579():
-    d = np.load(os.path.join(GOLDEN, "synth_jaspar579.npz"))
+    d = np.load(os.path.join(ROOT, "motifscan_amd", "data", "synth_jaspar579.npz"))       # package data: the benchmark motif set
     keys = [str(k) for k in d["cutoff_keys"]]
     return {"widths": d["widths"], "pwm_values": d["pwm_values"],
             "cutoffs": {k: d["cutoffs"][:, i].copy() for i, k in enumerate(keys)}, "bg": d["bg"]}

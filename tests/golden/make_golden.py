@@ -23,7 +23,7 @@ Outputs (all under tests/golden/):
                         cutoffs from c_score + get_score_cutoffs, sequences with N / soft-mask /
                         IUPAC / short and empty entries; full hit lists for strands 1,2,3;
                         Scanner.scan_motifs with and without de-dup; c_score on k-mers
-  synth_jaspar579.npz   the benchmark motif set: 579 JASPAR-width synthetic PFMs pushed through the
+  ../../motifscan_amd/data/synth_jaspar579.npz   the benchmark motif set (package data): 579 JASPAR-width synthetic PFMs pushed through the
                         reference's build pipeline (to_ppm().to_pwm(bg), cutoffs from 10^6 background
                         k-mers scored by the reference's c_score, get_score_cutoffs, around(,8))
 
@@ -453,7 +453,7 @@ def make_579(R, n_kmers):
     mats = build_pwms(R, rng, widths, bg)
     cuts, _ = reference_cutoffs(R, mats, rng, bgp, n_kmers, 8)
     keys = sorted(cuts[0].keys())
-    np.savez_compressed(os.path.join(HERE, "synth_jaspar579.npz"),
+    np.savez_compressed(os.path.join(HERE, "..", "..", "motifscan_amd", "data", "synth_jaspar579.npz"),
                         reference_version=np.array(R["version"]), n_kmers=np.array(n_kmers),
                         widths=widths, pwm_values=np.concatenate([m.ravel() for m in mats]),
                         cutoff_keys=np.array(keys),

@@ -420,7 +420,7 @@ def test_sweep_hands_out_more_than_2_to_the_32_sites_arithmetic():
     """The hand-out's prefix sums are 64-bit: exercised at a size the box can hold (a dense-hit sweep whose site count
     needs > 32 bits cannot be checked here), so check the widened path by a sweep with window / stride = 64."""
     vals, widths, _ = synth.load_motif_set(12)
-    cut2 = np.load(os.path.join(synth._GOLDEN, "synth_jaspar579.npz"))["cutoffs"][:12, 0]      # p = 1e-2: dense hits
+    cut2 = np.load(synth.MOTIF_SET)["cutoffs"][:12, 0]      # p = 1e-2: dense hits
     genome, _ = synth.make_regions(1, 3_000_000, seed=33, frac_n=0.0)
     pw = _lib.PwmSet(vals, widths, cut2)
     rg = _lib.ResidentGenome({"chr": genome})

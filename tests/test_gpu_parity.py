@@ -536,7 +536,7 @@ def test_positions_beyond_2_to_the_31(oracle):
 def test_buffer_growth_path():
     """A cutoff far below the p=1e-4 density forces the candidate / hit buffers to grow (second pass)."""
     vals, widths, _ = synth.load_motif_set(40)
-    cut2, = [np.load(synth.os.path.join(synth._GOLDEN, "synth_jaspar579.npz"))["cutoffs"][:40, 0]]
+    cut2, = [np.load(synth.MOTIF_SET)["cutoffs"][:40, 0]]
     bases, offsets = synth.make_regions(30_000, 500, seed=4)
     _lib.release_scratch()
     res = _lib.scan(_lib.PwmSet(vals, widths, cut2), _lib.SeqSet(bases, offsets), 3)

@@ -460,7 +460,7 @@ def test_streams_and_pinned_memory_fail_loudly_without_a_gpu():
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
     """measurement variables alone must not change what the library does; the retired engine / variant / tail switches
     of rounds 1-2 change nothing at all (host-visible part: the plan)."""
-    vals, widths, cutoffs = (np.load(os.path.join(ROOT, "tests", "golden", "synth_jaspar579.npz"))[k] for k in ("pwm_values", "widths", "cutoffs"))
+    vals, widths, cutoffs = (np.load(os.path.join(ROOT, "motifscan_amd", "data", "synth_jaspar579.npz"))[k] for k in ("pwm_values", "widths", "cutoffs"))
     n = 40
     pw = _lib.PwmSet(vals[:4 * int(widths[:n].sum())], widths[:n], cutoffs[:n, 2])
     monkeypatch.delenv("MS_MEASURE", raising=False)
