@@ -40,6 +40,8 @@ I8_MFMA_PEAK = 256 * 4 * 2048 * 2.4e9   # op/s: v_mfma_i32_32x32x32_i8 = 65536 o
 F6_MFMA_PEAK = 2 * I8_MFMA_PEAK         # op/s: v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 / fp4 operands = 131072 ops per 32 cycles per SIMD
                                         # (measured 32.6, tools/ubench/mfma_f6_probe) = 1.0e16 = the guide's ~10 PF dense FP6/FP4 peak
 
+PF_KERNEL = "prefilter_f6_kernel"    # the dominant kernel (ms_kernels.hip); rocprofv3 shows it as ms::prefilter_f6_kernel<2, false>
+
 WORKLOAD_TEXT = {
     "c4": "BASELINE configs[3] in full: 1M input + 1M control regions x 500 bp x 579 PWMs, region-sharded over the ranks",
     "c3": "BASELINE configs[2]: 100k x 1 kb regions x 579 PWMs",
@@ -53,8 +55,21 @@ WORKLOAD_TEXT = {
 }
 
 
+def visible_gpus():
+    """Devices this process could use, WITHOUT initialising the GPU (on this image torch.cuda.device_count() only reads the
+    driver's device list; no context is created, so starting child ranks afterwards stays legal)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
 def self_launch(a):
-    """Start --gpus ranks as fresh processes.  Nothing in THIS process has initialised the GPU (no torch import, no HIP call)."""
+    """Start --gpus ranks as fresh processes.  Nothing in THIS process has initialised the GPU (no HIP call)."""
+    n_dev = visible_gpus()
+    if a.gpus > n_dev and os.environ.get("MS_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) are visible: nothing was started")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -161,6 +176,28 @@ def parity_sample(wl, pw, sample):
     return {"regions": int(n), "hits": int(len(w_pos)), "identical_to_cpu_reference": bool(same)}
 
 
+def rank_parity_sample(wl, pw, n_regions=2000, strand=3):
+    """Every rank checks the first n_regions of ITS OWN shard against the oracle's C restatement (liboracle.so: test
+    infrastructure, the checker only), so that a multi-GPU line is self-verifying rank by rank."""
+    from oracle import oracle
+    from motifscan_amd import _lib
+    bases, offsets = wl["sets"][0]
+    n = int(min(n_regions, len(offsets) - 1))
+    if n <= 0:
+        return {"regions": 0, "hits": 0, "identical": True}
+    raw = bases[:int(offsets[n])]
+    threads = max(1, min(16, (os.cpu_count() or 1) // max(int(os.environ.get("WORLD_SIZE", "1")), 1)))
+    want = oracle.scan_arrays(wl["pwm_values"], wl["widths"], wl["cutoffs"], raw.tobytes(), offsets[:n + 1], strand, threads)
+    sq = _lib.SeqSet(raw, offsets[:n + 1])
+    res = _lib.scan(pw, sq, strand)
+    h = res.hits()
+    res.close(); sq.close()
+    same = (np.array_equal(h["motif_offsets"], want["motif_offsets"]) and np.array_equal(h["seq_idx"], want["seq_idx"])
+            and np.array_equal(h["pos"], want["pos"]) and np.array_equal(h["score"], want["score"])
+            and np.array_equal(h["strand"].astype(np.int64), want["strand"].astype(np.int64)))
+    return {"regions": n, "hits": int(len(want["pos"])), "identical": bool(same)}
+
+
 class _DevicePtr:
     """Lets torch wrap the library's device-resident count vector without a copy (CUDA array interface)."""
 
@@ -181,7 +218,13 @@ def main():
     ap.add_argument("--regions-per-set", type=int, default=None, help="c4 only: shrink the workload (development aid; the line then says so)")
     ap.add_argument("--genome-mbp", type=int, default=3000, help="c5 only: synthetic genome size in Mbp")
     ap.add_argument("--batch-regions", type=int, default=125_000, help="regions per batch of the end-to-end leg")
+    ap.add_argument("--p-value", default="1e-4", choices=["1e-2", "1e-3", "1e-4", "1e-5", "1e-6"],
+                    help="cutoff column of the motif set (the reference's -p, cli/main.py:520-521); anything but 1e-4 is a builder-run side workload, the line says so")
+    ap.add_argument("--strand", default="both", choices=["both", "+", "-"], help="the reference's --strand (cli/main.py:543); default both")
+    ap.add_argument("--extra-widths", default="", help="comma list: append one synthetic motif of each of these widths (side workload: motifs wider than the set holds)")
     a = ap.parse_args()
+    strand_mask = {"both": 3, "+": 1, "-": 2}[a.strand]
+    side = a.p_value != "1e-4" or a.strand != "both" or bool(a.extra_widths)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)                             # never returns
@@ -196,6 +239,21 @@ def main():
     if a.workload in ("c5", "c5shard"):
         return main_sweep(a, world, rank, local_rank)
     wl = load_workload(a.workload, rank, world, a)
+    if side:
+        from motifscan_amd import synth
+        vals, widths, cutoffs = synth.load_motif_set(wl["n_pwms"], a.p_value)
+        mats = [m for m in synth.matrices_of(vals, widths)]
+        cuts = list(cutoffs)
+        for w in [int(x) for x in a.extra_widths.split(",") if x]:
+            m, c = synth.random_motif(w, seed=900 + w, p_value=float(a.p_value))
+            mats.append(m)
+            cuts.append(c)
+        per_bp = wl["units"] // wl["n_pwms"]
+        wl["pwm_values"] = np.concatenate([m.ravel() for m in mats])
+        wl["widths"] = np.array([m.shape[1] for m in mats], dtype=np.int32)
+        wl["cutoffs"] = np.array(cuts, dtype=np.float64)
+        wl["n_pwms"] = len(mats)
+        wl["units"] = per_bp * len(mats)
 
     import torch                                   # device memory / streams / torch.distributed only
     import torch.distributed as dist
@@ -225,11 +283,13 @@ def main():
     counts = torch.zeros(n_sets * P, dtype=torch.int64, device=dev)          # this rank's counts, then the reduced vector
     local_counts = torch.zeros(n_sets * P, dtype=torch.int64, device=dev)
 
-    def step():
+    ar_events = []                                  # (start, end) CUDA events around the path's one collective, per timed step
+
+    def step(timed=False):
         stats = []
         for s, sq in enumerate(seqsets):
             sq.repack()                            # extraction: resident ASCII -> 2-bit codes + N mask
-            res = _lib.scan(pw, sq, 3)
+            res = _lib.scan(pw, sq, strand_mask)
             stats.append(res.stats())
             # the library's own device vector, wrapped in place: device -> device, no trip through the host
             counts[s * P:(s + 1) * P].copy_(torch.as_tensor(_DevicePtr(res.region_counts_device_ptr(), P), device=dev))
@@ -237,7 +297,13 @@ def main():
             res.close()
         local_counts.copy_(counts)
         if world > 1:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (stats.py:29-31 input)
+            if timed:
+                e1.record()
+                ar_events.append((e0, e1))
         return stats
 
     def fence():
@@ -261,7 +327,9 @@ def main():
     t0 = time.perf_counter()
     all_stats = []
     for _ in range(a.steps):
-        all_stats.extend(step())
+        all_stats.extend(step(timed=True))
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0          # this rank's own K steps (its last collective included), before the closing barrier
     fence()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -274,16 +342,31 @@ def main():
 
     # the collective, checked: all-reduced vector == sum over ranks of the vectors each rank's library handed over
     counts_check = None
+    ranks_report = None
     if world > 1:
         gathered = [torch.zeros_like(local_counts) for _ in range(world)]
         dist.all_gather(gathered, local_counts)
         counts_check = {"allreduce_equals_sum_of_rank_counts": bool(torch.equal(torch.stack(gathered).sum(0), counts)),
                         "max_regions_with_site": int(counts.max().item())}
+        # per rank: its own ms per step, the collective's own time, and 2000 of its regions checked against the oracle
+        ps = rank_parity_sample(wl, pw, strand=strand_mask)
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1)
+        mine = torch.tensor([own_elapsed / a.steps * 1e3, ar_ms, float(ps["regions"]), float(ps["hits"]), 1.0 if ps["identical"] else 0.0],
+                            dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        tab = torch.stack(per_rank).cpu().numpy()
+        ranks_report = {"ms_per_step_min": float(tab[:, 0].min()), "ms_per_step_max": float(tab[:, 0].max()),
+                        "ms_per_step_by_rank": [round(float(x), 3) for x in tab[:, 0]],
+                        "allreduce_ms_mean_by_rank": [round(float(x), 4) for x in tab[:, 1]],
+                        "parity_sample": {"regions_per_rank": int(tab[:, 2].min()), "hits_checked": int(tab[:, 3].sum()),
+                                          "ranks_identical_to_oracle": int(tab[:, 4].sum()), "ranks": world,
+                                          "checker": "oracle/cscore_oracle.c (liboracle.so), first regions of every rank's own shard"}}
 
     # ---- SURVEY.md 8(d) end-to-end: host ASCII (pinned) -> hit arrays in pinned host memory, through the batch stream ----
     e2e = None
     if not a.no_end_to_end:
-        e2e = end_to_end(a, wl, pw, world, dev, torch, dist if world > 1 else None)
+        e2e = end_to_end(a, wl, pw, world, dev, torch, dist if world > 1 else None, strand_mask)
 
     if rank == 0:
         n_launch = len(all_stats)
@@ -292,57 +375,48 @@ def main():
         lds_bytes = sum(s["lds_bytes_read"] for s in all_stats) / n_launch
         windows = sum(s["n_windows"] for s in all_stats) / n_launch
         achieved = alg_bytes / (pf_ms * 1e-3)
+        # HBM bytes per launch from a recorded PMC pass (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes: profiles/): only
+        # an entry recorded for THIS kernel on THIS workload and configuration counts, anything else prints null
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")             # recorded PMC pass (rocprofv3 --pmc), per launch
-        if os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile) and not side:
             try:
-                traffic = json.load(open(tfile)).get(a.workload, {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(tfile)).get(a.workload + "_r03", {})
+                if PF_KERNEL in ent.get("kernel", ""):
+                    traffic = ent.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
-        engine = all_stats[0]["pf_engine"]
-        hbm = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-               "traffic": traffic, "kernel": "prefilter_kernel", "kernel_ms": pf_ms, "algorithmic_bytes_per_launch": alg_bytes}
-        if engine >= 1:
-            # dominant kernel = prefilter_mfma_kernel, bound by the matrix pipe / VALU issue: algorithmic ops =
-            # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the
-            # kernel ISSUES is 4x that (one-hot: 4 k-slots per base) plus padding of widths to 8 (engine 3: 16) columns.
-            # peak = the dense matrix peak of the operand types the kernel feeds the pipe (engine 3: fp6 x fp4, 2x the int8 peak)
-            alg_ops = sum(s["mfma_ops_algorithmic"] for s in all_stats) / n_launch
-            issued = sum(s["mfma_ops"] for s in all_stats) / n_launch
-            peak = F6_MFMA_PEAK if engine == 3 else I8_MFMA_PEAK
-            roofline = {"bound": "mfma", "achieved": alg_ops / (pf_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                        "frac": alg_ops / (pf_ms * 1e-3) / peak, "traffic": traffic, "kernel": "prefilter_mfma_kernel",
-                        "kernel_ms": pf_ms, "algorithmic_ops_per_launch": alg_ops,
-                        "dtype": "fp6 (e2m3) x fp4 (e2m1, one-hot) -> f32, exact" if engine == 3 else "int8 x int8 -> int32",
-                        "frac_of_int8_peak": alg_ops / (pf_ms * 1e-3) / I8_MFMA_PEAK}
-            on_chip = {"bound": "matrix pipe (issued ops incl. one-hot zeros and width padding)",
-                       "achieved": issued / (pf_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TOP/s",
-                       "frac": issued / (pf_ms * 1e-3) / peak, "issued_ops_per_launch": issued,
-                       "lds_TBps": lds_bytes / (pf_ms * 1e-3) / 1e12, "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
-        else:
-            roofline = hbm
-            on_chip = {"bound": "lds", "achieved": lds_bytes / (pf_ms * 1e-3) / 1e12, "peak": LDS_PEAK / 1e12,
-                       "unit": "TB/s", "frac": lds_bytes / (pf_ms * 1e-3) / LDS_PEAK,
-                       "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
+        # dominant kernel = prefilter_f6_kernel, bound by VALU issue beside the matrix pipe: algorithmic ops =
+        # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the kernel ISSUES is 4x
+        # that (one-hot: 4 k-slots per base) plus the padding of widths to k-blocks of 16 columns.  peak = the dense matrix peak of
+        # the operand types the kernel feeds the pipe (fp6 x fp4: MI355X_MICROARCH.md ~10 PF)
+        alg_ops = sum(s["mfma_ops_algorithmic"] for s in all_stats) / n_launch
+        issued = sum(s["mfma_ops"] for s in all_stats) / n_launch
+        peak = F6_MFMA_PEAK
+        roofline = {"bound": "mfma", "achieved": alg_ops / (pf_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": alg_ops / (pf_ms * 1e-3) / peak, "traffic": traffic, "kernel": PF_KERNEL,
+                    "kernel_ms": pf_ms, "algorithmic_ops_per_launch": alg_ops,
+                    "dtype": "fp6 (e2m3) x fp4 (e2m1, one-hot) -> f32, exact",
+                    "frac_of_int8_peak": alg_ops / (pf_ms * 1e-3) / I8_MFMA_PEAK}
+        on_chip = {"bound": "matrix pipe (issued ops incl. one-hot zeros and width padding)",
+                   "achieved": issued / (pf_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TOP/s",
+                   "frac": issued / (pf_ms * 1e-3) / peak, "issued_ops_per_launch": issued,
+                   "lds_TBps": lds_bytes / (pf_ms * 1e-3) / 1e12, "windows_per_s_kernel": windows / (pf_ms * 1e-3)}
         shrunk = a.workload == "c4" and a.regions_per_set is not None
         line = {
-            "metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
+            "metric": f"scanned bp*motifs per second (region_bp x n_motifs), {'both strands' if a.strand == 'both' else 'strand ' + a.strand}, p={a.p_value} cutoffs"
+                      + (" [SIDE WORKLOAD: not BASELINE's configuration]" if side else ""),
             "value": total_units * a.steps / elapsed,
             "unit": "bp*motifs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f64 (every hit decision and score, as in the reference) behind an fp6 x fp4 one-hot matrix-core pre-filter (exact f32 accumulate)"
-                      if engine == 3 else
-                      "f64 (every hit decision and score, as in the reference) behind an int8 one-hot matrix-core pre-filter (i32 accumulate)"
-                      if engine == 1 else
-                      "f64 (every hit decision and score, as in the reference) behind an int8 Walsh-form matrix-core pre-filter (i32 accumulate)"
-                      if engine == 2 else
-                      "f64 (every hit decision and score, as in the reference) behind a u32 pre-filter of three packed 10-bit fixed-point fields"),
+            "dtype": "f64 (every hit decision and score, as in the reference) behind an fp6 x fp4 one-hot matrix-core pre-filter (exact f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[a.workload] + (f" [SHRUNK to {a.regions_per_set} regions per set: development run]" if shrunk else ""),
                        "regions_total": wl["n_regions_total"] * n_sets, "regions_per_gpu": wl["n_regions"] * n_sets,
-                       "region_bp": wl["length"], "n_pwms": P, "strands": "both", "p_value": "1e-4",
+                       "region_bp": wl["length"], "n_pwms": P, "strands": a.strand, "p_value": a.p_value,
+                       "motif_widths": f"{int(np.min(wl['widths']))}..{int(np.max(wl['widths']))}",
                        "sharding": f"{wl['n_regions_total']} + {wl['n_regions_total']} regions split contiguously over {world} GPU(s)"
                                    if n_sets == 2 else f"{wl['n_regions_total']} regions split contiguously over {world} GPU(s)",
                        "collective": f"1 all-reduce(sum) of the device-resident int64[{n_sets * P}] count vector per step",
@@ -359,9 +433,10 @@ def main():
         }
         if counts_check is not None:
             line["counts_check"] = counts_check
+            line["ranks"] = ranks_report
         if e2e is not None:
             line["value_end_to_end"] = e2e
-        if world == 1 and not a.no_cpu_baseline and wl["sets"]:
+        if world == 1 and not a.no_cpu_baseline and wl["sets"] and not side:
             line["cpu_baseline"], sample = cpu_baseline(wl)
             line["parity_sample"] = parity_sample(wl, pw, sample)
         print(json.dumps(line), flush=True)
@@ -370,7 +445,7 @@ def main():
         dist.destroy_process_group()
 
 
-def end_to_end(a, wl, pw, world, dev, torch, dist):
+def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     """Host ASCII in pinned memory -> hit arrays in pinned host memory, in batches of --batch-regions regions:
        pipelined  three stages of consecutive batches overlapped by the library's stream (ms_stream_*), hits copied out in the
                   compact 16-byte form (pipelined_25B: the int64/int64/f64/int8 arrays, 25 bytes per hit);
@@ -421,7 +496,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist):
             n = 0
             st = stages.setdefault("pipelined" if packed else "pipelined_25B", {})
             dev_ms = {"prefilter": 0.0, "fp64_stage": 0.0, "sort": 0.0, "finalize": 0.0, "scan_total": 0.0, "clock_mhz_sum": 0.0}
-            for res in _lib.scan_stream(pw, iter(batches), 3, 0, depth=2, packed=packed, stage_stats=st):
+            for res in _lib.scan_stream(pw, iter(batches), strand_mask, 0, depth=2, packed=packed, stage_stats=st):
                 n += res.n_hits                         # the arrays are already in pinned host memory at this point
                 s_ = res.stats()
                 for k_, f_ in (("prefilter", "ms_prefilter"), ("fp64_stage", "ms_exact"), ("sort", "ms_sort"), ("finalize", "ms_finalize"),
@@ -437,7 +512,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist):
         n = 0
         for b, o in batches:
             sq = _lib.SeqSet(b, o)
-            res = _lib.scan(pw, sq, 3)
+            res = _lib.scan(pw, sq, strand_mask)
             res.hits(copy=False)
             n += res.n_hits
             res.close(); sq.close()

@@ -109,6 +109,93 @@ def test_c4shard_workload_both_sets_and_count_vector(oracle):
     assert np.array_equal(out["counts"].ravel(), vec)
 
 
+def test_c4_full_size_set_as_one_scan(oracle):
+    """BASELINE configs[3] at the size bench.py launches at N = 1: ONE 1M x 500 bp set (500 Mbase, ~6e7 hits) as a single
+    ms_scan -- order key, ranges, region counts recounted, a 300-region sample from the far end bit for bit against the
+    oracle, and the set's first 125k regions equal to the same regions scanned as the 8-GPU shard."""
+    wl = synth.c4_shard(0, 1)
+    vals, widths, cutoffs, P = wl["pwm_values"], wl["widths"], wl["cutoffs"], wl["n_pwms"]
+    bases, offsets = wl["sets"][0]
+    R = len(offsets) - 1
+    assert R == 1_000_000 and int(offsets[-1]) == 500_000_000
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    sq = _lib.SeqSet(bases, offsets)
+    res = _lib.scan(pw, sq, 3)
+    st = res.stats()
+    h = res.hits(copy=False)
+    n = len(h["pos"])
+    assert n == st["n_hits"] > 50_000_000 and st["n_pwms_exact"] == 0 and st["n_passes"] == 1 and st["n_tiles"] == 1
+    assert st["n_windows"] == int(sum(500 - int(w) + 1 for w in widths)) * R
+    assert order_key_increasing(h, 10)
+    assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= 500).all() and (h["seq_idx"] >= 0).all() and (h["seq_idx"] < R).all()
+    assert (h["score"] - cutoffs[h["motif"]] >= -1e-10).all()
+    assert np.array_equal(res.region_counts(), recount_regions(h, P))
+    r0 = 987_650
+    sub_b, sub_o = dist.take_shard(bases, offsets, r0, r0 + 300)
+    want = oracle.scan_arrays(vals, widths, cutoffs, sub_b.tobytes(), sub_o, 3, 8)
+    m = (h["seq_idx"] >= r0) & (h["seq_idx"] < r0 + 300)
+    assert m.sum() == len(want["pos"]) > 0
+    assert np.array_equal(h["seq_idx"][m] - r0, want["seq_idx"]) and np.array_equal(h["pos"][m], want["pos"])
+    assert np.array_equal(h["score"][m], want["score"]) and np.array_equal(h["strand"][m].astype(np.int32), want["strand"])
+    # the first 125k regions are block 0 of the set = rank 0's shard of 8: the same hits whichever launch size scanned them
+    sh_b, sh_o = dist.take_shard(bases, offsets, 0, 125_000)
+    hs = _lib.scan(pw, _lib.SeqSet(sh_b, sh_o), 3).hits()
+    f = h["seq_idx"] < 125_000
+    assert f.sum() == len(hs["pos"])
+    assert all(np.array_equal(h[k][f], hs[k]) for k in ("seq_idx", "pos", "score", "strand"))
+    res.close(); sq.close()
+
+
+def test_host_streamed_sweep_with_the_default_span(oracle):
+    """BASELINE configs[4] with the product's own span size (375 Mbase): an 800 Mbp genome of 3 chromosomes on the host streamed
+    through ms_stream_submit_span -- span plan, properties of every span's result, window counts recounted, and the last 400
+    windows of the genome bit for bit against the oracle."""
+    window, stride = synth.C5_SHARD["window"], synth.C5_SHARD["stride"]
+    lens = [420_000_000, 250_000_000, 130_000_000]
+    chroms = []
+    for i, L in enumerate(lens):
+        b, _ = synth.make_regions(1, L, seed=7100 + i, frac_n=0.0)
+        b[L // 2:L // 2 + 20_000] = ord("N")                      # an assembly gap
+        b[L - 3000:L - 2950] = ord("n")
+        chroms.append(b)
+    vals, widths, cutoffs = synth.load_motif_set(579)
+    P = len(widths)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    max_span = 375_000_000
+    spans = _lib.sweep_spans(lens, window, stride, max_span)
+    assert len(spans) == 4 and [s[0] for s in spans] == [0, 0, 1, 2]
+    n_win_total = sum((L - window) // stride + 1 for L in lens)
+    assert sum(s[4] for s in spans) == n_win_total == spans[-1][3] + spans[-1][4]
+    counts = np.zeros(P, dtype=np.int64)
+    last = None
+    n_sites = 0
+    for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, spans=spans, packed=True):
+        h = res.hits(copy=False)
+        assert sp[2] - sp[1] <= max_span and (sp[4] - 1) * stride + window == sp[2] - sp[1]
+        assert len(h["pos"]) == res.n_hits > 10_000_000
+        assert order_key_increasing(h, 8)
+        assert (h["seq_idx"] >= 0).all() and (h["seq_idx"] < sp[4]).all()
+        assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= window).all()
+        rc = res.region_counts()
+        assert np.array_equal(rc, recount_regions(h, P))
+        counts += rc
+        n_sites += res.n_hits
+        if sp is spans[-1] or sp == spans[-1]:
+            keep = h["seq_idx"] >= sp[4] - 400
+            last = {k: h[k][keep].copy() for k in ("seq_idx", "pos", "score", "strand", "motif")}
+            last["seq_idx"] -= sp[4] - 400
+        res.close()
+    assert n_sites > 300_000_000 and (counts > 0).all()
+    b = chroms[-1]
+    k0 = (len(b) - window) // stride + 1 - 400
+    wins = np.concatenate([b[k * stride:k * stride + window] for k in range(k0, k0 + 400)])
+    want = oracle.scan_arrays(vals, widths, cutoffs, wins.tobytes(), np.arange(401, dtype=np.int64) * window, 3, 8)
+    wm = np.repeat(np.arange(P), np.diff(want["motif_offsets"]))
+    assert len(want["pos"]) == len(last["pos"]) > 1000
+    assert np.array_equal(last["motif"], wm) and np.array_equal(last["seq_idx"], want["seq_idx"]) and np.array_equal(last["pos"], want["pos"])
+    assert np.array_equal(last["score"], want["score"]) and np.array_equal(last["strand"].astype(np.int32), want["strand"])
+
+
 # ------------------------------------------------------------- configs[4]: the sweep shard --
 
 def test_c5shard_sweep_all_579_motifs(oracle):
@@ -522,6 +609,28 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["counts_check"]["allreduce_equals_sum_of_rank_counts"] is True
+    # the N > 1 line verifies itself: every rank's own step time, the collective's own time, and a sample of every rank's
+    # own shard compared with the oracle
+    rk = line["ranks"]
+    assert len(rk["ms_per_step_by_rank"]) == 2 and 0 < rk["ms_per_step_min"] <= rk["ms_per_step_max"] <= line["ms_per_step"] * 1.5
+    assert len(rk["allreduce_ms_mean_by_rank"]) == 2 and all(x >= 0 for x in rk["allreduce_ms_mean_by_rank"])
+    ps = rk["parity_sample"]
+    assert ps["ranks"] == 2 and ps["ranks_identical_to_oracle"] == 2 and ps["regions_per_rank"] > 0 and ps["hits_checked"] > 0
+    assert line["roofline"]["kernel"] == "prefilter_f6_kernel"
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N with N > visible devices: one line, non-zero exit, nothing spawned (and nothing generated)."""
+    import time
+    n = _lib.device_count() + 3
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MS_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "tiny"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "nothing was started" in out.stderr and not out.stdout.strip()
+    assert time.time() - t0 < 120
 
 
 # ----------------------------------------------------------- scan-once for overlapping regions --

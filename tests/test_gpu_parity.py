@@ -6,12 +6,16 @@ Bar: bit-exact positions, strands, order AND fp64 scores (north_star allows 1e-5
 re-scoring kernel repeats the reference's fp64 operations in the same order, so 0 is expected
 and asserted).
 """
+import os
+
 import numpy as np
 import pytest
 
 from motifscan_amd import _lib, cscore, scanner, synth, matrix
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -345,6 +349,82 @@ def test_wide_motif_classes_vs_oracle(oracle, monkeypatch, env):
     pw = _lib.PwmSet.from_matrices(mats, [0.55] * len(mats))
     res = _lib.scan(pw, _lib.SeqSet.from_strings(seqs), 3)
     assert res.stats()["n_pwms_exact"] == 2                      # only the 64- and 70-column motifs leave the pre-filter
+
+
+def test_pwm_with_minus_inf_entries_vs_oracle(oracle):
+    """An un-normalised PPM through to_pwm gives log(0) = -inf entries (matrix.py:149-171); the reference adds them like any
+    other double (cscore.c:345-353): a window touching one scores -inf and is no hit, the others are scored as usual.  Such a
+    motif leaves the pre-filter (ms_plan.cpp: non-finite entry) for the all-fp64 kernel."""
+    rng = np.random.default_rng(21)
+    mats = []
+    for w in (6, 11, 17):
+        counts = rng.integers(0, 30, size=(4, w)).astype(np.float64)
+        counts[rng.integers(0, 4), rng.integers(0, w)] = 0.0
+        counts[:, 2] = [0.0, 12.0, 0.0, 5.0]                      # a column with two impossible bases
+        ppm = matrix.PositionProbabilityMatrix(counts / counts.sum(axis=0))
+        with np.errstate(divide="ignore"):
+            pwm = ppm.to_pwm({"A": 0.295, "C": 0.205, "G": 0.205, "T": 0.295}).matrix
+        assert np.isneginf(pwm).any() and not np.isnan(pwm).any()
+        mats.append(pwm)
+    mats.append(np.round(rng.normal(0, 1.2, size=(4, 9)), 5))       # an ordinary motif beside them (stays on the pre-filter)
+    ml = [m.tolist() for m in mats]
+    seqs = ["".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=int(n))) for n in rng.integers(0, 600, size=60)]
+    seqs += ["", "N" * 40, "acgt" * 30]
+    for strand in (3, 1, 2):
+        for cut in (0.3, 0.05, -0.2):
+            cuts = [cut] * len(mats)
+            want = oracle.c_scan_motif(ml, cuts, seqs, strand, 8)
+            got = cscore.c_scan_motif(ml, cuts, seqs, strand, 1)
+            assert got == want, (strand, cut)
+            assert sum(len(x) for x in want[:3]) > 0
+    pw = _lib.PwmSet.from_matrices(mats, [0.3] * len(mats))
+    res = _lib.scan(pw, _lib.SeqSet.from_strings(seqs), 3)
+    assert res.stats()["n_pwms_exact"] == 3
+    sc_w = oracle.c_score(ml, [s for s in seqs if len(s) >= 17], 3, 4)
+    sc_g = cscore.c_score(ml, [s for s in seqs if len(s) >= 17], 3, 1)
+    assert np.array_equal(np.array(sc_g), np.array(sc_w), equal_nan=True)
+
+
+def test_integration_stub_of_the_reference_side_binding(oracle, small, tmp_path):
+    """INTEGRATION.md section 1 is the module a MotifScan maintainer would add as motifscan/motif/cscore_amd.py (replacing the
+    import at scanner.py:12 / cli/motif.py:24).  The text of that code block is extracted, written out and EXECUTED here: the
+    reference's own known answers (tests/test_motif_score.py:6-32), the G1 / G6 goldens and a seeded random case against the
+    oracle all go through it -- not through motifscan_amd/cscore.py."""
+    import importlib.util, re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"`motifscan/motif/cscore_amd.py`.*?```python\n(.*?)```", text, re.S).group(1)
+    path = tmp_path / "cscore_amd.py"
+    path.write_text(code)
+    os.environ["MOTIFSCAN_AMD_LIB"] = _lib.LIB_PATH
+    try:
+        spec = importlib.util.spec_from_file_location("cscore_amd_stub", str(path))
+        stub = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(stub)
+    finally:
+        os.environ.pop("MOTIFSCAN_AMD_LIB", None)
+    assert "motifscan_amd" not in code.replace("libmotifscan_amd", "").replace("MOTIFSCAN_AMD_LIB", "")      # ctypes + numpy only
+    m = [[[1.35, 0.21, -5.23], [0.07, -0.21, 0.6], [2.15, 2.22, -0.84], [-2.64, -1.89, 5.47]]]
+    seqs = ["NNN", "AGT", "ANT", "CTA"]
+    assert stub.c_score(m, seqs, 1, 1)[0] == pytest.approx([0.0, 0.9186991869918698, 0.693089430894309, -0.7164634146341464])
+    assert stub.c_score(m, seqs, 2, 1)[0] == pytest.approx([0.0, 0.6717479674796748, 0.693089430894309, -0.3323170731707317])
+    assert stub.c_score(m, seqs, 3, 1)[0] == pytest.approx([0.0, 0.9186991869918698, 0.693089430894309, -0.3323170731707317])
+    sites = stub.c_scan_motif(m, [0.2], ["NNNAG", "TANTCTA"], 3, 1)
+    assert len(sites) == 1 and len(sites[0]) == 4
+    assert sites[0][0] == pytest.approx([1, 1, 0.693089430894309, 1]) and sites[0][3] == pytest.approx([1, 3, 0.266260162601626, 1])
+    g = small["G1"]
+    for s in ("1", "2", "3"):
+        assert stub.c_score(g["matrix"], g["score_seqs"], int(s), 1) == g["score"][s]
+        assert stub.c_scan_motif(g["matrix"], g["scan_cutoffs"], g["scan_seqs"], int(s), 1) == g["scan"][s]
+    for case in small["G6"]:
+        if not case["pwms"] or any(len(r) == 0 for p in case["pwms"] for r in p):
+            continue                                               # (empty lists / width 0: the stub does no argument validation)
+        if case["kind"] == "scan":
+            assert stub.c_scan_motif(case["pwms"], case["cutoffs"], case["seqs"], case["strand"], 1) == case["out"], case["name"]
+    rng = np.random.default_rng(3)
+    mats = [np.round(rng.normal(0, 1.3, size=(4, w)), 5).tolist() for w in (5, 8, 12, 19, 33)]
+    rs = ["".join(rng.choice(list("ACGTNacgt"), size=int(n))) for n in rng.integers(0, 500, size=40)]
+    for strand in (1, 2, 3):
+        assert stub.c_scan_motif(mats, [0.35] * 5, rs, strand, 4) == oracle.c_scan_motif(mats, [0.35] * 5, rs, strand, 4)
 
 
 def test_edge_shapes_vs_oracle(oracle):

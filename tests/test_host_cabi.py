@@ -457,6 +457,17 @@ def test_streams_and_pinned_memory_fail_loudly_without_a_gpu():
         _lib.PinnedBuffer(1024)
 
 
+def test_bench_refuses_more_ranks_than_gpus_before_spawning():
+    """`bench.py --gpus N` with N > visible devices exits non-zero with one line, before any rank is started or any data generated."""
+    import subprocess, sys
+    if _lib.device_count() >= 2:
+        pytest.skip("two GPUs are visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MS_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "nothing was started" in out.stderr and not out.stdout.strip()
+
+
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
     """measurement variables alone must not change what the library does; the retired engine / variant / tail switches
     of rounds 1-2 change nothing at all (host-visible part: the plan)."""
