@@ -358,16 +358,14 @@ class ResidentGenome:
     __del__ = close
 
 
-class _OwnedArray(np.ndarray):
-    """A view of library-owned memory that keeps its owner (the ScanResult / pinned block) alive: slices and further views
-    reference this array as their base, so the owner lives as long as any of them does."""
-    _owner = None
-
-
-def _owned_view(arr, owner):
-    v = arr.view(_OwnedArray)
-    v._owner = owner
-    return v
+def _owned_array(address, ctype, n, dtype, owner):
+    """A numpy array over n items of library-owned memory at `address` that keeps `owner` (the ScanResult / pinned block that
+    frees the memory) alive for as long as ANY array derived from it lives.  numpy collapses `.base` to the object that owns
+    the memory -- np.asarray(view), slices, reshapes all end up referencing the ctypes array below, not an ndarray subclass in
+    between -- so the owner hangs on that object (an owner kept on an ndarray subclass was lost by np.asarray)."""
+    raw = (ctype * max(int(n), 1)).from_address(int(address))
+    raw._owner = owner
+    return np.frombuffer(raw, dtype=dtype, count=int(n))
 
 
 class ScanResult:
@@ -397,8 +395,10 @@ class ScanResult:
             pv, pd_ = ctypes.POINTER(ctypes.c_double)(), ctypes.POINTER(ctypes.c_int8)()
             check(lib().ms_result_hits_host(self.h, ctypes.byref(ps), ctypes.byref(pp), ctypes.byref(pv), ctypes.byref(pd_)))
             if n:
-                arrs = [np.ctypeslib.as_array(q, shape=(n,)) for q in (ps, pp, pv, pd_)]
-                arrs = [a.copy() for a in arrs] if copy else [_owned_view(a, self) for a in arrs]
+                spec = ((ps, ctypes.c_int64, np.int64), (pp, ctypes.c_int64, np.int64), (pv, ctypes.c_double, np.float64), (pd_, ctypes.c_int8, np.int8))
+                arrs = [_owned_array(ctypes.cast(q, ctypes.c_void_p).value, ct, n, dt, self) for q, ct, dt in spec]
+                if copy:
+                    arrs = [a.copy() for a in arrs]
             else:
                 arrs = [np.zeros(0, dtype=t) for t in (np.int64, np.int64, np.float64, np.int8)]
             motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
@@ -499,8 +499,14 @@ class PinnedBuffer:
         check(lib().ms_host_alloc(int(nbytes), ctypes.byref(p)))
         self.ptr = p
         self.nbytes = int(nbytes)
-        raw = (ctypes.c_uint8 * max(self.nbytes, 1)).from_address(p.value)
-        self.array = _owned_view(np.frombuffer(raw, dtype=np.uint8, count=self.nbytes), self)
+
+    @property
+    def array(self):
+        """uint8 view of the block; every view (and anything numpy derives from it) keeps the block alive.  Made on demand: a
+        view stored on the object itself would be a reference cycle and delay the release of the pinned memory to the cycle GC."""
+        if not getattr(self, "ptr", None):
+            raise ValueError("the pinned buffer is closed")
+        return _owned_array(self.ptr.value, ctypes.c_uint8, self.nbytes, np.uint8, self)
 
     def close(self):
         if getattr(self, "ptr", None):

@@ -93,6 +93,11 @@ int get_ctx(int device, DeviceCtx **out) {
     for (auto &ev : c->ev) MS_HIP(hipEventCreate(&ev));
     MS_HIP(hipMalloc(&c->sc.counters, 8 * sizeof(unsigned long long)));
     MS_HIP(hipHostMalloc(&c->sc.h_counters, 8 * sizeof(unsigned long long)));
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total > 0) c->pool.max_bytes = mem_total / 3;
+        else (void) hipGetLastError();
+    }
     *out = c.get();
     g_ctx[device] = std::move(c);
     return MS_OK;
@@ -130,16 +135,8 @@ int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
     }
     const uint64_t t0 = now_ns();
     char *p = nullptr;
-    int rc = dev_alloc(&p, want);
-    if (rc) {                                   // drop the cache and retry once
-        std::lock_guard<std::mutex> lk(c->pool.mu);
-        for (auto &b : c->pool.free_) (void) hipFree(b.first);
-        c->pool.n_driver_free += c->pool.free_.size();
-        c->pool.free_.clear();
-        c->pool.bytes = 0;
-        rc = dev_alloc(&p, want);
-        if (rc) return rc;
-    }
+    int rc = dev_alloc(&p, want);               // (dev_alloc itself drops the cache and retries once when the device is full)
+    if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(c->pool.mu);
         c->pool.n_miss++;
@@ -184,10 +181,30 @@ void pinned_free(void *p, size_t bytes) {
     g_pin_free.emplace_back(p, bytes);
 }
 
+size_t pool_trim_current_device() {
+    DeviceCtx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        auto it = g_ctx.find(g_device);
+        if (it == g_ctx.end()) return 0;
+        c = it->second.get();
+    }
+    std::vector<std::pair<void *, size_t>> victims;
+    {
+        std::lock_guard<std::mutex> lk(c->pool.mu);
+        victims.swap(c->pool.free_);
+        c->pool.bytes = 0;
+        c->pool.n_driver_free += victims.size();
+    }
+    size_t freed = 0;
+    for (auto &b : victims) { (void) hipFree(b.first); freed += b.second; }
+    return freed;
+}
+
 void pool_free(DeviceCtx *c, void *p, size_t bytes) {
     if (!p) return;
     std::unique_lock<std::mutex> lk(c->pool.mu);
-    if (c->pool.bytes + bytes <= BlockPool::kMaxBytes && c->pool.free_.size() < BlockPool::kMaxBlocks) {
+    if (c->pool.bytes + bytes <= c->pool.max_bytes && c->pool.free_.size() < BlockPool::kMaxBlocks) {
         c->pool.free_.emplace_back(p, bytes);
         c->pool.bytes += bytes;
         return;
@@ -197,7 +214,7 @@ void pool_free(DeviceCtx *c, void *p, size_t bytes) {
     for (size_t i = 0; i < c->pool.free_.size(); i++)
         if (c->pool.free_[i].second < bytes && (small == (size_t) -1 || c->pool.free_[i].second < c->pool.free_[small].second)) small = i;
     void *victim = p;
-    if (small != (size_t) -1 && c->pool.bytes - c->pool.free_[small].second + bytes <= BlockPool::kMaxBytes) {
+    if (small != (size_t) -1 && c->pool.bytes - c->pool.free_[small].second + bytes <= c->pool.max_bytes) {
         victim = c->pool.free_[small].first;
         c->pool.bytes += bytes - c->pool.free_[small].second;
         c->pool.free_[small] = {p, bytes};
@@ -672,6 +689,9 @@ int ms_seqset_size(const ms_seqset *s, int64_t *n_seqs, int64_t *n_bases) {
 void ms_seqset_free(ms_seqset *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
+    // the set may be freed on an error path with its memsets / upload / pack kernel still queued on its upload stream: the blocks
+    // must not go back to the pool (another thread can take them at once) before that work is done
+    if (s->up) (void) hipStreamSynchronize(s->up);
     DeviceCtx *c = nullptr;
     const bool have = get_ctx(s->device, &c) == MS_OK;
     if (s->d_ascii) { if (have) pool_free(c, s->d_ascii, s->ascii_bytes); else (void) hipFree(s->d_ascii); }
@@ -808,7 +828,7 @@ namespace ms {
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kF6LutBytes;                            // the B-operand table follows the tables
+    const size_t lds_fixed = kF6LutBytes + kPfStageBytes;            // the B-operand table and the waves' sequence staging follow the tables
     // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
     // (profiles/r02_wave_occupancy_ab.log)
     size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
@@ -881,12 +901,13 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     size_t want_cand = (size_t) std::min<double>(std::max<double>(1 << 20, 6e-4 * (double) fast_windows), 3.0e9);
     size_t want_hits = want_cand;
     if (!plan.exact_motifs.empty()) want_hits = std::max<size_t>(want_hits, 1 << 22);
-    // a wave reserves candidate slots in blocks (ms_kernels.hip, "candidate hand-off"): about an eighth of what it is expected to
-    // need, 64 ... 2048; the slots a wave leaves unused in its last block are head room on top
+    // a wave reserves candidate slots in blocks (ms_kernels.hip, "candidate hand-off"): about a quarter of what it is expected to
+    // need, 64 ... 2048 (its first block is its own, without an atomic); the slots a wave leaves unused in its last block are head
+    // room on top
     const int64_t pf_waves_max = (int64_t) c->n_cu * kPfBlocksPerCu * (kPfThreads / 64);
     uint32_t cand_block = 64;
-    while (cand_block < 2048 && (double) cand_block * 8.0 * (double) pf_waves_max < 1.5e-4 * (double) fast_windows) cand_block *= 2;
-    want_cand += (size_t) pf_waves_max * cand_block * (plan.tiles.size() > 1 ? 2 : 1);
+    while (cand_block < 2048 && (double) cand_block * 4.0 * (double) pf_waves_max < 1.5e-4 * (double) fast_windows) cand_block *= 2;
+    want_cand += (size_t) 2 * pf_waves_max * cand_block;          // the waves' own first blocks + the unused rest of their last ones
     want_cand = std::max(want_cand, sc.cand_cap);
     want_hits = std::max(want_hits, sc.hit_cap);
 
@@ -904,21 +925,19 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     const bool pf_meas = pf_no_emit != 0 || pf_clock;              // the measurement instantiation of the kernel
     raw->invalid = pf_no_emit != 0;                                // stage times only: the hit accessors refuse such a result
 
-    // counters: [0] candidate records, [1] hits
-    unsigned long long n_cand = 0, n_hits = 0;
-    for (int pass = 1;; pass++) {
-        if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
-        stt.n_passes = pass;
-        HitOut H;
-        H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
+    // counters: [0] candidate record slots, [1] hits
+    // pre-filter + fp64 stage of one pass, queued on the scan stream (events 0, 1, 2 around the two stages)
+    uint64_t cand_static = 0;                                      // the pre-filter waves' own first candidate blocks (set by front)
+    auto front = [&](const HitOut &H) -> int {
+        cand_static = 0;
         he = hipMemsetAsync(sc.counters, 0, 8 * sizeof(unsigned long long), c->stream);
-        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
         (void) hipEventRecord(c->ev[0], c->stream);
         if (!plan.tiles.empty()) {
             const int n_tiles = (int) plan.tiles.size();
             PfArgs A;
             A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
-            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16;
+            A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16; A.stage_off16 = lut_off16 + (uint32_t) (kF6LutBytes / 16);
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
             // While a batch stream is live and the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs (the
             // units are handed out dynamically: fewer blocks just take more each)
@@ -927,11 +946,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             int bpt_ = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * kPfBlocksPerCu / n_tiles));
             if (const char *e = measure_env("MS_PF_MAX_BLOCKS")) bpt_ = std::max(1, std::min(bpt_, atoi(e)));    // test aid: few blocks per tile, as a very large motif set would have
             const int bpt = bpt_;
-            const size_t counter_words = plan.tiles.size() * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
+            const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
             if (counter_words > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
                 sc.chunk_counters_cap = 0;
-                if ((rc = dev_alloc(&sc.chunk_counters, counter_words + 16))) return fail(rc);
+                if ((rc = dev_alloc(&sc.chunk_counters, counter_words + 16))) return rc;
                 sc.chunk_counters_cap = counter_words + 16;
             }
             A.chunk_counter = sc.chunk_counters;
@@ -957,35 +976,168 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 A.use_counters = counter_used ? 1 : 0;
             }
             if (counter_used) {
-                he = hipMemsetAsync(A.chunk_counter, 0, sizeof(unsigned int) * (size_t) n_tiles * kPfCounters * 16, c->stream);
-                if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+                he = hipMemsetAsync(A.chunk_counter, 0, sizeof(unsigned int) * counter_words, c->stream);
+                if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
             }
             A.clk = nullptr;
             if (pf_clock) {
                 clk_blocks = bpt * n_tiles;
-                if (!d_clk && (rc = dev_alloc(&d_clk, (size_t) 2 * clk_blocks))) return fail(rc);
+                if (!d_clk && (rc = dev_alloc(&d_clk, (size_t) 2 * clk_blocks))) return rc;
                 (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * 2 * clk_blocks, c->stream);
                 A.clk = d_clk;
+            }
+            {
+                const int64_t n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
+                cand_static = (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
+                A.cand_static = cand_static;
             }
             bool wide = false;
             for (const TileDesc &t : plan.tiles) wide = wide || t.max_nk > 2;
             const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0);
             if (lds_bytes > c->lds_set[li]) {
-                if ((rc = prefilter_set_lds(wide, pf_meas, lds_bytes))) return fail(rc);
+                if ((rc = prefilter_set_lds(wide, pf_meas, lds_bytes))) return rc;
                 c->lds_set[li] = lds_bytes;
             }
-            if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return fail(rc);
+            if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return rc;
         }
         (void) hipEventRecord(c->ev[1], c->stream);
-        if (!plan.fast_motifs.empty())
-            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, sc.cand_cap, pwms->d_group_fields, strand_mask, H, c->n_cu * 8, c->stream))) return fail(rc);
+        if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)
+            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_group_fields, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
         if (!plan.exact_motifs.empty())
-            if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return fail(rc);
+            if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return rc;
         (void) hipEventRecord(c->ev[2], c->stream);
+        return MS_OK;
+    };
+    // ordering + coordinates of the first n_sort slots of the hit list into the result block (events 3, 4, 5); n_dev != nullptr:
+    // only the device knows how many of them are hits (the rest are all-ones keys, which sort behind every hit)
+    const int end_bit = gbits + 1 + mbits;
+    auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
+        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
+        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+        (void) hipEventRecord(c->ev[3], c->stream);
+        if (n_sort > 0) {
+            size_t need = 0;
+            if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
+            if (need > sc.sort_tmp_bytes) {
+                if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
+                sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
+                unsigned char *tmp = nullptr;
+                if ((rc = dev_alloc(&tmp, need))) return rc;
+                sc.sort_tmp = tmp;
+                sc.sort_tmp_bytes = need;
+            }
+            size_t have = sc.sort_tmp_bytes;
+            if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
+        }
+        (void) hipEventRecord(c->ev[4], c->stream);
+        if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_sort, n_dev, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
+                                  raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) return rc;
+        (void) hipEventRecord(c->ev[5], c->stream);
+        // the complete per-motif offsets are on the device; one copy brings them to the host
+        he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+        if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+        return MS_OK;
+    };
+    auto result_block = [&](size_t n) -> int {
+        void *blk = nullptr;
+        size_t got = 0;
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, n), &blk, &got))) return rc;
+        raw->block = blk;
+        raw->block_bytes = got;
+        result_carve(raw, blk, n);
+        return MS_OK;
+    };
+    auto read_clock = [&]() {
+        if (!d_clk) return;                                  // median over blocks of cycles per 10 ns tick
+        std::vector<unsigned long long> h((size_t) 2 * clk_blocks);
+        if (hipMemcpy(h.data(), d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<double> mhz;
+            for (int b = 0; b < clk_blocks; b++)
+                if (h[2 * b + 1] > 0) mhz.push_back(100.0 * (double) h[2 * b] / (double) h[2 * b + 1]);
+            if (!mhz.empty()) { std::sort(mhz.begin(), mhz.end()); stt.pf_clock_mhz = mhz[mhz.size() / 2]; }
+        }
+        dev_free(d_clk);
+    };
+    auto finish = [&](unsigned long long n_cand, unsigned long long n_hits, bool with_back) {
+        stt.n_candidates = (int64_t) n_cand;
+        stt.n_hits = (int64_t) n_hits;
+        raw->n_hits = (int64_t) n_hits;
+        int64_t pwm_bytes = 0;
+        for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
+        // compulsory HBM bytes of one call
+        stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
+        float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
+        (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
+        (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
+        stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_total = ms01 + ms12;
+        if (with_back) {
+            (void) hipEventElapsedTime(&ms34, c->ev[3], c->ev[4]);
+            (void) hipEventElapsedTime(&ms45, c->ev[4], c->ev[5]);
+            (void) hipEventElapsedTime(&ms05, c->ev[0], c->ev[5]);
+            stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
+        }
+        if (stt.n_windows > 0 && !raw->invalid) {            // what the next scan of this set of PWMs may expect (below)
+            pwms->pred_density = (double) n_hits / (double) stt.n_windows;
+            pwms->pred_strand = strand_mask;
+            pwms->pred_cutoff_version = pwms->cutoff_version;
+            pwms->pred_exact_only = exact_only;
+        }
+    };
+
+    // ---- one-sync form: sizes PREDICTED from the previous scan of these PWMs.  The hit density of a motif set at its cutoffs is a
+    // property of the set (p-value x windows x strands): consecutive scans -- the batches of a stream, the input and control sets of
+    // a run, a benchmark's steps -- repeat it within a fraction of a percent.  The result block, the sort and the coordinate kernel
+    // are sized for the predicted count plus a margin, every launch is queued at once (the fp64 stage's real count stays on the
+    // device: the unused slots are filled with all-ones keys that sort last, finalize reads the count there), and ONE
+    // synchronisation at the very end validates the prediction.  A wrong prediction (count above the margin, or a scratch buffer
+    // too small) costs a second, exactly-sized run below and doubles the margin of the next scans.
+    const bool predicted = pwms->pred_density >= 0 && pwms->pred_strand == strand_mask && pwms->pred_cutoff_version == pwms->cutoff_version &&
+                           pwms->pred_exact_only == exact_only && !(flags & MS_SCAN_RAW_INTERNAL) && !pf_meas && !measure_env("MS_NO_PREDICT");
+    if (predicted) {
+        const double mu = pwms->pred_density * (double) stt.n_windows;
+        const size_t n_pred = (size_t) std::min<double>(mu * (1.0 + pwms->pred_margin) + 6.0 * std::sqrt(mu + 1.0) + 256.0, 3.0e9);
+        want_hits = std::max(want_hits, n_pred);
+        if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
+        if ((rc = result_block(n_pred))) return fail(rc);
+        stt.n_passes = 1;
+        HitOut H;
+        H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
+        if ((rc = front(H))) return fail(rc);
+        if ((rc = launch_fill_tail(sc.keys, sc.counters + 1, n_pred, c->stream))) return fail(rc);
+        if ((rc = back(n_pred, sc.counters + 1))) return fail(rc);
         he = hipMemcpyAsync(sc.h_counters, sc.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
-        n_cand = sc.h_counters[0];
+        const unsigned long long n_cand = cand_static + sc.h_counters[0], n_hits = sc.h_counters[1];
+        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap && n_hits <= n_pred) {
+            pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
+            read_clock();
+            finish(n_cand, n_hits, true);
+            *out = raw;
+            return MS_OK;
+        }
+        // the prediction failed: give the block back and run again with exact sizes
+        pool_free(c, raw->block, raw->block_bytes);
+        raw->block = nullptr;
+        raw->block_bytes = 0;
+        pwms->pred_margin = std::min(1.0, pwms->pred_margin * 2.0);
+        stt.n_passes = 1;
+        want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
+        const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
+        want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
+    }
+
+    unsigned long long n_cand = 0, n_hits = 0;
+    for (int pass = 1;; pass++) {
+        if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
+        stt.n_passes += 1;
+        HitOut H;
+        H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
+        if ((rc = front(H))) return fail(rc);
+        he = hipMemcpyAsync(sc.h_counters, sc.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+        n_cand = cand_static + sc.h_counters[0];
         n_hits = sc.h_counters[1];
         if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap) break;
         if (pass >= 5) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
@@ -995,29 +1147,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
         want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
     }
-    stt.n_candidates = (int64_t) n_cand;
-    if (d_clk) {                                             // median over blocks of cycles per 10 ns tick
-        std::vector<unsigned long long> h((size_t) 2 * clk_blocks);
-        if (hipMemcpy(h.data(), d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            std::vector<double> mhz;
-            for (int b = 0; b < clk_blocks; b++)
-                if (h[2 * b + 1] > 0) mhz.push_back(100.0 * (double) h[2 * b] / (double) h[2 * b + 1]);
-            if (!mhz.empty()) { std::sort(mhz.begin(), mhz.end()); stt.pf_clock_mhz = mhz[mhz.size() / 2]; }
-        }
-        dev_free(d_clk);
-    }
-    int64_t pwm_bytes = 0;
-    for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
-    // compulsory HBM bytes of one call
-    stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
+    read_clock();
 
     if (flags & MS_SCAN_RAW_INTERNAL) {                      // the caller takes the unordered hits from the scratch
-        float ms01 = 0, ms12 = 0;
-        (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
-        (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
-        stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_total = ms01 + ms12;
-        stt.n_hits = (int64_t) n_hits;
-        raw->n_hits = (int64_t) n_hits;
+        finish(n_cand, n_hits, false);
         raw->raw_gbits = gbits;
         raw->raw_pbits = pbits;
         *out = raw;
@@ -1025,52 +1158,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     }
 
     // one pooled block for everything the result owns
-    {
-        void *blk = nullptr;
-        size_t got = 0;
-        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, (size_t) n_hits), &blk, &got))) return fail(rc);
-        raw->block = blk;
-        raw->block_bytes = got;
-        result_carve(raw, blk, (size_t) n_hits);
-        const size_t P1 = (size_t) pwms->P + 1;
-        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
-        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
-    }
-    int64_t *d_motif_first = raw->d_motif_first;
-
-    (void) hipEventRecord(c->ev[3], c->stream);
-    if (n_hits > 0) {
-        const int end_bit = gbits + 1 + mbits;
-        size_t need = 0;
-        if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream))) return fail(rc);
-        if (need > sc.sort_tmp_bytes) {
-            if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
-            sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
-            he = hipMalloc(&sc.sort_tmp, need);
-            if (he != hipSuccess) { set_error("hipMalloc of %zu bytes (sort) failed: %s", need, hipGetErrorString(he)); return fail(MS_ERR_NOMEM); }
-            sc.sort_tmp_bytes = need;
-        }
-        size_t have = sc.sort_tmp_bytes;
-        if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, (size_t) n_hits, end_bit, c->stream))) return fail(rc);
-    }
-    (void) hipEventRecord(c->ev[4], c->stream);
-    if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_hits, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
-                              raw->d_strand, d_motif_first, raw->d_region_counts, c->stream))) return fail(rc);
-    (void) hipEventRecord(c->ev[5], c->stream);
-    // the complete per-motif offsets are on the device; one copy brings them to the host
-    he = hipMemcpyAsync(raw->motif_offsets.data(), d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if ((rc = result_block((size_t) n_hits))) return fail(rc);
+    if ((rc = back((size_t) n_hits, nullptr))) return fail(rc);
+    he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
-    stt.n_hits = (int64_t) n_hits;
-    raw->n_hits = (int64_t) n_hits;
-
-    float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
-    (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
-    (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
-    (void) hipEventElapsedTime(&ms34, c->ev[3], c->ev[4]);
-    (void) hipEventElapsedTime(&ms45, c->ev[4], c->ev[5]);
-    (void) hipEventElapsedTime(&ms05, c->ev[0], c->ev[5]);
-    stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
+    finish(n_cand, n_hits, true);
     *out = raw;
     return MS_OK;
 }
@@ -1267,16 +1359,19 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
     const size_t n = (size_t) r->n_hits;
-    uint32_t *d_keep = nullptr;
-    uint64_t *d_dst = nullptr;
-    void *d_tmp = nullptr, *blk = nullptr;
-    size_t tmp_bytes = 0, got = 0;
-    auto cleanup = [&]() { dev_free(d_keep); dev_free(d_dst); if (d_tmp) (void) hipFree(d_tmp); };
-    if ((rc = dev_alloc(&d_keep, n)) || (rc = dev_alloc(&d_dst, n))) { cleanup(); return rc; }
+    // keep flags, destinations and the prefix sum's work space in ONE pooled block: hipMalloc / hipFree stall every stage of a
+    // batch stream (hipFree waits for the whole device), and this runs per batch under MS_STREAM_DEDUP
+    void *wblk = nullptr, *blk = nullptr;
+    size_t tmp_bytes = 0, got = 0, wgot = 0;
+    auto cleanup = [&]() { if (wblk) pool_free(c, wblk, wgot); wblk = nullptr; };
+    const size_t n8 = (n + 31) & ~(size_t) 31;
+    if ((rc = exclusive_sum_u32(nullptr, &tmp_bytes, nullptr, nullptr, n, c->stream))) return rc;
+    if ((rc = pool_alloc(c, 12 * n8 + tmp_bytes + 256, &wblk, &wgot))) return rc;
+    uint64_t *d_dst = static_cast<uint64_t *>(wblk);
+    uint32_t *d_keep = reinterpret_cast<uint32_t *>(d_dst + n8);
+    void *d_tmp = d_keep + n8;
     rc = launch_dedup((int64_t) n, r->d_motif_first, r->P, pwms->d_width, r->d_seq_idx, r->d_pos, r->d_score, r->d_strand,
                       d_keep, c->stream);
-    if (!rc) rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_keep, d_dst, n, c->stream);
-    if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
     if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_keep, d_dst, n, c->stream);
     uint64_t last_dst = 0;
     uint32_t last_keep = 0;
@@ -1384,20 +1479,25 @@ int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *r1, int64_t s
     ms_result *raw = res.release();
     auto fail2 = [&](int code) { ms_result_free(raw); return fail(code); };
 
+    // counts, destinations and the prefix sum's work space in ONE pooled block (no hipMalloc / hipFree per span: ADVICE r2)
     uint32_t *d_cnt = nullptr;
     uint64_t *d_dst = nullptr;
-    void *d_tmp = nullptr;
-    auto cleanup = [&]() { dev_free(d_cnt); dev_free(d_dst); if (d_tmp) (void) hipFree(d_tmp); };
+    void *wblk = nullptr;
+    size_t wgot = 0;
+    auto cleanup = [&]() { if (wblk) pool_free(c, wblk, wgot); wblk = nullptr; };
     uint64_t total = 0;
     hipError_t he = hipSuccess;
     (void) hipEventRecord(c->ev[0], c->stream);
     if (n1 > 0) {
         size_t tmp_bytes = 0;
-        if ((rc = dev_alloc(&d_cnt, n1)) || (rc = dev_alloc(&d_dst, n1))) { cleanup(); return fail2(rc); }
+        const size_t n8 = (n1 + 31) & ~(size_t) 31;
+        if ((rc = exclusive_sum_u32(nullptr, &tmp_bytes, nullptr, nullptr, n1, c->stream))) return fail2(rc);
+        if ((rc = pool_alloc(c, 12 * n8 + tmp_bytes + 256, &wblk, &wgot))) return fail2(rc);
+        d_dst = static_cast<uint64_t *>(wblk);
+        d_cnt = reinterpret_cast<uint32_t *>(d_dst + n8);
+        void *d_tmp = d_cnt + n8;
         rc = launch_sweep_count((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, window, stride, n_windows,
                                 d_cnt, c->stream);
-        if (!rc) rc = exclusive_sum_u32(nullptr, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
-        if (!rc && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { set_error("hipMalloc (scan) failed"); rc = MS_ERR_NOMEM; }
         if (!rc) rc = exclusive_sum_u32(d_tmp, &tmp_bytes, d_cnt, d_dst, n1, c->stream);
         uint32_t last_cnt = 0;
         uint64_t last_dst = 0;

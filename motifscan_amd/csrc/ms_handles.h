@@ -33,7 +33,7 @@ struct BlockPool {
     // Blocks are handed out in size classes (pool_class: eight per octave), so that batches of similar but unequal size -- the
     // chromosomes of a sweep, the batches of a region stream -- reuse each other's blocks instead of going to the driver:
     // hipMalloc maps pages for milliseconds and hipFree waits for the whole device, either stalls every stage of a stream.
-    static constexpr size_t kMaxBytes = 96ull << 30;       // cached at most (of 288 GB)
+    size_t max_bytes = 96ull << 30;                        // cached at most: a third of the device's memory (set in get_ctx from hipMemGetInfo)
     static constexpr size_t kMaxBlocks = 64;
     uint64_t n_hit = 0, n_miss = 0, n_driver_free = 0, ns_driver = 0;
 };
@@ -78,11 +78,18 @@ int get_ctx(int device, DeviceCtx **out);
 int current_device();                 // the calling thread's device (ms_set_device)
 void set_current_device(int device);  // thread-local only; no HIP call
 
+// Give every cached block of the calling thread's device back to the driver (ms_api.hip); returns the bytes released.
+size_t pool_trim_current_device();
+
 template <typename T>
 inline int dev_alloc(T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+    if (e == hipErrorOutOfMemory && pool_trim_current_device() > 0) {       // the block cache may be what fills the device: drop it, once
+        (void) hipGetLastError();
+        e = hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+    }
     if (e != hipSuccess) {
         set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? MS_ERR_NOMEM : MS_ERR_RUNTIME;
@@ -123,6 +130,12 @@ struct ms_pwmset {
     double *d_max_raw = nullptr;
     double *d_cutoff = nullptr;
     double *d_raw_floor = nullptr;
+    // what the last scan with these PWMs found, for the one-sync form of the next (scan_locked): hits per window, and how far
+    // above it the next count may be before the prediction counts as failed
+    double pred_density = -1.0, pred_margin = 0.06;
+    int pred_strand = -1;
+    uint64_t pred_cutoff_version = 0;
+    bool pred_exact_only = false;
     // pre-filter plan (lazy, keyed by strand mask / cutoffs / LDS budget / exact-only)
     ms::PrefilterPlan plan;
     int plan_strand = -1;

@@ -8,6 +8,8 @@ constexpr int kPfThreads = 512;       // pre-filter block: 8 waves, two blocks p
 constexpr int kPfBlocksPerCu = 2;
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr size_t kF6LutBytes = 256 * 8;      // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables
+constexpr int kPfStageWords = 16;            // per wave: 8 code words + 4 non-ACGT words of the current pass (+ 4 spare), after the B-operand table
+constexpr size_t kPfStageBytes = (size_t) (kPfThreads / 64) * kPfStageWords * sizeof(uint32_t);
 
 struct DevSeq {
     const uint32_t *codes;
@@ -45,10 +47,12 @@ struct PfArgs {
     const uint4 *tables;
     const TileDesc *tiles;
     uint32_t lut_off16;       // start of the B-operand table in dynamic LDS (16-byte units)
+    uint32_t stage_off16;     // start of the per-wave sequence staging
     uint64_t *cand;           // candidate records; a wave reserves blocks of cand_block slots (unused slots are written as 0 = empty)
     unsigned long long *n_cand;   // slots reserved so far
     uint64_t cand_cap;
     uint32_t cand_block;      // >= 64
+    uint64_t cand_static;     // slots [0, cand_static) are the launch's waves' own first blocks (wave w: [w, w + 1) * cand_block)
     int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
@@ -62,12 +66,13 @@ int prefilter_set_lds(bool wide, bool meas, size_t bytes);
 int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
-int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
+int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
                    uint64_t cand_cap, const int32_t *group_fields, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S, int64_t *seq_idx,
-                    int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
+int launch_finalize(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S,
+                    int64_t *seq_idx, int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);
+int launch_fill_tail(uint64_t *keys, const unsigned long long *n_dev, uint64_t cap, hipStream_t st);
 int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,
                    int64_t R, int64_t n_out, uint32_t *codes, uint32_t *nmask, hipStream_t st);
 int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st);

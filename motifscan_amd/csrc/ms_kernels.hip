@@ -218,7 +218,7 @@ __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, 
     if (n_new > W.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
         pad_block(A, W, W.left);
         unsigned long long b = 0;
-        if ((threadIdx.x & 63u) == 0) b = atomicAdd(A.n_cand, (unsigned long long) A.cand_block);
+        if ((threadIdx.x & 63u) == 0) b = A.cand_static + atomicAdd(A.n_cand, (unsigned long long) A.cand_block);
         W.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b >> 32)) << 32) |
                  (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) b);          // wave-uniform: scalar registers
         W.left = A.cand_block;
@@ -248,8 +248,19 @@ __device__ __forceinline__ void clear_n(i32x8 &b, uint32_t n8) {
 // non-ACGT bits where it needs them (rare): the narrow classes' hot loops own every register they can get.
 struct PassSeq {
     uint64_t cw[2];
+    const uint32_t *stg; // the wave's staged sequence words of this pass (LDS): 8 code words, then 4 non-ACGT words, from pass0 on
     bool any_n;          // wave-uniform: some lane sees a non-ACGT base in the 96 bases from g0
 };
+
+// the 32 bases (2-bit codes) / their non-ACGT bits from window start pass0 + r + 32 i, cut out of the staged words (r = lane & 31)
+__device__ __forceinline__ uint64_t staged_cw(const uint32_t *stg, uint32_t r, int i) {
+    const uint32_t w = (r >> 4) + 2 * i, sh = (r & 15u) * 2u;
+    const uint64_t lo = ((uint64_t) stg[w + 1] << 32) | stg[w];
+    return sh ? (lo >> sh) | ((uint64_t) stg[w + 2] << (64u - sh)) : lo;
+}
+__device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, int i) {
+    return r ? (stg[8 + i] >> r) | (stg[9 + i] << (32u - r)) : stg[8 + i];
+}
 
 // All row tiles of one class (NK k-blocks each).  ILP row tiles' products are issued back to back (independent accumulators), then
 // inspected: a wave that spends more of its time issuing matrix instructions leaves the pipe idle less often (4 waves per SIMD).
@@ -263,11 +274,10 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     const char *p = lds + byte_off + lane * 8u;
     constexpr int kStep = NK * kF6BytesPerKb;
     constexpr int NW = NK > 2 ? 3 : 2;
-    auto start = [&](int i) { const int64_t g = pass0 + (lane & 31u) + 32 * i; return g < A.n_bases ? g : (int64_t) 0; };
     uint64_t cw[NW];
     cw[0] = Q.cw[0];
     cw[1] = Q.cw[1];
-    if constexpr (NW == 3) cw[2] = code_window(A.codes, start(2));
+    if constexpr (NW == 3) cw[2] = staged_cw(Q.stg, lane & 31u, 2);
     // B operands: k-block kb of the window at g0 covers bases 16 kb + 8 h ... + 7 from g0; of the window at g0 + 32 the same from there
     i32x8 b0[NK], b1[NK];
 #pragma unroll
@@ -279,7 +289,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     if (Q.any_n) {                                                                // rare, wave-uniform
         uint32_t nw[NW];
 #pragma unroll
-        for (int i = 0; i < NW; i++) nw[i] = n_window(A.nmask, start(i));
+        for (int i = 0; i < NW; i++) nw[i] = staged_nw(Q.stg, lane & 31u, i);
 #pragma unroll
         for (int kb = 0; kb < NK; kb++) {
             const int w = kb >> 1, sh = 16 * (kb & 1);
@@ -339,7 +349,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 }
 
 // grid = (blocks per tile, tiles); two 512-thread blocks per CU (16 waves per CU, <= 128 VGPRs), each with its own copy of the
-// LDS tile.  Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes).
+// LDS tile.  Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes) | per-wave sequence staging (kPfStageBytes).
 // Work is handed out per WAVE, without a barrier in the loop: a wave's first unit is its own number, every further unit one
 // atomicAdd on one of the tile's kPfCounters counter words (64 bytes apart; the blocks are dealt round-robin onto them and a word
 // hands out every kPfCounters-th unit), requested before the current unit is scanned (the atomic's latency hides behind the unit);
@@ -376,22 +386,38 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     const char *lds = reinterpret_cast<const char *>(lds4);
     const char *lut = reinterpret_cast<const char *>(lut4);
     const int n_classes = T->n_classes;
+    // every wave OWNS a first block of the candidate list (no atomic: 4096 waves reserving their first block on one counter word
+    // cost 45 us, the whole fixed cost of a small scan); further blocks come from the counter, behind the static ones
     MfWave W;
-    W.base = 0;
-    W.left = 0;
+    W.base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
+    W.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (W.base >> 32)) << 32) | (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) W.base);
+    W.left = A.cand_block;
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
+    // The sequence words of a pass, staged per wave in LDS: the wave's 64 window starts and the 32 (wide tiles: 64) bases behind the
+    // last one span 8 code words and 4 non-ACGT words from pass0 on (pass0 is a multiple of 64), which lanes 0 ... 11 fetch -- for
+    // the NEXT pass, before the current one is scanned, so that the global loads' latency hides behind a pass of matrix work --
+    // and every lane then cuts its own windows out of the staged words (rounds 1-2: ten global loads per lane and pass, their
+    // latency exposed once per pass: a third of the kernel's time on inputs with few row tiles per pass, profiles/r03_c2_latency.log).
+    uint32_t *stg = reinterpret_cast<uint32_t *>(lds4 + A.stage_off16) + (threadIdx.x >> 6) * kPfStageWords;
+    const int64_t n_code_words = 2 * ((A.n_bases + 31) / 32) + kPadWords, n_mask_words = (A.n_bases + 31) / 32 + kPadWords;
+    auto fetch = [&](int64_t pass0) -> uint32_t {                               // lanes 0..7: code words, 8..11: non-ACGT words of the pass
+        uint32_t v = 0;
+        if (lane < 8) { const int64_t w = (pass0 >> 4) + lane; v = A.codes[w < n_code_words ? w : n_code_words - 1]; }
+        else if (lane < 12) { const int64_t w = (pass0 >> 5) + (lane - 8); v = A.nmask[w < n_mask_words ? w : n_mask_words - 1]; }
+        return v;
+    };
     auto scan_pass = [&](int64_t pass0) {                                    // 64 window starts of this wave (pass0 ... + 63, wave-uniform) against every class
         const int64_t g0 = pass0 + r;
         bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
-        auto start = [&](int i) { return g0 + 32 * i < A.n_bases ? g0 + 32 * i : (int64_t) 0; };
         PassSeq Q;
-        Q.cw[0] = code_window(A.codes, start(0));
-        Q.cw[1] = code_window(A.codes, start(1));
-        const uint32_t nw0 = n_window(A.nmask, start(0)), nw1 = n_window(A.nmask, start(1));
-        const uint32_t nw2 = wide ? n_window(A.nmask, start(2)) : 0u;              // only classes of 3 or 4 k-blocks reach bases 64 ... 95
+        Q.stg = stg;
+        Q.cw[0] = staged_cw(stg, r, 0);
+        Q.cw[1] = staged_cw(stg, r, 1);
+        const uint32_t nw0 = staged_nw(stg, r, 0), nw1 = staged_nw(stg, r, 1);
+        const uint32_t nw2 = wide ? staged_nw(stg, r, 2) : 0u;                           // only classes of 3 or 4 k-blocks reach bases 64 ... 95
         Q.any_n = __any((nw0 | nw1 | nw2) != 0u);
         if (Q.any_n && A.skip_alln) {
             // a window whose bases are ALL non-ACGT (the tile's motifs span <= 32 bases, <= 64 with wide classes) scores 0 on every
@@ -438,8 +464,12 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                 next = waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
             }
             const uint32_t p0 = (v * K + g) * wave_passes;
-            for (uint32_t j = 0; j < wave_passes; j++)                            // passes past the end scan dead lanes (last unit only)
+            uint32_t words = fetch((int64_t) p0 * 64);
+            for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
+                if (lane < 12) stg[lane] = words;                                 // (the wave's LDS operations execute in order: no barrier)
+                if (j + 1 < wave_passes) words = fetch((int64_t) (p0 + j + 1) * 64);      // in flight while this pass is scanned
                 scan_pass((int64_t) (p0 + j) * 64);
+            }
             v = next;
         }
     }
@@ -480,13 +510,13 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
 constexpr int kRescoreU = 4;
 
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
-                                                      const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
+                                                      const unsigned long long *__restrict__ n_cand, uint64_t n_static, uint64_t cand_cap,
                                                       const int32_t *__restrict__ group_fields, int strand_mask,
                                                       const HitOut H) {
     __shared__ HitStage st;
     if (threadIdx.x == 0) st.n = 0;
     __syncthreads();
-    unsigned long long n = *n_cand;
+    unsigned long long n = n_static + *n_cand;            // the waves' own first blocks, then the blocks they reserved from the counter
     if (n > cand_cap) n = cand_cap;
     constexpr int U = kRescoreU;
     const bool both = strand_mask == 3;                  // both strands: fields 2k, 2k + 1 = motif slot k forward, reverse; one strand: field n = slot n
@@ -566,11 +596,14 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
 
 // ----------------------------------------------------------------------- finalize --
 
-__global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, int gbits, int32_t P,
-                                                       const DevSeq S,
+// n_dev != nullptr: the number of hits is only known on the device (a scan whose sizes were predicted, scan_locked): n is then
+// the launch's capacity and the true count min(*n_dev, n) is read here.
+__global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restrict__ keys, int64_t n, const unsigned long long *__restrict__ n_dev,
+                                                       int gbits, int32_t P, const DevSeq S,
                                                        int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
                                                        int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
                                                        unsigned long long *__restrict__ region_counts) {
+    if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     uint32_t motif = 0xFFFFFFFFu;
@@ -613,10 +646,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint64_t *__restric
 
 // The same when the keys carry (region, position inside the region): nothing to look up, only bits to unpack.
 // Four consecutive hits per thread: 16-byte loads and stores, the four strand bytes as one word.
-__global__ void __launch_bounds__(256) finalize_rp_kernel(const uint64_t *__restrict__ keys, int64_t n, int rbits, int pbits, int32_t P,
+__global__ void __launch_bounds__(256) finalize_rp_kernel(const uint64_t *__restrict__ keys, int64_t n, const unsigned long long *__restrict__ n_dev,
+                                                          int rbits, int pbits, int32_t P,
                                                           int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos,
                                                           int8_t *__restrict__ strand, int64_t *__restrict__ motif_first,
                                                           unsigned long long *__restrict__ region_counts) {
+    if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }
     const int64_t i0 = 4 * ((int64_t) blockIdx.x * blockDim.x + threadIdx.x);
     const bool live = i0 < n;
     uint32_t motif0 = 0xFFFFFFFFu;
@@ -1041,30 +1076,44 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
     return MS_OK;
 }
 
-int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand,
+int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
                    uint64_t cand_cap, const int32_t *group_fields, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st) {
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned) n_blocks), dim3(256), 0, st, S, Pw, cand, n_cand, cand_cap,
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned) n_blocks), dim3(256), 0, st, S, Pw, cand, n_cand, n_static, cand_cap,
                        group_fields, strand_mask, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
 
-int launch_finalize(const uint64_t *keys, int64_t n, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S, int64_t *seq_idx,
-                    int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
+int launch_finalize(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S,
+                    int64_t *seq_idx, int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st) {
-    if (n == 0) {                                    // no hits: every per-motif offset is 0
+    if (n == 0 || n_dev) {                           // no hits: every per-motif offset is 0 (with n_dev the kernel overwrites them unless the count is 0)
         MS_HIP(hipMemsetAsync(motif_first, 0, ((size_t) P + 1) * sizeof(int64_t), st));
-        return MS_OK;
+        if (n == 0) return MS_OK;
     }
     if (pbits > 0) {
-        hipLaunchKernelGGL(finalize_rp_kernel, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, st, keys, n, rbits, pbits, P,
+        hipLaunchKernelGGL(finalize_rp_kernel, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, st, keys, n, n_dev, rbits, pbits, P,
                            seq_idx, pos, strand, motif_first, region_counts);
         MS_HIP(hipGetLastError());
         return MS_OK;
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, gbits, P, S,
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, keys, n, n_dev, gbits, P, S,
                        seq_idx, pos, strand, motif_first, region_counts);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+// keys[i] = all ones for i in [min(*n_dev, cap), cap): the unused rest of a predicted-size hit list sorts behind every hit
+__global__ void __launch_bounds__(256) fill_tail_kernel(uint64_t *__restrict__ keys, const unsigned long long *__restrict__ n_dev, uint64_t cap) {
+    const unsigned long long n = *n_dev < cap ? *n_dev : cap;
+    for (unsigned long long i = n + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (unsigned long long) gridDim.x * blockDim.x)
+        keys[i] = ~0ULL;
+}
+
+int launch_fill_tail(uint64_t *keys, const unsigned long long *n_dev, uint64_t cap, hipStream_t st) {
+    if (cap == 0) return MS_OK;
+    hipLaunchKernelGGL(fill_tail_kernel, dim3(256), dim3(256), 0, st, keys, n_dev, cap);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -277,11 +277,11 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
         if ((rc = sort_hit_pairs(d_sort_tmp, &sort_bytes, d_keys, d_keys_sorted, d_vals, raw->d_score, (size_t) total,
                                  mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
         DevSeq none{};
-        if ((rc = launch_finalize(d_keys_sorted, (int64_t) total, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos,
+        if ((rc = launch_finalize(d_keys_sorted, (int64_t) total, nullptr, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos,
                                   raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) { cleanup(); return fail2(rc); }
     } else {
         DevSeq none{};
-        if ((rc = launch_finalize(nullptr, 0, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos, raw->d_strand,
+        if ((rc = launch_finalize(nullptr, 0, nullptr, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos, raw->d_strand,
                                   raw->d_motif_first, raw->d_region_counts, c->stream))) { cleanup(); return fail2(rc); }
     }
     (void) hipEventRecord(c->ev[1], c->stream);

@@ -198,7 +198,7 @@ class Scanner:
             region = h["seq_idx"] + r0
             return {"motif": h["motif"], "region": region, "start": (starts[region] + h["pos"]) if len(region) else h["pos"],
                     "score": h["score"], "strand": h["strand"], "motif_offsets": h["motif_offsets"],
-                    "n_regions_with_site": res.region_counts()}
+                    "n_regions_with_site": res.region_counts(), "_result": res}     # score / strand are views of the result's pinned block
 
         def batches():
             for r0, r1 in bounds:

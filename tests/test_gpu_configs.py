@@ -438,13 +438,22 @@ def test_owned_views_keep_the_result_alive():
     sq = _lib.SeqSet(bases, offsets)
     h = _lib.scan(pw, sq, 3).hits(copy=False)              # the ScanResult itself is dropped right here
     keep = h["score"][10:200]                              # a slice of a view
-    snap = keep.copy()
+    keep2 = np.asarray(h["pos"])                           # numpy collapses .base past any ndarray subclass in between
+    snap, snap2 = keep.copy(), keep2.copy()
     del h
     gc.collect()
     for _ in range(4):                                      # scans that would reuse a freed pinned block
         _lib.scan(pw, sq, 1).hits(copy=False)
         gc.collect()
-    assert np.array_equal(keep, snap)
+    assert np.array_equal(keep, snap) and np.array_equal(keep2, snap2)
+    pin = _lib.PinnedBuffer(1 << 16)
+    view = np.asarray(pin.array)[100:200]
+    view[:] = 7
+    del pin
+    gc.collect()
+    other = _lib.PinnedBuffer(1 << 16)                      # would take the freed block
+    other.array[:] = 1
+    assert (view == 7).all()
 
 
 # --------------------------------------------------------- host-streamed multi-chromosome sweep --

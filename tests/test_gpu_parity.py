@@ -627,6 +627,48 @@ def test_buffer_growth_path():
     assert (np.diff(key) > 0).all()
 
 
+def test_predicted_sizes_one_sync_form_and_its_fallback(oracle, jaspar579):
+    """The second and later scans with a PwmSet size their result from the previous scan's hit density and synchronise once
+    (scan_locked); a set far denser than predicted must fall back to the exactly-sized second run -- same hits either way."""
+    n = 120
+    widths = jaspar579["widths"][:n]
+    vals = jaspar579["pwm_values"][:4 * int(widths.sum())]
+    cutoffs = jaspar579["cutoffs"]["1e-4"][:n]
+    mats = synth.matrices_of(vals, widths)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    plain_b, plain_o = synth.make_regions(3000, 400, seed=61, frac_n=0.02, ragged=True)
+    rng = np.random.default_rng(62)
+    cons = ["".join("ACGT"[int(np.argmax(m[:, c]))] for c in range(m.shape[1])) for m in mats]       # consensus words: a hit each
+    dense = ["".join(cons[int(i)] for i in rng.integers(0, n, size=40)) for _ in range(1500)]
+    dense_sq = _lib.SeqSet.from_strings(dense)
+    plain_sq = _lib.SeqSet(plain_b, plain_o)
+    want_plain = oracle.scan_arrays(vals, widths, cutoffs, plain_b.tobytes(), plain_o, 3, 8)
+    want_dense = oracle.c_scan_motif([m.tolist() for m in mats], cutoffs.tolist(), dense, 3, 8)
+    r1 = _lib.scan(pw, plain_sq, 3)                             # first scan: sizes learnt through the two-sync form
+    r2 = _lib.scan(pw, plain_sq, 3)                             # predicted
+    assert r1.stats()["n_passes"] == 1 and r2.stats()["n_passes"] == 1
+    assert_same_hits(r1.hits(), want_plain)
+    assert_same_hits(r2.hits(), want_plain)
+    assert np.array_equal(r1.region_counts(), r2.region_counts())
+    r3 = _lib.scan(pw, dense_sq, 3)                             # > 10x the predicted density: the prediction fails, exact second run
+    assert r3.stats()["n_passes"] >= 2
+    assert r3.n_hits > 3 * r2.n_hits * dense_sq.n_bases / plain_sq.n_bases
+    h3 = r3.hits()
+    flat = [x for p in want_dense for x in p]
+    assert np.array_equal(h3["motif_offsets"], np.concatenate([[0], np.cumsum([len(p) for p in want_dense])]))
+    assert np.array_equal(h3["seq_idx"], np.array([x[0] for x in flat])) and np.array_equal(h3["pos"], np.array([x[1] for x in flat]))
+    assert np.array_equal(h3["score"], np.array([x[2] for x in flat])) and np.array_equal(h3["strand"], np.array([x[3] for x in flat]))
+    r4 = _lib.scan(pw, plain_sq, 3)                             # far SPARSER than the last scan: over-sized, still one pass, same hits
+    assert r4.stats()["n_passes"] == 1
+    assert_same_hits(r4.hits(), want_plain)
+    r5 = _lib.scan(pw, _lib.SeqSet.from_strings(["", "ACGT"]), 3)   # predicted count ~0
+    assert r5.n_hits == 0 and (r5.hits()["motif_offsets"] == 0).all()
+    pw.set_cutoffs(jaspar579["cutoffs"]["1e-3"][:n])           # new cutoffs: the prediction is void, the two-sync form learns again
+    want3 = oracle.scan_arrays(vals, widths, jaspar579["cutoffs"]["1e-3"][:n], plain_b.tobytes(), plain_o, 3, 8)
+    for _ in range(2):
+        assert_same_hits(_lib.scan(pw, plain_sq, 3).hits(), want3)
+
+
 def test_fuzz_decision_boundary(oracle):
     """tests/fuzz_parity.py: ties, cutoffs exactly on attainable scores (+- 1 ulp, +- 1e-10), max_raw == 0,
     huge / tiny magnitudes, widths either side of the 32-column fast path.  The integer pre-filter must

@@ -457,6 +457,32 @@ def test_streams_and_pinned_memory_fail_loudly_without_a_gpu():
         _lib.PinnedBuffer(1024)
 
 
+def test_views_of_library_memory_keep_their_owner_alive_through_numpy():
+    """np.asarray() of a view (numpy collapses .base to the object that owns the memory), slices, reshapes and
+    dtype views must all keep the owner -- the object whose release frees the memory -- alive; it goes when the last of them does."""
+    import gc, weakref
+
+    class Owner:
+        def __init__(self, n):
+            self.buf = (ctypes.c_int64 * n)(*range(n))
+
+    o = Owner(16)
+    ref = weakref.ref(o)
+    v = _lib._owned_array(ctypes.addressof(o.buf), ctypes.c_int64, 16, np.int64, o)
+    derived = [np.asarray(v), v[3:9], v.reshape(4, 4), v.view(np.uint8), np.asarray(v[2:])[::2]]
+    del o, v
+    gc.collect()
+    assert ref() is not None
+    assert derived[0][5] == 5 and derived[1][0] == 3 and derived[2][3, 3] == 15 and derived[4][1] == 4
+    while derived:
+        keep = derived.pop()
+        gc.collect()
+        assert ref() is not None or not derived
+        del keep
+    gc.collect()
+    assert ref() is None
+
+
 def test_bench_refuses_more_ranks_than_gpus_before_spawning():
     """`bench.py --gpus N` with N > visible devices exits non-zero with one line, before any rank is started or any data generated."""
     import subprocess, sys
