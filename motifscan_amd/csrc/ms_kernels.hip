@@ -359,7 +359,8 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 // 4 = the kernel that also knows row tiles of 3 and 4 k-blocks (its register allocation spills in rare paths).
 // MEAS: the measurement-only instantiation (drop candidates, clock stamps); the product kernel carries neither.
 // (Measured and dropped in rounds 1-2, tools/pf_variants.py history: fetching the next pass's sequence words early, class
-// descriptors in registers, waves walking the classes in rotated order, A operands fetched one row tile ahead, s_setprio around the
+// descriptors in registers, waves walking the classes in rotated order, A operands fetched one row tile ahead (again in round 3, for the
+// one-k-block class only, after tools/ubench/insp_probe.hip modes 6 / 7 promised -7 %: +6 % in the kernel), s_setprio around the
 // matrix instructions, 12 / 20 / 24 waves per CU, 128 windows per wave, a block-wide hand-out behind barriers, one branch per pair
 // of row tiles, a real function call for the rare path.)
 template <int MAXNK, bool MEAS>

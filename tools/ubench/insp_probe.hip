@@ -38,6 +38,45 @@ constexpr unsigned int kM0 = (1u << 5) | (1u << 11) | (1u << 17) | (1u << 23) | 
 constexpr unsigned int kM1 = (1u << 3) | (1u << 9) | (1u << 15) | (1u << 21) | (1u << 27);
 constexpr unsigned int kM2 = (1u << 1) | (1u << 7) | (1u << 13) | (1u << 19) | (1u << 25) | (1u << 31);
 
+// modes 6 / 7: the AND-chain inspection of mode 4 with the A operand READ FROM LDS every trip, as the kernel does (three ds_read_b64 per
+// row tile): 6 = read, wait, multiply (the kernel's order); 7 = the next trip's operand is read before this trip's inspection
+template <int MODE>
+__global__ void __launch_bounds__(1024) lds_kernel(const i32x8 *ab, int trips, unsigned int *sink, unsigned long long *clk) {
+    __shared__ unsigned long long tab[32 * 3 * 64];                       // 32 row tiles of one k-block: [tile][plane][lane]
+    for (int i = threadIdx.x; i < 32 * 3 * 64; i += blockDim.x) {
+        const i32x8 v = ab[i & 63];
+        const int pl = (i >> 6) % 3;
+        tab[i] = ((unsigned long long) (unsigned int) v[2 * pl + 1] << 32) | (unsigned int) v[2 * pl];
+    }
+    __syncthreads();
+    i32x8 b0 = ab[64 + (threadIdx.x & 63)], b1 = ab[128 + (threadIdx.x & 63)];
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int found = 0;
+    const unsigned int lane = threadIdx.x & 63;
+    auto load = [&](int t) {
+        const unsigned long long *q = tab + (t & 31) * 192 + lane;
+        const unsigned long long w0 = q[0], w1 = q[64], w2 = q[128];
+        return i32x8{(int) w0, (int) (w0 >> 32), (int) w1, (int) (w1 >> 32), (int) w2, (int) (w2 >> 32), 0, 0};
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    i32x8 a_next = load(0);
+    for (int t = 0; t < trips; t++) {
+        asm volatile("" : "+v"(b0), "+v"(b1));
+        i32x8 a;
+        if constexpr (MODE == 6) a = load(t); else { a = a_next; }
+        const f32x16 c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, z, 2, 4, 0, 127, 0, 127);
+        const f32x16 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, z, 2, 4, 0, 127, 0, 127);
+        if constexpr (MODE == 7) { a_next = load(t + 1); __builtin_amdgcn_sched_barrier(0); }
+        unsigned int x = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 16; i++) x &= (unsigned int) __float_as_int(c0[i]) & (unsigned int) __float_as_int(c1[i]);
+        if (__builtin_expect(__any((int) x >= 0), 0)) found += x;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (found == 0x12345u) sink[0] = found;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(1024) cost_kernel(const i32x8 *ab, int trips, unsigned int *sink, unsigned long long *clk) {
     i32x8 a = ab[threadIdx.x & 63], b0 = ab[64 + (threadIdx.x & 63)], b1 = ab[128 + (threadIdx.x & 63)];
@@ -106,9 +145,13 @@ static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, 
     for (const Cfg &c : cfgs) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int w = 0; w < 3; w++) hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
+        auto launch = [&]() {
+            if constexpr (MODE >= 6) hipLaunchKernelGGL((lds_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
+            else hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
+        };
+        for (int w = 0; w < 3; w++) launch();
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
+        launch();
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms = 0;
@@ -184,5 +227,7 @@ int main() {
     run_cost<3>("mode 3: 2 MFMA + cvt_2xpk16_fp6 alone", d_ab, d_sink, d_clk);
     run_cost<4>("mode 4: 2 MFMA + chain of 16 v_bitop3_b32 (AND) + cmp + branch", d_ab, d_sink, d_clk);
     run_cost<5>("mode 5: 2 MFMA + tree of 16 v_bitop3_b32 (AND) + cmp + branch", d_ab, d_sink, d_clk);
+    run_cost<6>("mode 6: mode 4 with the A operand read from LDS each trip (read, wait, multiply)", d_ab, d_sink, d_clk);
+    run_cost<7>("mode 7: mode 4 with the NEXT trip's A operand read before this trip's inspection", d_ab, d_sink, d_clk);
     return 0;
 }
