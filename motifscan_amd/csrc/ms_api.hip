@@ -641,6 +641,7 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
     hipError_t e = hipStreamSynchronize(raw->up);
     if (e != hipSuccess) { set_error("upload / pack failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     if (!keep_ascii) { pool_free(c, raw->d_ascii, raw->ascii_bytes); raw->d_ascii = nullptr; raw->ascii_bytes = 0; }
+    raw->built = true;
     *out = raw;
     return MS_OK;
 }
@@ -662,6 +663,7 @@ int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n
     if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up))) return fail(rc);
     hipError_t e = hipStreamSynchronize(raw->up);
     if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    raw->built = true;
     *out = raw;
     return MS_OK;
 }
@@ -689,9 +691,11 @@ int ms_seqset_size(const ms_seqset *s, int64_t *n_seqs, int64_t *n_bases) {
 void ms_seqset_free(ms_seqset *s) {
     if (!s) return;
     (void) hipSetDevice(s->device);
-    // the set may be freed on an error path with its memsets / upload / pack kernel still queued on its upload stream: the blocks
-    // must not go back to the pool (another thread can take them at once) before that work is done
-    if (s->up) (void) hipStreamSynchronize(s->up);
+    // a set freed on an ERROR path of its construction may still have its memsets / upload / pack kernel queued on the upload
+    // stream: the blocks must not go back to the pool (another thread can take them at once) before that work is done.
+    // A set that was built (built: its stream was synchronised then) needs no wait -- the stream is shared, waiting would stall
+    // behind the NEXT batch's upload.
+    if (!s->built && s->up) (void) hipStreamSynchronize(s->up);
     DeviceCtx *c = nullptr;
     const bool have = get_ctx(s->device, &c) == MS_OK;
     if (s->d_ascii) { if (have) pool_free(c, s->d_ascii, s->ascii_bytes); else (void) hipFree(s->d_ascii); }
@@ -794,6 +798,7 @@ int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_
     dev_free(d_src);
     if (rc) return fail(rc);
     if (he != hipSuccess) { set_error("extraction failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+    raw->built = true;
     *out = raw;
     return MS_OK;
 }
@@ -825,7 +830,72 @@ namespace ms {
 
 // The scan pipeline: pre-filter -> fp64 re-score of the candidates (+ motifs the filter cannot take) -> order -> coordinates.
 // The caller holds c->mu (one scan at a time per device: shared scratch) and pwms->mu (lazily cached device copies / plan).
-int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out) {
+int pending_scan_init(PendingScan *p) {
+    for (auto &e : p->ev) MS_HIP(hipEventCreate(&e));
+    MS_HIP(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    MS_HIP(hipHostMalloc(&p->h_counters, 4 * sizeof(unsigned long long)));
+    return MS_OK;
+}
+
+void pending_scan_destroy(PendingScan *p) {
+    for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
+    if (p->done) (void) hipEventDestroy(p->done);
+    if (p->h_counters) (void) hipHostFree(p->h_counters);
+    *p = PendingScan();
+}
+
+// stage times, counts and the next scan's prediction, once a scan's kernels are known to be done
+static void finish_scan(ms_result *raw, hipEvent_t *ev, ms_pwmset *pwms, int64_t n_bases, int64_t R, int strand_mask, bool exact_only,
+                        unsigned long long n_cand, unsigned long long n_hits, bool with_back) {
+    ms_scan_stats &stt = raw->stats;
+    stt.n_candidates = (int64_t) n_cand;
+    stt.n_hits = (int64_t) n_hits;
+    raw->n_hits = (int64_t) n_hits;
+    int64_t pwm_bytes = 0;
+    for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
+    // compulsory HBM bytes of one call
+    stt.hbm_bytes_algorithmic = (n_bases + 3) / 4 + (n_bases + 7) / 8 + 8 * (R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
+    float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
+    (void) hipEventElapsedTime(&ms01, ev[0], ev[1]);
+    (void) hipEventElapsedTime(&ms12, ev[1], ev[2]);
+    stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_total = ms01 + ms12;
+    if (with_back) {
+        (void) hipEventElapsedTime(&ms34, ev[3], ev[4]);
+        (void) hipEventElapsedTime(&ms45, ev[4], ev[5]);
+        (void) hipEventElapsedTime(&ms05, ev[0], ev[5]);
+        stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
+    }
+    if (stt.n_windows > 0 && !raw->invalid) {            // what the next scan of this set of PWMs may expect (scan_locked)
+        pwms->pred_density = (double) n_hits / (double) stt.n_windows;
+        pwms->pred_strand = strand_mask;
+        pwms->pred_cutoff_version = pwms->cutoff_version;
+        pwms->pred_exact_only = exact_only;
+    }
+}
+
+int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out) {
+    *out = nullptr;
+    if (!p || !p->active) { set_error("no pending scan"); return MS_ERR_INVALID; }
+    p->active = false;
+    ms_result *raw = p->raw;
+    p->raw = nullptr;
+    hipError_t he = hipEventSynchronize(p->done);
+    if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
+    const unsigned long long n_cand = p->cand_static + p->h_counters[0], n_hits = p->h_counters[1];
+    if (n_cand <= p->h_counters[2] && n_hits <= p->h_counters[3] && n_hits <= p->n_pred) {     // [2], [3]: the scratch capacities at queue time
+        pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
+        finish_scan(raw, p->ev, pwms, p->n_bases, p->R, p->strand_mask, p->exact_only, n_cand, n_hits, true);
+        *out = raw;
+        return MS_OK;
+    }
+    pwms->pred_margin = std::min(1.0, pwms->pred_margin * 2.0);
+    pwms->pred_density = -1.0;                           // learn again through the exactly-sized form
+    ms_result_free(raw);
+    (void) c;
+    return MS_SCAN_RETRY;
+}
+
+int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
     const size_t lds_fixed = kF6LutBytes + kPfStageBytes;            // the B-operand table and the waves' sequence staging follow the tables
@@ -927,12 +997,15 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
 
     // counters: [0] candidate record slots, [1] hits
     // pre-filter + fp64 stage of one pass, queued on the scan stream (events 0, 1, 2 around the two stages)
+    hipEvent_t *ev = c->ev;                                        // stage events of this scan (a pending scan's own set, below)
     uint64_t cand_static = 0;                                      // the pre-filter waves' own first candidate blocks (set by front)
     auto front = [&](const HitOut &H) -> int {
         cand_static = 0;
         he = hipMemsetAsync(sc.counters, 0, 8 * sizeof(unsigned long long), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
-        (void) hipEventRecord(c->ev[0], c->stream);
+        (void) hipEventRecord(ev[0], c->stream);
+        if (const char *e = measure_env("MS_EXTRA_MEMSETS"))       // measurement: what a tiny kernel costs at this point of a batch stream
+            for (int i = 0; i < atoi(e); i++) (void) hipMemsetAsync(sc.counters + 4, 0, 8, c->stream);
         if (!plan.tiles.empty()) {
             const int n_tiles = (int) plan.tiles.size();
             PfArgs A;
@@ -1000,12 +1073,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             }
             if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return rc;
         }
-        (void) hipEventRecord(c->ev[1], c->stream);
+        (void) hipEventRecord(ev[1], c->stream);
         if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)
             if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_group_fields, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
         if (!plan.exact_motifs.empty())
             if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return rc;
-        (void) hipEventRecord(c->ev[2], c->stream);
+        (void) hipEventRecord(ev[2], c->stream);
         return MS_OK;
     };
     // ordering + coordinates of the first n_sort slots of the hit list into the result block (events 3, 4, 5); n_dev != nullptr:
@@ -1014,7 +1087,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
-        (void) hipEventRecord(c->ev[3], c->stream);
+        (void) hipEventRecord(ev[3], c->stream);
         if (n_sort > 0) {
             size_t need = 0;
             if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
@@ -1029,10 +1102,19 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             size_t have = sc.sort_tmp_bytes;
             if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
         }
-        (void) hipEventRecord(c->ev[4], c->stream);
+        (void) hipEventRecord(ev[4], c->stream);
         if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_sort, n_dev, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
                                   raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) return rc;
-        (void) hipEventRecord(c->ev[5], c->stream);
+        if ((flags & MS_SCAN_PACK_INTERNAL) && n_sort > 0) {
+            const size_t n_round = (n_sort + 65535) & ~(size_t) 65535;
+            if ((rc = pool_alloc(c, 8 * n_round + 256, &raw->coord_blk, &raw->coord_bytes))) return rc;
+            raw->d_coord = static_cast<uint64_t *>(raw->coord_blk);
+            raw->d_coord_bad = reinterpret_cast<unsigned int *>(raw->d_coord + n_round);
+            he = hipMemsetAsync(raw->d_coord_bad, 0, sizeof(unsigned int), c->stream);
+            if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+            if ((rc = launch_pack_hits((int64_t) n_sort, n_dev, raw->d_seq_idx, raw->d_pos, raw->d_strand, raw->d_coord, raw->d_coord_bad, c->stream))) return rc;
+        }
+        (void) hipEventRecord(ev[5], c->stream);
         // the complete per-motif offsets are on the device; one copy brings them to the host
         he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
         if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
@@ -1059,29 +1141,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         dev_free(d_clk);
     };
     auto finish = [&](unsigned long long n_cand, unsigned long long n_hits, bool with_back) {
-        stt.n_candidates = (int64_t) n_cand;
-        stt.n_hits = (int64_t) n_hits;
-        raw->n_hits = (int64_t) n_hits;
-        int64_t pwm_bytes = 0;
-        for (int32_t p = 0; p < pwms->P; p++) pwm_bytes += 32LL * pwms->widths[p];
-        // compulsory HBM bytes of one call
-        stt.hbm_bytes_algorithmic = (seqs->n_bases + 3) / 4 + (seqs->n_bases + 7) / 8 + 8 * (seqs->R + 1) + pwm_bytes + 16 * (int64_t) n_hits + 8LL * pwms->P;
-        float ms01 = 0, ms12 = 0, ms34 = 0, ms45 = 0, ms05 = 0;
-        (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
-        (void) hipEventElapsedTime(&ms12, c->ev[1], c->ev[2]);
-        stt.ms_prefilter = ms01; stt.ms_exact = ms12; stt.ms_total = ms01 + ms12;
-        if (with_back) {
-            (void) hipEventElapsedTime(&ms34, c->ev[3], c->ev[4]);
-            (void) hipEventElapsedTime(&ms45, c->ev[4], c->ev[5]);
-            (void) hipEventElapsedTime(&ms05, c->ev[0], c->ev[5]);
-            stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
-        }
-        if (stt.n_windows > 0 && !raw->invalid) {            // what the next scan of this set of PWMs may expect (below)
-            pwms->pred_density = (double) n_hits / (double) stt.n_windows;
-            pwms->pred_strand = strand_mask;
-            pwms->pred_cutoff_version = pwms->cutoff_version;
-            pwms->pred_exact_only = exact_only;
-        }
+        finish_scan(raw, ev, pwms, seqs->n_bases, seqs->R, strand_mask, exact_only, n_cand, n_hits, with_back);
     };
 
     // ---- one-sync form: sizes PREDICTED from the previous scan of these PWMs.  The hit density of a motif set at its cutoffs is a
@@ -1092,8 +1152,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // synchronisation at the very end validates the prediction.  A wrong prediction (count above the margin, or a scratch buffer
     // too small) costs a second, exactly-sized run below and doubles the margin of the next scans.
     const bool predicted = pwms->pred_density >= 0 && pwms->pred_strand == strand_mask && pwms->pred_cutoff_version == pwms->cutoff_version &&
-                           pwms->pred_exact_only == exact_only && !(flags & MS_SCAN_RAW_INTERNAL) && !pf_meas && !measure_env("MS_NO_PREDICT");
+                           pwms->pred_exact_only == exact_only && !(flags & (MS_SCAN_RAW_INTERNAL | MS_SCAN_NO_PREDICT_INTERNAL)) && !pf_meas &&
+                           !measure_env("MS_NO_PREDICT");
     if (predicted) {
+        if (pend) ev = pend->ev;
         const double mu = pwms->pred_density * (double) stt.n_windows;
         const size_t n_pred = (size_t) std::min<double>(mu * (1.0 + pwms->pred_margin) + 6.0 * std::sqrt(mu + 1.0) + 256.0, 3.0e9);
         want_hits = std::max(want_hits, n_pred);
@@ -1105,6 +1167,26 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if ((rc = front(H))) return fail(rc);
         if ((rc = launch_fill_tail(sc.keys, sc.counters + 1, n_pred, c->stream))) return fail(rc);
         if ((rc = back(n_pred, sc.counters + 1))) return fail(rc);
+        if (pend) {
+            // queued, not waited for: the owner queues its next scan behind this one first (everything is in order on one stream:
+            // the next scan's kernels only touch the shared scratch after this scan's are done; a scratch buffer that has to grow
+            // is freed by hipFree, which waits for the device)
+            he = hipMemcpyAsync(pend->h_counters, sc.counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipEventRecord(pend->done, c->stream);
+            if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
+            pend->h_counters[2] = sc.cand_cap;
+            pend->h_counters[3] = sc.hit_cap;
+            pend->active = true;
+            pend->raw = raw;
+            pend->n_pred = n_pred;
+            pend->cand_static = cand_static;
+            pend->n_bases = seqs->n_bases;
+            pend->R = seqs->R;
+            pend->strand_mask = strand_mask;
+            pend->exact_only = exact_only;
+            *out = nullptr;
+            return MS_SCAN_PENDING;
+        }
         he = hipMemcpyAsync(sc.h_counters, sc.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
@@ -1116,10 +1198,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             *out = raw;
             return MS_OK;
         }
-        // the prediction failed: give the block back and run again with exact sizes
+        // the prediction failed: give the blocks back and run again with exact sizes
         pool_free(c, raw->block, raw->block_bytes);
         raw->block = nullptr;
         raw->block_bytes = 0;
+        if (raw->coord_blk) { pool_free(c, raw->coord_blk, raw->coord_bytes); raw->coord_blk = nullptr; raw->d_coord = nullptr; raw->d_coord_bad = nullptr; }
         pwms->pred_margin = std::min(1.0, pwms->pred_margin * 2.0);
         stt.n_passes = 1;
         want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
@@ -1266,7 +1349,20 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
             r->h_pinned = pinned_alloc(bytes, &r->h_pinned_bytes);
             if (!r->h_pinned) { set_error("pinned host allocation of %zu bytes failed", bytes); return MS_ERR_NOMEM; }
         }
-        if (n > 0) {
+        if (n > 0 && r->d_coord) {                      // the scan made the coordinate words already: copies only
+            DeviceCtx *c;
+            int rc = get_ctx(r->device, &c);
+            if (rc) return rc;
+            unsigned int bad = 0;
+            const hipStream_t down = c->stream_down;
+            char *hb = static_cast<char *>(r->h_pinned);
+            hipError_t he = hipMemcpyAsync(hb, r->d_coord, 8 * n, hipMemcpyDeviceToHost, down);
+            if (he == hipSuccess) he = hipMemcpyAsync(hb + 8 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, down);
+            if (he == hipSuccess) he = hipMemcpyAsync(&bad, r->d_coord_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, down);
+            const hipError_t hs = hipStreamSynchronize(down);
+            if (he != hipSuccess || hs != hipSuccess) { set_error("compact copy-out failed: %s", hipGetErrorString(he != hipSuccess ? he : hs)); return MS_ERR_RUNTIME; }
+            if (bad) { set_error("a hit does not fit the compact form (needs seq_idx < 2^32 and pos < 2^31): use ms_result_hits_host"); return MS_ERR_INVALID; }
+        } else if (n > 0) {
             DeviceCtx *c;
             int rc = get_ctx(r->device, &c);
             if (rc) return rc;
@@ -1278,7 +1374,7 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
             unsigned int bad = 0;
             const hipStream_t down = c->stream_down;
             hipError_t he = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), down);
-            if (he == hipSuccess) rc = launch_pack_hits((int64_t) n, r->d_seq_idx, r->d_pos, r->d_strand, d_coord, d_bad, down);
+            if (he == hipSuccess) rc = launch_pack_hits((int64_t) n, nullptr, r->d_seq_idx, r->d_pos, r->d_strand, d_coord, d_bad, down);
             char *hb = static_cast<char *>(r->h_pinned);
             if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb, d_coord, 8 * n, hipMemcpyDeviceToHost, down);
             if (he == hipSuccess && !rc) he = hipMemcpyAsync(hb + 8 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, down);
@@ -1352,6 +1448,11 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     if (pwms->P != r->P) { set_error("result and PWM set disagree on the number of PWMs"); return MS_ERR_INVALID; }
     if (r->deduped || r->n_hits == 0) { r->deduped = true; return MS_OK; }
+    if (r->coord_blk) {                                  // coordinate words of the hits before de-duplication: void
+        DeviceCtx *c0;
+        if (get_ctx(r->device, &c0) == MS_OK) pool_free(c0, r->coord_blk, r->coord_bytes); else (void) hipFree(r->coord_blk);
+        r->coord_blk = nullptr; r->d_coord = nullptr; r->d_coord_bad = nullptr;
+    }
     DeviceCtx *c;
     int rc = get_ctx(r->device, &c);
     if (rc) return rc;
@@ -1439,11 +1540,10 @@ void ms_result_free(ms_result *r) {
     if (!r) return;
     (void) hipSetDevice(r->device);
     if (r->h_pinned) pinned_free(r->h_pinned, r->h_pinned_bytes);
-    if (r->block) {
-        DeviceCtx *c = nullptr;
-        if (get_ctx(r->device, &c) == MS_OK) pool_free(c, r->block, r->block_bytes);
-        else (void) hipFree(r->block);
-    }
+    DeviceCtx *c = nullptr;
+    const bool have = (r->block || r->coord_blk) && get_ctx(r->device, &c) == MS_OK;
+    if (r->block) { if (have) pool_free(c, r->block, r->block_bytes); else (void) hipFree(r->block); }
+    if (r->coord_blk) { if (have) pool_free(c, r->coord_blk, r->coord_bytes); else (void) hipFree(r->coord_blk); }
     delete r;
 }
 

@@ -167,6 +167,7 @@ struct ms_seqset {
     int64_t *d_offsets = nullptr;
     int32_t *d_blk2reg = nullptr;         // region of position 64*b
     hipStream_t up = nullptr;             // the upload stream this set is being built on (DeviceCtx::stream_up, read once)
+    bool built = false;                   // construction finished (its work on `up` is done)
 };
 
 struct ms_result {
@@ -186,6 +187,10 @@ struct ms_result {
     unsigned long long *d_region_counts = nullptr;   // [P]
     int64_t *d_motif_first = nullptr;                 // [P+1]: after ms_scan returns, the per-motif offsets
     std::vector<int64_t> motif_offsets;               // [P+1]
+    void *coord_blk = nullptr;                        // MS_SCAN_PACK_INTERNAL: the compact coordinate words, made by the scan itself ...
+    size_t coord_bytes = 0;
+    uint64_t *d_coord = nullptr;                      // ... [n slots] + a "does not fit" flag word behind them
+    unsigned int *d_coord_bad = nullptr;
     void *h_pinned = nullptr;                         // host copy of the hit arrays (pinned), made on demand
     bool h_packed = false;                            // ... in the compact form (coord | score)
     size_t h_pinned_bytes = 0;
@@ -201,8 +206,38 @@ namespace ms {
 // hits anyway (ms_scan_regions_once) and keep holding c->mu until they are done with the scratch.
 #define MS_SCAN_RAW_INTERNAL 0x80000000u
 
-// The scan pipeline proper (ms_api.hip); the caller holds c->mu and pwms->mu.
-int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out);
+// Internal scan flag: also produce the compact coordinate words (ms_result_hits_packed_host) at the end of the scan, on the scan
+// stream -- a batch stream's copy-out then consists of copies only (a pack kernel launched on the copy-out stream would wait for
+// the next batch's pre-filter, whose persistent blocks fill every CU).
+#define MS_SCAN_PACK_INTERNAL 0x20000000u
+// Internal scan flag: never use the predicted-size form (the exactly-sized re-run after a failed prediction).
+#define MS_SCAN_NO_PREDICT_INTERNAL 0x40000000u
+
+// A scan whose launches are all queued but whose completion has not been waited for (the predicted-size form, scan_locked with
+// pend != nullptr): the owner -- a batch stream's scanner thread -- queues the NEXT batch's scan behind it before it waits, so
+// the device never idles between batches.  The slot's events and pinned counter words belong to one scan at a time.
+struct PendingScan {
+    hipEvent_t ev[6] = {};                   // around the stages, as DeviceCtx::ev
+    hipEvent_t done = nullptr;
+    unsigned long long *h_counters = nullptr;   // pinned, 4 words
+    bool active = false;
+    ms_result *raw = nullptr;
+    size_t n_pred = 0;
+    uint64_t cand_static = 0;
+    int64_t n_bases = 0, R = 0;
+    int strand_mask = 3;
+    bool exact_only = false;
+};
+constexpr int MS_SCAN_PENDING = 1000;        // scan_locked: queued, call scan_complete
+constexpr int MS_SCAN_RETRY = 1001;          // scan_complete: the prediction failed, run scan_locked(..., MS_SCAN_NO_PREDICT_INTERNAL) again
+int pending_scan_init(PendingScan *p);
+void pending_scan_destroy(PendingScan *p);
+// waits for a pending scan; MS_OK: *out is the result; MS_SCAN_RETRY: nothing was produced.  The caller holds pwms->mu.
+int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out);
+
+// The scan pipeline proper (ms_api.hip); the caller holds c->mu and pwms->mu.  pend != nullptr: if the sizes can be predicted the
+// scan is only QUEUED (returns MS_SCAN_PENDING, finish with scan_complete); otherwise it runs to the end as usual.
+int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend = nullptr);
 // Hand the hits of a span scan (one region) to the windows of a fixed-stride sweep, in place of *span_res (ms_api.hip);
 // the caller holds c->mu and pwms->mu.
 int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *span_res, int64_t span_bases, int32_t window, int32_t stride,

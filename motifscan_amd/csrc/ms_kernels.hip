@@ -996,9 +996,10 @@ __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict_
 
 // coord = seq_idx << 32 | pos << 1 | (strand - 1): 8 bytes per hit on the host link instead of 17 (ms_result_hits_packed_host).
 // bad[0] is set if a hit does not fit the format.
-__global__ void __launch_bounds__(256) pack_hits_kernel(int64_t n, const int64_t *__restrict__ seq_idx, const int64_t *__restrict__ pos,
-                                                        const int8_t *__restrict__ strand, uint64_t *__restrict__ coord,
-                                                        unsigned int *__restrict__ bad) {
+__global__ void __launch_bounds__(256) pack_hits_kernel(int64_t n, const unsigned long long *__restrict__ n_dev, const int64_t *__restrict__ seq_idx,
+                                                        const int64_t *__restrict__ pos, const int8_t *__restrict__ strand,
+                                                        uint64_t *__restrict__ coord, unsigned int *__restrict__ bad) {
+    if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }     // (finalize_kernel: a predicted-size scan)
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t sq = (uint64_t) seq_idx[i], ps = (uint64_t) pos[i];
@@ -1006,10 +1007,10 @@ __global__ void __launch_bounds__(256) pack_hits_kernel(int64_t n, const int64_t
     coord[i] = (sq << 32) | ((ps & 0x7FFFFFFFull) << 1) | (uint64_t) (strand[i] == 2 ? 1 : 0);
 }
 
-int launch_pack_hits(int64_t n, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord, unsigned int *bad,
-                     hipStream_t st) {
+int launch_pack_hits(int64_t n, const unsigned long long *n_dev, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord,
+                     unsigned int *bad, hipStream_t st) {
     if (n == 0) return MS_OK;
-    hipLaunchKernelGGL(pack_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, seq_idx, pos, strand, coord, bad);
+    hipLaunchKernelGGL(pack_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, n_dev, seq_idx, pos, strand, coord, bad);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -40,6 +40,19 @@ public:
         q_.push_back(j);
         not_empty_.notify_one();
     }
+    // true: *out is a job, or nullptr when the queue is closed and drained; false: nothing there right now
+    bool try_pop(Job **out) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (q_.empty()) {
+            if (!closed_) return false;
+            *out = nullptr;
+            return true;
+        }
+        *out = q_.front();
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
     Job *pop() {                      // nullptr = closed and drained
         std::unique_lock<std::mutex> lk(mu_);
         not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
@@ -122,26 +135,97 @@ struct ms_stream {
         });
     }
 
-    void scanner() {
-        run_stage(1, *q_up, *q_scan, [this](Job *j) {
-            if (j->rc == MS_OK) {
-                DeviceCtx *c = nullptr;
-                int rc = get_ctx(device, &c);
-                if (!rc) {
-                    std::lock_guard<std::mutex> lk_dev(c->mu);
-                    std::lock_guard<std::mutex> lk_pwm(pwms->mu);
-                    rc = scan_locked(c, pwms, j->seqs, strand, (flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT, &j->res);
-                    if (!rc && j->kind == 1) {
-                        ms_result *r1 = j->res;
-                        j->res = nullptr;
-                        rc = sweep_handout_locked(c, pwms, r1, j->seqs->n_bases, j->window, j->stride, j->n_windows, &j->res);
-                    }
-                }
-                if (!rc && (flags & MS_STREAM_DEDUP)) rc = ms_result_dedup(j->res, pwms);
-                if (rc) fail_job(j, rc);
+    // The scan stage keeps ONE scan queued behind the one it is waiting for: a plain batch whose sizes can be predicted
+    // (scan_locked with a PendingScan) is only queued; the stage then takes the next batch, queues its scan too, and only then
+    // waits for the first -- the device goes from one batch's last kernel straight into the next batch's first.  Sweep spans
+    // and de-duplicated batches need their result at once and run to the end as before.
+    PendingScan pend_slot[2];
+    bool pend_ok = false;
+
+    // returns true if the job's scan is pending (finish with scan_finish), false if the job is done (or failed)
+    bool scan_start(Job *j, PendingScan *slot) {
+        if (j->rc != MS_OK) return false;
+        DeviceCtx *c = nullptr;
+        int rc = get_ctx(device, &c);
+        bool pending = false;
+        if (!rc) {
+            std::lock_guard<std::mutex> lk_dev(c->mu);
+            std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+            const bool simple = j->kind == 0 && !(flags & MS_STREAM_DEDUP);
+            const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) |
+                                ((simple && (flags & MS_STREAM_PACKED) && !(flags & MS_STREAM_NO_HITS)) ? MS_SCAN_PACK_INTERNAL : 0u);
+            const bool plain = simple && pend_ok && slot;
+            rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? slot : nullptr);
+            if (rc == MS_SCAN_PENDING) { rc = MS_OK; pending = true; }
+            if (!rc && !pending && j->kind == 1) {
+                ms_result *r1 = j->res;
+                j->res = nullptr;
+                rc = sweep_handout_locked(c, pwms, r1, j->seqs->n_bases, j->window, j->stride, j->n_windows, &j->res);
             }
-            if (j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
-        });
+        }
+        if (!rc && !pending && (flags & MS_STREAM_DEDUP)) rc = ms_result_dedup(j->res, pwms);
+        if (rc) fail_job(j, rc);
+        if (!pending && j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
+        return pending;
+    }
+
+    void scan_finish(Job *j, PendingScan *slot) {
+        DeviceCtx *c = nullptr;
+        int rc = get_ctx(device, &c);
+        if (!rc) {
+            {
+                std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+                rc = scan_complete(c, pwms, slot, &j->res);
+            }
+            if (rc == MS_SCAN_RETRY) {                       // the predicted sizes were too small: once more, exactly sized
+                std::lock_guard<std::mutex> lk_dev(c->mu);
+                std::lock_guard<std::mutex> lk_pwm(pwms->mu);
+                const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) | MS_SCAN_NO_PREDICT_INTERNAL |
+                                    (((flags & MS_STREAM_PACKED) && !(flags & MS_STREAM_NO_HITS)) ? MS_SCAN_PACK_INTERNAL : 0u);
+                rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res);
+            }
+        }
+        if (rc) fail_job(j, rc);
+        if (j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
+    }
+
+    void scanner() {
+        set_current_device(device);
+        (void) hipSetDevice(device);
+        pend_ok = pending_scan_init(&pend_slot[0]) == MS_OK && pending_scan_init(&pend_slot[1]) == MS_OK;
+        JobQueue &in = *q_up, &out = *q_scan;
+        Job *waiting = nullptr;                               // its scan is queued on the device, not yet waited for
+        int wslot = 0;
+        bool drained = false;
+        auto span = [&](std::atomic<uint64_t> &acc, auto &&fn) { const double t0 = now_s(); fn(); StageClock::add(acc, now_s() - t0); };
+        while (!drained || waiting) {
+            Job *j = nullptr;
+            if (!drained) {
+                bool have = true;
+                span(clk[1].wait_in_us, [&] {
+                    if (waiting) have = in.try_pop(&j);              // a scan is in flight: take the next batch only if it is already there
+                    else j = in.pop();
+                });
+                if (have && !j) drained = true;
+            }
+            bool j_pending = false;
+            if (j) span(clk[1].work_us, [&] { j_pending = scan_start(j, &pend_slot[wslot ^ 1]); });   // queued BEHIND the waiting scan (or run to the end)
+            if (waiting) {
+                span(clk[1].work_us, [&] { scan_finish(waiting, &pend_slot[wslot]); });
+                span(clk[1].wait_out_us, [&] { out.push(waiting); });
+                clk[1].jobs.fetch_add(1);
+                waiting = nullptr;
+            }
+            if (j) {
+                if (j_pending) { waiting = j; wslot ^= 1; }
+                else {
+                    span(clk[1].wait_out_us, [&] { out.push(j); });
+                    clk[1].jobs.fetch_add(1);
+                }
+            }
+        }
+        out.close();
+        if (pend_ok) { pending_scan_destroy(&pend_slot[0]); pending_scan_destroy(&pend_slot[1]); }
     }
 
     void downloader() {
