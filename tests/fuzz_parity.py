@@ -5,7 +5,7 @@ to sit ON the decision boundary of cscore.c:360-389 (`score / max_raw - cutoff >
   * matrices with few distinct values (integers, halves, one repeated value) so many windows tie;
   * cutoffs placed exactly on attainable scores (k / max_raw), one ulp either side of them, and
     1e-10 either side (the reference's own slack);
-  * widths 1..40 (both sides of the 32-column fast path), all-negative matrices (max_raw == 0),
+  * widths 1..66 (every k-block class of the pre-filter, and the all-fp64 kernel past 63 columns), all-negative matrices (max_raw == 0),
     huge / tiny magnitudes, cutoffs <= 0 (everything hits) and > 1 (nothing can);
   * sequences with N runs, lower case, other IUPAC letters, empty and shorter-than-W regions.
 
@@ -110,7 +110,7 @@ def attainable_cutoff(rng, m, seqs):
 def make_case(seed):
     rng = np.random.default_rng(seed)
     n_motifs = int(rng.choice([1, 2, 5, 13, 40, 97, 200]))
-    wmax = int(rng.choice([8, 16, 32, 40]))
+    wmax = int(rng.choice([8, 16, 32, 40, 66]))            # 66: row tiles of 3 and 4 k-blocks, and the all-fp64 kernel past 63 columns
     mats = [random_matrix(rng, int(rng.integers(1, wmax + 1))) for _ in range(n_motifs)]
     seqs = random_sequences(rng, int(rng.choice([1, 7, 60, 300])), int(rng.choice([20, 150, 700])))
     cutoffs = np.array([attainable_cutoff(rng, m, seqs) for m in mats], dtype=np.float64)

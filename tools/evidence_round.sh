@@ -1,32 +1,40 @@
 # Round evidence on the GPU box: tests, bench lines, profiles.  Usage: bash tools/evidence_round.sh <tag> [quick]
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
-python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -n 2 $OUT/pytest_gpu.log
+python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -n 2 $OUT/pytest_gpu.log
 if [ "$2" = "quick" ]; then QUICK=1; fi
 python bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 MS_BENCH_BACKEND=gloo MS_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 5 --no-cpu-baseline > $OUT/bench_c4_2ranks_one_gpu_gloo.json 2> $OUT/bench_c4_2ranks_one_gpu_gloo.log
+python bench.py --gpus 9 > $OUT/bench_refuses_9_ranks.log 2>&1; echo "exit code $?" >> $OUT/bench_refuses_9_ranks.log
 if [ -z "$QUICK" ]; then
 python bench.py --workload c3 --no-end-to-end > $OUT/bench_c3.json 2> /dev/null
 python bench.py --workload c2 --steps 200 --warmup 20 --no-end-to-end > $OUT/bench_c2.json 2> /dev/null
 python bench.py --workload c5shard --steps 4 --warmup 1 > $OUT/bench_c5shard.json 2> /dev/null
 python bench.py --workload c5 --genome-mbp 3000 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_3000mbp.json 2> $OUT/bench_c5.err
-python tools/pf_clock.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_clock.log
+# side workloads: other p-values, one strand, motifs wider than 32 columns -- on the full configs[3] regions
+python bench.py --no-cpu-baseline --no-end-to-end --p-value 1e-3 > $OUT/bench_c4_p1e-3.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-end-to-end --p-value 1e-5 > $OUT/bench_c4_p1e-5.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-end-to-end --strand + > $OUT/bench_c4_strand_plus.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-end-to-end --extra-widths 33,40 > $OUT/bench_c4_plus_w33_w40.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-end-to-end --extra-widths 30,30 > $OUT/bench_c4_plus_w30_w30.json 2> /dev/null
+python tools/pf_variants.py c4shard 3 1e-4 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_stage_times.log
+python tools/pf_variants.py c4shard 3 1e-3 2>&1 | grep -v amdgpu.ids >> $OUT/prefilter_stage_times.log
+python tools/pf_variants.py c4shard 1 1e-4 2>&1 | grep -v amdgpu.ids >> $OUT/prefilter_stage_times.log
+EXTRA_W=33,40 python tools/pf_variants.py c4shard 3 1e-4 2>&1 | grep -v amdgpu.ids >> $OUT/prefilter_stage_times.log
 python tools/pf_uniform.py 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_uniform_width.log
-python tools/pf_variants.py c4shard 46:2 44:2 47:1 31:1 28:1 29:1 30:2 33:2 16:1 4:1 2>&1 | grep -v amdgpu.ids > $OUT/prefilter_variants.log
+python tools/pf_zero_operands.py 2>&1 | grep -v amdgpu.ids > $OUT/operand_activity.log
+python tools/pf_many_motifs.py 2>&1 | grep -v amdgpu.ids > $OUT/many_motifs.log
 python tools/once_overlap.py 2>&1 | grep -v amdgpu.ids > $OUT/scan_once_overlap.log
 python tools/n_fraction.py 2>&1 | grep -v amdgpu.ids > $OUT/n_fraction.log
-./tools/ubench/mfma_i8_rate > $OUT/mfma_i8_rate.log 2>&1
-./tools/ubench/mfma_f6_probe > $OUT/mfma_f6_probe.log 2>&1
-timeout 60 ./tools/ubench/valu_rate.bin > $OUT/valu_rate.log 2>&1
-timeout 60 ./tools/ubench/issue_model.bin > $OUT/issue_model.log 2>&1
-timeout 100 ./tools/ubench/cumask_probe.bin > $OUT/cumask_probe.log 2>&1
-timeout 60 ./tools/ubench/cu_share_probe.bin > $OUT/cu_share_probe.log 2>&1
-python tools/h2d_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/h2d_probe.log
+python tools/c2_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/c2_latency.log
 python tools/c2_scaling.py 2>&1 | grep -v amdgpu.ids > $OUT/c2_scaling.log
-python bench.py --workload c5 --genome-mbp 3000 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_3000mbp_again.json 2> /dev/null
-python tests/fuzz_parity.py --cases 1500 --seed 20000 > $OUT/fuzz.log 2>&1
-python tests/fuzz_parity.py --cases 300 --seed 30000 --sweep >> $OUT/fuzz.log 2>&1
+python tools/fixed_cost.py 2>&1 | grep -v amdgpu.ids > $OUT/fixed_cost.log
+python tools/e2e_stages.py 125000 2 2>&1 | grep -v amdgpu.ids > $OUT/e2e_stages.log
+./tools/ubench/insp_probe.bin > $OUT/insp_probe.log 2>&1
+timeout 60 ./tools/ubench/issue_model.bin > $OUT/issue_model.log 2>&1
+python tests/fuzz_parity.py --cases 1500 --seed 40000 > $OUT/fuzz.log 2>&1
+python tests/fuzz_parity.py --cases 300 --seed 50000 --sweep >> $OUT/fuzz.log 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export MS_SYNTH_WORKERS=1      # no forked workers under rocprofv3 (a forked child once hung in the tool's signal handler: 46 minutes)
@@ -41,5 +49,6 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/
 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/lds -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/lds.err
 for q in sq1 sq2 fetch write lds; do python3 tools/pmc_summary.py $P/$q $OUT/pmc_$q.csv; done
 cp $(ls $P/stats/*/*kernel_stats.csv | head -n 1) $OUT/kernel_stats_c4.csv
-rm -rf $P/sq1 $P/sq2 $P/fetch $P/write $P/lds $P/stats
+cp $P/bench_under_rocprof.json $OUT/bench_under_rocprof_c4.json
+rm -rf $P
 ls $OUT

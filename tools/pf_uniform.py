@@ -24,14 +24,12 @@ def run(tag, pw):
         lds = best["lds_bytes_read"] / (best["ms_prefilter"] * 1e-3)
         line = (f"{tag:28s} noemit {noemit}: {best['ms_prefilter']:.3f} ms, tiles {best['n_tiles']}, cand {best['n_candidates']}, "
                 f"LDS {lds/1e12:.1f} TB/s = {100*lds/(256*256*best['pf_clock_mhz']*1e6):.1f}% at {best['pf_clock_mhz']:.0f} MHz")
-        if best["pf_engine"] == 1:                                   # matrix-core engine: cycles per instruction per SIMD
-            n_mfma = best["mfma_ops"] / 65536 / 1024
+        if best["pf_engine"] == 3:                                   # cycles per matrix instruction (32x32x64: 131072 ops) per SIMD
+            n_mfma = best["mfma_ops"] / 131072 / 1024
             line += f", {best['ms_prefilter'] * 1e-3 * best['pf_clock_mhz'] * 1e6 / n_mfma:.1f} cycles per MFMA per SIMD"
         print(line, flush=True)
 
-if os.environ.get("MS_PF_VARIANT"):
-    print("MS_PF_VARIANT", os.environ["MS_PF_VARIANT"])
-only = [int(x) for x in os.environ.get("PF_WIDTHS", "8,12,16,21").split(",")]
+only = [int(x) for x in os.environ.get("PF_WIDTHS", "8,12,15,16,21").split(",")]
 run("benchmark set", _lib.PwmSet(vals, widths, cutoffs))
 for W in only:
     sel = [i for i in range(579) if widths[i] == W]

@@ -13,14 +13,7 @@ os.environ["MS_PF_NOEMIT"] = os.environ.get("NOEMIT", "1")
 wl = synth.workload("c4shard")
 sq = _lib.SeqSet(*wl["sets"][0])
 cases = [("benchmark tables", wl["cutoffs"], None), ("all-dead tables (zeros)", np.full(len(wl["cutoffs"]), 2.0), None)]
-for bq in os.environ.get("BQ_LIST", "").split(","):
-    if bq:
-        cases.append((f"benchmark tables, <= {bq} levels", wl["cutoffs"], bq))
 for tag, cut, bq in cases + cases:              # every case twice: order effects show
-    if bq:
-        os.environ["MS_PF_BQ_MAX"] = bq
-    else:
-        os.environ.pop("MS_PF_BQ_MAX", None)
     pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], cut)
     best = None
     for _ in range(6):
