@@ -883,6 +883,8 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
     if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
     const unsigned long long n_cand = p->cand_static + p->h_counters[0], n_hits = p->h_counters[1];
     if (n_cand <= p->h_counters[2] && n_hits <= p->h_counters[3] && n_hits <= p->n_pred) {     // [2], [3]: the scratch capacities at queue time
+        he = hipMemcpy(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
         pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
         finish_scan(raw, p->ev, pwms, p->n_bases, p->R, p->strand_mask, p->exact_only, n_cand, n_hits, true);
         *out = raw;
@@ -1115,9 +1117,13 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             if ((rc = launch_pack_hits((int64_t) n_sort, n_dev, raw->d_seq_idx, raw->d_pos, raw->d_strand, raw->d_coord, raw->d_coord_bad, c->stream))) return rc;
         }
         (void) hipEventRecord(ev[5], c->stream);
-        // the complete per-motif offsets are on the device; one copy brings them to the host
-        he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-        if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+        // the complete per-motif offsets are on the device; one copy brings them to the host.  (Not for a scan that is only being
+        // QUEUED: the destination is pageable memory, for which the "async" copy makes the host wait for everything queued before
+        // it -- scan_complete fetches the offsets once the scan is done.)
+        if (!pend) {
+            he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+            if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+        }
         return MS_OK;
     };
     auto result_block = [&](size_t n) -> int {
