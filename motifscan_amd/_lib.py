@@ -134,7 +134,7 @@ def lib():
         "ms_score_ranks": (c_int, [vp, vp, c_int, pi64, c_i32, pd]),
         "ms_dedup_hits": (c_int, [pi64, c_i32, pi32, pi64, pi64, pd, pi8, pu8]),
         "ms_debug_plan_dims": (c_int, [vp, c_int, c_i64, pi32, pi32, pi32, pi32]),
-        "ms_debug_plan_rows": (c_int, [vp, pi32, ctypes.POINTER(ctypes.c_int16), pi32, pi32, pi32, pi32]),
+        "ms_debug_plan_rows": (c_int, [vp, pi32, ctypes.POINTER(ctypes.c_int16), pi32, pi32, pi32, pi32, pi32, pi32]),
         "ms_debug_release_scratch": (c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -225,7 +225,8 @@ class PwmSet:
         """Host-side view of the pre-filter plan, decoded from the operand image the kernel reads (tests only):
         group_fields [groups][16] motif of the field (-1 empty; both strands: field n = slot n >> 1, even forward, odd reverse;
         one strand: field n = slot n), rows [groups][16][64 columns][4 bases] and bias [groups][16] in units of 1/8,
-        group_kb [groups] k-blocks of 16 columns."""
+        group_kb [groups] matrix instructions per row tile, group_cols [groups] columns of the group's fields incl. the bias
+        column (16 per instruction; paired rows: 8), group_paired [groups] 0 = plain row, 1 / 2 = field X / Y of a paired row."""
         L = lib()
         nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
         check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
@@ -236,10 +237,14 @@ class PwmSet:
         rows = np.zeros((nq.value, 16, 64, 4), dtype=np.int16)
         bias = np.zeros((nq.value, 16), dtype=np.int32)
         kb = np.zeros(nq.value, dtype=np.int32)
+        cols = np.zeros(nq.value, dtype=np.int32)
+        paired = np.zeros(nq.value, dtype=np.int32)
         check(L.ms_debug_plan_rows(self.h, ptr(gf, ctypes.c_int32), ptr(rows, ctypes.c_int16), ptr(bias, ctypes.c_int32),
-                                   ptr(kb, ctypes.c_int32), ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
+                                   ptr(kb, ctypes.c_int32), ptr(cols, ctypes.c_int32), ptr(paired, ctypes.c_int32),
+                                   ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
         return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "strand_mask": strand_mask, "group_fields": gf,
-                "rows": rows, "bias": bias, "group_kb": kb, "exact_motifs": ex[:ne.value], "tile_first_group": tf}
+                "rows": rows, "bias": bias, "group_kb": kb, "group_cols": cols, "group_paired": paired,
+                "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 
     def close(self):
         if getattr(self, "h", None):

@@ -357,8 +357,10 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
 
 static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool exact_only, bool need_device,
                        int device) {
+    const char *pe = measure_env("MS_PF_PAIR");                          // measurement only: "0" = no paired rows
+    const bool pair_rows = !(pe && pe[0] == '0');
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
-                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only;
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_pair != pair_rows;
     if (stale) {
         if (exact_only) {
             p->plan = PrefilterPlan();
@@ -366,10 +368,11 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
             int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(), p->max_raw.data(),
-                                p->P, strand_mask, lds_budget, &p->plan);
+                                p->P, strand_mask, lds_budget, pair_rows, &p->plan);
             if (rc) return rc;
         }
         p->plan_strand = strand_mask;
+        p->plan_pair = pair_rows;
         p->plan_cutoff_version = p->cutoff_version;
         p->plan_lds = lds_budget;
         p->plan_exact_only = exact_only;
@@ -1014,6 +1017,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16; A.stage_off16 = lut_off16 + (uint32_t) (kF6LutBytes / 16);
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
+            A.unit_slots = 0; A.unit_cnt = nullptr;
             // While a batch stream is live and the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs (the
             // units are handed out dynamically: fewer blocks just take more each)
             const int reserve = c->n_streams.load() > 0 ? c->n_cu_copy : 0;
@@ -1829,10 +1833,11 @@ int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_bud
 // The plan built by the last ms_debug_plan_dims call, decoded from the PHYSICAL operand image the kernel reads (any pointer
 // may be NULL): group_fields [n_groups][16] motif of the field (-1 = empty), rows [n_groups][16 fields][64 columns][4 bases]
 // int16 = what the product adds for that base at that column, units of 1/8 (the bias column reads 0 here), bias [n_groups][16]
-// = the entry of the row tile's last column (MS_ERR_RUNTIME if its four bases disagree), group_kb [n_groups] k-blocks,
-// exact_motifs [n_exact], tile_first_group [n_tiles + 1].
+// = the entry of the field's last column (MS_ERR_RUNTIME if its four bases disagree), group_kb [n_groups] matrix instructions
+// per row tile, group_cols [n_groups] columns of the group's fields incl. the bias column (16 per instruction, paired rows: 8),
+// group_paired [n_groups] 0 = plain row, 1 / 2 = field X / Y of a paired row, exact_motifs [n_exact], tile_first_group [n_tiles + 1].
 int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *rows, int32_t *bias, int32_t *group_kb,
-                       int32_t *exact_motifs, int32_t *tile_first_group) {
+                       int32_t *group_cols, int32_t *group_paired, int32_t *exact_motifs, int32_t *tile_first_group) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     std::lock_guard<std::mutex> lk(pwms->mu);
@@ -1847,30 +1852,37 @@ int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *
         tile_first_group[pl.tiles.size()] = (int32_t) nq;
     }
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(pl.tables.data());
-    size_t off = 0;
     for (size_t q = 0; q < nq; q++) {
-        const int kb_n = pl.group_kb[q];
-        const int h = (int) (q & 1);
-        const int n_cols = kF6Cols * kb_n;
-        if (group_kb) group_kb[q] = kb_n;
+        const GroupInfo &gi = pl.group_info[q];
+        const int n_cols = pl.group_cols[q];
+        const uint8_t *tab = bytes + gi.tab_off;
+        // column c of the field: plain rows -- column c % 16 of k-block c / 16; paired rows -- column c % 8 of half-block c / 8 in k-half `sel`
+        auto entry = [&](int row, int c, int b) {
+            return gi.paired ? f6_value(f6_get(tab, c / kPairCols, row, kPairCols * gi.sel + c % kPairCols, b))
+                             : f6_value(f6_get(tab, c / kF6Cols, row, c % kF6Cols, b));
+        };
+        if (group_kb) group_kb[q] = gi.nk;
+        if (group_cols) group_cols[q] = n_cols;
+        if (group_paired) group_paired[q] = gi.paired ? 1 + gi.sel : 0;
         for (int f = 0; f < kGroupFields; f++) {
-            const int row = mfma_row_of(h, f);
-            const int b0 = f6_value(f6_get(bytes + off, (n_cols - 1) / kF6Cols, row, (n_cols - 1) % kF6Cols, 0));
-            for (int b = 1; b < 4; b++)
-                if (f6_value(f6_get(bytes + off, (n_cols - 1) / kF6Cols, row, (n_cols - 1) % kF6Cols, b)) != b0) {
-                    set_error("bias column of group %zu field %d differs between bases", q, f);
-                    return MS_ERR_RUNTIME;
-                }
+            const int row = mfma_row_of(gi.h, f);
+            int b0 = entry(row, n_cols - 1, 0);
+            if (gi.paired) {                                    // what the kernel's constant B slots make of the four entries, less the field offset
+                b0 = -kPairOffset;
+                for (int b = 0; b < 4; b++) b0 += kPairBiasW[b] * entry(row, n_cols - 1, b);
+            } else {
+                for (int b = 1; b < 4; b++)
+                    if (entry(row, n_cols - 1, b) != b0) {
+                        set_error("bias column of group %zu field %d differs between bases", q, f);
+                        return MS_ERR_RUNTIME;
+                    }
+            }
             if (bias) bias[q * kGroupFields + f] = b0;
             if (rows)
                 for (int c = 0; c < kF6Cols * kF6MaxKb; c++)
-                    for (int b = 0; b < 4; b++) {
-                        int v = 0;
-                        if (c < n_cols - 1) v = f6_value(f6_get(bytes + off, c / kF6Cols, row, c % kF6Cols, b));       // units of 1/8
-                        rows[((q * kGroupFields + f) * (kF6Cols * kF6MaxKb) + c) * 4 + b] = (int16_t) v;
-                    }
+                    for (int b = 0; b < 4; b++)
+                        rows[((q * kGroupFields + f) * (kF6Cols * kF6MaxKb) + c) * 4 + b] = (int16_t) (c < n_cols - 1 ? entry(row, c, b) : 0);       // units of 1/8
         }
-        if (h == 1) off += (size_t) kb_n * kF6BytesPerKb;
     }
     return MS_OK;
 }

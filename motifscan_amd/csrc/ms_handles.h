@@ -142,6 +142,7 @@ struct ms_pwmset {
     uint64_t plan_cutoff_version = 0;
     size_t plan_lds = 0;
     bool plan_exact_only = false;
+    bool plan_pair = true;                        // paired rows in the plan (always, but for MS_MEASURE=1 MS_PF_PAIR=0)
     int plan_device = -1;
     uint4 *d_tables = nullptr;
     ms::TileDesc *d_tiles = nullptr;

@@ -73,21 +73,58 @@ __host__ __device__ inline uint64_t cand_pack(uint64_t g, uint32_t group, uint32
 // Non-ACGT bases are all-zero one-hot columns (the kernel clears them in the B operand; the bias column is exempt), exactly the
 // reference's "adds nothing" (cscore.c:345-353): because t_c never exceeds the column's best contribution, dropping a column
 // can only lower acc by less than the true score loses, so windows with N go through the same filter -- no separate N path.
+//
+// PAIRED ROWS (round 3; motifs of <= 15 columns, i.e. most of a JASPAR-like set): the A operand's block scale is per lane = per
+// (row, k-half), so one matrix row can carry TWO fields.  k-half 0 holds 8 columns of field X, k-half 1 holds 8 columns of field Y,
+// BOTH k-halves of the B operand hold the same 8 bases of the window, the block scales are 2^-6 (X) and 2^-18 (Y), and the
+// accumulator starts at the inline constant 4.0 -- whose unit in the last place, 2^-21, is then exactly one level (1/8) of field Y and
+// 2^-12 of a level of field X.  With both fields' sums offset by 1024 levels the result is
+//     4.0 + 2^-21 (2^12 (X + 1024) + (Y + 1024)),     X, Y = the two fields' sums in levels, -1024 <= X, Y < 1024:
+// exact in f32 (an integer below 2^23 on top of the fixed leading bit), bit pattern 0x40800000 | (X + 1024) << 12 | (Y + 1024), i.e.
+// bit 22 <=> X >= 0, bit 10 <=> Y >= 0 (kPairMask).  The offset rides on the bias column: its four k-slots of the B operand are
+// not one-hot but the constants (6, 6, 6, 1) (kPairBiasB), and the field's four bias entries u_j on the e2m3 grid satisfy
+// 6 (u_0 + u_1 + u_2) + u_3 = b0 + 1024 (pair_bias_entries: always solvable for |b0| <= 60).  A paired row tile is 32 rows x {X, Y}
+// = FOUR table groups (lane half h, field select s: group 4t + 2h + s) of W / 8 + 1 HALF-blocks (8 columns, the last column of the
+// last one is the bias column), so a result register answers for two (motif, strand) rows: half the result inspection per motif,
+// and motifs of <= 7 columns cost half the matrix instructions.  |entry| <= 60 and <= 15 columns keep |X|, |Y| <= 960.
+// Probed with exact data over the whole range, chained instructions included: tools/ubench/pair_probe.hip,
+// profiles/r03b_pair_probe.log.
 constexpr int kF6Cols = 16;                     // motif columns per k-block (the last one of a row tile is the bias column)
 constexpr int kF6MaxKb = 4;
 constexpr int kF6BytesPerKb = 3 * 64 * 8;       // 1536
 constexpr int kF6Levels = 56;
 constexpr int kGroupFields = 16;                // fields per table group = result registers per lane
-constexpr int kMaxClasses = kF6MaxKb;
+constexpr int kMaxClasses = 6;                  // paired 1 / 2 half-blocks, plain 1 ... 4 k-blocks
+constexpr int kPairCols = 8;                    // columns per half-block of a paired row
+constexpr int kPairMaxWidth = 2 * kPairCols - 1;
+constexpr int kPairScaleX = 127 - 6;            // E8M0 block scales of the two k-halves: X one level = 2^-9, Y one level = 2^-21
+constexpr int kPairScaleY = 127 - 18;
+constexpr float kPairC = 4.0f;                  // inline constant of the matrix instruction; ulp(4.0) = 2^-21
+constexpr int kPairOffset = 1024;               // added to both fields' sums (through the bias column)
+constexpr uint32_t kPairPattern = 0x40800000u;  // result = kPairPattern | (X + 1024) << 12 | (Y + 1024)
+constexpr uint32_t kPairMask = (1u << 22) | (1u << 10);
+constexpr uint32_t kPairBiasB = 0x2777u;        // the bias column of the B operand: k-slots (6.0, 6.0, 6.0, 1.0) in fp4 (e2m1), low nibble first
+constexpr int kPairBiasW[4] = {6, 6, 6, 1};
 
 inline int f6_kb_of_width(int W) { return W / kF6Cols + 1; }
+inline int pair_kb_of_width(int W) { return W / kPairCols + 1; }
 inline int mfma_row_of(int h, int field) { const int j = 15 - field; return (j & 3) + 8 * (j >> 2) + 4 * h; }
 
 struct ClassDesc {
-    int32_t nk;            // k-blocks of every row tile in the class
+    int32_t nk;            // matrix instructions per row tile and 32 windows: k-blocks (plain) / half-blocks (paired)
     int32_t n_row_tiles;
     uint32_t base16;       // offset of the class's tables inside the LDS tile, 16-byte units
     int32_t first_group;   // global index of the class's first table group
+    int32_t paired;        // != 0: paired rows, four table groups per row tile
+};
+
+// where a table group's fields sit in the operand image (host side: tests decode the physical image through this)
+struct GroupInfo {
+    uint32_t tab_off;      // byte offset of the group's row tile in PrefilterPlan::tables
+    int8_t nk;             // instructions per row tile
+    int8_t paired;
+    int8_t h;              // lane half of the group's result registers
+    int8_t sel;            // paired rows: 0 = field X (k-half 0, scale 2^12), 1 = field Y
 };
 
 struct TileDesc {
@@ -105,7 +142,9 @@ struct PrefilterPlan {
     std::vector<int32_t> fast_motifs;    // motif ids on the pre-filter path, in group order
     std::vector<int32_t> exact_motifs;   // motif ids scored in fp64 at every window
     std::vector<int32_t> group_fields;   // [n_groups][kGroupFields] motif id of the field, -1 = empty
-    std::vector<int32_t> group_kb;       // [n_groups] k-blocks of the group's row tile
+    std::vector<int32_t> group_kb;       // [n_groups] matrix instructions (k-blocks / half-blocks) of the group's row tile
+    std::vector<int32_t> group_cols;     // [n_groups] columns of the group's fields, the bias column included (16 / 8 per instruction)
+    std::vector<GroupInfo> group_info;   // [n_groups]
     std::vector<uint32_t> tables;        // the operand image, row tile after row tile
     std::vector<TileDesc> tiles;
     int64_t lds_bytes_per_position = 0;  // A-operand bytes read per window start
@@ -130,6 +169,20 @@ inline int f6_value(uint32_t code) {            // back to units of 1/8
     const int e = (int) (code >> 3) & 3, m = (int) code & 7;
     const int v = e == 0 ? m : (8 + m) << (e - 1);
     return (code & 32u) ? -v : v;
+}
+// the four bias-column entries (units of 1/8, on the e2m3 grid) with 6 (u0 + u1 + u2) + u3 = total; false if there are none
+inline bool pair_bias_entries(int total, int u[4]) {
+    static const int grid[] = {60, 56, 52, 48, 44, 40, 36, 32, 30, 28, 26, 24, 22, 20, 18, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0};
+    for (int a : grid)
+        for (int b : grid) {
+            if (b > a) continue;
+            for (int c : grid) {
+                if (c > b) continue;
+                const int rest = total - 6 * (a + b + c);
+                if (rest >= -60 && rest <= 60 && f6_representable(rest)) { u[0] = a; u[1] = b; u[2] = c; u[3] = rest; return true; }
+            }
+        }
+    return false;
 }
 inline size_t f6_bit_index(int kb, int row, int col_in_kb, int base, int *bit_in_lane) {   // byte offset of the lane's plane 0 word inside a row tile
     const int khalf = col_in_kb >> 3;
@@ -158,8 +211,9 @@ inline uint32_t f6_get(const uint8_t *tile, int kb, int row, int col_in_kb, int 
 }
 
 // Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes.
+// pair_rows: motifs of <= kPairMaxWidth columns go to paired rows (the product default; false = measurement only).
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths, const double *cutoffs,
-               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, PrefilterPlan *plan);
+               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan);
 
 // Sort (ms_sort.hip): keys ascending over bits [0, end_bit).  Query temp size with temp == nullptr.
 int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,

@@ -53,6 +53,8 @@ struct PfArgs {
     uint64_t cand_cap;
     uint32_t cand_block;      // >= 64
     uint64_t cand_static;     // slots [0, cand_static) are the launch's waves' own first blocks (wave w: [w, w + 1) * cand_block)
+    uint32_t unit_slots;      // != 0: the unit-ordered form -- unit u of LDS tile t owns slots [(t * n_units + u) * unit_slots, + unit_slots)
+    uint32_t *unit_cnt;       // ... and unit_cnt[t * n_units + u] receives the number of records the unit produced (may exceed unit_slots)
     int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr

@@ -215,6 +215,14 @@ __device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, 
     const unsigned long long mask = __ballot(flagged);
     if (mask == 0) return;
     const uint32_t n_new = (uint32_t) __popcll(mask);
+    if (A.unit_slots) {
+        // unit-ordered form (the ordered tail, rescore_ordered_kernel): the records of a unit of window starts go to the unit's own
+        // slots of the list, no atomic at all; W.left counts what the unit wrote (beyond unit_slots: dropped, the host grows the slots)
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+        if (flagged && W.left + rank < A.unit_slots) A.cand[W.base + W.left + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
+        W.left += n_new;
+        return;
+    }
     if (n_new > W.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
         pad_block(A, W, W.left);
         unsigned long long b = 0;
@@ -348,6 +356,109 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     }
 }
 
+// bits of a paired row's 16 results: field X's flag is bit 22, field Y's bit 10 (ms_internal.h).  Two accumulators of eight registers
+// each: m = 2 m | (c & mask) walks a register's two bits upwards one position per register (v_add_u32 + v_bitop3_b32, the fast
+// VALU class: profiles/r03b_valu_rate.log).  fx / fy: bit n = result register 15 - n, as nonneg_flags.
+__device__ __forceinline__ void pair_flags(const f32x16 &c, uint32_t &fx, uint32_t &fy) {
+    uint32_t ma = 0, mb = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        ma = (ma + ma) | ((uint32_t) __float_as_int(c[j]) & kPairMask);
+        mb = (mb + mb) | ((uint32_t) __float_as_int(c[8 + j]) & kPairMask);
+    }
+    // register j <= 7: X at bit 29 - j, Y at bit 17 - j of ma; register 8 + j: the same of mb
+    fx = ((ma >> 14) & 0xFF00u) | ((mb >> 22) & 0xFFu);
+    fy = ((ma >> 2) & 0xFF00u) | ((mb >> 10) & 0xFFu);
+}
+
+// OR of the 16 result patterns: some field of the lane is a candidate <=> (x & kPairMask) != 0.  v_bitop3_b32 by name: left alone
+// hipcc picks v_or3_b32, which costs the SIMD 4.4 cycles against 2.7 (profiles/r03b_valu_rate.log)
+__device__ __forceinline__ uint32_t or16(const f32x16 &c) {
+    uint32_t x = __builtin_amdgcn_bitop3_b32((uint32_t) __float_as_int(c[0]), (uint32_t) __float_as_int(c[1]), (uint32_t) __float_as_int(c[2]), 0xFE);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) x = __builtin_amdgcn_bitop3_b32(x, (uint32_t) __float_as_int(c[i]), (uint32_t) __float_as_int(c[i + 1]), 0xFE);
+    return x | (uint32_t) __float_as_int(c[15]);
+}
+
+// All row tiles of one class of PAIRED rows (ms_internal.h): NK half-blocks of 8 columns, k-half 0 = field X, k-half 1 = field Y (block
+// scales 2^-6 / 2^-18), both k-halves of the B operand = the same 8 bases, accumulators started at the inline constant 4.0, the bias
+// column's B slots constant.  A row tile answers for 32 motifs x 2 strands with the 32 result registers that answer for 16 in a
+// plain row tile.
+template <int NK, bool MEAS>
+__device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
+                                              uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
+                                              int64_t pass0, bool live0, bool live1) {
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
+    const char *p = lds + byte_off + lane * 8u;
+    constexpr int kStep = NK * kF6BytesPerKb;
+    // B operands: half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
+    i32x8 b0[NK], b1[NK];
+#pragma unroll
+    for (int kb = 0; kb < NK; kb++) {
+        b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[0] >> (16 * kb)) & 0xFFFFu);
+        b1[kb] = onehot_f4(lut, (uint32_t) (Q.cw[1] >> (16 * kb)) & 0xFFFFu);
+    }
+    if (Q.any_n) {                                                                // rare, wave-uniform
+        const uint32_t nw0 = staged_nw(Q.stg, lane & 31u, 0), nw1 = staged_nw(Q.stg, lane & 31u, 1);
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) {
+            const uint32_t keep = kb == NK - 1 ? 0x7Fu : 0xFFu;                   // the fields' last column carries the bias: never cleared
+            clear_n(b0[kb], (nw0 >> (8 * kb)) & keep);
+            clear_n(b1[kb], (nw1 >> (8 * kb)) & keep);
+        }
+    }
+    // the bias column (last column of the last half-block): constant k-slots in place of the base's one-hot image
+    b0[NK - 1][3] = (int) (((uint32_t) b0[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
+    b1[NK - 1][3] = (int) (((uint32_t) b1[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
+    // The two products of a row tile start from DIFFERENT inline constants, 4.0 and 2.0, with block scales one binade apart: the same
+    // mantissa layout either way (a constant shared by two instructions is put into 16 registers by hipcc, eight v_mov per row tile)
+    const int scale0 = h ? kPairScaleY : kPairScaleX, scale1 = scale0 - 1;
+    f32x16 cc0, cc1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
+    auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
+        i32x8 a[NK];
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) {
+            const int2 w0 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb);
+            const int2 w1 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 512);
+            const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
+            a[kb] = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+        }
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], cc0, 2, 4, 0, scale0, 0, 127);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], cc1, 2, 4, 0, scale1, 0, 127);
+#pragma unroll
+        for (int kb = 1; kb < NK; kb++) {
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b0[kb], c0, 2, 4, 0, scale0, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, scale1, 0, 127);
+        }
+    };
+    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) {
+        const uint32_t x0 = or16(c0), x1 = or16(c1);
+        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0)) {
+            // rare path: which of the two 32-window operands, which fields of X and of Y (table groups 4 t + 2 h and + 1)
+            const int32_t group = first_group + 4 * t + 2 * (int32_t) h;
+            if (__any((x0 & kPairMask) != 0u)) {
+                uint32_t fx, fy;
+                pair_flags(c0, fx, fy);
+                emit_rec(A, W, live0, pass0 + (lane & 31u), fx, group);
+                emit_rec(A, W, live0, pass0 + (lane & 31u), fy, group + 1);
+            }
+            if (__any((x1 & kPairMask) != 0u)) {
+                uint32_t fx, fy;
+                pair_flags(c1, fx, fy);
+                emit_rec(A, W, live1, pass0 + (lane & 31u) + 32, fx, group);
+                emit_rec(A, W, live1, pass0 + (lane & 31u) + 32, fy, group + 1);
+            }
+        }
+    };
+    for (int t = 0; t < n_row_tiles; t++, p += kStep) {
+        f32x16 c0, c1;
+        product(p, c0, c1);
+        test(c0, c1, t);
+    }
+}
+
 // grid = (blocks per tile, tiles); two 512-thread blocks per CU (16 waves per CU, <= 128 VGPRs), each with its own copy of the
 // LDS tile.  Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes) | per-wave sequence staging (kPfStageBytes).
 // Work is handed out per WAVE, without a barrier in the loop: a wave's first unit is its own number, every further unit one
@@ -393,6 +504,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     W.base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
     W.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (W.base >> 32)) << 32) | (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) W.base);
     W.left = A.cand_block;
+    if (A.unit_slots) { W.base = 0; W.left = 0; }
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
@@ -433,6 +545,11 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         for (int i = 0; i < n_classes; i++) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
+            if (cd.paired) {
+                if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1);
+                else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1);
+                continue;
+            }
             switch (cd.nk) {
                 case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
                 case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
@@ -464,17 +581,23 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                 if (lane == 0) u = atomicAdd(word, 1u);
                 next = waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
             }
-            const uint32_t p0 = (v * K + g) * wave_passes;
+            const uint32_t uid = v * K + g;                                       // the unit: window starts [uid, uid + 1) * 64 * wave_passes
+            const uint32_t p0 = uid * wave_passes;
+            if (A.unit_slots) {
+                W.base = ((unsigned long long) blockIdx.y * n_units + uid) * A.unit_slots;
+                W.left = 0;
+            }
             uint32_t words = fetch((int64_t) p0 * 64);
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
                 if (lane < 12) stg[lane] = words;                                 // (the wave's LDS operations execute in order: no barrier)
                 if (j + 1 < wave_passes) words = fetch((int64_t) (p0 + j + 1) * 64);      // in flight while this pass is scanned
                 scan_pass((int64_t) (p0 + j) * 64);
             }
+            if (A.unit_slots && lane == 0) A.unit_cnt[(size_t) blockIdx.y * n_units + uid] = W.left;
             v = next;
         }
     }
-    for (uint32_t i = 0; i < W.left; i += 64) {                                   // the unused rest of the last block: empty records
+    for (uint32_t i = 0; !A.unit_slots && i < W.left; i += 64) {                  // the unused rest of the last block: empty records
         const unsigned long long j = W.base + i + lane;
         if (i + lane < W.left && j < A.cand_cap) A.cand[j] = 0ULL;
     }

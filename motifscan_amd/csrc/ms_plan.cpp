@@ -127,7 +127,7 @@ struct FastMotif {
 }  // namespace
 
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths, const double *cutoffs,
-               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, PrefilterPlan *plan) {
+               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan) {
     *plan = PrefilterPlan();
     plan->strand_mask = strand_mask;
     std::vector<FastMotif> fast;
@@ -153,81 +153,114 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
         if (ok) { fast.push_back(fm); plan->alln_can_hit = plan->alln_can_hit || alln; }
         else plan->exact_motifs.push_back(p);
     }
-    std::stable_sort(fast.begin(), fast.end(), [](const FastMotif &a, const FastMotif &b) {
-        const int ka = f6_kb_of_width(a.W), kb = f6_kb_of_width(b.W);
-        return ka != kb ? ka < kb : a.W < b.W;
+    // paired rows first (narrow to wide), then plain rows (narrow to wide)
+    auto paired = [&](const FastMotif &a) { return pair_rows && a.W <= kPairMaxWidth; };
+    std::stable_sort(fast.begin(), fast.end(), [&](const FastMotif &a, const FastMotif &b) {
+        const bool pa = paired(a), pb = paired(b);
+        if (pa != pb) return pa;
+        return a.W < b.W;
     });
+    size_t n_paired = 0;
+    while (n_paired < fast.size() && paired(fast[n_paired])) n_paired++;
 
-    // row tiles, narrow to wide: 16 motifs x {fwd, rev} with both strands, 32 motifs with one
+    // row tiles: plain = 16 motifs x {fwd, rev} with both strands, 32 motifs with one; paired = twice that
     const bool both = strand_mask == 3;
     const int sd_single = strand_mask == 2 ? 1 : 0;
-    const size_t per_rt = both ? 16 : 32, per_group = per_rt / 2;
-    const size_t n_rt = (fast.size() + per_rt - 1) / per_rt;
-    std::vector<int> rt_kb(n_rt, 0);
-    std::vector<size_t> rt_off(n_rt + 1, 0);
-    for (size_t t = 0; t < n_rt; t++) {
-        for (size_t j = per_rt * t; j < std::min(fast.size(), per_rt * (t + 1)); j++) rt_kb[t] = std::max(rt_kb[t], f6_kb_of_width(fast[j].W));
-        rt_off[t + 1] = rt_off[t] + (size_t) rt_kb[t] * kF6BytesPerKb;
-        plan->kb_total += rt_kb[t];
+    struct RowTile { bool paired; int nk; size_t first, count, off; };
+    std::vector<RowTile> rts;
+    auto cut = [&](size_t lo, size_t hi, bool pr) {
+        const size_t per_rt = (both ? 16 : 32) * (pr ? 2 : 1);
+        for (size_t j = lo; j < hi; j += per_rt) {
+            RowTile rt{pr, 0, j, std::min(per_rt, hi - j), 0};
+            for (size_t q = j; q < j + rt.count; q++) rt.nk = std::max(rt.nk, pr ? pair_kb_of_width(fast[q].W) : f6_kb_of_width(fast[q].W));
+            rts.push_back(rt);
+        }
+    };
+    cut(0, n_paired, true);
+    cut(n_paired, fast.size(), false);
+    const size_t n_rt = rts.size();
+    size_t total = 0;
+    for (RowTile &rt : rts) {
+        rt.off = total;
+        total += (size_t) rt.nk * kF6BytesPerKb;
+        plan->kb_total += rt.nk;
+        plan->lds_bytes_per_position += (int64_t) rt.nk * (int64_t) kF6BytesPerKb / 64;        // A-operand bytes per window start (2 x 32 windows share a read)
     }
-    std::vector<uint8_t> bytes(rt_off[n_rt], 0);
-    plan->group_fields.assign(2 * n_rt * kGroupFields, -1);
-    plan->group_kb.assign(2 * n_rt, 0);
+    std::vector<uint8_t> bytes(total, 0);
     for (size_t t = 0; t < n_rt; t++) {
-        uint8_t *tab = bytes.data() + rt_off[t];
-        const int n_cols = kF6Cols * rt_kb[t];
-        for (int h = 0; h < 2; h++) {
-            const size_t grp = 2 * t + h;
-            plan->group_kb[grp] = rt_kb[t];
+        const RowTile &rt = rts[t];
+        uint8_t *tab = bytes.data() + rt.off;
+        const int cols_per_kb = rt.paired ? kPairCols : kF6Cols;
+        const int n_cols = cols_per_kb * rt.nk;
+        const int n_groups = rt.paired ? 4 : 2;
+        const size_t per_group = both ? 8 : 16;
+        for (int gi = 0; gi < n_groups; gi++) {
+            const int h = rt.paired ? gi >> 1 : gi, sel = rt.paired ? gi & 1 : 0;
+            const size_t grp = plan->group_kb.size();
+            plan->group_kb.push_back(rt.nk);
+            plan->group_cols.push_back(n_cols);
+            plan->group_info.push_back(GroupInfo{(uint32_t) rt.off, (int8_t) rt.nk, (int8_t) rt.paired, (int8_t) h, (int8_t) sel});
+            plan->group_fields.resize((grp + 1) * kGroupFields, -1);
             for (int n = 0; n < kGroupFields; n++) {
-                const size_t j = per_rt * t + per_group * h + (both ? (size_t) (n >> 1) : (size_t) n);
+                const size_t slot = per_group * (size_t) gi + (both ? (size_t) (n >> 1) : (size_t) n);
+                const size_t j = rt.first + slot;
                 const int sd = both ? (n & 1) : sd_single;
                 const int row = mfma_row_of(h, n);
-                const F6Strand *fs = j < fast.size() ? &fast[j].f6[sd] : nullptr;
-                // empty field: bias -1/8 and nothing else -> never a candidate; columns past W stay +0; the bias sits in the row
-                // tile's LAST column for all four bases (the kernel never clears that column for non-ACGT bases)
+                const F6Strand *fs = slot < rt.count ? &fast[j].f6[sd] : nullptr;
+                // empty field: bias -1/8 and nothing else -> never a candidate; columns past W stay +0; the bias sits in the field's
+                // LAST column for all four bases (the kernel never clears that column for non-ACGT bases)
+                int pb[4] = {0, 0, 0, 0};                                   // paired rows: the bias column also carries the field's offset
+                if (rt.paired && !pair_bias_entries((fs ? fs->bias : -1) + kPairOffset, pb)) {
+                    set_error("internal: no bias entries for %d", (fs ? fs->bias : -1) + kPairOffset);
+                    return MS_ERR_RUNTIME;
+                }
                 for (int c = 0; c < n_cols; c++)
                     for (int b = 0; b < 4; b++) {
                         int u = 0;
-                        if (c == n_cols - 1) u = fs ? fs->bias : -1;
+                        if (c == n_cols - 1) u = rt.paired ? pb[b] : (fs ? fs->bias : -1);
                         else if (fs && c < fast[j].W) u = fs->u[c][b];
-                        f6_put(tab, c / kF6Cols, row, c % kF6Cols, b, f6_code(u));
+                        // plain: column c of k-block c / 16; paired: column c % 8 of half-block c / 8, in k-half `sel`
+                        if (rt.paired) f6_put(tab, c / kPairCols, row, kPairCols * sel + c % kPairCols, b, f6_code(u));
+                        else f6_put(tab, c / kF6Cols, row, c % kF6Cols, b, f6_code(u));
                     }
                 if (fs) plan->group_fields[grp * kGroupFields + n] = fast[j].id;
             }
         }
-        plan->lds_bytes_per_position += (int64_t) rt_kb[t] * (int64_t) kF6BytesPerKb / 64;     // A-operand bytes per window start (2 x 32 windows share a read)
     }
     for (const FastMotif &fm : fast) plan->fast_motifs.push_back(fm.id);
     plan->tables.resize(bytes.size() / 4);
     if (!bytes.empty()) std::memcpy(plan->tables.data(), bytes.data(), bytes.size());
 
-    // LDS tiles (whole row tiles; work ~ bytes), classes = runs of equal k-block count
+    // LDS tiles (whole row tiles; work ~ bytes), classes = runs of equal (paired, instruction count)
     if (n_rt > 0) {
-        const size_t total = rt_off[n_rt];
         const size_t budget = std::max<size_t>(lds_budget, (size_t) kF6MaxKb * kF6BytesPerKb);
         const size_t n_tiles = (total + budget - 1) / budget;
         const size_t target = (total + n_tiles - 1) / n_tiles;
         size_t q = 0;
+        int32_t group = 0;
         while (q < n_rt) {
             TileDesc t;
             std::memset(&t, 0, sizeof(t));
-            t.table_off16 = (uint32_t) (rt_off[q] / 16);
-            t.first_group = (int32_t) (2 * q);
+            t.table_off16 = (uint32_t) (rts[q].off / 16);
+            t.first_group = group;
             size_t used = 0;
             while (q < n_rt) {
-                const size_t need = (size_t) rt_kb[q] * kF6BytesPerKb;
+                const size_t need = (size_t) rts[q].nk * kF6BytesPerKb;
                 if (used > 0 && (used + need > budget || used >= target)) break;
-                if (t.n_classes == 0 || t.cls[t.n_classes - 1].nk != rt_kb[q]) {
+                const bool new_class = t.n_classes == 0 || t.cls[t.n_classes - 1].nk != rts[q].nk || (t.cls[t.n_classes - 1].paired != 0) != rts[q].paired;
+                if (new_class) {
+                    if (t.n_classes == kMaxClasses) break;                   // (cannot happen: the row tiles are sorted by class)
                     ClassDesc &cd = t.cls[t.n_classes++];
-                    cd.nk = rt_kb[q];
+                    cd.nk = rts[q].nk;
                     cd.n_row_tiles = 0;
                     cd.base16 = (uint32_t) (used / 16);
-                    cd.first_group = (int32_t) (2 * q);
+                    cd.first_group = group;
+                    cd.paired = rts[q].paired ? 1 : 0;
                 }
                 t.cls[t.n_classes - 1].n_row_tiles++;
-                t.max_nk = std::max(t.max_nk, rt_kb[q]);
+                if (!rts[q].paired) t.max_nk = std::max(t.max_nk, rts[q].nk);
                 used += need;
+                group += rts[q].paired ? 4 : 2;
                 q++;
             }
             t.table_len16 = (uint32_t) (used / 16);

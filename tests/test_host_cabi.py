@@ -98,13 +98,15 @@ def emulate_prefilter(plan, codes, isn):
     flagged = set()
     rows = plan["rows"].astype(np.int64)
     for q in range(rows.shape[0]):
-        ncol = 16 * int(plan["group_kb"][q]) - 1                # the last column of the row tile carries the bias
+        ncol = int(plan["group_cols"][q]) - 1                   # the last column of the group's fields carries the bias
         assert not rows[q, :, ncol:, :].any()
         for n in range(16):
             m = int(plan["group_fields"][q, n])
             acc = np.full(L, int(plan["bias"][q, n]), dtype=np.int64)
             for c in range(ncol):
                 acc += np.where(pn[c:c + L], 0, rows[q, n, c][pc[c:c + L]])
+            if plan["group_paired"][q]:                         # a paired row's field must stay inside its 11 bits (ms_internal.h)
+                assert acc.min() >= -1024 and acc.max() < 1024
             hot = np.nonzero(acc >= 0)[0]
             if m < 0:
                 assert len(hot) == 0                          # empty fields never flag
@@ -120,13 +122,19 @@ def check_plan_shape(plan, n_motifs, widths):
     gf = plan["group_fields"]
     fast = set(gf.ravel().tolist()) - {-1}
     assert fast | set(plan["exact_motifs"].tolist()) == set(range(n_motifs)) and not (fast & set(plan["exact_motifs"].tolist()))
-    assert gf.shape[0] % 2 == 0                                 # two table groups per 32-row operand tile
-    assert (plan["group_kb"][0::2] == plan["group_kb"][1::2]).all()
+    kb, cols, paired = plan["group_kb"], plan["group_cols"], plan["group_paired"]
+    q = 0
+    while q < gf.shape[0]:                                      # a 32-row operand tile = two table groups, or four (fields X, Y) with paired rows
+        n = 4 if paired[q] else 2
+        assert q + n <= gf.shape[0] and (kb[q:q + n] == kb[q]).all() and (cols[q:q + n] == (8 if paired[q] else 16) * kb[q]).all()
+        assert paired[q:q + n].tolist() == ([1, 2, 1, 2] if paired[q] else [0, 0])
+        q += n
     for q in range(gf.shape[0]):
         for n in range(16):
             m = int(gf[q, n])
             if m >= 0:
-                assert widths[m] <= 16 * plan["group_kb"][q] - 1   # the motif's columns stay clear of the bias column
+                assert widths[m] <= cols[q] - 1                 # the motif's columns stay clear of the bias column
+                assert (widths[m] <= 15) == bool(paired[q])     # every motif of <= 15 columns rides a paired row
                 if plan["strand_mask"] == 3:
                     assert gf[q, n ^ 1] == m                    # forward and reverse of a motif share a slot
     mag = np.abs(plan["rows"].astype(np.int64))                 # fp6 e2m3: every entry is on the grid (units of 1/8): sums are exact in f32
@@ -269,29 +277,38 @@ def test_prefilter_routes_degenerate_pwms_to_exact_path():
 
 
 def test_plan_tiles_respect_lds_budget(jaspar579):
-    """16 motifs x {fwd, rev} (one strand: 32 motifs) per 32-row operand tile, W // 16 + 1 k-blocks of 1.5 KiB, narrow to wide;
-    LDS tiles hold whole row tiles and stay inside the budget."""
+    """Motifs of <= 15 columns ride PAIRED rows: 32 motifs x {fwd, rev} (one strand: 64 motifs) per 32-row operand tile, four table
+    groups, W // 8 + 1 half-blocks of 1.5 KiB; wider motifs plain rows: 16 (32) motifs per tile, two groups, W // 16 + 1 k-blocks;
+    narrow to wide within each kind; LDS tiles hold whole row tiles and stay inside the budget."""
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
-    widths = jaspar579["widths"]
+    widths = np.asarray(jaspar579["widths"])
+    n_pair, n_plain = int((widths <= 15).sum()), int((widths > 15).sum())
     for strand, per_rt in ((3, 16), (1, 32), (2, 32)):
         for budget in (24 * 1024, 70 * 1024):
             plan = pw.plan(strand, budget)
             assert plan["n_exact"] == 0 and plan["n_fast"] == 579
             check_plan_shape(plan, 579, widths)
-            gf, kb, tf = plan["group_fields"], plan["group_kb"], plan["tile_first_group"]
-            assert len(kb) == 2 * ((579 + per_rt - 1) // per_rt)
-            assert (np.diff(kb) >= 0).all() and kb.max() == 2 and kb.min() == 1
+            gf, kb, tf, paired = plan["group_fields"], plan["group_kb"], plan["tile_first_group"], plan["group_paired"]
+            rt_pair, rt_plain = (n_pair + 2 * per_rt - 1) // (2 * per_rt), (n_plain + per_rt - 1) // per_rt
+            assert len(kb) == 4 * rt_pair + 2 * rt_plain
+            assert (paired[:4 * rt_pair] > 0).all() and (paired[4 * rt_pair:] == 0).all()     # paired row tiles first
+            assert (np.diff(kb[:4 * rt_pair]) >= 0).all() and (np.diff(kb[4 * rt_pair:]) >= 0).all() and kb.max() == 2 and kb.min() == 1
             assert sorted(set(gf[gf >= 0].tolist())) == list(range(579))
             assert (gf >= 0).sum() == 579 * (2 if strand == 3 else 1)
             assert plan["n_tiles"] == len(tf) - 1 and tf[-1] == len(kb) and (np.array(tf) % 2 == 0).all()
+            first_of_rt = np.ones(len(kb), dtype=bool)             # one entry per row tile: its first group
+            first_of_rt[:4 * rt_pair] = np.arange(4 * rt_pair) % 4 == 0
+            first_of_rt[4 * rt_pair:] = np.arange(2 * rt_plain) % 2 == 0
             for t in range(len(tf) - 1):
-                tile_bytes = int(kb[tf[t]:tf[t + 1]:2].sum()) * 1536
+                tile_bytes = int(kb[tf[t]:tf[t + 1]][first_of_rt[tf[t]:tf[t + 1]]].sum()) * 1536
                 assert 0 < tile_bytes <= budget
             assert (plan["n_tiles"] == 1) == (budget > 64 * 1024)
-    # the benchmark set at both strands: 37 row tiles, one k-block up to W = 15, two up to W = 31
+    # the benchmark set at both strands: matrix instructions per 32 windows
     plan = pw.plan(3)
-    want = sum(sorted(int(w) // 16 + 1 for w in widths)[15::16]) + (0 if 579 % 16 == 0 else int(max(widths)) // 16 + 1)
-    assert int(plan["group_kb"][0::2].sum()) == want
+    wp, wl = sorted(int(w) for w in widths if w <= 15), sorted(int(w) for w in widths if w > 15)
+    want = sum(wp[min(i + 31, len(wp) - 1)] // 8 + 1 for i in range(0, len(wp), 32)) + sum(wl[min(i + 15, len(wl) - 1)] // 16 + 1 for i in range(0, len(wl), 16))
+    rt_pair = (len(wp) + 31) // 32
+    assert int(plan["group_kb"][:4 * rt_pair:4].sum()) + int(plan["group_kb"][4 * rt_pair::2].sum()) == want
 
 
 # --------------------------------------------------------------------------- dedup --

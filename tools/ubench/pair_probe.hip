@@ -1,0 +1,244 @@
+// pair_probe.hip -- measurement only (gfx950): TWO pre-filter fields in one f32 result of v_mfma_scale_f32_32x32x64_f8f6f4.
+//
+// Idea under test: the A operand's block scale is per lane = per (row, k-half).  Give k-half 0 a scale 2^12 times that of k-half 1,
+// let BOTH k-halves of the B operand hold the same 8 bases, and start the accumulator at a constant C whose unit in the last place
+// is one level (1/8 of an entry) of k-half 1: then
+//     result = C + ulp(C) (2^12 X' + Y'),      X', Y' = the two fields' sums in levels (integers, 0 <= X' < 2048, 0 <= Y' < 4096)
+// has a fixed exponent, so the f32 pattern is pattern(C) | X' << 12 | Y': with X' = X + 1024, Y' = Y + 1024 bit 22 <=> X >= 0,
+// bit 10 <=> Y >= 0.  One result register then answers for two (motif, strand) rows.  The kernel's form: C = the INLINE constant 4.0
+// (2.0 for the row tile's second product: a constant shared by two instructions would be put into 16 registers), block scales
+// 2^-6 / 2^-18 (2^-7 / 2^-19), and the +1024 delivered by the bias column, whose B k-slots are the constants (6, 6, 6, 1).
+//   (1) semantics: per-lane scales honoured? sums exact over the whole 24-bit range, also through a chained second instruction,
+//       also with the kernel's constants?
+//   (2) cost per row tile beside the matrix pipe (as insp_probe.hip measures it):
+//         mode 0  2 MFMA (C = 0), AND chain of the sign bits           -- the round-3 kernel's one-k-block row tile (16 motifs)
+//         mode 1  2 MFMA (C = 4.0 / 2.0 inline, per-lane scale), OR chain + mask  -- paired row tile of one half-block (32 motifs of <= 7 columns)
+//         mode 2  4 MFMA (chained pairs, the same), OR chain + mask               -- paired row tile of two half-blocks (32 motifs of <= 15 columns)
+//         mode 3  4 MFMA (chained pairs, C = 0), AND chain             -- the round-3 kernel's two-k-block row tile (16 motifs of <= 31 columns)
+//       modes 4..7: the same with the A operands read from LDS every trip (three ds_read_b64 per k-block), as the kernel does.
+// Build: hipcc -O3 --offload-arch=gfx950 pair_probe.hip -o pair_probe.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float kC = 1048576.0f + 524288.0f + 128.0f;                      // (2^23 + 2^22 + 2^10) / 8
+constexpr unsigned int kHitMask = (1u << 22) | (1u << 10);
+
+// one or two chained instructions; out[case][lane][16]
+__global__ void sem_kernel(const i32x8 *a, const i32x8 *b, int n_kb, int shift, int scale_y, float cinit, float *out) {
+    const int l = threadIdx.x, cs = blockIdx.x;
+    const int scale = l < 32 ? scale_y + shift : scale_y;
+    f32x16 c;
+    for (int j = 0; j < 16; j++) c[j] = cinit;
+    for (int kb = 0; kb < n_kb; kb++)
+        c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(cs * 2 + kb) * 64 + l], b[(cs * 2 + kb) * 64 + l], c, 2, 4, 0, scale, 0, 127);
+    for (int j = 0; j < 16; j++) out[(cs * 64 + l) * 16 + j] = c[j];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) cost_kernel(const i32x8 *ab, int trips, unsigned int *sink, unsigned long long *clk) {
+    constexpr bool LDS = MODE >= 4;
+    constexpr int M = MODE & 3;
+    constexpr int NK = (M == 0 || M == 1) ? 1 : 2;
+    constexpr bool PACKED = M == 1 || M == 2;
+    __shared__ unsigned long long tab[LDS ? 16 * 2 * 3 * 64 : 1];           // 16 row tiles of two k-blocks: [tile][kb][plane][lane]
+    if constexpr (LDS) {
+        for (int i = threadIdx.x; i < 16 * 2 * 3 * 64; i += blockDim.x) {
+            const i32x8 v = ab[i & 63];
+            const int pl = (i >> 6) % 3;
+            tab[i] = ((unsigned long long) (unsigned int) v[2 * pl + 1] << 32) | (unsigned int) v[2 * pl];
+        }
+        __syncthreads();
+    }
+    const unsigned int lane = threadIdx.x & 63;
+    i32x8 areg[2] = {ab[lane], ab[192 + lane]};
+    i32x8 b0[2] = {ab[64 + lane], ab[256 + lane]}, b1[2] = {ab[128 + lane], ab[320 + lane]};
+    const int scale = PACKED ? (lane < 32 ? 121 : 109) : 127, scale1 = PACKED ? scale - 1 : 127;
+    f32x16 cc, cc1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { cc[j] = PACKED ? 4.0f : 0.0f; cc1[j] = PACKED ? 2.0f : 0.0f; }     // inline constants of the instruction
+    unsigned int found = 0;
+    auto load = [&](int t, int kb) {
+        const unsigned long long *q = tab + ((t & 15) * 2 + kb) * 192 + lane;
+        const unsigned long long w0 = q[0], w1 = q[64], w2 = q[128];
+        return i32x8{(int) w0, (int) (w0 >> 32), (int) w1, (int) (w1 >> 32), (int) w2, (int) (w2 >> 32), 0, 0};
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; t++) {
+        asm volatile("" : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]));
+        i32x8 a[2];
+        if constexpr (LDS) { a[0] = load(t, 0); if constexpr (NK == 2) a[1] = load(t, 1); }
+        else { asm volatile("" : "+v"(areg[0]), "+v"(areg[1])); a[0] = areg[0]; a[1] = areg[1]; }
+        f32x16 c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], cc, 2, 4, 0, scale, 0, 127);
+        f32x16 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], cc1, 2, 4, 0, scale1, 0, 127);
+        if constexpr (NK == 2) {
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b0[1], c0, 2, 4, 0, scale, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b1[1], c1, 2, 4, 0, scale1, 0, 127);
+        }
+        if constexpr (PACKED) {
+            unsigned int x = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) x = __builtin_amdgcn_bitop3_b32(x, (unsigned int) __float_as_int(c0[i]), (unsigned int) __float_as_int(c1[i]), 0xFE);
+            if (__builtin_expect(__any((x & kHitMask) != 0u), 0)) found += x;
+        } else {
+            unsigned int x = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < 16; i++) x &= (unsigned int) __float_as_int(c0[i]) & (unsigned int) __float_as_int(c1[i]);
+            if (__builtin_expect(__any((int) x >= 0), 0)) found += x;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (found == 0x12345u) sink[0] = found;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+static int f6_value(unsigned code) {            // e2m3 -> units of 1/8
+    const int e = (int) (code >> 3) & 3, m = (int) code & 7;
+    const int v = e == 0 ? m : (8 + m) << (e - 1);
+    return (code & 32u) ? -v : v;
+}
+static void put_bits(unsigned *w, int bit, int nbits, unsigned v) {
+    for (int i = 0; i < nbits; i++) if ((v >> i) & 1) w[(bit + i) >> 5] |= 1u << ((bit + i) & 31);
+}
+
+template <int MODE>
+static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, unsigned long long *d_clk) {
+    const int trips = 40000;
+    printf("%-52s\n", what);
+    struct Cfg { int blocks, threads; const char *name; } cfgs[] = {
+        {256, 512, "2 waves/SIMD"}, {256, 1024, "4 waves/SIMD"}, {512, 512, "2 x 512 per CU (4 waves/SIMD)"}};
+    for (const Cfg &c : cfgs) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        auto launch = [&]() { hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk); };
+        for (int w = 0; w < 3; w++) launch();
+        CK(hipEventRecord(e0, 0));
+        launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(2 * c.blocks);
+        CK(hipMemcpy(h.data(), d_clk, h.size() * 8, hipMemcpyDeviceToHost));
+        double mhz = 0; int n = 0;
+        for (int b = 0; b < c.blocks; b++) if (h[2 * b + 1]) { mhz += 100.0 * (double) h[2 * b] / (double) h[2 * b + 1]; n++; }
+        mhz /= n ? n : 1;
+        const int wps = c.blocks * c.threads / 64 / 1024;
+        const double cyc = ms * 1e-3 * mhz * 1e6 / ((double) trips * wps);
+        printf("    %-32s %8.3f ms  clock %6.0f MHz  %6.1f cycles per row tile per SIMD\n", c.name, ms, mhz, cyc);
+    }
+}
+
+int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    // ---- (1) semantics ----
+    {
+        const int n_cases = 256;
+        std::vector<unsigned> a((size_t) n_cases * 2 * 64 * 8, 0), b((size_t) n_cases * 2 * 64 * 8, 0);
+        std::vector<int> av((size_t) n_cases * 2 * 32 * 64), bv((size_t) n_cases * 2 * 64 * 32);      // A[case][kb][row][k] in 1/8, B[case][kb][k][col] in {0, 1}
+        srand(12345);
+        for (int cs = 0; cs < n_cases; cs++)
+            for (int kb = 0; kb < 2; kb++) {
+                const int kind = cs & 3;                                            // 0/1 random, 2 all -7.5 (most negative sums), 3 all +7.5
+                for (int row = 0; row < 32; row++)
+                    for (int k = 0; k < 64; k++) {
+                        unsigned code = (unsigned) (rand() & 63);
+                        if (code == 32u) code = 0;                                  // never -0
+                        if (kind == 2) code = 0x3F;
+                        if (kind == 3) code = 0x1F;
+                        av[((size_t) (cs * 2 + kb) * 32 + row) * 64 + k] = f6_value(code);
+                        put_bits(&a[((size_t) (cs * 2 + kb) * 64 + (k >> 5) * 32 + row) * 8], 6 * (k & 31), 6, code);
+                    }
+                for (int col = 0; col < 32; col++)
+                    for (int grp = 0; grp < 16; grp++) {                            // 16 groups of 4 k-slots: one-hot, or empty (a non-ACGT base)
+                        const int pick = (kind >= 2) ? (rand() & 3) : (rand() % 5);
+                        const bool bias_col = kind == 1 && kb == 1 && (grp & 7) == 7;  // the kernel's bias column: constant k-slots (6, 6, 6, 1)
+                        static const int bw[4] = {6, 6, 6, 1};
+                        static const unsigned bc[4] = {0x7u, 0x7u, 0x7u, 0x2u};
+                        for (int j = 0; j < 4; j++) {
+                            const int k = 4 * grp + j, v = bias_col ? bw[j] : ((j == pick) ? 1 : 0);
+                            bv[((size_t) (cs * 2 + kb) * 64 + k) * 32 + col] = v;
+                            if (v) put_bits(&b[((size_t) (cs * 2 + kb) * 64 + (k >> 5) * 32 + col) * 8], 4 * (k & 31), 4, bias_col ? bc[j] : 0x2u);
+                        }
+                    }
+            }
+        i32x8 *d_a, *d_b; float *d_out;
+        CK(hipMalloc(&d_a, a.size() * 4)); CK(hipMalloc(&d_b, b.size() * 4)); CK(hipMalloc(&d_out, (size_t) n_cases * 64 * 16 * 4));
+        CK(hipMemcpy(d_a, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        std::vector<float> out((size_t) n_cases * 64 * 16);
+        struct Var { int n_kb, shift, scale_y; float cinit; const char *name; } vars[] = {
+            {1, 0, 127, 0.0f, "1 instruction, scales 2^0 / 2^0, C = 0 (plain rows)"},
+            {1, 12, 127, 0.0f, "1 instruction, scales 2^12 / 2^0, C = 0"},
+            {1, 12, 127, kC, "1 instruction, scales 2^12 / 2^0, C = (2^23 + 2^22 + 2^10) / 8"},
+            {2, 12, 127, kC, "2 chained instructions, scales 2^12 / 2^0, C = (2^23 + 2^22 + 2^10) / 8"},
+            {2, 11, 127, kC, "2 chained instructions, scales 2^11 / 2^0, same C"},
+            {2, 12, 109, 4.0f, "2 chained instructions, scales 2^-6 / 2^-18, C = 4.0 (the kernel's first product)"},
+            {2, 12, 108, 2.0f, "2 chained instructions, scales 2^-7 / 2^-19, C = 2.0 (the kernel's second product)"}};
+        for (const Var &v : vars) {
+            hipLaunchKernelGGL(sem_kernel, dim3(n_cases), dim3(64), 0, 0, d_a, d_b, v.n_kb, v.shift, v.scale_y, v.cinit, d_out);
+            CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+            long bad = 0, total = 0, in_range = 0, flag_bad = 0;
+            double worst = 0;
+            long xmin = 0, xmax = 0;
+            for (int cs = 0; cs < n_cases; cs++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 16; j++) {
+                        const int col = l & 31, row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5);
+                        long X = 0, Y = 0;
+                        for (int kb = 0; kb < v.n_kb; kb++)
+                            for (int k = 0; k < 64; k++) {
+                                const long p = (long) av[((size_t) (cs * 2 + kb) * 32 + row) * 64 + k] * bv[((size_t) (cs * 2 + kb) * 64 + k) * 32 + col];
+                                if (k < 32) X += p; else Y += p;
+                            }
+                        const double expect = (double) v.cinit + ((double) X * (double) (1L << v.shift) + (double) Y) / 8.0 * ldexp(1.0, v.scale_y - 127);
+                        const float got = out[((size_t) cs * 64 + l) * 16 + j];
+                        total++;
+                        xmin = X < xmin ? X : xmin; xmax = X > xmax ? X : xmax;
+                        if ((double) got != expect) { bad++; worst = fmax(worst, fabs((double) got - expect)); }
+                        if (v.cinit == kC && v.shift == 12 && X >= -1024 && X < 1024 && Y >= -1024 && Y < 1024) {
+                            in_range++;
+                            unsigned int pat; memcpy(&pat, &got, 4);
+                            const unsigned int want = 0x49800000u | ((unsigned int) (X + 1024) << 12) | (unsigned int) (Y + 1024);
+                            if (pat != want) flag_bad++;
+                        }
+                        if (v.scale_y != 127 && X >= 0 && X < 2048 && Y >= 0 && Y < 4096) {       // the kernel's form: the offsets come with the sums
+                            in_range++;
+                            unsigned int pat, base; memcpy(&pat, &got, 4); memcpy(&base, &v.cinit, 4);
+                            if (pat != (base | ((unsigned int) X << 12) | (unsigned int) Y)) flag_bad++;
+                        }
+                    }
+            printf("%-78s: %ld of %ld results differ from the exact sum (worst |diff| %.3f); field sums span [%ld, %ld] / 8", v.name, bad, total, worst, xmin, xmax);
+            if (in_range) printf("; bit pattern = pattern(C) | X' << 12 | Y': %ld of %ld wrong", flag_bad, in_range);
+            printf("\n");
+        }
+    }
+    // ---- (2) cost ----
+    std::vector<unsigned> ab(6 * 64 * 8, 0);
+    for (int s = 0; s < 2; s++)
+        for (int l = 0; l < 64; l++) {
+            for (int j = 0; j < 32; j++) put_bits(&ab[(s * 192 + l) * 8], 6 * j, 6, 0x20u | (unsigned) (1 + ((l + j + s) % 24)));      // A: negative fp6 values
+            for (int j = 0; j < 32; j++) put_bits(&ab[(s * 192 + 64 + l) * 8], 4 * j, 4, ((j + l + s) & 3) == 0 ? 0x2u : 0u);           // B: one-hot fp4
+            for (int j = 0; j < 32; j++) put_bits(&ab[(s * 192 + 128 + l) * 8], 4 * j, 4, ((j + l + s) & 3) == 1 ? 0x2u : 0u);
+        }
+    i32x8 *d_ab; unsigned int *d_sink; unsigned long long *d_clk;
+    CK(hipMalloc(&d_ab, ab.size() * 4)); CK(hipMalloc(&d_sink, 64)); CK(hipMalloc(&d_clk, 2 * 512 * 8));
+    CK(hipMemcpy(d_ab, ab.data(), ab.size() * 4, hipMemcpyHostToDevice));
+    run_cost<0>("mode 0: 2 MFMA (C = 0) + AND chain            [16 motifs x 2 strands, <= 15 columns]", d_ab, d_sink, d_clk);
+    run_cost<1>("mode 1: 2 MFMA (C const, lane scales) + OR chain [32 motifs x 2 strands, <= 7 columns]", d_ab, d_sink, d_clk);
+    run_cost<2>("mode 2: 4 MFMA (C const, lane scales) + OR chain [32 motifs x 2 strands, <= 15 columns]", d_ab, d_sink, d_clk);
+    run_cost<3>("mode 3: 4 MFMA (C = 0) + AND chain            [16 motifs x 2 strands, <= 31 columns]", d_ab, d_sink, d_clk);
+    run_cost<4>("mode 4: mode 0 with the A operand read from LDS each trip", d_ab, d_sink, d_clk);
+    run_cost<5>("mode 5: mode 1 with the A operand read from LDS each trip", d_ab, d_sink, d_clk);
+    run_cost<6>("mode 6: mode 2 with the A operands read from LDS each trip", d_ab, d_sink, d_clk);
+    run_cost<7>("mode 7: mode 3 with the A operands read from LDS each trip", d_ab, d_sink, d_clk);
+    return 0;
+}
