@@ -903,7 +903,7 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kF6LutBytes + kPfStageBytes;            // the B-operand table and the waves' sequence staging follow the tables
+    const size_t lds_fixed = kF6LutBytes + kPfStageBytes + kPfRareBytes + kPfEmitBytes;   // the B-operand table, the waves' sequence staging and their candidate parking space follow the tables
     // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
     // (profiles/r02_wave_occupancy_ab.log)
     size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
@@ -1016,6 +1016,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             PfArgs A;
             A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16; A.stage_off16 = lut_off16 + (uint32_t) (kF6LutBytes / 16);
+            A.rare_off16 = A.stage_off16 + (uint32_t) (kPfStageBytes / 16);
+            A.emit_off16 = A.rare_off16 + (uint32_t) (kPfRareBytes / 16);
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
             A.unit_slots = 0; A.unit_cnt = nullptr;
             // While a batch stream is live and the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs (the
@@ -1059,10 +1061,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
             }
             A.clk = nullptr;
+            A.cls_clk = pf_clock && atoi(measure_env("MS_PF_CLOCK")) == 2;
             if (pf_clock) {
                 clk_blocks = bpt * n_tiles;
-                if (!d_clk && (rc = dev_alloc(&d_clk, (size_t) 2 * clk_blocks))) return rc;
-                (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * 2 * clk_blocks, c->stream);
+                if (!d_clk && (rc = dev_alloc(&d_clk, (size_t) kPfClkWords * clk_blocks))) return rc;
+                (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * kPfClkWords * clk_blocks, c->stream);
                 A.clk = d_clk;
             }
             {
@@ -1141,12 +1144,27 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     };
     auto read_clock = [&]() {
         if (!d_clk) return;                                  // median over blocks of cycles per 10 ns tick
-        std::vector<unsigned long long> h((size_t) 2 * clk_blocks);
+        std::vector<unsigned long long> h((size_t) kPfClkWords * clk_blocks);
         if (hipMemcpy(h.data(), d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
             std::vector<double> mhz;
             for (int b = 0; b < clk_blocks; b++)
-                if (h[2 * b + 1] > 0) mhz.push_back(100.0 * (double) h[2 * b] / (double) h[2 * b + 1]);
+                if (h[(size_t) kPfClkWords * b + 1] > 0) mhz.push_back(100.0 * (double) h[(size_t) kPfClkWords * b] / (double) h[(size_t) kPfClkWords * b + 1]);
             if (!mhz.empty()) { std::sort(mhz.begin(), mhz.end()); stt.pf_clock_mhz = mhz[mhz.size() / 2]; }
+            if (atoi(measure_env("MS_PF_CLOCK")) == 2) {              // where a wave's cycles go: per class of the first LDS tile, and outside the classes
+                double tot = 0, cls[kMaxClasses] = {0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < clk_blocks / (int) plan.tiles.size(); b++) {
+                    tot += (double) h[(size_t) kPfClkWords * b];
+                    for (int i = 0; i < kMaxClasses; i++) cls[i] += (double) h[(size_t) kPfClkWords * b + 2 + i];
+                }
+                fprintf(stderr, "pf wave-0 cycles:");
+                double in = 0;
+                const TileDesc &t0 = plan.tiles[0];
+                for (int i = 0; i < t0.n_classes; i++) {
+                    fprintf(stderr, " [%s nk %d x %d row tiles] %.1f %%", t0.cls[i].paired ? "paired" : "plain", t0.cls[i].nk, t0.cls[i].n_row_tiles, 100.0 * cls[i] / tot);
+                    in += cls[i];
+                }
+                fprintf(stderr, " [outside the classes] %.1f %%\n", 100.0 * (tot - in) / tot);
+            }
         }
         dev_free(d_clk);
     };

@@ -4,12 +4,21 @@
 
 namespace ms {
 
-constexpr int kPfThreads = 512;       // pre-filter block: 8 waves, two blocks per CU
-constexpr int kPfBlocksPerCu = 2;
+constexpr int kPfThreads = 1024;      // pre-filter block: 16 waves, one block per CU (4 waves per SIMD: <= 128 VGPRs) -- its waves never meet at a barrier
+constexpr int kPfBlocksPerCu = 1;     // after the tables are loaded, so the block shape only decides how many copies of the tables a CU's LDS holds
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr size_t kF6LutBytes = 256 * 8;      // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables
 constexpr int kPfStageWords = 16;            // per wave: 8 code words + 4 non-ACGT words of the current pass (+ 4 spare), after the B-operand table
 constexpr size_t kPfStageBytes = (size_t) (kPfThreads / 64) * kPfStageWords * sizeof(uint32_t);
+// per wave: the lanes that hold a candidate park their 16 result registers here; the flag words are decoded later, one parked entry
+// per lane (ms_kernels.hip, "candidate hand-off")
+constexpr int kPfClkWords = 2 + kMaxClasses;
+constexpr int kRareCap = 48;                 // entries per wave
+constexpr int kRareFlushAt = kRareCap - 16;  // decode when fewer than 16 entries are free (an event that does not fit parks what fits and comes back)
+constexpr int kRareEntryWords = 20;          // 16 result registers + {position low word, position high bits | group << 8 | paired << 31} + 2 spare: 80 bytes (16-byte stores)
+constexpr size_t kPfRareBytes = (size_t) (kPfThreads / 64) * kRareCap * kRareEntryWords * sizeof(uint32_t);
+constexpr int kPfEmitWords = 16;             // per wave: its place in the global candidate list and the launch's constants (PfEmit, ms_kernels.hip)
+constexpr size_t kPfEmitBytes = (size_t) (kPfThreads / 64) * kPfEmitWords * sizeof(uint32_t);
 
 struct DevSeq {
     const uint32_t *codes;
@@ -48,6 +57,8 @@ struct PfArgs {
     const TileDesc *tiles;
     uint32_t lut_off16;       // start of the B-operand table in dynamic LDS (16-byte units)
     uint32_t stage_off16;     // start of the per-wave sequence staging
+    uint32_t rare_off16;      // start of the per-wave parking space for candidate lanes' result registers
+    uint32_t emit_off16;      // start of the per-wave PfEmit
     uint64_t *cand;           // candidate records; a wave reserves blocks of cand_block slots (unused slots are written as 0 = empty)
     unsigned long long *n_cand;   // slots reserved so far
     uint64_t cand_cap;
@@ -57,7 +68,8 @@ struct PfArgs {
     uint32_t *unit_cnt;       // ... and unit_cnt[t * n_units + u] receives the number of records the unit produced (may exceed unit_slots)
     int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
-    unsigned long long *clk;  // measurement only: per block {shader cycles, 100 MHz ticks}, or nullptr
+    int cls_clk;              // measurement only: also time the classes (MS_PF_CLOCK=2: the stamps themselves cost a few per cent)
+    unsigned long long *clk;  // measurement only: per block kPfClkWords words {shader cycles, 100 MHz ticks, wave 0's cycles inside each class}, or nullptr
     unsigned int *chunk_counter;   // [LDS tiles][kPfCounters] words 64 bytes apart, zeroed: the units behind the waves' own first ones
     int use_counters;              // 0: a small input, one even unit per wave and no atomics
     int wave_passes;               // per-wave hand-out: passes of 64 window starts a wave takes per atomic (scan_locked sizes it)

@@ -181,10 +181,31 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// What a wave keeps in registers about its candidates: the parking space (below) -- the rest of the hand-off lives in LDS (PfEmit)
 struct MfWave {
-    unsigned long long base;   // next free slot of this wave's block in the global candidate list (wave-uniform)
-    uint32_t left;             // slots left in the block (wave-uniform)
+    uint32_t *rq;              // the wave's parking space in LDS: kRareCap entries of kRareEntryWords words
+    uint32_t rq_n;             // entries parked (wave-uniform)
 };
+
+// Where a class was when its wave's parking space ran full: row tile t is re-entered (its products are computed again) at operand
+// `op` (0 / 1: the windows from g0 / from g0 + 32), past the first `skip` candidate lanes of that operand's event
+struct PfResume {
+    int t;
+    uint32_t op, skip;
+};
+
+// The wave's place in the global candidate list and the launch's constants, in LDS (one per wave: kPfEmitWords words): only the
+// out-of-line decode (pf_flush) works with them, so none of it occupies registers of the scanning loop
+struct PfEmit {
+    unsigned long long base;   // next free slot of this wave's block in the global candidate list
+    uint32_t left;             // slots left in the block (unit-ordered form: records the unit produced so far)
+    uint32_t unit_slots;
+    uint64_t *cand;
+    unsigned long long *n_cand;
+    uint64_t cand_cap, cand_static;
+    uint32_t cand_block, pad[3];
+};                             // (pf_flush reads it as seven 8-byte words)
+static_assert(sizeof(PfEmit) == kPfEmitWords * sizeof(uint32_t), "PfEmit layout");
 
 // bit n of the result = result register 15 - n is non-negative (field n of the lane's table group)
 __device__ __forceinline__ uint32_t nonneg_flags(const f32x16 &c) {
@@ -204,37 +225,139 @@ __device__ __forceinline__ uint32_t all_negative(const f32x16 &c) {
     return x & (uint32_t) __float_as_int(c[15]);
 }
 
-// empty records into the `n` (< 64) slots at W.base
-__device__ __forceinline__ void pad_block(const PfArgs &A, const MfWave &W, uint32_t n) {
-    const uint32_t lane = threadIdx.x & 63u;
-    if (lane < n && W.base + lane < A.cand_cap) A.cand[W.base + lane] = 0ULL;
-}
-
-__device__ __forceinline__ void emit_rec(const PfArgs &A, MfWave &W, bool live, int64_t g, uint32_t flags, int32_t group) {
+// One record per flagged lane into the wave's block of the global list (E: a register copy of the wave's PfEmit)
+__device__ __forceinline__ void emit_rec(PfEmit &E, bool live, int64_t g, uint32_t flags, int32_t group) {
     const bool flagged = live && flags != 0;
     const unsigned long long mask = __ballot(flagged);
     if (mask == 0) return;
     const uint32_t n_new = (uint32_t) __popcll(mask);
-    if (A.unit_slots) {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    if (E.unit_slots) {
         // unit-ordered form (the ordered tail, rescore_ordered_kernel): the records of a unit of window starts go to the unit's own
-        // slots of the list, no atomic at all; W.left counts what the unit wrote (beyond unit_slots: dropped, the host grows the slots)
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-        if (flagged && W.left + rank < A.unit_slots) A.cand[W.base + W.left + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
-        W.left += n_new;
+        // slots of the list, no atomic at all; E.left counts what the unit wrote (beyond unit_slots: dropped, the host grows the slots)
+        if (flagged && E.left + rank < E.unit_slots) E.cand[E.base + E.left + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
+        E.left += n_new;
         return;
     }
-    if (n_new > W.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
-        pad_block(A, W, W.left);
+    if (n_new > E.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane < E.left && E.base + lane < E.cand_cap) E.cand[E.base + lane] = 0ULL;      // the abandoned rest of the block: empty records
         unsigned long long b = 0;
-        if ((threadIdx.x & 63u) == 0) b = A.cand_static + atomicAdd(A.n_cand, (unsigned long long) A.cand_block);
-        W.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b >> 32)) << 32) |
-                 (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) b);          // wave-uniform: scalar registers
-        W.left = A.cand_block;
+        if (lane == 0) b = E.cand_static + atomicAdd(E.n_cand, (unsigned long long) E.cand_block);
+        E.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b >> 32)) << 32) |
+                 (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+        E.left = E.cand_block;
     }
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    if (flagged && W.base + rank < A.cand_cap) A.cand[W.base + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
-    W.base += n_new;
-    W.left -= n_new;
+    if (flagged && E.base + rank < E.cand_cap) E.cand[E.base + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
+    E.base += n_new;
+    E.left -= n_new;
+}
+
+// bits of a paired row's 16 results: field X's flag is bit 22, field Y's bit 10 (ms_internal.h).  Two accumulators of eight registers
+// each: m = 2 m | (c & mask) walks a register's two bits upwards one position per register (v_add_u32 + v_bitop3_b32, the fast
+// VALU class: profiles/r03b_valu_rate.log).  fx / fy: bit n = result register 15 - n, as nonneg_flags.
+__device__ __forceinline__ void pair_flags(const f32x16 &c, uint32_t &fx, uint32_t &fy) {
+    uint32_t ma = 0, mb = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        ma = (ma + ma) | ((uint32_t) __float_as_int(c[j]) & kPairMask);
+        mb = (mb + mb) | ((uint32_t) __float_as_int(c[8 + j]) & kPairMask);
+    }
+    // register j <= 7: X at bit 29 - j, Y at bit 17 - j of ma; register 8 + j: the same of mb
+    fx = ((ma >> 14) & 0xFF00u) | ((mb >> 22) & 0xFFu);
+    fy = ((ma >> 2) & 0xFF00u) | ((mb >> 10) & 0xFFu);
+}
+
+// ---- parked candidates ----
+// A row tile holds a candidate in about one lane of its 64 windows x 32 rows, but decoding WHICH fields (one or two VALU operations
+// per result register) and queueing the record costs the wave the same whether one lane needs it or all 64: in round 3's first
+// paired kernel that was 28 % of the pre-filter (profiles/r03b_pf_pair.log), and -- inlined into every class -- the reason the
+// kernel spilled registers it reloaded once per class and pass.  So the lanes that hold a candidate only PARK their 16 result
+// registers and a two-word header (position, table group, kind) in the wave's LDS space -- four ds_write_b128 and one ds_write_b64
+// under the lanes' exec mask -- and when the space runs low the class returns to the one place that calls pf_flush, an ordinary
+// (not inlined) function: it decodes the parked entries one per lane and queues the records.  An event with more candidate lanes
+// than free entries parks what fits; the class comes back to the same row tile after the flush (PfResume).
+
+// Parks the event's candidate lanes number skip, skip + 1, ... while entries are free.  True: all parked (skip is 0 again).
+__device__ __forceinline__ bool rare_park(MfWave &W, const f32x16 &c, bool hit, int64_t g, int32_t group, uint32_t paired, uint32_t &skip) {
+    const unsigned long long mask = __ballot(hit);
+    const uint32_t n_new = (uint32_t) __popcll(mask) - skip, n_free = (uint32_t) kRareCap - W.rq_n;
+    const uint32_t n_take = n_new < n_free ? n_new : n_free;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u)) - skip;   // (wraps for the lanes already parked)
+    if (hit && rank < n_take) {
+        uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank) * (uint32_t) kRareEntryWords);      // 80-byte entries: four 16-byte stores + one of 8
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c[4 * j]), __float_as_uint(c[4 * j + 1]), __float_as_uint(c[4 * j + 2]), __float_as_uint(c[4 * j + 3]));
+        *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g, (uint32_t) ((uint64_t) g >> 32) | ((uint32_t) group << 8) | (paired << 31));
+    }
+    W.rq_n += n_take;
+    if (n_take < n_new) { skip += n_take; return false; }
+    skip = 0;
+    return true;
+}
+
+// The candidate lanes of a row tile's two operands (hit0 / hit1) into the parking space; R says where to pick up after a flush.
+// True: the space ran full, the class must leave for a flush and come back to this row tile.
+__device__ __forceinline__ bool rare_park2(MfWave &W, PfResume &R, const f32x16 &c0, const f32x16 &c1, bool hit0, bool hit1, int64_t g0,
+                                           int32_t group, uint32_t paired) {
+    if (R.op == 0 && __any(hit0) && !rare_park(W, c0, hit0, g0, group, paired, R.skip)) return true;
+    R.op = 1;
+    if (__any(hit1) && !rare_park(W, c1, hit1, g0 + 32, group, paired, R.skip)) return true;
+    R.op = 0;
+    return false;
+}
+
+// Decode and queue the n parked entries of a wave (lane i takes entry i).  All lanes of the wave, at a wave-uniform point.  NOT
+// inlined, and everything it needs comes through two LDS addresses: its registers are its own business.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+__device__ __attribute__((noinline)) void pf_flush(uint32_t em_lds, uint32_t rq_lds, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool mine = lane < n;
+    lds_u32x2 *em2 = (lds_u32x2 *) (uintptr_t) em_lds;
+    PfEmit E;
+    {
+        const u32x2 w0 = em2[0], w1 = em2[1], w2 = em2[2], w3 = em2[3], w4 = em2[4], w5 = em2[5], w6 = em2[6];
+        E.base = ((unsigned long long) w0.y << 32) | w0.x;
+        E.left = w1.x; E.unit_slots = w1.y;
+        E.cand = reinterpret_cast<uint64_t *>(((unsigned long long) w2.y << 32) | w2.x);
+        E.n_cand = reinterpret_cast<unsigned long long *>(((unsigned long long) w3.y << 32) | w3.x);
+        E.cand_cap = ((unsigned long long) w4.y << 32) | w4.x;
+        E.cand_static = ((unsigned long long) w5.y << 32) | w5.x;
+        E.cand_block = w6.x;
+    }
+    f32x16 c;
+    u32x2 hd = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; j++) c[j] = 0.0f;
+    if (mine) {
+        lds_u32x2 *e = (lds_u32x2 *) (uintptr_t) (rq_lds + lane * (uint32_t) (kRareEntryWords * 4));
+        const u32x2 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5], q6 = e[6], q7 = e[7];
+        hd = e[8];
+        c = f32x16{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q1.x), __uint_as_float(q1.y),
+                   __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q3.x), __uint_as_float(q3.y),
+                   __uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q5.x), __uint_as_float(q5.y),
+                   __uint_as_float(q6.x), __uint_as_float(q6.y), __uint_as_float(q7.x), __uint_as_float(q7.y)};
+    }
+    const bool paired = (hd.y >> 31) != 0u;
+    const int64_t g = (int64_t) (((uint64_t) (hd.y & 0xFFu) << 32) | hd.x);
+    const int32_t group = (int32_t) ((hd.y >> 8) & 0x3FFFu);
+    uint32_t fx, fy;
+    pair_flags(c, fx, fy);
+    const uint32_t fs = nonneg_flags(c);
+    emit_rec(E, mine, g, paired ? fx : fs, group);
+    emit_rec(E, mine && paired, g, fy, group + 1);
+    if (lane == 0) { em2[0] = u32x2{(uint32_t) E.base, (uint32_t) (E.base >> 32)}; ((lds_u32 *) (uintptr_t) em_lds)[2] = E.left; }
+}
+
+// OR of the 16 result patterns: some field of the lane is a candidate <=> (x & kPairMask) != 0.  v_bitop3_b32 by name: left alone
+// hipcc picks v_or3_b32, which costs the SIMD 4.4 cycles against 2.7 (profiles/r03b_valu_rate.log)
+__device__ __forceinline__ uint32_t or16(const f32x16 &c) {
+    uint32_t x = __builtin_amdgcn_bitop3_b32((uint32_t) __float_as_int(c[0]), (uint32_t) __float_as_int(c[1]), (uint32_t) __float_as_int(c[2]), 0xFE);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) x = __builtin_amdgcn_bitop3_b32(x, (uint32_t) __float_as_int(c[i]), (uint32_t) __float_as_int(c[i + 1]), 0xFE);
+    return x | (uint32_t) __float_as_int(c[15]);
 }
 
 // The lane's 8 bases of one k-block half as 32 fp4 one-hot k-slots: two reads of the 256-entry table (byte of four 2-bit codes ->
@@ -260,27 +383,29 @@ struct PassSeq {
     bool any_n;          // wave-uniform: some lane sees a non-ACGT base in the 96 bases from g0
 };
 
-// the 32 bases (2-bit codes) / their non-ACGT bits from window start pass0 + r + 32 i, cut out of the staged words (r = lane & 31)
+// the 32 bases (2-bit codes) / their non-ACGT bits from window start pass0 + r + 32 i, cut out of the staged words (r = lane & 31):
+// funnel shifts (v_alignbit_b32: a shift of 0 is the low operand itself, no special case)
 __device__ __forceinline__ uint64_t staged_cw(const uint32_t *stg, uint32_t r, int i) {
     const uint32_t w = (r >> 4) + 2 * i, sh = (r & 15u) * 2u;
-    const uint64_t lo = ((uint64_t) stg[w + 1] << 32) | stg[w];
-    return sh ? (lo >> sh) | ((uint64_t) stg[w + 2] << (64u - sh)) : lo;
+    const uint32_t lo = __builtin_amdgcn_alignbit(stg[w + 1], stg[w], sh), hi = __builtin_amdgcn_alignbit(stg[w + 2], stg[w + 1], sh);
+    return ((uint64_t) hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, int i) {
-    return r ? (stg[8 + i] >> r) | (stg[9 + i] << (32u - r)) : stg[8 + i];
+    return __builtin_amdgcn_alignbit(stg[9 + i], stg[8 + i], r);
 }
 
-// All row tiles of one class (NK k-blocks each).  ILP row tiles' products are issued back to back (independent accumulators), then
-// inspected: a wave that spends more of its time issuing matrix instructions leaves the pipe idle less often (4 waves per SIMD).
+// All row tiles of one class of plain rows (NK k-blocks each).
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                          uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
-                                         int64_t pass0, bool live0, bool live1) {
+                                         int64_t pass0, bool live0, bool live1, PfResume &R) {
     // pass0 = the pass's first window start (wave-uniform: scalar registers); this lane's two window starts are pass0 + r and
     // pass0 + r + 32 with r = lane & 31 -- recomputed where needed (rare paths), not carried
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
-    const char *p = lds + byte_off + lane * 8u;
+    // R.t: the row tile to start at; the class returns early, with the row tile to come back to in R, when the wave's parking space
+    // runs low or full (the caller has the parked entries decoded -- ONE call site for all classes -- and comes back)
     constexpr int kStep = NK * kF6BytesPerKb;
+    const char *p = lds + byte_off + lane * 8u + (uint32_t) R.t * (uint32_t) kStep;
     constexpr int NW = NK > 2 ? 3 : 2;
     uint64_t cw[NW];
     cw[0] = Q.cw[0];
@@ -324,60 +449,22 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, 127, 0, 127);
         }
     };
-    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) {
+    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) -> bool {        // true: the parking space ran full inside this row tile
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
-            // rare path (about one row tile in four holds a candidate in some lane): which of the two 32-window operands, which fields
-            const int32_t group = first_group + 2 * t + (int32_t) h;
-            if (__any((int) x0 >= 0)) emit_rec(A, W, live0, pass0 + (lane & 31u), nonneg_flags(c0), group);
-            if (__any((int) x1 >= 0)) emit_rec(A, W, live1, pass0 + (lane & 31u) + 32, nonneg_flags(c1), group);
-        }
+        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0))
+            // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
+            return rare_park2(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u);
+        return false;
     };
-    constexpr int ILP = NK <= 2 ? 2 : 1;
-    int t = 0;
-    for (; t + ILP <= n_row_tiles; t += ILP, p += ILP * kStep) {
-        f32x16 c0[ILP], c1[ILP];
-#pragma unroll
-        for (int u = 0; u < ILP; u++) product(p + u * kStep, c0[u], c1[u]);
-        // keep BOTH tiles' matrix instructions ahead of the first inspection (left alone, hipcc sinks the second tile's below
-        // the first tile's test and the wave sits out its own result latency once per tile)
-        if constexpr (ILP > 1) {
-#pragma unroll
-            for (int u = 0; u < ILP; u++) asm volatile("" : "+v"(c0[u]), "+v"(c1[u]));      // (an empty asm "uses" the results here: the IR-level sinking cannot pass it)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int u = 0; u < ILP; u++) test(c0[u], c1[u], t + u);
-    }
-    for (; t < n_row_tiles; t++, p += kStep) {
+    // one row tile in flight per wave: with paired rows most instructions belong to four-instruction row tiles, and a second set of
+    // 32 accumulators (round 2's two tiles in flight for the narrow classes) costs the whole kernel its registers
+    for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
         f32x16 c0, c1;
         product(p, c0, c1);
-        test(c0, c1, t);
+        if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
+        if (__builtin_expect(W.rq_n >= (uint32_t) kRareFlushAt, 0)) { R.t = t + 1; return; }
     }
-}
-
-// bits of a paired row's 16 results: field X's flag is bit 22, field Y's bit 10 (ms_internal.h).  Two accumulators of eight registers
-// each: m = 2 m | (c & mask) walks a register's two bits upwards one position per register (v_add_u32 + v_bitop3_b32, the fast
-// VALU class: profiles/r03b_valu_rate.log).  fx / fy: bit n = result register 15 - n, as nonneg_flags.
-__device__ __forceinline__ void pair_flags(const f32x16 &c, uint32_t &fx, uint32_t &fy) {
-    uint32_t ma = 0, mb = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        ma = (ma + ma) | ((uint32_t) __float_as_int(c[j]) & kPairMask);
-        mb = (mb + mb) | ((uint32_t) __float_as_int(c[8 + j]) & kPairMask);
-    }
-    // register j <= 7: X at bit 29 - j, Y at bit 17 - j of ma; register 8 + j: the same of mb
-    fx = ((ma >> 14) & 0xFF00u) | ((mb >> 22) & 0xFFu);
-    fy = ((ma >> 2) & 0xFF00u) | ((mb >> 10) & 0xFFu);
-}
-
-// OR of the 16 result patterns: some field of the lane is a candidate <=> (x & kPairMask) != 0.  v_bitop3_b32 by name: left alone
-// hipcc picks v_or3_b32, which costs the SIMD 4.4 cycles against 2.7 (profiles/r03b_valu_rate.log)
-__device__ __forceinline__ uint32_t or16(const f32x16 &c) {
-    uint32_t x = __builtin_amdgcn_bitop3_b32((uint32_t) __float_as_int(c[0]), (uint32_t) __float_as_int(c[1]), (uint32_t) __float_as_int(c[2]), 0xFE);
-#pragma unroll
-    for (int i = 3; i < 15; i += 2) x = __builtin_amdgcn_bitop3_b32(x, (uint32_t) __float_as_int(c[i]), (uint32_t) __float_as_int(c[i + 1]), 0xFE);
-    return x | (uint32_t) __float_as_int(c[15]);
+    R.t = n_row_tiles;
 }
 
 // All row tiles of one class of PAIRED rows (ms_internal.h): NK half-blocks of 8 columns, k-half 0 = field X, k-half 1 = field Y (block
@@ -387,10 +474,10 @@ __device__ __forceinline__ uint32_t or16(const f32x16 &c) {
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                               uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
-                                              int64_t pass0, bool live0, bool live1) {
+                                              int64_t pass0, bool live0, bool live1, PfResume &R) {
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
-    const char *p = lds + byte_off + lane * 8u;
     constexpr int kStep = NK * kF6BytesPerKb;
+    const char *p = lds + byte_off + lane * 8u + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
     // B operands: half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
     i32x8 b0[NK], b1[NK];
 #pragma unroll
@@ -416,8 +503,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     f32x16 cc0, cc1;
 #pragma unroll
     for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
-    auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
-        i32x8 a[NK];
+    auto load_a = [&](const char *q, i32x8 (&a)[NK]) {
 #pragma unroll
         for (int kb = 0; kb < NK; kb++) {
             const int2 w0 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb);
@@ -425,6 +511,8 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
             a[kb] = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
         }
+    };
+    auto product = [&](const i32x8 (&a)[NK], f32x16 &c0, f32x16 &c1) {
         c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], cc0, 2, 4, 0, scale0, 0, 127);
         c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], cc1, 2, 4, 0, scale1, 0, 127);
 #pragma unroll
@@ -433,34 +521,31 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, scale1, 0, 127);
         }
     };
-    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) {
+    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) -> bool {        // true: the parking space ran full inside this row tile
         const uint32_t x0 = or16(c0), x1 = or16(c1);
-        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0)) {
-            // rare path: which of the two 32-window operands, which fields of X and of Y (table groups 4 t + 2 h and + 1)
-            const int32_t group = first_group + 4 * t + 2 * (int32_t) h;
-            if (__any((x0 & kPairMask) != 0u)) {
-                uint32_t fx, fy;
-                pair_flags(c0, fx, fy);
-                emit_rec(A, W, live0, pass0 + (lane & 31u), fx, group);
-                emit_rec(A, W, live0, pass0 + (lane & 31u), fy, group + 1);
-            }
-            if (__any((x1 & kPairMask) != 0u)) {
-                uint32_t fx, fy;
-                pair_flags(c1, fx, fy);
-                emit_rec(A, W, live1, pass0 + (lane & 31u) + 32, fx, group);
-                emit_rec(A, W, live1, pass0 + (lane & 31u) + 32, fy, group + 1);
-            }
-        }
+        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0))
+            // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
+            return rare_park2(W, R, c0, c1, live0 && (x0 & kPairMask) != 0u, live1 && (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
+                              first_group + 4 * t + 2 * (int32_t) h, 1u);
+        return false;
     };
-    for (int t = 0; t < n_row_tiles; t++, p += kStep) {
+    for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
+        // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
+        i32x8 a[NK];
+        load_a(p, a);
         f32x16 c0, c1;
-        product(p, c0, c1);
-        test(c0, c1, t);
+        product(a, c0, c1);
+        if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
+        if (__builtin_expect(W.rq_n >= (uint32_t) kRareFlushAt, 0)) { R.t = t + 1; return; }
     }
+    R.t = n_row_tiles;
 }
 
-// grid = (blocks per tile, tiles); two 512-thread blocks per CU (16 waves per CU, <= 128 VGPRs), each with its own copy of the
-// LDS tile.  Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes) | per-wave sequence staging (kPfStageBytes).
+// grid = (blocks per tile, tiles); ONE 1024-thread block per CU (16 waves per CU, <= 128 VGPRs): its waves never meet at a barrier
+// after the tables are loaded, so against round 2's two 512-thread blocks the only difference is ONE copy of the tables per CU --
+// the other ~60 KB of LDS are the waves' parking space for candidates (and room for larger motif sets in one tile).
+// Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes) | per-wave sequence staging (kPfStageBytes) | per-wave
+// parking space (kPfRareBytes) | per-wave PfEmit (kPfEmitBytes).
 // Work is handed out per WAVE, without a barrier in the loop: a wave's first unit is its own number, every further unit one
 // atomicAdd on one of the tile's kPfCounters counter words (64 bytes apart; the blocks are dealt round-robin onto them and a word
 // hands out every kPfCounters-th unit), requested before the current unit is scanned (the atomic's latency hides behind the unit);
@@ -501,12 +586,20 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // every wave OWNS a first block of the candidate list (no atomic: 4096 waves reserving their first block on one counter word
     // cost 45 us, the whole fixed cost of a small scan); further blocks come from the counter, behind the static ones
     MfWave W;
-    W.base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
-    W.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (W.base >> 32)) << 32) | (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) W.base);
-    W.left = A.cand_block;
-    if (A.unit_slots) { W.base = 0; W.left = 0; }
+    W.rq = reinterpret_cast<uint32_t *>(lds4 + A.rare_off16) + (threadIdx.x >> 6) * (uint32_t) (kRareCap * kRareEntryWords);
+    W.rq_n = 0;
+    PfEmit *em = reinterpret_cast<PfEmit *>(reinterpret_cast<uint32_t *>(lds4 + A.emit_off16) + (threadIdx.x >> 6) * (uint32_t) kPfEmitWords);
+    const uint32_t em_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) em;
+    const uint32_t rq_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) W.rq;
+    if ((threadIdx.x & 63u) == 0) {
+        em->base = A.unit_slots ? 0ULL : ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
+        em->left = A.unit_slots ? 0u : A.cand_block;
+        em->unit_slots = A.unit_slots;
+        em->cand = A.cand; em->n_cand = A.n_cand; em->cand_cap = A.cand_cap; em->cand_static = A.cand_static; em->cand_block = A.cand_block;
+    }
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     unsigned long long t0 = 0, r0 = 0;
+    unsigned long long cls_cyc[kMaxClasses] = {0, 0, 0, 0, 0, 0};               // measurement only: this wave's cycles inside each class
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
     // The sequence words of a pass, staged per wave in LDS: the wave's 64 window starts and the 32 (wide tiles: 64) bases behind the
@@ -545,18 +638,25 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         for (int i = 0; i < n_classes; i++) {
             const ClassDesc cd = T->cls[i];
             const uint32_t off = cd.base16 * 16u;
-            if (cd.paired) {
-                if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1);
-                else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1);
-                continue;
+            PfResume R{0, 0u, 0u};
+            unsigned long long tc0 = 0;
+            if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
+            while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
+                if (cd.paired) {
+                    if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
+                    else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
+                } else {
+                    switch (cd.nk) {
+                        case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
+                        case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
+                        case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); else R.t = cd.n_row_tiles; break;
+                        case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); else R.t = cd.n_row_tiles; break;
+                        default: R.t = cd.n_row_tiles; break;
+                    }
+                }
+                if (W.rq_n >= (uint32_t) kRareFlushAt) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
             }
-            switch (cd.nk) {
-                case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
-                case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
-                case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
-                case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1); break;
-                default: break;
-            }
+            if constexpr (MEAS) { if (A.cls_clk) cls_cyc[i] += __builtin_amdgcn_s_memtime() - tc0; }
         }
     };
     {
@@ -574,6 +674,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         const uint32_t units_g = n_units > g ? (n_units - g + K - 1) / K : 0u;
         unsigned int *word = A.chunk_counter + ((size_t) blockIdx.y * kPfCounters + g) * 16;
         uint32_t v = (blockIdx.x / K) * wpb + (threadIdx.x >> 6);
+        uint32_t words = v < units_g ? fetch((int64_t) ((v * K + g) * wave_passes) * 64) : 0u;
         while (v < units_g) {
             uint32_t next = 0xFFFFFFFFu;
             if (dyn) {                                                            // asked for before this unit is scanned
@@ -583,30 +684,41 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             }
             const uint32_t uid = v * K + g;                                       // the unit: window starts [uid, uid + 1) * 64 * wave_passes
             const uint32_t p0 = uid * wave_passes;
-            if (A.unit_slots) {
-                W.base = ((unsigned long long) blockIdx.y * n_units + uid) * A.unit_slots;
-                W.left = 0;
+            if (A.unit_slots && lane == 0) {
+                em->base = ((unsigned long long) blockIdx.y * n_units + uid) * A.unit_slots;
+                em->left = 0;
             }
-            uint32_t words = fetch((int64_t) p0 * 64);
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
                 if (lane < 12) stg[lane] = words;                                 // (the wave's LDS operations execute in order: no barrier)
-                if (j + 1 < wave_passes) words = fetch((int64_t) (p0 + j + 1) * 64);      // in flight while this pass is scanned
+                // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
+                // flight while this pass is scanned
+                if (j + 1 < wave_passes) words = fetch((int64_t) (p0 + j + 1) * 64);
+                else if (next < units_g) words = fetch((int64_t) ((next * K + g) * wave_passes) * 64);
                 scan_pass((int64_t) (p0 + j) * 64);
             }
-            if (A.unit_slots && lane == 0) A.unit_cnt[(size_t) blockIdx.y * n_units + uid] = W.left;
+            if (A.unit_slots) {                                                   // the unit's records belong to the unit's slots
+                if (W.rq_n) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
+                if (lane == 0) A.unit_cnt[(size_t) blockIdx.y * n_units + uid] = em->left;
+            }
             v = next;
         }
     }
-    for (uint32_t i = 0; !A.unit_slots && i < W.left; i += 64) {                  // the unused rest of the last block: empty records
-        const unsigned long long j = W.base + i + lane;
-        if (i + lane < W.left && j < A.cand_cap) A.cand[j] = 0ULL;
+    if (W.rq_n) pf_flush(em_lds, rq_lds, W.rq_n);
+    if (!A.unit_slots) {                                                          // the unused rest of the last block: empty records
+        const unsigned long long base = em->base;
+        const uint32_t left = em->left;
+        for (uint32_t i = 0; i < left; i += 64) {
+            const unsigned long long j = base + i + lane;
+            if (i + lane < left && j < A.cand_cap) A.cand[j] = 0ULL;
+        }
     }
     if constexpr (MEAS) {
         if (A.clk && threadIdx.x == 0) {
             const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
             const size_t b = (size_t) blockIdx.y * gridDim.x + blockIdx.x;
-            A.clk[2 * b] = t1 - t0;
-            A.clk[2 * b + 1] = r1 - r0;
+            A.clk[kPfClkWords * b] = t1 - t0;
+            A.clk[kPfClkWords * b + 1] = r1 - r0;
+            for (int i = 0; i < kMaxClasses; i++) A.clk[kPfClkWords * b + 2 + i] = cls_cyc[i];
         }
     }
 }

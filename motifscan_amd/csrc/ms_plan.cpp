@@ -168,12 +168,27 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
     const int sd_single = strand_mask == 2 ? 1 : 0;
     struct RowTile { bool paired; int nk; size_t first, count, off; };
     std::vector<RowTile> rts;
+    // Row tiles = runs of consecutive motifs (sorted by width: a tile pays for its widest), cut so that the instruction count is
+    // minimal -- e.g. the last few narrow motifs get a short tile of their own rather than riding a tile of wider ones
     auto cut = [&](size_t lo, size_t hi, bool pr) {
-        const size_t per_rt = (both ? 16 : 32) * (pr ? 2 : 1);
-        for (size_t j = lo; j < hi; j += per_rt) {
-            RowTile rt{pr, 0, j, std::min(per_rt, hi - j), 0};
-            for (size_t q = j; q < j + rt.count; q++) rt.nk = std::max(rt.nk, pr ? pair_kb_of_width(fast[q].W) : f6_kb_of_width(fast[q].W));
+        const size_t per_rt = (both ? 16 : 32) * (pr ? 2 : 1), n = hi - lo;
+        auto nk_of = [&](size_t q) { return pr ? pair_kb_of_width(fast[q].W) : f6_kb_of_width(fast[q].W); };
+        std::vector<long> cost(n + 1, 0);
+        std::vector<size_t> from(n + 1, 0);
+        for (size_t i = 1; i <= n; i++) {
+            cost[i] = -1;
+            for (size_t j = i > per_rt ? i - per_rt : 0; j < i; j++) {
+                const long c = cost[j] + 64L * nk_of(lo + i - 1) + 1;             // instructions first, then the number of tiles
+                if (cost[i] < 0 || c < cost[i]) { cost[i] = c; from[i] = j; }
+            }
+        }
+        std::vector<size_t> ends;
+        for (size_t i = n; i > 0; i = from[i]) ends.push_back(i);
+        size_t j = 0;
+        for (size_t k = ends.size(); k-- > 0;) {
+            RowTile rt{pr, nk_of(lo + ends[k] - 1), lo + j, ends[k] - j, 0};
             rts.push_back(rt);
+            j = ends[k];
         }
     };
     cut(0, n_paired, true);

@@ -279,7 +279,8 @@ def test_prefilter_routes_degenerate_pwms_to_exact_path():
 def test_plan_tiles_respect_lds_budget(jaspar579):
     """Motifs of <= 15 columns ride PAIRED rows: 32 motifs x {fwd, rev} (one strand: 64 motifs) per 32-row operand tile, four table
     groups, W // 8 + 1 half-blocks of 1.5 KiB; wider motifs plain rows: 16 (32) motifs per tile, two groups, W // 16 + 1 k-blocks;
-    narrow to wide within each kind; LDS tiles hold whole row tiles and stay inside the budget."""
+    narrow to wide within each kind, the row tiles cut so that the instruction count is minimal; LDS tiles hold whole row tiles
+    and stay inside the budget."""
     pw = _lib.PwmSet(jaspar579["pwm_values"], jaspar579["widths"], jaspar579["cutoffs"]["1e-4"])
     widths = np.asarray(jaspar579["widths"])
     n_pair, n_plain = int((widths <= 15).sum()), int((widths > 15).sum())
@@ -289,7 +290,8 @@ def test_plan_tiles_respect_lds_budget(jaspar579):
             assert plan["n_exact"] == 0 and plan["n_fast"] == 579
             check_plan_shape(plan, 579, widths)
             gf, kb, tf, paired = plan["group_fields"], plan["group_kb"], plan["tile_first_group"], plan["group_paired"]
-            rt_pair, rt_plain = (n_pair + 2 * per_rt - 1) // (2 * per_rt), (n_plain + per_rt - 1) // per_rt
+            rt_pair, rt_plain = int((paired == 1).sum()) // 2, int((paired == 0).sum()) // 2
+            assert rt_pair >= (n_pair + 2 * per_rt - 1) // (2 * per_rt) and rt_plain >= (n_plain + per_rt - 1) // per_rt
             assert len(kb) == 4 * rt_pair + 2 * rt_plain
             assert (paired[:4 * rt_pair] > 0).all() and (paired[4 * rt_pair:] == 0).all()     # paired row tiles first
             assert (np.diff(kb[:4 * rt_pair]) >= 0).all() and (np.diff(kb[4 * rt_pair:]) >= 0).all() and kb.max() == 2 and kb.min() == 1
@@ -303,12 +305,18 @@ def test_plan_tiles_respect_lds_budget(jaspar579):
                 tile_bytes = int(kb[tf[t]:tf[t + 1]][first_of_rt[tf[t]:tf[t + 1]]].sum()) * 1536
                 assert 0 < tile_bytes <= budget
             assert (plan["n_tiles"] == 1) == (budget > 64 * 1024)
-    # the benchmark set at both strands: matrix instructions per 32 windows
+    # the benchmark set at both strands: matrix instructions per 32 windows = the least any cut into runs of <= 32 / <= 16 motifs allows
     plan = pw.plan(3)
-    wp, wl = sorted(int(w) for w in widths if w <= 15), sorted(int(w) for w in widths if w > 15)
-    want = sum(wp[min(i + 31, len(wp) - 1)] // 8 + 1 for i in range(0, len(wp), 32)) + sum(wl[min(i + 15, len(wl) - 1)] // 16 + 1 for i in range(0, len(wl), 16))
-    rt_pair = (len(wp) + 31) // 32
-    assert int(plan["group_kb"][:4 * rt_pair:4].sum()) + int(plan["group_kb"][4 * rt_pair::2].sum()) == want
+
+    def least(ws, per, cols):
+        best = [0] + [10 ** 9] * len(ws)
+        for i in range(1, len(ws) + 1):
+            best[i] = min(best[j] for j in range(max(0, i - per), i)) + ws[i - 1] // cols + 1
+        return best[-1]
+    want = least(sorted(int(w) for w in widths if w <= 15), 32, 8) + least(sorted(int(w) for w in widths if w > 15), 16, 16)
+    paired = plan["group_paired"]
+    rt_pair = int((paired == 1).sum()) // 2
+    assert int(plan["group_kb"][:4 * rt_pair:4].sum()) + int(plan["group_kb"][4 * rt_pair::2].sum()) == want == 41
 
 
 # --------------------------------------------------------------------------- dedup --

@@ -109,6 +109,55 @@ static void put_bits(unsigned *w, int bit, int nbits, unsigned v) {
     for (int i = 0; i < nbits; i++) if ((v >> i) & 1) w[(bit + i) >> 5] |= 1u << ((bit + i) & 31);
 }
 
+// modes 8 / 9: a paired row tile of two / one half-blocks read from LDS ONCE and multiplied with TWO sets of B operands one after
+// the other (128 windows per wave and row tile visit): per visit 8 / 4 MFMA and two inspections, reported per 64 windows
+template <int NK>
+__global__ void __launch_bounds__(1024) twice_kernel(const i32x8 *ab, int trips, unsigned int *sink, unsigned long long *clk) {
+    __shared__ unsigned long long tab[16 * 2 * 3 * 64];
+    for (int i = threadIdx.x; i < 16 * 2 * 3 * 64; i += blockDim.x) {
+        const i32x8 v = ab[i & 63];
+        const int pl = (i >> 6) % 3;
+        tab[i] = ((unsigned long long) (unsigned int) v[2 * pl + 1] << 32) | (unsigned int) v[2 * pl];
+    }
+    __syncthreads();
+    const unsigned int lane = threadIdx.x & 63;
+    i32x8 b[4][2];
+    for (int w = 0; w < 4; w++) for (int kb = 0; kb < 2; kb++) b[w][kb] = ab[64 + ((w * 2 + kb) % 5) * 64 % 320 + lane];
+    const int scale = lane < 32 ? 121 : 109, scale1 = scale - 1;
+    f32x16 cc, cc1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { cc[j] = 4.0f; cc1[j] = 2.0f; }
+    unsigned int found = 0;
+    auto load = [&](int t, int kb) {
+        const unsigned long long *q = tab + ((t & 15) * 2 + kb) * 192 + lane;
+        const unsigned long long w0 = q[0], w1 = q[64], w2 = q[128];
+        return i32x8{(int) w0, (int) (w0 >> 32), (int) w1, (int) (w1 >> 32), (int) w2, (int) (w2 >> 32), 0, 0};
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; t++) {
+        asm volatile("" : "+v"(b[0][0]), "+v"(b[1][0]), "+v"(b[2][0]), "+v"(b[3][0]));
+        i32x8 a[2];
+        a[0] = load(t, 0);
+        if constexpr (NK == 2) a[1] = load(t, 1);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x16 c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[2 * half][0], cc, 2, 4, 0, scale, 0, 127);
+            f32x16 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[2 * half + 1][0], cc1, 2, 4, 0, scale1, 0, 127);
+            if constexpr (NK == 2) {
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[2 * half][1], c0, 2, 4, 0, scale, 0, 127);
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[2 * half + 1][1], c1, 2, 4, 0, scale1, 0, 127);
+            }
+            unsigned int x = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) x = __builtin_amdgcn_bitop3_b32(x, (unsigned int) __float_as_int(c0[i]), (unsigned int) __float_as_int(c1[i]), 0xFE);
+            if (__builtin_expect(__any((x & kHitMask) != 0u), 0)) found += x;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (found == 0x12345u) sink[0] = found;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int MODE>
 static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, unsigned long long *d_clk) {
     const int trips = 40000;
@@ -118,7 +167,11 @@ static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, 
     for (const Cfg &c : cfgs) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        auto launch = [&]() { hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk); };
+        auto launch = [&]() {
+            if constexpr (MODE == 8) hipLaunchKernelGGL((twice_kernel<2>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips / 2, d_sink, d_clk);
+            else if constexpr (MODE == 9) hipLaunchKernelGGL((twice_kernel<1>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips / 2, d_sink, d_clk);
+            else hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
+        };
         for (int w = 0; w < 3; w++) launch();
         CK(hipEventRecord(e0, 0));
         launch();
@@ -240,5 +293,7 @@ int main() {
     run_cost<5>("mode 5: mode 1 with the A operand read from LDS each trip", d_ab, d_sink, d_clk);
     run_cost<6>("mode 6: mode 2 with the A operands read from LDS each trip", d_ab, d_sink, d_clk);
     run_cost<7>("mode 7: mode 3 with the A operands read from LDS each trip", d_ab, d_sink, d_clk);
+    run_cost<8>("mode 8: mode 6, one A read for TWO 64-window halves (per 64 windows)", d_ab, d_sink, d_clk);
+    run_cost<9>("mode 9: mode 5, one A read for TWO 64-window halves (per 64 windows)", d_ab, d_sink, d_clk);
     return 0;
 }
