@@ -903,7 +903,7 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kF6LutBytes + kPfStageBytes + kPfRareBytes + kPfEmitBytes;   // the B-operand table, the waves' sequence staging and their candidate parking space follow the tables
+    const size_t lds_fixed = kF6LutBytes + kPfStageBytes + kPfEmitBytes + kPfRareBytesMin;   // the B-operand table, the waves' sequence staging, their PfEmit and (at least) kRareCapMin parking entries follow the tables
     // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
     // (profiles/r02_wave_occupancy_ab.log)
     size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
@@ -992,6 +992,15 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
     const uint32_t lut_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
+    // the waves' candidate parking space takes what the tables leave of the block's LDS: kRareCapMin ... kRareCapMax entries per wave
+    uint32_t rare_cap = (uint32_t) kRareCapMin;
+    {
+        const size_t per_entry = (size_t) (kPfThreads / 64) * kRareEntryWords * sizeof(uint32_t);
+        const size_t avail = c->lds_max / (size_t) kPfBlocksPerCu;
+        if (avail > lds_bytes) rare_cap = (uint32_t) std::min<size_t>((size_t) kRareCapMax, (size_t) kRareCapMin + (avail - lds_bytes) / per_entry);
+        if (const char *e = measure_env("MS_PF_RARE_CAP")) rare_cap = (uint32_t) std::max(kRareCapMin, std::min((int) rare_cap, atoi(e)));    // test aid
+        lds_bytes += (size_t) (rare_cap - (uint32_t) kRareCapMin) * per_entry;
+    }
     int pf_no_emit = 0;
     if (const char *e = measure_env("MS_PF_NOEMIT")) pf_no_emit = atoi(e);
     const bool pf_clock = measure_env("MS_PF_CLOCK") && atoi(measure_env("MS_PF_CLOCK")) != 0;
@@ -1016,8 +1025,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             PfArgs A;
             A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16; A.stage_off16 = lut_off16 + (uint32_t) (kF6LutBytes / 16);
-            A.rare_off16 = A.stage_off16 + (uint32_t) (kPfStageBytes / 16);
-            A.emit_off16 = A.rare_off16 + (uint32_t) (kPfRareBytes / 16);
+            A.emit_off16 = A.stage_off16 + (uint32_t) (kPfStageBytes / 16);
+            A.rare_off16 = A.emit_off16 + (uint32_t) (kPfEmitBytes / 16);
+            A.rare_cap = rare_cap;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
             A.unit_slots = 0; A.unit_cnt = nullptr;
             // While a batch stream is live and the device is partitioned (StreamSel): the scan owns n_cu - n_cu_copy CUs (the

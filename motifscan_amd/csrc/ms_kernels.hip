@@ -183,8 +183,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // What a wave keeps in registers about its candidates: the parking space (below) -- the rest of the hand-off lives in LDS (PfEmit)
 struct MfWave {
-    uint32_t *rq;              // the wave's parking space in LDS: kRareCap entries of kRareEntryWords words
+    uint32_t *rq;              // the wave's parking space in LDS: rq_cap entries of kRareEntryWords words
     uint32_t rq_n;             // entries parked (wave-uniform)
+    uint32_t rq_cap, rq_flush; // PfArgs::rare_cap; the fill at which the parked entries are decoded
 };
 
 // Where a class was when its wave's parking space ran full: row tile t is re-entered (its products are computed again) at operand
@@ -281,7 +282,7 @@ __device__ __forceinline__ void pair_flags(const f32x16 &c, uint32_t &fx, uint32
 // Parks the event's candidate lanes number skip, skip + 1, ... while entries are free.  True: all parked (skip is 0 again).
 __device__ __forceinline__ bool rare_park(MfWave &W, const f32x16 &c, bool hit, int64_t g, int32_t group, uint32_t paired, uint32_t &skip) {
     const unsigned long long mask = __ballot(hit);
-    const uint32_t n_new = (uint32_t) __popcll(mask) - skip, n_free = (uint32_t) kRareCap - W.rq_n;
+    const uint32_t n_new = (uint32_t) __popcll(mask) - skip, n_free = W.rq_cap - W.rq_n;
     const uint32_t n_take = n_new < n_free ? n_new : n_free;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u)) - skip;   // (wraps for the lanes already parked)
     if (hit && rank < n_take) {
@@ -462,7 +463,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
         f32x16 c0, c1;
         product(p, c0, c1);
         if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
-        if (__builtin_expect(W.rq_n >= (uint32_t) kRareFlushAt, 0)) { R.t = t + 1; return; }
+        if (__builtin_expect(W.rq_n >= W.rq_flush, 0)) { R.t = t + 1; return; }
     }
     R.t = n_row_tiles;
 }
@@ -536,7 +537,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
         f32x16 c0, c1;
         product(a, c0, c1);
         if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
-        if (__builtin_expect(W.rq_n >= (uint32_t) kRareFlushAt, 0)) { R.t = t + 1; return; }
+        if (__builtin_expect(W.rq_n >= W.rq_flush, 0)) { R.t = t + 1; return; }
     }
     R.t = n_row_tiles;
 }
@@ -545,7 +546,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
 // after the tables are loaded, so against round 2's two 512-thread blocks the only difference is ONE copy of the tables per CU --
 // the other ~60 KB of LDS are the waves' parking space for candidates (and room for larger motif sets in one tile).
 // Dynamic LDS: operand tables of the tile | B-operand table (kF6LutBytes) | per-wave sequence staging (kPfStageBytes) | per-wave
-// parking space (kPfRareBytes) | per-wave PfEmit (kPfEmitBytes).
+// PfEmit (kPfEmitBytes) | per-wave parking space (what is left, 16 ... 64 entries per wave).
 // Work is handed out per WAVE, without a barrier in the loop: a wave's first unit is its own number, every further unit one
 // atomicAdd on one of the tile's kPfCounters counter words (64 bytes apart; the blocks are dealt round-robin onto them and a word
 // hands out every kPfCounters-th unit), requested before the current unit is scanned (the atomic's latency hides behind the unit);
@@ -586,7 +587,9 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // every wave OWNS a first block of the candidate list (no atomic: 4096 waves reserving their first block on one counter word
     // cost 45 us, the whole fixed cost of a small scan); further blocks come from the counter, behind the static ones
     MfWave W;
-    W.rq = reinterpret_cast<uint32_t *>(lds4 + A.rare_off16) + (threadIdx.x >> 6) * (uint32_t) (kRareCap * kRareEntryWords);
+    W.rq = reinterpret_cast<uint32_t *>(lds4 + A.rare_off16) + (threadIdx.x >> 6) * (A.rare_cap * (uint32_t) kRareEntryWords);
+    W.rq_cap = A.rare_cap;
+    W.rq_flush = A.rare_cap - (A.rare_cap > 32u ? A.rare_cap / 4u : 8u);
     W.rq_n = 0;
     PfEmit *em = reinterpret_cast<PfEmit *>(reinterpret_cast<uint32_t *>(lds4 + A.emit_off16) + (threadIdx.x >> 6) * (uint32_t) kPfEmitWords);
     const uint32_t em_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) em;
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                         default: R.t = cd.n_row_tiles; break;
                     }
                 }
-                if (W.rq_n >= (uint32_t) kRareFlushAt) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
+                if (W.rq_n >= W.rq_flush) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
             }
             if constexpr (MEAS) { if (A.cls_clk) cls_cyc[i] += __builtin_amdgcn_s_memtime() - tc0; }
         }
