@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--min-warm-seconds", type=float, default=2.0, help="untimed warm-up steps continue until this much wall time has passed (DVFS steady state)")
     ap.add_argument("--regions-per-set", type=int, default=None, help="c4 only: shrink the workload (development aid; the line then says so)")
     ap.add_argument("--genome-mbp", type=int, default=3000, help="c5 only: synthetic genome size in Mbp")
-    ap.add_argument("--batch-regions", type=int, default=125_000, help="regions per batch of the end-to-end leg")
+    ap.add_argument("--batch-regions", type=int, default=125_000, help="end-to-end leg: the batches of a pass grow from a quarter of this ...")
+    ap.add_argument("--max-batch-regions", type=int, default=250_000, help="... to this many regions, and shrink again at the end of the pass")
     ap.add_argument("--p-value", default="1e-4", choices=["1e-2", "1e-3", "1e-4", "1e-5", "1e-6"],
                     help="cutoff column of the motif set (the reference's -p, cli/main.py:520-521); anything but 1e-4 is a builder-run side workload, the line says so")
     ap.add_argument("--strand", default="both", choices=["both", "+", "-"], help="the reference's --strand (cli/main.py:543); default both")
@@ -453,21 +454,16 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     Whole-job rates (max time over ranks)."""
     from motifscan_amd import _lib, dist as msdist
     pins, batches, cuts = [], [], []
-    for bases, offsets in wl["sets"]:
+    n_sets = len(wl["sets"])
+    for k, (bases, offsets) in enumerate(wl["sets"]):
         pin = _lib.PinnedBuffer(max(bases.size, 1))
         pin.array[:bases.size] = bases
         pins.append(pin)
-        n = len(offsets) - 1
-        for r0 in range(0, n, a.batch_regions):
-            cuts.append((len(pins) - 1, r0, min(n, r0 + a.batch_regions)))
-    if not a.no_batch_ramp and len(cuts) >= 4:
-        # the pass begins with an upload nothing overlaps and ends with a copy-out nothing overlaps: make those two batches small
-        # (first batch cut 1/4 + 1/4 + 1/2, last 1/2 + 1/4 + 1/4); what the pipeline does per region is unchanged
-        def split(c, fr):
-            k, r0, r1 = c
-            pts = [r0 + int((r1 - r0) * f) for f in fr] + [r1]
-            return [(k, x, y) for x, y in zip(pts[:-1], pts[1:]) if y > x]
-        cuts = split(cuts[0], (0.0, 0.25, 0.5)) + cuts[1:-1] + split(cuts[-1], (0.0, 0.5, 0.75))
+        # batches grow from --batch-regions / 4 to --max-batch-regions at the start of a pass and shrink again at its end
+        # (dist.batch_bounds): the pass begins with an upload nothing overlaps and ends with a copy-out nothing overlaps
+        for r0, r1 in msdist.batch_bounds(len(offsets) - 1, a.batch_regions, ramp=not a.no_batch_ramp, max_batch=a.max_batch_regions,
+                                          ramp_up=k == 0, ramp_down=k == n_sets - 1):
+            cuts.append((k, r0, r1))
     for k, r0, r1 in cuts:
         offsets = wl["sets"][k][1]
         lo, hi = int(offsets[r0]), int(offsets[r1])
@@ -526,7 +522,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
         pin.close()
     return {"pipelined": v_p16, "pipelined_25B": v_p25, "serial": v_s, "unit": "bp*motifs/s",
             "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s},
-            "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
+            "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "max_batch_regions": a.max_batch_regions, "batch_sizes": [int(len(o) - 1) for _, o in batches], "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
             "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
             "cu_partition": "while a stream is live the copy / pack kernels own 1 CU of every 32 (CU masks), the scan the other 31",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "

@@ -7,19 +7,19 @@
 // the work is laid out:
 //   * the pre-filter hands its window starts out in UNITS of consecutive positions and writes each unit's candidate records into
 //     the unit's own slots of the list (ms_kernels.hip, emit_rec: no atomics);
-//   * a CHUNK = a fixed number of consecutive units = a contiguous range of positions.  One block re-scores a chunk's records,
+//   * a CHUNK = a fixed number k of consecutive units = a contiguous range of positions.  One block re-scores a chunk's records,
 //     stages the hits in LDS, groups them by motif (counting sort: LDS histogram + exclusive scan) and ranks each hit inside its
 //     (chunk, motif) group -- a handful of hits -- by key.  The chunk's hits leave the block sorted by (motif, coordinate, strand),
 //     to one contiguous piece of the hit list, together with the row cnt[chunk][motif] of a count matrix;
 //   * since chunk c holds only positions below chunk c + 1's, the final rank of a hit is
 //         motif_first[m] + sum_{c' < c} cnt[c'][m] + (its rank inside its (chunk, motif) group):
-//     a column-wise prefix sum over the count matrix (three small kernels over n_chunks x P 16-bit cells) and one placement kernel
+//     a column-wise prefix sum over the count matrix (small kernels over n_chunks x P 16-bit cells) and one placement kernel
 //     that reads the chunk-sorted hits once and writes the result arrays (seq_idx, pos, score, strand) once.
-// Traffic per hit: 16 B written + 16 B read + 25 B written (+ ~6 B of matrix) against 16 + 5 x 32 + 8 + 17 B before.
+// Traffic per hit: 16 B written + 16 B read + 25 B written (+ ~10 B of matrix) against 16 + 5 x 32 + 8 + 17 B before.
 //
-// Limits (the host falls back to the sorted tail beyond them, scan_locked): P <= kOrdMaxMotifs (LDS histogram), no motif on the
-// all-fp64 path (exact_all_kernel emits unordered), a chunk's hits <= kOrdStage (else the chunk size is halved and the pass re-run),
-// a unit's records <= its slots (else the slots grow and the pass is re-run).
+// Limits (the host keeps the sorted tail for the rest, scan_locked): P <= kOrdMaxMotifs (LDS histogram), no motif on the all-fp64
+// path (exact_all_kernel emits unordered), hit coordinates of the (region, position) form, a chunk's hits <= kOrdStage (else the
+// host halves the chunk and runs the pass again), a unit's records <= its slots (else the slots grow and the pass runs again).
 #include <algorithm>
 
 #include "ms_device.h"
@@ -39,13 +39,14 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
     return x - v;
 }
 
-// exclusive prefix sum of a[0..n) in LDS, in place; returns the total.  256 threads; scratch: 8 words of LDS.
+// exclusive prefix sum of a[0..n) in LDS, in place; returns the total.  256 threads (all of them call); scratch: 8 words of LDS.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, int n, uint32_t *scratch) {
     const int tid = threadIdx.x, per = (n + 255) / 256;
     uint32_t local = 0;
     for (int i = tid * per; i < n && i < (tid + 1) * per; i++) local += a[i];
     uint32_t wtot;
-    uint32_t pre = wave_excl_scan(local, wtot);
+    const uint32_t pre = wave_excl_scan(local, wtot);
+    __syncthreads();                                                   // (scratch may still be read by the previous call's callers)
     if ((tid & 63) == 63) scratch[tid >> 6] = wtot;
     __syncthreads();
     uint32_t wbase = 0, total = 0;
@@ -59,7 +60,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, int n, uint32_t
 }  // namespace
 
 // grid: blocks loop over chunks.  Dynamic LDS: stage keys [kOrdStage] u64 | stage vals [kOrdStage] f64 | hist [P] u32 | start [P] u32 |
-// cursor [P] u32 | order [kOrdStage] u16 | src_off [n_src + 1] u32
+// cursor [P] u32 | src_off [n_src + 1] u32 | order [kOrdStage] u16
 __global__ void __launch_bounds__(256) rescore_ordered_kernel(const OrdArgs O) {
     extern __shared__ unsigned char ord_lds[];
     uint64_t *st_key = reinterpret_cast<uint64_t *>(ord_lds);
@@ -67,14 +68,14 @@ __global__ void __launch_bounds__(256) rescore_ordered_kernel(const OrdArgs O) {
     uint32_t *hist = reinterpret_cast<uint32_t *>(st_val + kOrdStage);
     uint32_t *start = hist + O.P;
     uint32_t *cursor = start + O.P;
-    uint16_t *order = reinterpret_cast<uint16_t *>(cursor + O.P);
-    uint32_t *src_off = reinterpret_cast<uint32_t *>(order + kOrdStage);
+    const int n_src = O.n_tiles * O.k;                                 // (tile, unit of the chunk) sources of records
+    uint32_t *src_off = cursor + O.P;
+    uint16_t *order = reinterpret_cast<uint16_t *>(src_off + n_src + 1);
     __shared__ uint32_t s_n, s_scratch[8];
     __shared__ unsigned long long s_base;
     const DevSeq &S = O.S;
     const DevPwm &Pw = O.Pw;
     const int tid = threadIdx.x;
-    const int n_src = O.n_tiles * O.k;                                 // (tile, unit of the chunk) sources of records
     const bool both = O.strand_mask == 3;
     for (int64_t c = blockIdx.x; c < O.n_chunks; c += gridDim.x) {
         for (int m = tid; m < O.P; m += 256) { hist[m] = 0; cursor[m] = 0; }
@@ -85,15 +86,18 @@ __global__ void __launch_bounds__(256) rescore_ordered_kernel(const OrdArgs O) {
                 const int64_t u = c * O.k + (s % O.k);
                 if (u < O.n_units) {
                     cntv = O.unit_cnt[(int64_t) (s / O.k) * O.n_units + u];
-                    if (cntv > O.unit_slots) { cntv = O.unit_slots; atomicMax(O.overflow, 1u); }      // the unit dropped records: the host grows the slots
+                    if (cntv > O.unit_slots) {                         // the unit dropped records: the host grows the slots and runs the pass again
+                        atomicOr(O.overflow, 1u);
+                        atomicMax(O.overflow + 1, cntv);
+                        cntv = O.unit_slots;
+                    }
                 }
             }
             src_off[s] = cntv;
         }
         __syncthreads();
-        const uint32_t n_rec = block_excl_scan(src_off, n_src + 1, s_scratch) ;       // src_off[s] = first record of source s; src_off[n_src] = total
-        (void) n_rec;
-        const uint32_t total_rec = src_off[n_src];
+        const uint32_t total_rec = block_excl_scan(src_off, n_src + 1, s_scratch);       // src_off[s] = first record of source s; src_off[n_src] = total
+        if (tid == 0 && total_rec) atomicAdd(O.n_rec, (unsigned long long) total_rec);
         // ---- re-score the chunk's records: kOrdU of them in flight per thread (the kernel is a chain of dependent gathers)
         for (uint32_t base = 0; base < total_rec; base += 256u * kOrdU) {
             uint64_t rec[kOrdU];
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256) rescore_ordered_kernel(const OrdArgs O) {
                 g[u] = (int64_t) (rec[u] >> 30);
                 group[u] = (int32_t) ((rec[u] >> 16) & 0x3FFFu);
                 const uint32_t f = (uint32_t) rec[u] & 0xFFFFu;
-                flags[u] = both ? (f | (f >> 1)) & 0x5555u : f;
+                flags[u] = both ? (f | (f >> 1)) & 0x5555u : f;          // a motif's two strands are re-scored together anyway
                 lo_r[u] = S.blk2reg[g[u] >> 6];
                 cw[u] = code_window(S.codes, g[u]);
                 nw[u] = n_window(S.nmask, g[u]);
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(256) rescore_ordered_kernel(const OrdArgs O) {
 #pragma unroll
             for (int u = 0; u < kOrdU; u++) {
                 if (!live[u]) continue;
-                const int64_t gk = O.pbits ? (int64_t) (((uint64_t) r[u] << O.pbits) | (uint64_t) (g[u] - beg[u])) : g[u];
+                const int64_t gk = (int64_t) (((uint64_t) r[u] << O.pbits) | (uint64_t) (g[u] - beg[u]));
                 bool first = true;
                 while (flags[u]) {
                     const int field = __ffs((int) flags[u]) - 1;
@@ -182,7 +186,10 @@ __global__ void __launch_bounds__(256) rescore_ordered_kernel(const OrdArgs O) {
         }
         __syncthreads();
         uint32_t n = s_n;
-        if (n > (uint32_t) kOrdStage) { n = kOrdStage; if (tid == 0) atomicMax(O.overflow, 2u); }      // the chunk holds too many hits: the host halves the chunk
+        if (n > (uint32_t) kOrdStage) {                                // the chunk holds too many hits: the host halves the chunks
+            if (tid == 0) { atomicOr(O.overflow, 2u); atomicMax(O.overflow + 2, n); }
+            n = kOrdStage;
+        }
         // ---- group by motif: row of the count matrix, group starts
         uint16_t *row = O.cnt_cm + c * O.P;
         for (int m = tid; m < O.P; m += 256) { const uint32_t h = hist[m]; row[m] = (uint16_t) h; start[m] = h; }
@@ -230,23 +237,37 @@ __global__ void __launch_bounds__(256) ord_seg_sum_kernel(const uint16_t *__rest
     if (rl == 0 && col < P) seg_sum[(int64_t) blockIdx.y * P + col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
-// per motif: seg_sum -> exclusive prefix over the segments (in place), motif totals; then motif_first = exclusive prefix of the totals.
-// ONE block of 1024 threads (P <= kOrdMaxMotifs).
-__global__ void __launch_bounds__(1024) ord_seg_scan_kernel(uint32_t *__restrict__ seg_sum, int32_t n_seg, int32_t P, int64_t *__restrict__ motif_first,
-                                                            const unsigned long long *__restrict__ n_hits) {
-    __shared__ unsigned long long tot[kOrdMaxMotifs];
-    for (int m = threadIdx.x; m < P; m += 1024) {
-        unsigned long long run = 0;
-        for (int s = 0; s < n_seg; s++) { const uint32_t v = seg_sum[(int64_t) s * P + m]; seg_sum[(int64_t) s * P + m] = (uint32_t) run; run += v; }
-        tot[m] = run;
+// one WAVE per motif: seg_sum[.][m] -> exclusive prefix over the segments (in place; a motif has < 2^32 hits per call), motif_tot[m]
+__global__ void __launch_bounds__(256) ord_seg_scan_kernel(uint32_t *__restrict__ seg_sum, int32_t n_seg, int32_t P, unsigned long long *__restrict__ motif_tot) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= P) return;
+    const int per = (n_seg + 63) / 64, s0 = lane * per, s1 = s0 + per < n_seg ? s0 + per : n_seg;
+    uint32_t local = 0;
+    for (int s = s0; s < s1; s++) local += seg_sum[(int64_t) s * P + m];
+    uint32_t tot;
+    uint32_t run = wave_excl_scan(local, tot);
+    for (int s = s0; s < s1; s++) { const uint32_t v = seg_sum[(int64_t) s * P + m]; seg_sum[(int64_t) s * P + m] = run; run += v; }
+    if (lane == 0) motif_tot[m] = tot;
+}
+
+// motif_first = exclusive prefix of the motif totals ([P + 1]: the last entry is the number of hits).  ONE block of 256 threads.
+__global__ void __launch_bounds__(256) ord_motif_first_kernel(const unsigned long long *__restrict__ motif_tot, int32_t P, int64_t *__restrict__ motif_first) {
+    __shared__ unsigned long long wsum[4];
+    const int tid = threadIdx.x, per = (P + 255) / 256;
+    unsigned long long local = 0;
+    for (int i = tid * per; i < P && i < (tid + 1) * per; i++) local += motif_tot[i];
+    unsigned long long x = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(x, o);
+        if ((tid & 63) >= o) x += y;
     }
+    if ((tid & 63) == 63) wsum[tid >> 6] = x;
     __syncthreads();
-    if (threadIdx.x == 0) {                                            // P <= 2048 serial adds
-        unsigned long long run = 0;
-        for (int m = 0; m < P; m++) { motif_first[m] = (int64_t) run; run += tot[m]; }
-        motif_first[P] = (int64_t) run;                                // == *n_hits unless a chunk overflowed
-        (void) n_hits;
-    }
+    unsigned long long run = x - local;
+    for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+    for (int i = tid * per; i < P && i < (tid + 1) * per; i++) { motif_first[i] = (int64_t) run; run += motif_tot[i]; }
+    if (tid == 255) motif_first[P] = (int64_t) (wsum[0] + wsum[1] + wsum[2] + wsum[3]);
 }
 
 // off[c][m] = seg prefix + prefix inside the segment.  grid = (ceil(P / 64), n_seg), 64 threads: one column each, the segment's chunks in turn
@@ -271,13 +292,13 @@ __global__ void __launch_bounds__(64) ord_seg_prefix_kernel(const uint16_t *__re
 // Dynamic LDS: a [P] u32 (group starts inside the chunk) | dst [P] u64 (motif_first + column prefix)
 __global__ void __launch_bounds__(256) ord_place_kernel(const OrdArgs O, const uint32_t *__restrict__ off, const int64_t *__restrict__ motif_first,
                                                         int64_t *__restrict__ seq_idx, int64_t *__restrict__ pos, double *__restrict__ score,
-                                                        int8_t *__restrict__ strand, const DevSeq S, int rbits) {
+                                                        int8_t *__restrict__ strand, int rbits, uint64_t out_cap) {
     extern __shared__ unsigned char ord_lds[];
     uint32_t *a = reinterpret_cast<uint32_t *>(ord_lds);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a + ((O.P + 1) & ~1));
     __shared__ uint32_t s_scratch[8];
     const int tid = threadIdx.x;
-    const uint64_t rmask = (1ULL << rbits) - 1ULL, pmask = O.pbits ? (1ULL << O.pbits) - 1ULL : 0ULL, gmask = (1ULL << O.gbits) - 1ULL;
+    const uint64_t rmask = (1ULL << rbits) - 1ULL, pmask = (1ULL << O.pbits) - 1ULL, gmask = (1ULL << O.gbits) - 1ULL;
     for (int64_t c = blockIdx.x; c < O.n_chunks; c += gridDim.x) {
         const uint32_t n = O.chunk_n[c];
         if (n == 0) continue;                                          // (block-uniform)
@@ -289,15 +310,14 @@ __global__ void __launch_bounds__(256) ord_place_kernel(const OrdArgs O, const u
         __syncthreads();
         (void) block_excl_scan(a, O.P, s_scratch);
         for (uint32_t i = tid; i < n; i += 256) {
+            if (cbase + i >= O.hit_cap) break;                         // (the hit list overflowed: the host runs the pass again)
             const uint64_t key = O.keys[cbase + i];
             const uint32_t m = (uint32_t) (key >> (O.gbits + 1));
             const unsigned long long d = dst[m] + (i - a[m]);
+            if (d >= out_cap) continue;                                // (more hits than predicted: the host runs the pass again)
             const uint64_t coord = (key >> 1) & gmask;
-            int64_t sq, ps;
-            if (O.pbits) { sq = (int64_t) ((coord >> O.pbits) & rmask); ps = (int64_t) (coord & pmask); }
-            else { const int64_t r = find_region(S, (int64_t) coord); sq = r; ps = (int64_t) coord - S.offsets[r]; }
-            seq_idx[d] = sq;
-            pos[d] = ps;
+            seq_idx[d] = (int64_t) ((coord >> O.pbits) & rmask);
+            pos[d] = (int64_t) (coord & pmask);
             score[d] = O.vals[cbase + i];
             strand[d] = (int8_t) ((key & 1ULL) ? 2 : 1);
         }
@@ -306,10 +326,10 @@ __global__ void __launch_bounds__(256) ord_place_kernel(const OrdArgs O, const u
 }
 
 // regions with >= 1 hit per motif (stats.py:29-31), from the placed arrays: one atomic per (wave, motif)
-__global__ void __launch_bounds__(256) ord_region_counts_kernel(const unsigned long long *__restrict__ n_hits, const int64_t *__restrict__ motif_first, int32_t P,
+__global__ void __launch_bounds__(256) ord_region_counts_kernel(const int64_t *__restrict__ motif_first, int32_t P, uint64_t out_cap,
                                                                 const int64_t *__restrict__ seq_idx, unsigned long long *__restrict__ region_counts) {
-    const int64_t n = motif_first[P];
-    (void) n_hits;
+    int64_t n = motif_first[P];
+    if ((uint64_t) n > out_cap) n = (int64_t) out_cap;
     for (int64_t i0 = (int64_t) blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t) gridDim.x * blockDim.x) {
         const int64_t i = i0 + threadIdx.x;
         const bool live = i < n;
@@ -333,7 +353,7 @@ __global__ void __launch_bounds__(256) ord_region_counts_kernel(const unsigned l
 }
 
 size_t ord_rescore_lds_bytes(int32_t P, int n_src) {
-    return (size_t) kOrdStage * 16 + (size_t) P * 12 + (size_t) kOrdStage * 2 + ((size_t) n_src + 2) * 4 + 64;
+    return (size_t) kOrdStage * 16 + (size_t) P * 12 + ((size_t) n_src + 2) * 4 + (size_t) kOrdStage * 2 + 64;
 }
 
 int launch_rescore_ordered(const OrdArgs &O, int n_blocks, hipStream_t st) {
@@ -350,22 +370,29 @@ int launch_rescore_ordered(const OrdArgs &O, int n_blocks, hipStream_t st) {
 }
 
 // count matrix -> per-(chunk, motif) offsets and per-motif offsets; then every hit to its place, then the region counts.
-// seg_sum: [n_seg][P] u32 work space; off: [n_chunks][P] u32 work space.
-int launch_ordered_place(const OrdArgs &O, uint32_t *seg_sum, uint32_t *off, int64_t *motif_first, int64_t *seq_idx, int64_t *pos, double *score,
-                         int8_t *strand, unsigned long long *region_counts, const DevSeq &S, int rbits, int n_cu, hipStream_t st) {
+// seg_sum: [n_seg][P] u32 work space; off: [n_chunks][P] u32 work space; motif_tot: [P] u64 work space.
+int launch_ordered_place(const OrdArgs &O, uint32_t *seg_sum, uint32_t *off, unsigned long long *motif_tot, int64_t *motif_first,
+                         int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand, uint64_t out_cap, int rbits, int n_cu, hipStream_t st) {
     const int n_seg = (int) ((O.n_chunks + kOrdSeg - 1) / kOrdSeg);
     const unsigned ct = (unsigned) ((O.P + 63) / 64);
     hipLaunchKernelGGL(ord_seg_sum_kernel, dim3(ct, (unsigned) n_seg), dim3(256), 0, st, O.cnt_cm, O.n_chunks, O.P, seg_sum);
     MS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ord_seg_scan_kernel, dim3(1), dim3(1024), 0, st, seg_sum, n_seg, O.P, motif_first, O.n_hits);
+    hipLaunchKernelGGL(ord_seg_scan_kernel, dim3((unsigned) ((O.P + 3) / 4)), dim3(256), 0, st, seg_sum, n_seg, O.P, motif_tot);
+    MS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ord_motif_first_kernel, dim3(1), dim3(256), 0, st, motif_tot, O.P, motif_first);
     MS_HIP(hipGetLastError());
     hipLaunchKernelGGL(ord_seg_prefix_kernel, dim3(ct, (unsigned) n_seg), dim3(64), 0, st, O.cnt_cm, O.n_chunks, O.P, seg_sum, off);
     MS_HIP(hipGetLastError());
     const size_t lds = (size_t) ((O.P + 1) & ~1) * 4 + (size_t) O.P * 8 + 64;
     const int64_t nb = std::max<int64_t>(1, std::min<int64_t>((int64_t) n_cu * 8, O.n_chunks));
-    hipLaunchKernelGGL(ord_place_kernel, dim3((unsigned) nb), dim3(256), lds, st, O, off, motif_first, seq_idx, pos, score, strand, S, rbits);
+    hipLaunchKernelGGL(ord_place_kernel, dim3((unsigned) nb), dim3(256), lds, st, O, off, motif_first, seq_idx, pos, score, strand, rbits, out_cap);
     MS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ord_region_counts_kernel, dim3((unsigned) (n_cu * 8)), dim3(256), 0, st, O.n_hits, motif_first, O.P, seq_idx, region_counts);
+    return MS_OK;
+}
+
+int launch_ordered_region_counts(const int64_t *motif_first, int32_t P, uint64_t out_cap, const int64_t *seq_idx, unsigned long long *region_counts,
+                                 int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(ord_region_counts_kernel, dim3((unsigned) (n_cu * 8)), dim3(256), 0, st, motif_first, P, out_cap, seq_idx, region_counts);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

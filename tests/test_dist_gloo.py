@@ -122,9 +122,15 @@ def test_batch_bounds_cover_every_region_once_with_and_without_ramp():
             if n / step > 5000:
                 continue
             for ramp in (False, True):
-                b = msdist.batch_bounds(n, step, ramp=ramp)
-                assert b[0][0] == 0 and b[-1][1] == max(n, 0) or (n == 0 and b == [(0, 0)])
-                assert all(x[1] == y[0] for x, y in zip(b[:-1], b[1:])), (n, step, ramp)
-                assert all(0 < r1 - r0 <= step for r0, r1 in b) or n == 0
+                for up, down in ((True, True), (True, False), (False, True), (False, False)):
+                    b = msdist.batch_bounds(n, step, ramp=ramp, ramp_up=up, ramp_down=down)
+                    assert b[0][0] == 0 and b[-1][1] == max(n, 0) or (n == 0 and b == [(0, 0)])
+                    assert all(x[1] == y[0] for x, y in zip(b[:-1], b[1:])), (n, step, ramp)
+                    assert all(0 < r1 - r0 <= (2 * step if ramp else step) for r0, r1 in b) or n == 0
+    # a pass grows from a quarter of the batch size by doubling to twice it, and shrinks again at the end
     b = msdist.batch_bounds(1000, 100, ramp=True)
-    assert b[:3] == [(0, 25), (25, 50), (50, 100)] and b[-3:] == [(900, 950), (950, 975), (975, 1000)] and len(b) == 14
+    assert [r1 - r0 for r0, r1 in b] == [25, 25, 50, 100, 200, 200, 200, 100, 50, 25, 25]
+    b = msdist.batch_bounds(1_000_000, 125_000, max_batch=500_000, ramp_down=False)
+    assert [r1 - r0 for r0, r1 in b] == [31_250, 31_250, 62_500, 125_000, 250_000, 500_000]
+    b = msdist.batch_bounds(300, 100, ramp=True)                  # short sets keep round 2's cut of the first and last batch
+    assert [r1 - r0 for r0, r1 in b] == [100, 100, 100]
