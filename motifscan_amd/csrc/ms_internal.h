@@ -97,6 +97,12 @@ constexpr int kGroupFields = 16;                // fields per table group = resu
 constexpr int kMaxClasses = 6;                  // paired 1 / 2 half-blocks, plain 1 ... 4 k-blocks
 constexpr int kPairCols = 8;                    // columns per half-block of a paired row
 constexpr int kPairMaxWidth = 2 * kPairCols - 1;
+// Motifs of 16 ... 23 columns COULD ride paired rows of three half-blocks at 36 budget levels (deficits of 40 and more stored as 40:
+// 24 x 40 + 60 < 1024; set kPairWideMaxWidth = 3 * kPairCols - 1 and dispatch f6_pair_class<3>): built and measured -- 38 instead of
+// 41 instructions per 32 windows on the benchmark set, pre-filter 18.9-19.2 against 19.3 ms per 500 Mbase, but the coarser rows pass
+// 4 % more candidates and the fp64 stage takes back what the pre-filter saved (3.4 against 3.2 ms; profiles/r03k_ab_full.log).  Off.
+constexpr int kPairWideMaxWidth = kPairMaxWidth;
+constexpr int kPairWideLevels = 36;
 constexpr int kPairScaleX = 127 - 6;            // E8M0 block scales of the two k-halves: X one level = 2^-9, Y one level = 2^-21
 constexpr int kPairScaleY = 127 - 18;
 constexpr float kPairC = 4.0f;                  // inline constant of the matrix instruction; ulp(4.0) = 2^-21

@@ -504,22 +504,23 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     f32x16 cc0, cc1;
 #pragma unroll
     for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
-    auto load_a = [&](const char *q, i32x8 (&a)[NK]) {
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            const int2 w0 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb);
-            const int2 w1 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 512);
-            const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
-            a[kb] = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
-        }
+    auto load_a = [&](const char *q, int kb) {
+        const int2 w0 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb);
+        const int2 w1 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 512);
+        const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
+        return i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
     };
-    auto product = [&](const i32x8 (&a)[NK], f32x16 &c0, f32x16 &c1) {
-        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], cc0, 2, 4, 0, scale0, 0, 127);
-        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], cc1, 2, 4, 0, scale1, 0, 127);
+    auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
+        // (three half-blocks: the A operands are read one or two at a time -- 6 B operands of 4 registers, 3 A operands of 6 and the
+        // 32 results do not fit beside the rest)
+        i32x8 a = load_a(q, 0);
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0[0], cc0, 2, 4, 0, scale0, 0, 127);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1[0], cc1, 2, 4, 0, scale1, 0, 127);
 #pragma unroll
         for (int kb = 1; kb < NK; kb++) {
-            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b0[kb], c0, 2, 4, 0, scale0, 0, 127);
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, scale1, 0, 127);
+            a = load_a(q, kb);
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0[kb], c0, 2, 4, 0, scale0, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1[kb], c1, 2, 4, 0, scale1, 0, 127);
         }
     };
     auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) -> bool {        // true: the parking space ran full inside this row tile
@@ -532,10 +533,8 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     };
     for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
         // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
-        i32x8 a[NK];
-        load_a(p, a);
         f32x16 c0, c1;
-        product(a, c0, c1);
+        product(p, c0, c1);
         if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
         if (__builtin_expect(W.rq_n >= W.rq_flush, 0)) { R.t = t + 1; return; }
     }
@@ -611,16 +610,27 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // and every lane then cuts its own windows out of the staged words (rounds 1-2: ten global loads per lane and pass, their
     // latency exposed once per pass: a third of the kernel's time on inputs with few row tiles per pass, profiles/r03_c2_latency.log).
     uint32_t *stg = reinterpret_cast<uint32_t *>(lds4 + A.stage_off16) + (threadIdx.x >> 6) * kPfStageWords;
-    const int64_t n_code_words = 2 * ((A.n_bases + 31) / 32) + kPadWords, n_mask_words = (A.n_bases + 31) / 32 + kPadWords;
-    auto fetch = [&](int64_t pass0) -> uint32_t {                               // lanes 0..7: code words, 8..11: non-ACGT words of the pass
-        uint32_t v = 0;
-        if (lane < 8) { const int64_t w = (pass0 >> 4) + lane; v = A.codes[w < n_code_words ? w : n_code_words - 1]; }
-        else if (lane < 12) { const int64_t w = (pass0 >> 5) + (lane - 8); v = A.nmask[w < n_mask_words ? w : n_mask_words - 1]; }
-        return v;
+    // (32-bit word indices: a set holds <= 2^34 bases = 2^30 code words; the loads then take a scalar base and a 32-bit lane offset)
+    const uint32_t n_code_words = (uint32_t) (2 * ((A.n_bases + 31) / 32) + kPadWords), n_mask_words = (uint32_t) ((A.n_bases + 31) / 32 + kPadWords);
+    struct PassWords { uint32_t c, n; };                                        // what lane l loaded: code word l & 7 and non-ACGT word l & 3 of the pass
+    auto fetch = [&](uint32_t pass) -> PassWords {                              // pass = pass0 / 64
+        // every lane loads from both arrays -- the same few cache lines -- through a SCALAR base (the pass is wave-uniform) and a small
+        // lane offset: a per-lane 64-bit address costs a register pair that the kernel has not got.  The two results stay two
+        // registers until they are staged: choosing between them here would make the wave wait for the loads here
+        // (kPadWords >= 8 zero words follow both arrays: only the BASE needs clamping, for the dead passes behind the input's end)
+        const uint32_t bc = pass * 4u < n_code_words - 8u ? pass * 4u : n_code_words - 8u, bn = pass * 2u < n_mask_words - 4u ? pass * 2u : n_mask_words - 4u;
+        typedef const __attribute__((address_space(1))) uint32_t *gptr;          // (a GLOBAL pointer: through an integer it would come back generic)
+        auto uniform = [](const uint32_t *q) {                                  // the pointer into scalar registers, whatever the compiler thought of it
+            const uint64_t a = reinterpret_cast<uint64_t>(q);
+            return (gptr) (((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (a >> 32)) << 32) | (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) a));
+        };
+        return PassWords{uniform(A.codes + bc)[lane & 7u], uniform(A.nmask + bn)[lane & 3u]};
     };
     auto scan_pass = [&](int64_t pass0) {                                    // 64 window starts of this wave (pass0 ... + 63, wave-uniform) against every class
-        const int64_t g0 = pass0 + r;
-        bool live0 = g0 < A.n_bases, live1 = g0 + 32 < A.n_bases;
+        // (32-bit: what is left of the input from pass0 on is wave-uniform; a 64-bit position per lane costs two register pairs)
+        const int64_t left64 = A.n_bases - pass0;
+        const uint32_t left = left64 >= 64 ? 64u : (left64 > 0 ? (uint32_t) left64 : 0u);
+        bool live0 = r < left, live1 = r + 32u < left;
         PassSeq Q;
         Q.stg = stg;
         Q.cw[0] = staged_cw(stg, r, 0);
@@ -676,8 +686,8 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         const uint32_t waves_g = ((gridDim.x - g + K - 1) / K) * wpb;
         const uint32_t units_g = n_units > g ? (n_units - g + K - 1) / K : 0u;
         unsigned int *word = A.chunk_counter + ((size_t) blockIdx.y * kPfCounters + g) * 16;
-        uint32_t v = (blockIdx.x / K) * wpb + (threadIdx.x >> 6);
-        uint32_t words = v < units_g ? fetch((int64_t) ((v * K + g) * wave_passes) * 64) : 0u;
+        uint32_t v = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((blockIdx.x / K) * wpb + (threadIdx.x >> 6)));     // wave-uniform: everything derived from it lives in scalar registers
+        PassWords words = v < units_g ? fetch((v * K + g) * wave_passes) : PassWords{0u, 0u};
         while (v < units_g) {
             uint32_t next = 0xFFFFFFFFu;
             if (dyn) {                                                            // asked for before this unit is scanned
@@ -692,11 +702,11 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                 em->left = 0;
             }
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
-                if (lane < 12) stg[lane] = words;                                 // (the wave's LDS operations execute in order: no barrier)
+                if (lane < 12) stg[lane] = lane < 8 ? words.c : words.n;          // (the wave's LDS operations execute in order: no barrier)
                 // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
                 // flight while this pass is scanned
-                if (j + 1 < wave_passes) words = fetch((int64_t) (p0 + j + 1) * 64);
-                else if (next < units_g) words = fetch((int64_t) ((next * K + g) * wave_passes) * 64);
+                if (j + 1 < wave_passes) words = fetch(p0 + j + 1);
+                else if (next < units_g) words = fetch((next * K + g) * wave_passes);
                 scan_pass((int64_t) (p0 + j) * 64);
             }
             if (A.unit_slots) {                                                   // the unit's records belong to the unit's slots

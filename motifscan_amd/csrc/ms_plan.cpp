@@ -67,7 +67,9 @@ void f6_dead(F6Strand *out) {                   // acc = -1/8 for every window: 
 }
 
 // Returns false if the strand needs the fp64 path (a threshold so low that filtering is pointless, or out of the grid's range).
-bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, F6Strand *out, bool *alln_can_hit) {
+// Bq budget levels, deficits of `clamp` (> Bq, on the grid) and more stored as `clamp`: 56 / 60 wherever the row can carry it; 36 / 40
+// for the paired rows of motifs of 16 ... 23 columns, whose field must stay inside +-1024 (24 x 40 + 60 < 1024).
+bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, int Bq, int clamp, F6Strand *out, bool *alln_can_hit) {
     f6_dead(out);
     double hi[kMaxFastWidth], sum_hi = 0, sum_hi_pos = 0, lowest = 0;
     for (int c = 0; c < W; c++) {
@@ -81,7 +83,6 @@ bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, F6Str
     if (!(budget >= 0)) return false;           // only windows with non-ACGT bases could reach T: not worth a table
     if (!(T > lowest)) return false;            // every window passes
     if (!(T > 0)) *alln_can_hit = true;         // a window of non-ACGT bases only scores 0 and may be reported
-    const int Bq = kF6Levels;
     const double s = budget > 0 ? ((double) Bq + 0.5) / budget : 1e300;
     int t[kMaxFastWidth], dq[kMaxFastWidth][4];
     long pen = 0, sum_t = 0;
@@ -90,7 +91,7 @@ bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, F6Str
             const double d = hi[c] - e[b][c];
             double q = d <= 0 ? 0.0 : std::floor(std::min(d * s * (1 - 1e-12) - 1e-7, 1e6));
             if (!(q >= 0)) q = 0;
-            dq[c][b] = f6_grid_floor((int) std::min(q, 60.0));        // always DOWN (to the grid, to the range): 60 sinks the window alone
+            dq[c][b] = f6_grid_floor((int) std::min(q, (double) clamp));  // always DOWN (to the grid, to the range): `clamp` sinks the window alone
         }
         if (hi[c] >= 0) {
             double lim = std::floor(std::min(hi[c] * s * (1 - 1e-12) - 1e-7, 1e6));
@@ -121,7 +122,10 @@ bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, F6Str
 struct FastMotif {
     int32_t id;
     int32_t W;
-    F6Strand f6[2];
+    F6Strand f6[2];                 // 56 levels
+    F6Strand f6w[2];                // 36 levels (motifs of 16 ... kPairWideMaxWidth columns that may ride a paired row)
+    bool wide_ok;
+    bool use_wide;
 };
 
 }  // namespace
@@ -141,58 +145,86 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
         fm.id = p;
         fm.W = W;
         bool alln = false;
-        for (int sd = 0; sd < 2; sd++) f6_dead(&fm.f6[sd]);              // never a candidate unless quantised below
+        for (int sd = 0; sd < 2; sd++) { f6_dead(&fm.f6[sd]); f6_dead(&fm.f6w[sd]); }     // never a candidate unless quantised below
+        fm.wide_ok = pair_rows && W > kPairMaxWidth && W <= kPairWideMaxWidth;
+        fm.use_wide = false;
         for (int sd = 0; ok && sd < 2; sd++) {
             if (!(strand_mask & (1 << sd))) continue;                    // strand not asked for
             double e[4][kMaxFastWidth];
             for (int b = 0; b < 4; b++)
                 for (int c = 0; c < W; c++)
                     e[b][c] = sd == 0 ? m[(int64_t) b * W + c] : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
-            ok = quantize_strand_f6(e, W, T, &fm.f6[sd], &alln);
+            ok = quantize_strand_f6(e, W, T, kF6Levels, 60, &fm.f6[sd], &alln);
+            if (ok && fm.wide_ok) { bool alln2 = false; fm.wide_ok = quantize_strand_f6(e, W, T, kPairWideLevels, 40, &fm.f6w[sd], &alln2); }
         }
         if (ok) { fast.push_back(fm); plan->alln_can_hit = plan->alln_can_hit || alln; }
         else plan->exact_motifs.push_back(p);
     }
-    // paired rows first (narrow to wide), then plain rows (narrow to wide)
-    auto paired = [&](const FastMotif &a) { return pair_rows && a.W <= kPairMaxWidth; };
-    std::stable_sort(fast.begin(), fast.end(), [&](const FastMotif &a, const FastMotif &b) {
-        const bool pa = paired(a), pb = paired(b);
-        if (pa != pb) return pa;
-        return a.W < b.W;
-    });
-    size_t n_paired = 0;
-    while (n_paired < fast.size() && paired(fast[n_paired])) n_paired++;
-
-    // row tiles: plain = 16 motifs x {fwd, rev} with both strands, 32 motifs with one; paired = twice that
+    // Paired rows first (narrow to wide), then plain rows (narrow to wide).  Motifs of 16 ... kPairWideMaxWidth columns may go either way
+    // (three half-blocks at 36 levels for 32 motifs, or two k-blocks at 56 levels for 16): the narrowest n_w of them ride paired rows,
+    // n_w chosen so that the plan's instruction count is minimal.
     const bool both = strand_mask == 3;
     const int sd_single = strand_mask == 2 ? 1 : 0;
     struct RowTile { bool paired; int nk; size_t first, count, off; };
-    std::vector<RowTile> rts;
-    // Row tiles = runs of consecutive motifs (sorted by width: a tile pays for its widest), cut so that the instruction count is
-    // minimal -- e.g. the last few narrow motifs get a short tile of their own rather than riding a tile of wider ones
-    auto cut = [&](size_t lo, size_t hi, bool pr) {
-        const size_t per_rt = (both ? 16 : 32) * (pr ? 2 : 1), n = hi - lo;
-        auto nk_of = [&](size_t q) { return pr ? pair_kb_of_width(fast[q].W) : f6_kb_of_width(fast[q].W); };
+    auto nk_of = [&](const FastMotif &a, bool pr) { return pr ? pair_kb_of_width(a.W) : f6_kb_of_width(a.W); };
+    // Row tiles = runs of consecutive motifs of `v` (sorted by width: a tile pays for its widest), cut so that the instruction count
+    // is minimal -- e.g. the last few narrow motifs get a short tile of their own rather than riding a tile of wider ones
+    auto cut = [&](const std::vector<const FastMotif *> &v, bool pr, size_t base, std::vector<RowTile> *out) -> long {
+        const size_t per_rt = (both ? 16 : 32) * (pr ? 2 : 1), n = v.size();
         std::vector<long> cost(n + 1, 0);
         std::vector<size_t> from(n + 1, 0);
         for (size_t i = 1; i <= n; i++) {
             cost[i] = -1;
             for (size_t j = i > per_rt ? i - per_rt : 0; j < i; j++) {
-                const long c = cost[j] + 64L * nk_of(lo + i - 1) + 1;             // instructions first, then the number of tiles
-                if (cost[i] < 0 || c < cost[i]) { cost[i] = c; from[i] = j; }
+                const long cst = cost[j] + 64L * nk_of(*v[i - 1], pr) + 1;         // instructions first, then the number of tiles
+                if (cost[i] < 0 || cst < cost[i]) { cost[i] = cst; from[i] = j; }
             }
         }
-        std::vector<size_t> ends;
-        for (size_t i = n; i > 0; i = from[i]) ends.push_back(i);
-        size_t j = 0;
-        for (size_t k = ends.size(); k-- > 0;) {
-            RowTile rt{pr, nk_of(lo + ends[k] - 1), lo + j, ends[k] - j, 0};
-            rts.push_back(rt);
-            j = ends[k];
+        if (out) {
+            std::vector<size_t> ends;
+            for (size_t i = n; i > 0; i = from[i]) ends.push_back(i);
+            size_t j = 0;
+            for (size_t k = ends.size(); k-- > 0;) {
+                out->push_back(RowTile{pr, nk_of(*v[ends[k] - 1], pr), base + j, ends[k] - j, 0});
+                j = ends[k];
+            }
         }
+        return cost[n];
     };
-    cut(0, n_paired, true);
-    cut(n_paired, fast.size(), false);
+    std::stable_sort(fast.begin(), fast.end(), [](const FastMotif &a, const FastMotif &b) { return a.W < b.W; });
+    std::vector<const FastMotif *> narrow, mid, rest;                           // <= 15 columns | either way | plain only
+    for (const FastMotif &fm : fast) (pair_rows && fm.W <= kPairMaxWidth ? narrow : (fm.wide_ok ? mid : rest)).push_back(&fm);
+    size_t best_w = 0;
+    {
+        long best = -1;
+        for (size_t n_w = 0; n_w <= mid.size(); n_w++) {
+            std::vector<const FastMotif *> pv(narrow), lv(mid.begin() + (long) n_w, mid.end());
+            pv.insert(pv.end(), mid.begin(), mid.begin() + (long) n_w);
+            lv.insert(lv.end(), rest.begin(), rest.end());
+            std::stable_sort(lv.begin(), lv.end(), [](const FastMotif *a, const FastMotif *b) { return a->W < b->W; });
+            const long cst = cut(pv, true, 0, nullptr) + cut(lv, false, 0, nullptr);
+            if (best < 0 || cst < best) { best = cst; best_w = n_w; }
+        }
+    }
+    std::vector<FastMotif> ordered;
+    ordered.reserve(fast.size());
+    for (const FastMotif *f : narrow) ordered.push_back(*f);
+    for (size_t i = 0; i < best_w; i++) { ordered.push_back(*mid[i]); ordered.back().use_wide = true; }
+    const size_t n_paired = ordered.size();
+    {
+        std::vector<const FastMotif *> lv(mid.begin() + (long) best_w, mid.end());
+        lv.insert(lv.end(), rest.begin(), rest.end());
+        std::stable_sort(lv.begin(), lv.end(), [](const FastMotif *a, const FastMotif *b) { return a->W < b->W; });
+        for (const FastMotif *f : lv) ordered.push_back(*f);
+    }
+    fast.swap(ordered);
+    std::vector<RowTile> rts;
+    {
+        std::vector<const FastMotif *> pv, lv;
+        for (size_t i = 0; i < fast.size(); i++) (i < n_paired ? pv : lv).push_back(&fast[i]);
+        (void) cut(pv, true, 0, &rts);
+        (void) cut(lv, false, n_paired, &rts);
+    }
     const size_t n_rt = rts.size();
     size_t total = 0;
     for (RowTile &rt : rts) {
@@ -221,7 +253,7 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                 const size_t j = rt.first + slot;
                 const int sd = both ? (n & 1) : sd_single;
                 const int row = mfma_row_of(h, n);
-                const F6Strand *fs = slot < rt.count ? &fast[j].f6[sd] : nullptr;
+                const F6Strand *fs = slot < rt.count ? (fast[j].use_wide ? &fast[j].f6w[sd] : &fast[j].f6[sd]) : nullptr;
                 // empty field: bias -1/8 and nothing else -> never a candidate; columns past W stay +0; the bias sits in the field's
                 // LAST column for all four bases (the kernel never clears that column for non-ACGT bases)
                 int pb[4] = {0, 0, 0, 0};                                   // paired rows: the bias column also carries the field's offset
