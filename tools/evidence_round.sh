@@ -32,6 +32,15 @@ python tools/c2_scaling.py 2>&1 | grep -v amdgpu.ids > $OUT/c2_scaling.log
 python tools/fixed_cost.py 2>&1 | grep -v amdgpu.ids > $OUT/fixed_cost.log
 python tools/e2e_stages.py 125000 2 2>&1 | grep -v amdgpu.ids > $OUT/e2e_stages.log
 ./tools/ubench/insp_probe.bin > $OUT/insp_probe.log 2>&1
+./tools/ubench/pair_probe.bin > $OUT/pair_probe.log 2>&1
+timeout 120 ./tools/ubench/valu_rate.bin > $OUT/valu_rate.log 2>&1
+python tools/pf_class_clock.py 3 1e-4 2>&1 | grep -v amdgpu.ids > $OUT/class_clock.log
+python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase > $OUT/full_size_stage_times.log
+python tools/ab_full.py 1 1e-4 2>&1 | grep Mbase >> $OUT/full_size_stage_times.log
+python tools/ab_full.py 3 1e-3 2>&1 | grep Mbase >> $OUT/full_size_stage_times.log
+MS_MEASURE=1 MS_PF_PAIR=0 python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/plain rows only (MS_PF_PAIR=0): /" >> $OUT/full_size_stage_times.log
+MS_MEASURE=1 MS_TAIL=ordered python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/ordered tail (MS_TAIL=ordered): /" >> $OUT/full_size_stage_times.log
+if [ -d tools/ab/r03a ]; then (cd tools/ab/r03a && python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/the round's first evidence build (366afa7): /") >> $OUT/full_size_stage_times.log; fi
 timeout 60 ./tools/ubench/issue_model.bin > $OUT/issue_model.log 2>&1
 python tests/fuzz_parity.py --cases 1500 --seed 40000 > $OUT/fuzz.log 2>&1
 python tests/fuzz_parity.py --cases 300 --seed 50000 --sweep >> $OUT/fuzz.log 2>&1
