@@ -211,6 +211,11 @@ int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, i
 /* Queue one span of a window sweep: n_bases of ONE chromosome starting at a window start; the result is what
  * ms_scan_sweep gives for it (seq_idx = window index inside the span: add ms_span.first_window). */
 int ms_stream_submit_span(ms_stream *st, const char *bases, int64_t n_bases, int32_t window, int32_t stride);
+/* A batch of regions of a genome that is resident in HBM (ms_genome_create): what ms_seqset_from_genome + ms_scan give for them,
+ * with the cut of batch i + 1 out of the 2-bit genome overlapping the scan of batch i and the copy-out of batch i - 1
+ * (scanner.py:71-87 + 125 per batch; the genome must outlive the batch's result).  The arrays are copied. */
+int ms_stream_submit_regions(ms_stream *st, const ms_genome *genome, const int32_t *chrom, const int64_t *start, const int64_t *end,
+                             int64_t n_regions);
 /* The oldest batch's result (submission order), its hit arrays already in pinned host memory (ms_result_hits_host /
  * ms_result_hits_packed_host return at once).  *out = NULL when nothing is in flight.  The caller frees the result. */
 int ms_stream_next(ms_stream *st, ms_result **out);

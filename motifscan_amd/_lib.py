@@ -118,6 +118,7 @@ def lib():
         "ms_stream_create": (c_int, [vp, c_int, c_u32, c_int, pvp]),
         "ms_stream_submit": (c_int, [vp, vp, pi64, c_i64]),
         "ms_stream_submit_span": (c_int, [vp, vp, c_i64, c_i32, c_i32]),
+        "ms_stream_submit_regions": (c_int, [vp, vp, pi32, pi64, pi64, c_i64]),
         "ms_stream_next": (c_int, [vp, pvp]),
         "ms_stream_in_flight": (c_int, [vp, ctypes.POINTER(c_int)]),
         "ms_stream_capacity": (c_int, [vp, ctypes.POINTER(c_int)]),
@@ -549,6 +550,17 @@ class Stream:
         check(lib().ms_stream_submit(self.h, ctypes.c_void_p(bases.ctypes.data), ptr(offsets, ctypes.c_int64), offsets.size - 1))
         self._keep.append(bases)
 
+    def submit_regions(self, genome, chrom_idx, starts, ends):
+        """A batch of regions of a ResidentGenome (chromosome indices, 0-based half-open): cut on the device while the previous
+        batch is scanned."""
+        ci = np.ascontiguousarray(chrom_idx, dtype=np.int32)
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        en = np.ascontiguousarray(ends, dtype=np.int64)
+        if not (ci.size == st.size == en.size):
+            raise ValueError("chrom_idx, starts and ends must have one entry per region")
+        check(lib().ms_stream_submit_regions(self.h, genome.h, ptr(ci, ctypes.c_int32), ptr(st, ctypes.c_int64), ptr(en, ctypes.c_int64), ci.size))
+        self._keep.append(genome)
+
     def submit_span(self, bases, window, stride):
         bases = np.ascontiguousarray(bases, dtype=np.uint8) if isinstance(bases, np.ndarray) else np.frombuffer(bytes(bases), dtype=np.uint8)
         check(lib().ms_stream_submit_span(self.h, ctypes.c_void_p(bases.ctypes.data), bases.size, int(window), int(stride)))
@@ -611,14 +623,17 @@ def merge_hits(parts, n_pwms):
 
 
 def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None):
-    """Generator: push (bases, offsets) batches through a Stream, yield each batch's ScanResult in order (the caller
-    closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end."""
+    """Generator: push (bases, offsets) batches -- or (ResidentGenome, chrom_idx, starts, ends) batches of a genome that sits in
+    HBM -- through a Stream, yield each batch's ScanResult in order (the caller closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end."""
     st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
     try:
-        for bases, offsets in batches:
+        for batch in batches:                             # (bases, offsets), or (ResidentGenome, chrom_idx, starts, ends)
             while st.in_flight >= st.capacity:
                 yield st.next()
-            st.submit(bases, offsets)
+            if len(batch) == 4:
+                st.submit_regions(*batch)
+            else:
+                st.submit(*batch)
         while st.in_flight:
             yield st.next()
         if stage_stats is not None:

@@ -1192,6 +1192,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // ordering + coordinates of the first n_sort slots of the hit list into the result block (events 3, 4, 5); n_dev != nullptr:
     // only the device knows how many of them are hits (the rest are all-ones keys, which sort behind every hit)
     const int end_bit = gbits + 1 + mbits;
+    bool queue_only = false;                     // this back() belongs to a scan that is only queued (scan_complete finishes it)
     auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
@@ -1239,7 +1240,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         // the complete per-motif offsets are on the device; one copy brings them to the host.  (Not for a scan that is only being
         // QUEUED: the destination is pageable memory, for which the "async" copy makes the host wait for everything queued before
         // it -- scan_complete fetches the offsets once the scan is done.)
-        if (!pend) {
+        if (!queue_only) {
             he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
             if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
         }
@@ -1306,7 +1307,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
         if ((rc = front(H))) return fail(rc);
         if (!ord && (rc = launch_fill_tail(sc.keys, sc.counters + 1, n_pred, c->stream))) return fail(rc);
-        if ((rc = back(n_pred, sc.counters + 1))) return fail(rc);
+        queue_only = pend != nullptr;
+        rc = back(n_pred, sc.counters + 1);
+        queue_only = false;                      // (the exactly-sized form below always runs to the end, with or without a PendingScan slot:
+        if (rc) return fail(rc);                 //  the first batch of a stream, whose PWM set has no prediction yet, came back with all-zero offsets)
         if (pend) {
             // queued, not waited for: the owner queues its next scan behind this one first (everything is in order on one stream:
             // the next scan's kernels only touch the shared scratch after this scan's are done; a scratch buffer that has to grow

@@ -19,7 +19,10 @@ using namespace ms;
 namespace {
 
 struct Job {
-    int kind = 0;                     // 0: batch of regions; 1: span of a window sweep
+    int kind = 0;                     // 0: batch of regions (host ASCII); 1: span of a window sweep; 2: batch of regions of a resident genome
+    const ms_genome *genome = nullptr;                 // kind 2 (borrowed)
+    std::vector<int32_t> chrom;                        // kind 2: [n_seqs]
+    std::vector<int64_t> ends;                         // kind 2: [n_seqs] (offsets holds the starts)
     const char *bases = nullptr;      // borrowed
     std::vector<int64_t> offsets;     // [n_seqs + 1]
     int64_t n_seqs = 0;
@@ -130,7 +133,9 @@ struct ms_stream {
     void uploader() {
         run_stage(0, *q_in, *q_up, [](Job *j) {
             if (j->rc != MS_OK) return;
-            const int rc = ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+            // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
+            const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
+                                        : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
             if (rc) fail_job(j, rc);
         });
     }
@@ -151,7 +156,7 @@ struct ms_stream {
         if (!rc) {
             std::lock_guard<std::mutex> lk_dev(c->mu);
             std::lock_guard<std::mutex> lk_pwm(pwms->mu);
-            const bool simple = j->kind == 0 && !(flags & MS_STREAM_DEDUP);
+            const bool simple = j->kind != 1 && !(flags & MS_STREAM_DEDUP);
             const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) |
                                 ((simple && (flags & MS_STREAM_PACKED) && !(flags & MS_STREAM_NO_HITS)) ? MS_SCAN_PACK_INTERNAL : 0u);
             const bool plain = simple && pend_ok && slot;
@@ -303,6 +308,22 @@ int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, i
     catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
     j->bases = bases;
     j->n_seqs = n_seqs;
+    return stream_enqueue(st, std::move(j));
+}
+
+int ms_stream_submit_regions(ms_stream *st, const ms_genome *genome, const int32_t *chrom, const int64_t *start, const int64_t *end, int64_t n_regions) {
+    if (!st || !genome) { set_error("NULL handle"); return MS_ERR_INVALID; }
+    if (n_regions < 0 || (n_regions > 0 && (!chrom || !start || !end))) { set_error("bad region arrays"); return MS_ERR_INVALID; }
+    std::unique_ptr<Job> j(new (std::nothrow) Job());
+    if (!j) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    try {
+        j->chrom.assign(chrom, chrom + n_regions);
+        j->offsets.assign(start, start + n_regions);
+        j->ends.assign(end, end + n_regions);
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    j->kind = 2;
+    j->genome = genome;
+    j->n_seqs = n_regions;
     return stream_enqueue(st, std::move(j));
 }
 

@@ -209,19 +209,13 @@ class Scanner:
                 yield np.frombuffer(b"".join(seqs), dtype=np.uint8), offsets
 
         try:
-            if self._resident is not None:               # regions are cut on the device: nothing to upload, batches run in turn
+            flags = _lib.MS_STREAM_DEDUP if self.remove_dup else 0
+            if self._resident is not None:               # regions are cut on the device (ms_stream_submit_regions): nothing to upload
                 g, idx = self._resident
-                for r0, r1 in bounds:
-                    sq = g.extract(idx[r0:r1], self.seq_starts[r0:r1], self.seq_ends[r0:r1])
-                    try:
-                        res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
-                    finally:
-                        sq.close()
-                    if self.remove_dup:
-                        res.dedup(pw)
+                cuts = ((g, idx[r0:r1], self.seq_starts[r0:r1], self.seq_ends[r0:r1]) for r0, r1 in bounds)
+                for (r0, r1), res in zip(bounds, _lib.scan_stream(pw, cuts, _STRAND_FLAG[self.strand], flags, depth)):
                     yield r0, r1, arrays(r0, res)
             else:
-                flags = _lib.MS_STREAM_DEDUP if self.remove_dup else 0
                 for (r0, r1), res in zip(bounds, _lib.scan_stream(pw, batches(), _STRAND_FLAG[self.strand], flags, depth)):
                     yield r0, r1, arrays(r0, res)
         finally:

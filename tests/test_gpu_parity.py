@@ -245,6 +245,44 @@ def test_resident_genome_extraction_equals_host_strings(rnd):
         rg.extract([7], [0], [10])
 
 
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("dup", [False, True])
+def test_scanner_batches_equal_the_single_call(rnd, resident, dup):
+    """Scanner.scan_batches -- host strings through ms_stream_submit, a genome resident in HBM through ms_stream_submit_regions (the
+    cut of batch i + 1 overlaps the scan of batch i; VERDICT r2 "missing" #5) -- concatenated per motif == scan_motifs_arrays."""
+    names = [str(x) for x in rnd["g4_chrom_names"]]
+    raw = rnd["g4_chrom_bytes"].tobytes().decode()
+    n = len(raw) // len(names)
+    chroms = {nm: raw[i * n:(i + 1) * n] for i, nm in enumerate(names)}
+    genome = _lib.ResidentGenome(chroms, keep_host=True) if resident else type("G", (), {
+        "fetch_sequence": staticmethod(lambda c, a, b: chroms[c][a:b]), "chrom_sizes": {k: len(v) for k, v in chroms.items()}})()
+
+    class Reg:
+        def __init__(self, row):
+            self.chrom, self.start, self.end, self.summit = names[int(row[0])], int(row[1]), int(row[2]), int(row[3])
+
+    class P:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = m, {"1e-3": c}, m.shape[1]
+
+    pw = [P(m, c) for m, c in zip(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])]
+    regs = [Reg(r) for r in rnd["g4_regions"]]
+    sc = scanner.Scanner(genome, regs, window_size=200, p_value="1e-3", remove_dup=dup)
+    want = sc.scan_motifs_arrays(pw)
+    for batch in (7, 23, len(regs) + 5):
+        parts, seen = [], []
+        for r0, r1, a in sc.scan_batches(pw, batch_regions=batch):
+            seen.append((r0, r1))
+            parts.append(({k2: np.array(a[k1]) for k1, k2 in (("region", "seq_idx"), ("start", "pos"), ("score", "score"), ("strand", "strand"),
+                                                               ("motif_offsets", "motif_offsets"))}, 0))      # (copies: the views die with the result)
+            a["_result"].close()
+        assert seen[0][0] == 0 and seen[-1][1] == len(regs) and all(x[1] == y[0] for x, y in zip(seen[:-1], seen[1:]))
+        got = _lib.merge_hits(parts, len(pw))
+        assert len(got["pos"]) == len(want["start"]) > 50
+        assert np.array_equal(got["motif"], want["motif"]) and np.array_equal(got["seq_idx"], want["region"])
+        assert np.array_equal(got["pos"], want["start"]) and np.array_equal(got["score"], want["score"]) and np.array_equal(got["strand"], want["strand"])
+
+
 def test_g5_c_score_kmers_exact(rnd):
     kmers = [row.tobytes().decode() for row in rnd["kmer_bytes"]]
     pw = _lib.PwmSet.from_matrices(rnd["mats"])
