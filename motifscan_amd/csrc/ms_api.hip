@@ -885,13 +885,7 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
     hipError_t he = hipEventSynchronize(p->done);
     if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
     const unsigned long long n_cand = p->cand_static + p->h_counters[0], n_hits = p->h_counters[1];
-    const unsigned int *ov = reinterpret_cast<const unsigned int *>(p->h_counters + 4);           // the ordered tail's overflow words (scan_locked, ord_learn)
-    if (p->ordered) {
-        if (ov[0] & 1u) pwms->ord_slot_boost = std::min(64.0, pwms->ord_slot_boost * std::max(1.25, 1.15 * (double) ov[1] / (double) std::max(1u, p->ord_slots)));
-        if (ov[0] & 2u) pwms->ord_chunk_shrink = std::max(1e-3, pwms->ord_chunk_shrink * std::min(0.5, 0.8 * (double) kOrdStage / (double) std::max(1u, ov[2])));
-        if (ov[0] == 0u && p->ord_cells > 0) pwms->ord_rec_density = (double) p->h_counters[0] / p->ord_cells;
-    }
-    if ((p->ordered ? ov[0] == 0u : n_cand <= p->cand_cap) && n_hits <= p->hit_cap && n_hits <= p->n_pred) {
+    if (n_cand <= p->cand_cap && n_hits <= p->hit_cap && n_hits <= p->n_pred) {
         he = hipMemcpy(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
         if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
         pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
@@ -1045,70 +1039,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         }
         pf_wave_passes = wp;
     }
-    const int64_t pf_n_units = ((S.n_bases + 63) / 64 + pf_wave_passes - 1) / pf_wave_passes;      // as the kernel counts them
-
-    // ---- the ORDERED tail (ms_order.hip): the pre-filter writes a unit's records into the unit's own slots, chunks of k units are
-    // re-scored and grouped by motif in LDS, a column prefix over the (chunk, motif) count matrix places every hit -- no sort.  Not
-    // for plans with all-fp64 motifs (exact_all_kernel emits unordered), global hit coordinates, more motifs than the LDS histogram
-    // holds, or hit densities beyond a chunk's LDS staging.  MEASURED AND NOT ADOPTED (profiles/r03i_ordered_tail.log): parity-green,
-    // but the in-LDS grouping makes the fp64 stage 50 % slower and the placement + region counts cost what the five radix passes
-    // saved (3.72 against 3.56 ms per 62.5-Mbase scan), and fixed per-unit slots must be sized for the FULLEST unit of a set -- 423
-    // records against a mean of 19 on the benchmark's regions -- 25x the memory of the block list.  It runs only with
-    // MS_MEASURE=1 MS_TAIL=ordered.
-    const char *tail_env = measure_env("MS_TAIL");
-    bool ord = n_tiles > 0 && plan.exact_motifs.empty() && pbits > 0 && pwms->P <= kOrdMaxMotifs && n_tiles <= kOrdMaxSources &&
-               !(flags & MS_SCAN_RAW_INTERNAL) && !pf_no_emit && tail_env && tail_env[0] == 'o';
-    uint32_t ord_slots = 0;
-    int ord_k = 1;
-    int64_t ord_chunks = 0;
-    struct OrdWork { uint32_t *unit_cnt; uint16_t *cnt_cm; uint32_t *off; uint32_t *seg_sum; unsigned long long *motif_tot; unsigned long long *chunk_off; uint32_t *chunk_n; } ow = {};
-    const double unit_len = (double) pf_wave_passes * 64.0;
-    auto ord_plan = [&]() -> int {                                 // sizes from what is known of this PWM set, work space carved
-        const bool known = pwms->pred_density >= 0 && pwms->pred_strand == strand_mask && pwms->pred_cutoff_version == pwms->cutoff_version;
-        const double guess = 6e-4 * (double) fast_windows / (double) S.n_bases;                    // records per position, ~4x the CLI default's
-        const double rho = known && pwms->ord_rec_density >= 0 ? pwms->ord_rec_density : guess / n_tiles;
-        const double eta = known ? pwms->pred_density * (double) stt.n_windows / (double) S.n_bases : guess / 1.5;
-        const double mean = rho * unit_len;
-        ord_slots = (uint32_t) std::min<double>(mean * 1.5 * pwms->ord_slot_boost + 8.0 * std::sqrt(mean) + 32.0, 1.0e6);
-        ord_slots = (ord_slots + 7u) & ~7u;
-        const double per_unit = std::max(eta * unit_len, 1e-9);
-        if (per_unit > 0.5 * kOrdStage) { ord = false; return MS_OK; }             // one unit would fill the chunk's LDS staging: sorted tail
-        double k = 0.4 * (double) kOrdStage / per_unit * pwms->ord_chunk_shrink;
-        k = std::min(k, (double) (kOrdMaxSources / n_tiles));
-        k = std::min(k, std::max(1.0, (double) pf_n_units / (4.0 * c->n_cu)));       // enough chunks to occupy the device
-        ord_k = (int) std::max(1.0, std::min(k, 64.0));
-        ord_chunks = (pf_n_units + ord_k - 1) / ord_k;
-        const size_t P = (size_t) pwms->P, n_seg = (size_t) ((ord_chunks + kOrdSeg - 1) / kOrdSeg);
-        size_t off = 0;
-        auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t) 255; return at; };
-        const size_t a_unit = take(4 * (size_t) n_tiles * (size_t) pf_n_units), a_cnt = take(2 * (size_t) ord_chunks * P), a_off = take(4 * (size_t) ord_chunks * P),
-                     a_seg = take(4 * n_seg * P), a_tot = take(8 * P), a_coff = take(8 * (size_t) ord_chunks), a_cn = take(4 * (size_t) ord_chunks);
-        if (off > sc.ord_bytes) {
-            dev_free(sc.ord);
-            sc.ord_bytes = 0;
-            int rc2;
-            if ((rc2 = dev_alloc(&sc.ord, off + off / 8))) return rc2;
-            sc.ord_bytes = off + off / 8;
-        }
-        ow.unit_cnt = reinterpret_cast<uint32_t *>(sc.ord + a_unit); ow.cnt_cm = reinterpret_cast<uint16_t *>(sc.ord + a_cnt);
-        ow.off = reinterpret_cast<uint32_t *>(sc.ord + a_off); ow.seg_sum = reinterpret_cast<uint32_t *>(sc.ord + a_seg);
-        ow.motif_tot = reinterpret_cast<unsigned long long *>(sc.ord + a_tot); ow.chunk_off = reinterpret_cast<unsigned long long *>(sc.ord + a_coff);
-        ow.chunk_n = reinterpret_cast<uint32_t *>(sc.ord + a_cn);
-        want_cand = std::max(want_cand, (size_t) n_tiles * (size_t) pf_n_units * ord_slots);
-        return MS_OK;
-    };
-    if (ord && (rc = ord_plan())) return fail(rc);
-    // what a finished pass says about the ordered tail's sizes (h: the 8 counter words): true if the pass is valid
-    auto ord_learn = [&](const unsigned long long *h) -> bool {
-        const unsigned int *ov = reinterpret_cast<const unsigned int *>(h + 4);
-        if (measure_env("MS_ORD_DEBUG"))
-            fprintf(stderr, "ordered tail: units %lld x %d tiles, unit %d positions, slots %u, k %d, chunks %lld; flags %u max unit %u max chunk %u; records %llu hits %llu\n",
-                    (long long) pf_n_units, n_tiles, (int) unit_len, ord_slots, ord_k, (long long) ord_chunks, ov[0], ov[1], ov[2], h[0], h[1]);
-        if (ov[0] & 1u) pwms->ord_slot_boost = std::min(64.0, pwms->ord_slot_boost * std::max(1.25, 1.15 * (double) ov[1] / (double) ord_slots));
-        if (ov[0] & 2u) pwms->ord_chunk_shrink = std::max(1e-3, pwms->ord_chunk_shrink * std::min(0.5, 0.8 * (double) kOrdStage / (double) ov[2]));
-        if (ov[0] == 0u) pwms->ord_rec_density = (double) h[0] / ((double) n_tiles * (double) S.n_bases);
-        return ov[0] == 0u;
-    };
 
     // counters: [0] candidate record slots, [1] hits
     // pre-filter + fp64 stage of one pass, queued on the scan stream (events 0, 1, 2 around the two stages)
@@ -1129,12 +1059,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.rare_off16 = A.emit_off16 + (uint32_t) (kPfEmitBytes / 16);
             A.rare_cap = rare_cap;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
-            A.unit_slots = 0; A.unit_cnt = nullptr;
-            if (ord) {
-                A.unit_slots = ord_slots; A.unit_cnt = ow.unit_cnt;
-                he = hipMemsetAsync(ow.unit_cnt, 0, 4 * (size_t) n_tiles * (size_t) pf_n_units, c->stream);
-                if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
-            }
             const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
             if (counter_words > sc.chunk_counters_cap) {
                 dev_free(sc.chunk_counters);
@@ -1159,7 +1083,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             }
             {
                 const int64_t n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
-                cand_static = ord ? 0 : (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
+                cand_static = (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
                 A.cand_static = cand_static;
             }
             bool wide = false;
@@ -1172,16 +1096,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return rc;
         }
         (void) hipEventRecord(ev[1], c->stream);
-        if (ord) {
-            OrdArgs O;
-            O.S = S; O.Pw = Pw; O.cand = sc.cand; O.unit_cnt = ow.unit_cnt; O.unit_slots = ord_slots; O.n_units = pf_n_units; O.n_tiles = n_tiles;
-            O.k = ord_k; O.n_chunks = ord_chunks; O.group_fields = pwms->d_group_fields; O.strand_mask = strand_mask; O.P = pwms->P;
-            O.gbits = gbits; O.pbits = pbits; O.keys = H.keys; O.vals = H.vals; O.hit_cap = H.cap; O.n_hits = H.n_hits; O.n_rec = sc.counters;
-            O.overflow = reinterpret_cast<unsigned int *>(sc.counters + 4); O.cnt_cm = ow.cnt_cm; O.chunk_off = ow.chunk_off; O.chunk_n = ow.chunk_n;
-            if ((rc = launch_rescore_ordered(O, c->n_cu * 3, c->stream))) return rc;
-            (void) hipEventRecord(ev[2], c->stream);
-            return MS_OK;
-        }
         if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)
             if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_group_fields, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
         if (!plan.exact_motifs.empty())
@@ -1197,18 +1111,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
         (void) hipEventRecord(ev[3], c->stream);
-        if (ord) {
-            // n_sort: the capacity of the result arrays (the predicted count, or the exact one); the chunk-sorted hits go to their ranks
-            OrdArgs O;
-            O.S = S; O.Pw = Pw; O.cand = sc.cand; O.unit_cnt = ow.unit_cnt; O.unit_slots = ord_slots; O.n_units = pf_n_units; O.n_tiles = n_tiles;
-            O.k = ord_k; O.n_chunks = ord_chunks; O.group_fields = pwms->d_group_fields; O.strand_mask = strand_mask; O.P = pwms->P;
-            O.gbits = gbits; O.pbits = pbits; O.keys = sc.keys; O.vals = sc.vals; O.hit_cap = sc.hit_cap; O.n_hits = sc.counters + 1; O.n_rec = sc.counters;
-            O.overflow = reinterpret_cast<unsigned int *>(sc.counters + 4); O.cnt_cm = ow.cnt_cm; O.chunk_off = ow.chunk_off; O.chunk_n = ow.chunk_n;
-            if ((rc = launch_ordered_place(O, ow.seg_sum, ow.off, ow.motif_tot, raw->d_motif_first, raw->d_seq_idx, raw->d_pos, raw->d_score, raw->d_strand,
-                                           (uint64_t) n_sort, rbits, c->n_cu, c->stream))) return rc;
-            (void) hipEventRecord(ev[4], c->stream);
-            if (n_sort > 0 && (rc = launch_ordered_region_counts(raw->d_motif_first, pwms->P, (uint64_t) n_sort, raw->d_seq_idx, raw->d_region_counts, c->n_cu, c->stream))) return rc;
-        } else {
         if (n_sort > 0) {
             size_t need = 0;
             if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
@@ -1226,7 +1128,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         (void) hipEventRecord(ev[4], c->stream);
         if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_sort, n_dev, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
                                   raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) return rc;
-        }
         if ((flags & MS_SCAN_PACK_INTERNAL) && n_sort > 0) {
             const size_t n_round = (n_sort + 65535) & ~(size_t) 65535;
             if ((rc = pool_alloc(c, 8 * n_round + 256, &raw->coord_blk, &raw->coord_bytes))) return rc;
@@ -1306,7 +1207,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         HitOut H;
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
         if ((rc = front(H))) return fail(rc);
-        if (!ord && (rc = launch_fill_tail(sc.keys, sc.counters + 1, n_pred, c->stream))) return fail(rc);
+        if ((rc = launch_fill_tail(sc.keys, sc.counters + 1, n_pred, c->stream))) return fail(rc);
         queue_only = pend != nullptr;
         rc = back(n_pred, sc.counters + 1);
         queue_only = false;                      // (the exactly-sized form below always runs to the end, with or without a PendingScan slot:
@@ -1320,9 +1221,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             pend->cand_cap = sc.cand_cap;
             pend->hit_cap = sc.hit_cap;
-            pend->ordered = ord;
-            pend->ord_slots = ord_slots;
-            pend->ord_cells = (double) n_tiles * (double) S.n_bases;
             pend->active = true;
             pend->raw = raw;
             pend->n_pred = n_pred;
@@ -1338,7 +1236,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         const unsigned long long n_cand = cand_static + sc.h_counters[0], n_hits = sc.h_counters[1];
-        if ((ord ? ord_learn(sc.h_counters) : n_cand <= sc.cand_cap) && n_hits <= sc.hit_cap && n_hits <= n_pred) {
+        if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap && n_hits <= n_pred) {
             pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
             read_clock();
             finish(n_cand, n_hits, true);
@@ -1352,14 +1250,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (raw->coord_blk) { pool_free(c, raw->coord_blk, raw->coord_bytes); raw->coord_blk = nullptr; raw->d_coord = nullptr; raw->d_coord_bad = nullptr; }
         pwms->pred_margin = std::min(1.0, pwms->pred_margin * 2.0);
         stt.n_passes = 1;
-        if (ord) {
-            if ((rc = ord_plan())) return fail(rc);                // (ord_learn has adjusted the PWM set's slot / chunk factors)
-            want_hits = std::max<size_t>(sc.hit_cap, (size_t) (n_hits + n_hits / 16 + 1024));
-        } else {
-            want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
-            const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
-            want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
-        }
+        want_cand = std::max<size_t>(sc.cand_cap, (size_t) (n_cand + n_cand / 16 + 1024));
+        const unsigned long long hit_need = n_cand > sc.cand_cap ? std::max<unsigned long long>(n_hits, 2 * n_cand) : n_hits;
+        want_hits = std::max<size_t>(sc.hit_cap, (size_t) (hit_need + hit_need / 16 + 1024));
     }
 
     unsigned long long n_cand = 0, n_hits = 0;
@@ -1374,16 +1267,6 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
         n_cand = cand_static + sc.h_counters[0];
         n_hits = sc.h_counters[1];
-        if (ord) {
-            // the ordered tail: a unit that outgrew its slots or a chunk that outgrew its LDS staging costs another pass with the sizes
-            // the device reported (ord_learn); past a few of those the sorted tail takes over
-            const bool sized = ord_learn(sc.h_counters);
-            if (sized && n_hits <= sc.hit_cap) break;
-            if (pass >= 8) { set_error("scan buffers kept overflowing (%llu records, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
-            if (pass >= 4 && !sized) ord = false; else if ((rc = ord_plan())) return fail(rc);
-            want_hits = std::max<size_t>(sc.hit_cap, (size_t) (n_hits + n_hits / 16 + 1024));
-            continue;
-        }
         if (n_cand <= sc.cand_cap && n_hits <= sc.hit_cap) break;
         if (pass >= 8) { set_error("scan buffers kept overflowing (%llu candidates, %llu hits)", n_cand, n_hits); return fail(MS_ERR_RUNTIME); }
         // a buffer was too small: the counters hold the exact need (a truncated candidate list
@@ -1476,7 +1359,7 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
             DeviceCtx *c;
             int rc = get_ctx(r->device, &c);
             if (rc) return rc;
-            // the device block may have been carved for more hits than there are (the ordered re-scoring sizes it by a bound):
+            // the device block may have been carved for more hits than there are (a predicted-size scan sizes it by a bound):
             // four copies, packed n_round elements apart on the host
             char *hb = static_cast<char *>(r->h_pinned);
             const hipStream_t down = c->stream_down;
@@ -2047,9 +1930,8 @@ int ms_debug_release_scratch(void) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     Scratch &sc = c->sc;
-    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.chunk_counters); dev_free(sc.ord);
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.chunk_counters);
     sc.chunk_counters_cap = 0;
-    sc.ord_bytes = 0;
     if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
     sc.sort_tmp = nullptr;
     sc.cand_cap = sc.hit_cap = sc.sort_tmp_bytes = 0;

@@ -20,7 +20,6 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
     unsigned int *chunk_counters = nullptr;    size_t chunk_counters_cap = 0;   // per LDS tile: the pre-filter's chunk dispenser
-    unsigned char *ord = nullptr;              size_t ord_bytes = 0;            // the ordered tail's work space (unit counts, count matrix, offsets)
     unsigned long long *counters = nullptr;      // 8 words, see scan_locked
     unsigned long long *h_counters = nullptr;    // pinned
 };
@@ -134,9 +133,6 @@ struct ms_pwmset {
     // what the last scan with these PWMs found, for the one-sync form of the next (scan_locked): hits per window, and how far
     // above it the next count may be before the prediction counts as failed
     double pred_density = -1.0, pred_margin = 0.06;
-    // the ordered tail's sizes (ms_order.hip), learned like the hit density: candidate records per (LDS tile, position) of the last
-    // scan, how much more than the formula the fullest unit needed, how much smaller than the formula the chunks had to be
-    double ord_rec_density = -1.0, ord_slot_boost = 1.0, ord_chunk_shrink = 1.0;
     int pred_strand = -1;
     uint64_t pred_cutoff_version = 0;
     bool pred_exact_only = false;
@@ -226,9 +222,6 @@ struct PendingScan {
     hipEvent_t done = nullptr;
     unsigned long long *h_counters = nullptr;   // pinned, 8 words
     size_t cand_cap = 0, hit_cap = 0;           // the scratch capacities at queue time
-    bool ordered = false;                       // the ordered tail ran: counters[4 ...] hold its overflow words
-    uint32_t ord_slots = 0;                     // ... with this many record slots per unit
-    double ord_cells = 0;                       // ... LDS tiles x positions, for the record density
     bool active = false;
     ms_result *raw = nullptr;
     size_t n_pred = 0;

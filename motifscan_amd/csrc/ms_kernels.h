@@ -65,8 +65,6 @@ struct PfArgs {
     uint64_t cand_cap;
     uint32_t cand_block;      // >= 64
     uint64_t cand_static;     // slots [0, cand_static) are the launch's waves' own first blocks (wave w: [w, w + 1) * cand_block)
-    uint32_t unit_slots;      // != 0: the unit-ordered form -- unit u of LDS tile t owns slots [(t * n_units + u) * unit_slots, + unit_slots)
-    uint32_t *unit_cnt;       // ... and unit_cnt[t * n_units + u] receives the number of records the unit produced (may exceed unit_slots)
     int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     int cls_clk;              // measurement only: also time the classes (MS_PF_CLOCK=2: the stamps themselves cost a few per cent)
@@ -76,41 +74,6 @@ struct PfArgs {
     int wave_passes;               // per-wave hand-out: passes of 64 window starts a wave takes per atomic (scan_locked sizes it)
 };
 
-// ---- the ordered tail (ms_order.hip)
-constexpr int kOrdStage = 2048;       // hits a chunk may hold (LDS staging of rescore_ordered_kernel)
-constexpr int kOrdU = 4;              // candidate records in flight per thread
-constexpr int kOrdSeg = 64;           // chunks per segment of the count matrix's column prefix
-constexpr int kOrdMaxMotifs = 2048;   // LDS histogram of a chunk
-constexpr int kOrdMaxSources = 512;   // (LDS tile, unit) sources of a chunk
-
-struct OrdArgs {
-    DevSeq S;
-    DevPwm Pw;
-    const uint64_t *cand;             // unit-ordered candidate slots (PfArgs::unit_slots)
-    const uint32_t *unit_cnt;         // [n_tiles][n_units] records a unit produced
-    uint32_t unit_slots;
-    int64_t n_units;
-    int32_t n_tiles;
-    int32_t k;                        // units per chunk
-    int64_t n_chunks;
-    const int32_t *group_fields;
-    int32_t strand_mask, P, gbits, pbits;
-    uint64_t *keys;                   // the chunk-sorted hit list
-    double *vals;
-    uint64_t hit_cap;
-    unsigned long long *n_hits;
-    unsigned long long *n_rec;        // candidate records read
-    unsigned int *overflow;           // [0] bit 0: a unit dropped records, bit 1: a chunk held more than kOrdStage hits; [1] the largest such unit count; [2] the largest such chunk
-    uint16_t *cnt_cm;                 // [n_chunks][P] hits of the chunk per motif
-    unsigned long long *chunk_off;    // [n_chunks] first slot of the chunk's hits in keys / vals
-    uint32_t *chunk_n;                // [n_chunks]
-};
-size_t ord_rescore_lds_bytes(int32_t P, int n_src);
-int launch_rescore_ordered(const OrdArgs &O, int n_blocks, hipStream_t st);
-int launch_ordered_place(const OrdArgs &O, uint32_t *seg_sum, uint32_t *off, unsigned long long *motif_tot, int64_t *motif_first,
-                         int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand, uint64_t out_cap, int rbits, int n_cu, hipStream_t st);
-int launch_ordered_region_counts(const int64_t *motif_first, int32_t P, uint64_t out_cap, const int64_t *seq_idx, unsigned long long *region_counts,
-                                 int n_cu, hipStream_t st);
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
 int prefilter_set_lds(bool wide, bool meas, size_t bytes);

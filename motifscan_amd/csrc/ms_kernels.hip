@@ -199,8 +199,8 @@ struct PfResume {
 // out-of-line decode (pf_flush) works with them, so none of it occupies registers of the scanning loop
 struct PfEmit {
     unsigned long long base;   // next free slot of this wave's block in the global candidate list
-    uint32_t left;             // slots left in the block (unit-ordered form: records the unit produced so far)
-    uint32_t unit_slots;
+    uint32_t left;             // slots left in the block
+    uint32_t pad0;
     uint64_t *cand;
     unsigned long long *n_cand;
     uint64_t cand_cap, cand_static;
@@ -233,13 +233,6 @@ __device__ __forceinline__ void emit_rec(PfEmit &E, bool live, int64_t g, uint32
     if (mask == 0) return;
     const uint32_t n_new = (uint32_t) __popcll(mask);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    if (E.unit_slots) {
-        // unit-ordered form (the ordered tail, rescore_ordered_kernel): the records of a unit of window starts go to the unit's own
-        // slots of the list, no atomic at all; E.left counts what the unit wrote (beyond unit_slots: dropped, the host grows the slots)
-        if (flagged && E.left + rank < E.unit_slots) E.cand[E.base + E.left + rank] = cand_pack((uint64_t) g, (uint32_t) group, flags);
-        E.left += n_new;
-        return;
-    }
     if (n_new > E.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
         const uint32_t lane = threadIdx.x & 63u;
         if (lane < E.left && E.base + lane < E.cand_cap) E.cand[E.base + lane] = 0ULL;      // the abandoned rest of the block: empty records
@@ -321,7 +314,7 @@ __device__ __attribute__((noinline)) void pf_flush(uint32_t em_lds, uint32_t rq_
     {
         const u32x2 w0 = em2[0], w1 = em2[1], w2 = em2[2], w3 = em2[3], w4 = em2[4], w5 = em2[5], w6 = em2[6];
         E.base = ((unsigned long long) w0.y << 32) | w0.x;
-        E.left = w1.x; E.unit_slots = w1.y;
+        E.left = w1.x;
         E.cand = reinterpret_cast<uint64_t *>(((unsigned long long) w2.y << 32) | w2.x);
         E.n_cand = reinterpret_cast<unsigned long long *>(((unsigned long long) w3.y << 32) | w3.x);
         E.cand_cap = ((unsigned long long) w4.y << 32) | w4.x;
@@ -594,9 +587,8 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     const uint32_t em_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) em;
     const uint32_t rq_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) W.rq;
     if ((threadIdx.x & 63u) == 0) {
-        em->base = A.unit_slots ? 0ULL : ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
-        em->left = A.unit_slots ? 0u : A.cand_block;
-        em->unit_slots = A.unit_slots;
+        em->base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
+        em->left = A.cand_block;
         em->cand = A.cand; em->n_cand = A.n_cand; em->cand_cap = A.cand_cap; em->cand_static = A.cand_static; em->cand_block = A.cand_block;
     }
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
@@ -697,10 +689,6 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             }
             const uint32_t uid = v * K + g;                                       // the unit: window starts [uid, uid + 1) * 64 * wave_passes
             const uint32_t p0 = uid * wave_passes;
-            if (A.unit_slots && lane == 0) {
-                em->base = ((unsigned long long) blockIdx.y * n_units + uid) * A.unit_slots;
-                em->left = 0;
-            }
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
                 if (lane < 12) stg[lane] = lane < 8 ? words.c : words.n;          // (the wave's LDS operations execute in order: no barrier)
                 // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
@@ -709,15 +697,11 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                 else if (next < units_g) words = fetch((next * K + g) * wave_passes);
                 scan_pass((int64_t) (p0 + j) * 64);
             }
-            if (A.unit_slots) {                                                   // the unit's records belong to the unit's slots
-                if (W.rq_n) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
-                if (lane == 0) A.unit_cnt[(size_t) blockIdx.y * n_units + uid] = em->left;
-            }
             v = next;
         }
     }
     if (W.rq_n) pf_flush(em_lds, rq_lds, W.rq_n);
-    if (!A.unit_slots) {                                                          // the unused rest of the last block: empty records
+    {                                                                             // the unused rest of the last block: empty records
         const unsigned long long base = em->base;
         const uint32_t left = em->left;
         for (uint32_t i = 0; i < left; i += 64) {

@@ -344,10 +344,9 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
                                  {"MS_PF_LDS_BUDGET": "24576", "MS_PF_MAX_BLOCKS": "5"},
                                  {"MS_PF_RARE_CAP": "16"},                                      # the smallest parking space: events that park in pieces
                                  {"MS_PF_PAIR": "0"},                                           # plain rows only (one field per matrix row)
-                                 {"MS_TAIL": "ordered"},                                        # the ordered tail (built, measured, not adopted)
-                                 {"MS_TAIL": "ordered", "MS_PF_LDS_BUDGET": "24576"}])
+                                 ])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
-    """Number of LDS tiles, blocks per tile, the hit-key form, the parking space, paired rows and the form of the tail are tuning
+    """Number of LDS tiles, blocks per tile, the hit-key form, the parking space and paired rows are tuning
     knobs: every setting must give the same (bit-exact) hits on every strand mask (one strand: 32 / 64 motifs per row tile)."""
     monkeypatch.setenv("MS_MEASURE", "1")                       # measurement switches are only honoured with the explicit opt-in
     for k, v in env.items():
@@ -488,12 +487,11 @@ def test_edge_shapes_vs_oracle(oracle):
         cscore.c_scan_motif(ml[:1], [0.1], ["ACGT"], 4, 1)
 
 
-@pytest.mark.parametrize("env", [{}, {"MS_PF_RARE_CAP": "16"}, {"MS_TAIL": "ordered"}])
+@pytest.mark.parametrize("env", [{}, {"MS_PF_RARE_CAP": "16"}])
 def test_low_complexity_sequences_flood_the_candidate_path(oracle, monkeypatch, env):
     """Homopolymers and short tandem repeats: whole waves flag the same motif at every position, so a wave's parking space fills
     within one row tile (the event parks in pieces, the class comes back to the row tile after every decode), the candidate blocks
-    turn over on every append and the hit stager overflows to direct emission; with the ordered tail a unit's slots and a chunk's
-    LDS staging overflow (the pass is run again with the sizes the device reported, or the sorted tail takes over)."""
+    turn over on every append and the hit stager overflows to direct emission."""
     monkeypatch.setenv("MS_MEASURE", "1")
     for k, v in env.items():
         monkeypatch.setenv(k, v)

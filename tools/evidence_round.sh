@@ -39,7 +39,6 @@ python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase > $OUT/full_size_stage_times.lo
 python tools/ab_full.py 1 1e-4 2>&1 | grep Mbase >> $OUT/full_size_stage_times.log
 python tools/ab_full.py 3 1e-3 2>&1 | grep Mbase >> $OUT/full_size_stage_times.log
 MS_MEASURE=1 MS_PF_PAIR=0 python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/plain rows only (MS_PF_PAIR=0): /" >> $OUT/full_size_stage_times.log
-MS_MEASURE=1 MS_TAIL=ordered python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/ordered tail (MS_TAIL=ordered): /" >> $OUT/full_size_stage_times.log
 if [ -d tools/ab/r03a ]; then (cd tools/ab/r03a && python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/the round's first evidence build (366afa7): /") >> $OUT/full_size_stage_times.log; fi
 timeout 60 ./tools/ubench/issue_model.bin > $OUT/issue_model.log 2>&1
 python tests/fuzz_parity.py --cases 1500 --seed 40000 > $OUT/fuzz.log 2>&1
