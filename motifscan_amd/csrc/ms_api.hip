@@ -280,8 +280,8 @@ static double c_max_raw(const double *m, int W) {
 
 static void pwmset_free_device(ms_pwmset *p) {
     if (p->device >= 0 || p->plan_device >= 0) (void) hipSetDevice(p->device >= 0 ? p->device : p->plan_device);
-    dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff); dev_free(p->d_raw_floor);
-    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_fields); dev_free(p->d_exact_motifs);
+    dev_free(p->d_tab2); dev_free(p->d_tab_off); dev_free(p->d_width); dev_free(p->d_max_raw); dev_free(p->d_cutoff); dev_free(p->d_raw_floor); dev_free(p->d_thresh);
+    dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_fields); dev_free(p->d_exact_motifs); dev_free(p->d_field_meta);
     p->device = -1;
     p->plan_device = -1;
     p->dev_cutoff_version = 0;
@@ -293,7 +293,9 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
         MS_HIP(hipSetDevice(device));
         size_t total_w = 0;
         for (int32_t i = 0; i < p->P; i++) total_w += (size_t) p->widths[i];
-        std::vector<double2> tab(total_w * 4);
+        std::vector<double2> tab(total_w * 4 + 1);       // (+ one all-zero entry at the end: what a column that adds nothing reads, DevPwm::zero_bytes)
+        tab[total_w * 4].x = 0.0;
+        tab[total_w * 4].y = 0.0;
         std::vector<int64_t> off(p->P);
         size_t o = 0;
         for (int32_t i = 0; i < p->P; i++) {
@@ -309,6 +311,8 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
                 }
             o += (size_t) W * 4;
         }
+        p->tab2_entries = (int64_t) total_w * 4;
+        p->tab_off_host = off;
         int rc;
         if ((rc = dev_alloc(&p->d_tab2, tab.size()))) return rc;
         if ((rc = dev_alloc(&p->d_tab_off, (size_t) p->P))) return rc;
@@ -316,6 +320,7 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
         if ((rc = dev_alloc(&p->d_max_raw, (size_t) p->P))) return rc;
         if ((rc = dev_alloc(&p->d_cutoff, (size_t) p->P))) return rc;
         if ((rc = dev_alloc(&p->d_raw_floor, (size_t) p->P))) return rc;
+        if ((rc = dev_alloc(&p->d_thresh, (size_t) p->P * 4 + 4))) return rc;
         if (p->P > 0) {
             MS_HIP(hipMemcpy(p->d_tab2, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice));
             MS_HIP(hipMemcpy(p->d_tab_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -348,6 +353,9 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
                 fl[(size_t) i] = finite ? (p->cutoffs[i] - 1e-10) * p->max_raw[i] - 2e-9 * (1.0 + abs_sum) : -INFINITY;
             }
             MS_HIP(hipMemcpy(p->d_raw_floor, fl.data(), (size_t) p->P * sizeof(double), hipMemcpyHostToDevice));
+            std::vector<double> th((size_t) p->P * 4, 0.0);              // the hit test's three numbers side by side (rescore_kernel: one 16-byte + one 8-byte read)
+            for (int32_t i = 0; i < p->P; i++) { th[4 * (size_t) i] = fl[(size_t) i]; th[4 * (size_t) i + 1] = p->max_raw[i]; th[4 * (size_t) i + 2] = p->cutoffs[i]; }
+            MS_HIP(hipMemcpy(p->d_thresh, th.data(), th.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         p->dev_cutoff_version = p->cutoff_version;
     }
@@ -378,7 +386,7 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         p->plan_exact_only = exact_only;
         if (p->plan_device >= 0) {
             (void) hipSetDevice(p->plan_device);
-            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_fields); dev_free(p->d_exact_motifs);
+            dev_free(p->d_tables); dev_free(p->d_tiles); dev_free(p->d_group_fields); dev_free(p->d_exact_motifs); dev_free(p->d_field_meta);
             p->plan_device = -1;
         }
     }
@@ -400,6 +408,18 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
         if (!pl.exact_motifs.empty())
             MS_HIP(hipMemcpy(p->d_exact_motifs, pl.exact_motifs.data(), pl.exact_motifs.size() * sizeof(int32_t),
                              hipMemcpyHostToDevice));
+        {   // per field of every table group: motif, width, table offset (pwmset_upload has run: scan_locked's order)
+            std::vector<FieldMeta> fmv(pl.group_fields.size());
+            for (size_t i = 0; i < fmv.size(); i++) {
+                const int32_t m = pl.group_fields[i];
+                fmv[i].motif = m;
+                fmv[i].width = m >= 0 ? p->widths[m] : 0;
+                fmv[i].tab_bytes = m >= 0 && (size_t) m < p->tab_off_host.size() ? (uint32_t) ((uint64_t) p->tab_off_host[m] * sizeof(double2)) : 0u;
+                fmv[i].pad = 0;
+            }
+            if ((rc = dev_alloc(&p->d_field_meta, fmv.size() + 1))) return rc;
+            if (!fmv.empty()) MS_HIP(hipMemcpy(p->d_field_meta, fmv.data(), fmv.size() * sizeof(FieldMeta), hipMemcpyHostToDevice));
+        }
         p->plan_device = device;
     }
     return MS_OK;
@@ -408,6 +428,9 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
 static DevPwm dev_pwm(const ms_pwmset *p) {
     DevPwm d;
     d.tab2 = p->d_tab2; d.tab_off = p->d_tab_off; d.width = p->d_width; d.max_raw = p->d_max_raw;
+    d.thresh = p->d_thresh;
+    d.zero_bytes = (uint32_t) ((uint64_t) p->tab2_entries * sizeof(double2));
+    d.tab32 = (uint64_t) (p->tab2_entries + 1) * sizeof(double2) <= 0xFFFFFFFFull ? 1 : 0;
     d.cutoff = p->d_cutoff; d.raw_floor = p->d_raw_floor; d.P = p->P;
     return d;
 }
@@ -1097,7 +1120,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         }
         (void) hipEventRecord(ev[1], c->stream);
         if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)
-            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_group_fields, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
+            if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_field_meta, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
         if (!plan.exact_motifs.empty())
             if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return rc;
         (void) hipEventRecord(ev[2], c->stream);

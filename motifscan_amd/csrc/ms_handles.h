@@ -127,6 +127,10 @@ struct ms_pwmset {
     double2 *d_tab2 = nullptr;
     int64_t *d_tab_off = nullptr;
     int32_t *d_width = nullptr;
+    int64_t tab2_entries = 0;                     // entries of d_tab2 before its closing all-zero entry
+    std::vector<int64_t> tab_off_host;            // the motifs' offsets in d_tab2 (entries)
+    double *d_thresh = nullptr;                   // [P][4] {raw_floor, max_raw, cutoff, 0} (DevPwm::thresh)
+    ms::FieldMeta *d_field_meta = nullptr;        // [table groups][16] of the plan (rescore_kernel)
     double *d_max_raw = nullptr;
     double *d_cutoff = nullptr;
     double *d_raw_floor = nullptr;

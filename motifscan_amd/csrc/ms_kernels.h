@@ -37,6 +37,17 @@ struct DevPwm {
     const double *cutoff;     // [P]
     const double *raw_floor;  // [P] a raw (un-normalised) sum below this can never pass the hit test (-inf if unknown)
     int32_t P;
+    uint32_t zero_bytes;      // byte offset of tab2's closing all-zero entry (what a column that adds nothing reads: score_window32)
+    int32_t tab32;            // != 0: every entry of tab2 lies below 4 GB, byte offsets fit 32 bits
+    const double *thresh;     // [P][4] {raw_floor, max_raw, cutoff, 0}: what the hit test reads, side by side
+};
+
+// What rescore_kernel needs to know about a field of a table group, in one 16-byte read (plan-specific: ms_pwmset::d_field_meta)
+struct FieldMeta {
+    int32_t motif;            // -1: empty field
+    int32_t width;
+    uint32_t tab_bytes;       // byte offset of the motif's table in DevPwm::tab2 (DevPwm::tab32)
+    uint32_t pad;
 };
 
 struct HitOut {
@@ -81,7 +92,7 @@ int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile,
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
-                   uint64_t cand_cap, const int32_t *group_fields, int strand_mask, const HitOut &H, int n_blocks,
+                   uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
 int launch_finalize(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S,
                     int64_t *seq_idx, int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,

@@ -97,12 +97,13 @@ __device__ __forceinline__ void stage_flush(HitStage &st, const HitOut &H) {
 
 __device__ __forceinline__ void test_and_stage(HitStage &st, const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
                                                double fwd, double rev, int strand_mask) {
-    const double floor_ = Pw.raw_floor[motif];               // see test_and_emit
+    const double2 fm = *reinterpret_cast<const double2 *>(Pw.thresh + 4 * (size_t) motif);      // {raw_floor, max_raw}: one read
+    const double floor_ = fm.x;                              // see test_and_emit
     const bool try_f = (strand_mask & 1) && !(fwd < floor_);
     const bool try_r = (strand_mask & 2) && !(rev < floor_);
     if (!try_f && !try_r) return;
-    const double max_raw = Pw.max_raw[motif];
-    const double cutoff = Pw.cutoff[motif];
+    const double max_raw = fm.y;
+    const double cutoff = Pw.thresh[4 * (size_t) motif + 2];
     if (try_f) {
         const double s = fwd / max_raw;
         if (s - cutoff >= -1e-10) stage_hit(st, H, motif, g, 0u, s);
@@ -744,7 +745,7 @@ constexpr int kRescoreU = 4;
 
 __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
                                                       const unsigned long long *__restrict__ n_cand, uint64_t n_static, uint64_t cand_cap,
-                                                      const int32_t *__restrict__ group_fields, int strand_mask,
+                                                      const FieldMeta *__restrict__ field_meta, int strand_mask,
                                                       const HitOut H) {
     __shared__ HitStage st;
     if (threadIdx.x == 0) st.n = 0;
@@ -756,6 +757,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
     const unsigned long long per_sub = (unsigned long long) gridDim.x * blockDim.x;
     const unsigned long long per_round = per_sub * U;
     const unsigned long long rounds = (n + per_round - 1) / per_round;
+    const int4 *__restrict__ meta4 = reinterpret_cast<const int4 *>(field_meta);
     for (unsigned long long rd = 0; rd < rounds; rd++) {
         const unsigned long long i0 = rd * per_round + (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
         uint64_t c[U];
@@ -765,11 +767,12 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             live[u] = i0 + u * per_sub < n;
             c[u] = live[u] ? cand[i0 + u * per_sub] : 0;
         }
-        // independent of each other: region hint, sequence words, N words, first flagged motif
+        // independent of each other: region hint, sequence words, N words, the first flagged field's motif / width / table (one read)
         int64_t g[U], lo[U];
         uint64_t cw[U];
         uint32_t nw[U], flags[U];
-        int32_t group[U], pm[U];
+        int32_t group[U];
+        int4 fm[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             g[u] = (int64_t) (c[u] >> 30);
@@ -779,12 +782,10 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             lo[u] = S.blk2reg[g[u] >> 6];
             cw[u] = code_window(S.codes, g[u]);
             nw[u] = n_window(S.nmask, g[u]);
-            pm[u] = flags[u] ? group_fields[group[u] * kGroupFields + (__ffs((int) flags[u]) - 1)] : -1;
+            fm[u] = flags[u] ? meta4[group[u] * kGroupFields + (__ffs((int) flags[u]) - 1)] : make_int4(-1, 0, 0, 0);
         }
-        // second hop: the region's bounds, the first motif's width / table offset
+        // second hop: the region's bounds
         int64_t r[U], beg[U], end[U];
-        int W[U];
-        int64_t toff[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int64_t o0 = S.offsets[lo[u]], o1 = S.offsets[lo[u] + 1];
@@ -792,8 +793,6 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             if (g[u] < o1) { r[u] = lo[u]; beg[u] = o0; end[u] = o1; }
             else if (g[u] < o2) { r[u] = lo[u] + 1; beg[u] = o1; end[u] = o2; }
             else { r[u] = find_region(S, g[u]); beg[u] = S.offsets[r[u]]; end[u] = S.offsets[r[u] + 1]; }      // tiny regions
-            W[u] = pm[u] >= 0 ? Pw.width[pm[u]] : 0;
-            toff[u] = pm[u] >= 0 ? Pw.tab_off[pm[u]] : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -803,19 +802,16 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             while (flags[u]) {
                 const int field = __ffs((int) flags[u]) - 1;
                 flags[u] &= flags[u] - 1u;
-                int32_t m = pm[u];
-                int w = W[u];
-                int64_t to = toff[u];
-                if (!first) {                                            // further motifs of the group: rare
-                    m = group_fields[group[u] * kGroupFields + field];
-                    if (m >= 0) { w = Pw.width[m]; to = Pw.tab_off[m]; }
-                }
+                int4 f4 = fm[u];
+                if (!first) f4 = meta4[group[u] * kGroupFields + field];           // further motifs of the group: rare
                 first = false;
+                const int32_t m = f4.x;
+                const int w = f4.y;
                 if (m < 0) continue;
                 if (g[u] + w > end[u]) continue;                         // window runs past its region (cscore.c:340)
                 double fwd, rev;
-                if (w <= 32) score_window32(Pw.tab2 + to, w, cw[u], nw[u], fwd, rev);     // non-ACGT bases add nothing (cscore.c:345-353)
-                else score_window(S, Pw.tab2 + to, w, g[u], fwd, rev);
+                if (w <= 32 && Pw.tab32) score_window32(Pw.tab2, (uint32_t) f4.z, Pw.zero_bytes, w, cw[u], nw[u], fwd, rev);     // non-ACGT bases add nothing (cscore.c:345-353)
+                else score_window(S, Pw.tab2 + Pw.tab_off[m], w, g[u], fwd, rev);
                 test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask);
             }
         }
@@ -1311,10 +1307,10 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 }
 
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
-                   uint64_t cand_cap, const int32_t *group_fields, int strand_mask, const HitOut &H, int n_blocks,
+                   uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st) {
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned) n_blocks), dim3(256), 0, st, S, Pw, cand, n_cand, n_static, cand_cap,
-                       group_fields, strand_mask, H);
+                       field_meta, strand_mask, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
