@@ -1129,6 +1129,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // ordering + coordinates of the first n_sort slots of the hit list into the result block (events 3, 4, 5); n_dev != nullptr:
     // only the device knows how many of them are hits (the rest are all-ones keys, which sort behind every hit)
     const int end_bit = gbits + 1 + mbits;
+    // the radix passes cover the key bits above kSortLowBits, sort_fixup_kernel the rest (MS_SORT_FULL: all bits by radix passes)
+    const int sort_begin = (end_bit > 2 * kSortLowBits && !measure_env("MS_SORT_FULL")) ? kSortLowBits : 0;
     bool queue_only = false;                     // this back() belongs to a scan that is only queued (scan_complete finishes it)
     auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
@@ -1136,7 +1138,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         (void) hipEventRecord(ev[3], c->stream);
         if (n_sort > 0) {
             size_t need = 0;
-            if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
+            if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, sort_begin, end_bit, c->stream))) return rc;
             if (need > sc.sort_tmp_bytes) {
                 if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
                 sc.sort_tmp = nullptr; sc.sort_tmp_bytes = 0;
@@ -1146,7 +1148,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 sc.sort_tmp_bytes = need;
             }
             size_t have = sc.sort_tmp_bytes;
-            if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, end_bit, c->stream))) return rc;
+            if ((rc = sort_hit_pairs(sc.sort_tmp, &have, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, sort_begin, end_bit, c->stream))) return rc;
+            if (sort_begin && (rc = launch_sort_fixup(sc.keys_sorted, raw->d_score, (int64_t) n_sort, n_dev, c->stream))) return rc;
         }
         (void) hipEventRecord(ev[4], c->stream);
         if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_sort, n_dev, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,

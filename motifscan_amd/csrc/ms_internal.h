@@ -221,9 +221,10 @@ inline uint32_t f6_get(const uint8_t *tile, int kb, int row, int col_in_kb, int 
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths, const double *cutoffs,
                const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan);
 
-// Sort (ms_sort.hip): keys ascending over bits [0, end_bit).  Query temp size with temp == nullptr.
+// Sort (ms_sort.hip): keys ascending over bits [begin_bit, end_bit) (stable).  Query temp size with temp == nullptr.
+constexpr int kSortLowBits = 8;        // a scan's hits are radix-sorted over the key bits above these; sort_fixup_kernel orders the rest
 int sort_hit_pairs(void *temp, size_t *temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                   const double *vals_in, double *vals_out, size_t n, int end_bit, hipStream_t stream);
+                   const double *vals_in, double *vals_out, size_t n, int begin_bit, int end_bit, hipStream_t stream);
 
 // Descending sort of one row of fp64 scores (cutoff builder).  Query temp size with temp == nullptr.
 int sort_doubles_desc(void *temp, size_t *temp_bytes, const double *in, double *out, size_t n, hipStream_t stream);

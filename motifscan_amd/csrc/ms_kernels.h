@@ -94,6 +94,8 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
                    uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);
+// after a sort over the key bits above kSortLowBits: runs of hits equal in those bits into full key order (in place)
+int launch_sort_fixup(uint64_t *keys, double *vals, int64_t n, const unsigned long long *n_dev, hipStream_t st);
 int launch_finalize(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int rbits, int pbits, int32_t P, const DevSeq &S,
                     int64_t *seq_idx, int64_t *pos, int8_t *strand, int64_t *motif_first, unsigned long long *region_counts,
                     hipStream_t st);

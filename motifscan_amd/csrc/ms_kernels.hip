@@ -1341,6 +1341,50 @@ __global__ void __launch_bounds__(256) fill_tail_kernel(uint64_t *__restrict__ k
         keys[i] = ~0ULL;
 }
 
+// The radix sort orders a scan's hits over the key bits ABOVE kSortLowBits only (one eight-bit pass fewer over 62 M pairs of 16 bytes);
+// hits that agree in those bits -- the same motif, region and 128-base stretch: a motif's two strands at one position, mostly -- are
+// neighbours afterwards, in the order the list held them.  This kernel finishes the order: the first hit of every such run sorts its
+// run in place by the whole key (runs hold <= 2^kSortLowBits hits: the keys of a scan are distinct; all-ones padding keys are left alone).
+__global__ void __launch_bounds__(256) sort_fixup_kernel(uint64_t *__restrict__ keys, double *__restrict__ vals, int64_t n, const unsigned long long *__restrict__ n_dev) {
+    if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }
+    const int64_t i0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;     // four consecutive hits per thread: two 16-byte reads
+    if (i0 >= n) return;
+    uint64_t hi[6];                                                               // the high bits of hits i0 - 1 ... i0 + 4 (all-ones: none)
+    hi[0] = i0 > 0 ? keys[i0 - 1] >> kSortLowBits : ~0ULL;
+    if (i0 + 4 <= n) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(keys + i0), b = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
+        hi[1] = a.x >> kSortLowBits; hi[2] = a.y >> kSortLowBits; hi[3] = b.x >> kSortLowBits; hi[4] = b.y >> kSortLowBits;
+    } else {
+        for (int q = 0; q < 4; q++) hi[1 + q] = i0 + q < n ? keys[i0 + q] >> kSortLowBits : ~0ULL;
+    }
+    hi[5] = i0 + 4 < n ? keys[i0 + 4] >> kSortLowBits : ~0ULL;
+    // (the high bits of a run's members do not change while another thread sorts the run: what is compared here is stable)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int64_t i = i0 + q;
+        if (i >= n || hi[1 + q] == hi[q] || hi[1 + q] != hi[2 + q]) continue;   // not the first of a run of two or more
+        if (i + 1 >= n) continue;
+        const uint64_t h = hi[1 + q];
+        int64_t len = 2;
+        while (i + len < n && len < ((int64_t) 1 << kSortLowBits) && (keys[i + len] >> kSortLowBits) == h) len++;
+        for (int64_t a = 1; a < len; a++) {                                      // insertion sort: runs of 2 ... 4 in practice
+            const uint64_t ka = keys[i + a];
+            const double va = vals[i + a];
+            int64_t b = a;
+            while (b > 0 && keys[i + b - 1] > ka) { keys[i + b] = keys[i + b - 1]; vals[i + b] = vals[i + b - 1]; b--; }
+            keys[i + b] = ka;
+            vals[i + b] = va;
+        }
+    }
+}
+
+int launch_sort_fixup(uint64_t *keys, double *vals, int64_t n, const unsigned long long *n_dev, hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(sort_fixup_kernel, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, st, keys, vals, n, n_dev);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
 int launch_fill_tail(uint64_t *keys, const unsigned long long *n_dev, uint64_t cap, hipStream_t st) {
     if (cap == 0) return MS_OK;
     hipLaunchKernelGGL(fill_tail_kernel, dim3(256), dim3(256), 0, st, keys, n_dev, cap);

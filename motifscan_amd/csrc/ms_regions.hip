@@ -265,7 +265,7 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
     if (total > 0) {
         const size_t nt = up8((size_t) total);
         size_t sort_bytes = 0;
-        if ((rc = sort_hit_pairs(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t) total, mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
+        if ((rc = sort_hit_pairs(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t) total, 0, mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
         if ((rc = pool_alloc(c, 24 * nt + sort_bytes + 256, &wblk, &wgot))) { cleanup(); return fail2(rc); }
         uint64_t *d_keys = static_cast<uint64_t *>(wblk), *d_keys_sorted = d_keys + nt;
         double *d_vals = reinterpret_cast<double *>(d_keys_sorted + nt);
@@ -275,7 +275,7 @@ extern "C" int ms_scan_regions_once(const ms_pwmset *pwms_c, const ms_genome *g,
         he = hipGetLastError();
         if (he != hipSuccess) { cleanup(); set_error("hand-out kernel failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
         if ((rc = sort_hit_pairs(d_sort_tmp, &sort_bytes, d_keys, d_keys_sorted, d_vals, raw->d_score, (size_t) total,
-                                 mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
+                                 0, mbits + rbits + pbits + 1, c->stream))) { cleanup(); return fail2(rc); }
         DevSeq none{};
         if ((rc = launch_finalize(d_keys_sorted, (int64_t) total, nullptr, rbits + pbits, rbits, pbits, pwms->P, none, raw->d_seq_idx, raw->d_pos,
                                   raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) { cleanup(); return fail2(rc); }

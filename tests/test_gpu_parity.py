@@ -344,6 +344,7 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
                                  {"MS_PF_LDS_BUDGET": "24576", "MS_PF_MAX_BLOCKS": "5"},
                                  {"MS_PF_RARE_CAP": "16"},                                      # the smallest parking space: events that park in pieces
                                  {"MS_PF_PAIR": "0"},                                           # plain rows only (one field per matrix row)
+                                 {"MS_SORT_FULL": "1"},                                         # every key bit by radix passes (no fix-up kernel)
                                  ])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
     """Number of LDS tiles, blocks per tile, the hit-key form, the parking space and paired rows are tuning
