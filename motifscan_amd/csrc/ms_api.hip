@@ -1129,13 +1129,17 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // ordering + coordinates of the first n_sort slots of the hit list into the result block (events 3, 4, 5); n_dev != nullptr:
     // only the device knows how many of them are hits (the rest are all-ones keys, which sort behind every hit)
     const int end_bit = gbits + 1 + mbits;
-    // the radix passes cover the key bits above kSortLowBits, sort_fixup_kernel the rest (MS_SORT_FULL: all bits by radix passes)
-    const int sort_begin = (end_bit > 2 * kSortLowBits && !measure_env("MS_SORT_FULL")) ? kSortLowBits : 0;
+    // the radix passes cover the key bits above kSortLowBits, sort_fixup_kernel the rest (MS_SORT_FULL: all bits by radix passes;
+    // a short hit list is ordered by launch latencies, not passes: one kernel fewer matters more there)
+    const int sort_begin_large = (end_bit > 2 * kSortLowBits && !measure_env("MS_SORT_FULL")) ? kSortLowBits : 0;
     bool queue_only = false;                     // this back() belongs to a scan that is only queued (scan_complete finishes it)
     auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
         (void) hipEventRecord(ev[3], c->stream);
+        size_t fixup_min = (size_t) 1 << 20;
+        if (const char *e = measure_env("MS_SORT_FIXUP_MIN")) fixup_min = (size_t) std::max(0, atoi(e));     // test aid: the fix-up form on short lists too
+        const int sort_begin = n_sort >= fixup_min ? sort_begin_large : 0;
         if (n_sort > 0) {
             size_t need = 0;
             if ((rc = sort_hit_pairs(nullptr, &need, sc.keys, sc.keys_sorted, sc.vals, raw->d_score, n_sort, sort_begin, end_bit, c->stream))) return rc;
