@@ -354,7 +354,8 @@ int ms::pwmset_upload(ms_pwmset *p, int device, hipStream_t st) {
             }
             MS_HIP(hipMemcpy(p->d_raw_floor, fl.data(), (size_t) p->P * sizeof(double), hipMemcpyHostToDevice));
             std::vector<double> th((size_t) p->P * 4, 0.0);              // the hit test's three numbers side by side (rescore_kernel: one 16-byte + one 8-byte read)
-            for (int32_t i = 0; i < p->P; i++) { th[4 * (size_t) i] = fl[(size_t) i]; th[4 * (size_t) i + 1] = p->max_raw[i]; th[4 * (size_t) i + 2] = p->cutoffs[i]; }
+            for (int32_t i = 0; i < p->P; i++) { th[4 * (size_t) i] = p->max_raw[i]; th[4 * (size_t) i + 1] = p->cutoffs[i]; th[4 * (size_t) i + 2] = fl[(size_t) i]; }
+            p->raw_floor_host = fl;
             MS_HIP(hipMemcpy(p->d_thresh, th.data(), th.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         p->dev_cutoff_version = p->cutoff_version;
@@ -415,7 +416,12 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
                 fmv[i].motif = m;
                 fmv[i].width = m >= 0 ? p->widths[m] : 0;
                 fmv[i].tab_bytes = m >= 0 && (size_t) m < p->tab_off_host.size() ? (uint32_t) ((uint64_t) p->tab_off_host[m] * sizeof(double2)) : 0u;
-                fmv[i].pad = 0;
+                float f32 = -INFINITY;                          // rounded DOWN: never above the fp64 floor
+                if (m >= 0 && (size_t) m < p->raw_floor_host.size() && std::isfinite(p->raw_floor_host[m])) {
+                    f32 = (float) p->raw_floor_host[m];
+                    if ((double) f32 > p->raw_floor_host[m] || !std::isfinite(f32)) f32 = std::isfinite(f32) ? std::nextafterf(f32, -INFINITY) : -INFINITY;
+                }
+                fmv[i].floor32 = f32;
             }
             if ((rc = dev_alloc(&p->d_field_meta, fmv.size() + 1))) return rc;
             if (!fmv.empty()) MS_HIP(hipMemcpy(p->d_field_meta, fmv.data(), fmv.size() * sizeof(FieldMeta), hipMemcpyHostToDevice));
@@ -437,7 +443,7 @@ static DevPwm dev_pwm(const ms_pwmset *p) {
 
 static DevSeq dev_seq(const ms_seqset *s) {
     DevSeq d;
-    d.codes = s->d_codes; d.nmask = s->d_nmask; d.offsets = s->d_offsets; d.blk2reg = s->d_blk2reg; d.R = s->R;
+    d.codes = s->d_codes; d.nmask = s->d_nmask; d.offsets = s->d_offsets; d.blk2reg = s->d_blk2reg; d.blkinfo = s->d_blkinfo; d.R = s->R;
     d.n_bases = s->n_bases;
     return d;
 }
@@ -622,16 +628,18 @@ static int seqset_alloc_packed(ms_seqset *s) {
     const size_t b_nmask = (n_units + kPadWords) * sizeof(uint32_t);
     const size_t b_off = ((size_t) s->R + 1) * sizeof(int64_t);
     const size_t b_blk = ((size_t) (s->n_bases / 64) + 2) * sizeof(int32_t);
+    const size_t b_info = ((size_t) (s->n_bases / 64) + 2) * sizeof(int4);
     auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
     DeviceCtx *c;
     int rc = get_ctx(s->device, &c);
     if (rc) return rc;
-    if ((rc = pool_alloc(c, up(b_codes) + up(b_nmask) + up(b_off) + up(b_blk), &s->block, &s->block_bytes))) return rc;
+    if ((rc = pool_alloc(c, up(b_codes) + up(b_nmask) + up(b_off) + up(b_blk) + up(b_info), &s->block, &s->block_bytes))) return rc;
     char *b = static_cast<char *>(s->block);
     s->d_codes = reinterpret_cast<uint32_t *>(b);
     s->d_nmask = reinterpret_cast<uint32_t *>(b + up(b_codes));
     s->d_offsets = reinterpret_cast<int64_t *>(b + up(b_codes) + up(b_nmask));
     s->d_blk2reg = reinterpret_cast<int32_t *>(b + up(b_codes) + up(b_nmask) + up(b_off));
+    s->d_blkinfo = reinterpret_cast<int4 *>(b + up(b_codes) + up(b_nmask) + up(b_off) + up(b_blk));
     // only the pad words behind the packed data need clearing: the kernels write everything else
     // sequence sets are built on the upload stream: a batch can be packed while the previous one is being scanned
     s->up = c->stream_up;                                 // read once: every step of building this set stays on one stream
@@ -663,7 +671,7 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
         if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     }
     if ((rc = launch_pack(raw->d_ascii, raw->n_bases, raw->d_codes, raw->d_nmask, raw->up))) return fail(rc);
-    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up))) return fail(rc);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->d_blkinfo, raw->up))) return fail(rc);
     hipError_t e = hipStreamSynchronize(raw->up);
     if (e != hipSuccess) { set_error("upload / pack failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     if (!keep_ascii) { pool_free(c, raw->d_ascii, raw->ascii_bytes); raw->d_ascii = nullptr; raw->ascii_bytes = 0; }
@@ -686,7 +694,7 @@ int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n
     if ((rc = seqset_alloc_packed(raw))) return fail(rc);
     if ((rc = launch_pack(static_cast<const uint8_t *>(d_bases), raw->n_bases, raw->d_codes, raw->d_nmask, raw->up)))
         return fail(rc);
-    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up))) return fail(rc);
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->d_blkinfo, raw->up))) return fail(rc);
     hipError_t e = hipStreamSynchronize(raw->up);
     if (e != hipSuccess) { set_error("pack kernel failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     raw->built = true;
@@ -702,7 +710,7 @@ int ms_seqset_repack(ms_seqset *s) {
     if (rc) return rc;
     const hipStream_t up = c->stream_up;
     if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, up))) return rc;
-    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, up))) return rc;
+    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, s->d_blkinfo, up))) return rc;
     MS_HIP(hipStreamSynchronize(up));
     return MS_OK;
 }
@@ -818,7 +826,7 @@ int ms_seqset_from_genome(const ms_genome *g, const int32_t *chrom, const int64_
     hipError_t he = hipMemcpyAsync(d_src, src.data(), ((size_t) n_regions + 1) * sizeof(int64_t), hipMemcpyHostToDevice, raw->up);
     if (he == hipSuccess) {
         rc = launch_extract(G->d_codes, G->d_nmask, d_src, raw->d_offsets, raw->R, raw->n_bases, raw->d_codes, raw->d_nmask, raw->up);
-        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->up);
+        if (!rc) rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->d_blkinfo, raw->up);
         if (!rc) he = hipStreamSynchronize(raw->up);
     }
     dev_free(d_src);

@@ -129,7 +129,8 @@ struct ms_pwmset {
     int32_t *d_width = nullptr;
     int64_t tab2_entries = 0;                     // entries of d_tab2 before its closing all-zero entry
     std::vector<int64_t> tab_off_host;            // the motifs' offsets in d_tab2 (entries)
-    double *d_thresh = nullptr;                   // [P][4] {raw_floor, max_raw, cutoff, 0} (DevPwm::thresh)
+    double *d_thresh = nullptr;                   // [P][4] {max_raw, cutoff, raw_floor, 0} (DevPwm::thresh)
+    std::vector<double> raw_floor_host;           // [P] (FieldMeta::floor32 is made of it)
     ms::FieldMeta *d_field_meta = nullptr;        // [table groups][16] of the plan (rescore_kernel)
     double *d_max_raw = nullptr;
     double *d_cutoff = nullptr;
@@ -171,6 +172,7 @@ struct ms_seqset {
     uint32_t *d_nmask = nullptr;
     int64_t *d_offsets = nullptr;
     int32_t *d_blk2reg = nullptr;         // region of position 64*b
+    int4 *d_blkinfo = nullptr;            // ... with the region's and the next two regions' starts relative to 64*b (DevSeq::blkinfo)
     hipStream_t up = nullptr;             // the upload stream this set is being built on (DeviceCtx::stream_up, read once)
     bool built = false;                   // construction finished (its work on `up` is done)
 };

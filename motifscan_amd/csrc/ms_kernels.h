@@ -25,6 +25,7 @@ struct DevSeq {
     const uint32_t *nmask;
     const int64_t *offsets;   // [R+1]
     const int32_t *blk2reg;   // [n_bases/64 + 2] region of position 64*b
+    const int4 *blkinfo;      // [n_bases/64 + 2] {that region, its start, the next region's, the one after's: relative to 64*b} (blk2reg_kernel)
     int64_t R;
     int64_t n_bases;
 };
@@ -39,7 +40,7 @@ struct DevPwm {
     int32_t P;
     uint32_t zero_bytes;      // byte offset of tab2's closing all-zero entry (what a column that adds nothing reads: score_window32)
     int32_t tab32;            // != 0: every entry of tab2 lies below 4 GB, byte offsets fit 32 bits
-    const double *thresh;     // [P][4] {raw_floor, max_raw, cutoff, 0}: what the hit test reads, side by side
+    const double *thresh;     // [P][4] {max_raw, cutoff, raw_floor, 0}: what the hit test reads, side by side
 };
 
 // What rescore_kernel needs to know about a field of a table group, in one 16-byte read (plan-specific: ms_pwmset::d_field_meta)
@@ -47,7 +48,7 @@ struct FieldMeta {
     int32_t motif;            // -1: empty field
     int32_t width;
     uint32_t tab_bytes;       // byte offset of the motif's table in DevPwm::tab2 (DevPwm::tab32)
-    uint32_t pad;
+    float floor32;            // the motif's raw-sum floor (DevPwm::raw_floor) rounded DOWN to a float: a sum below it is no hit
 };
 
 struct HitOut {
@@ -102,7 +103,7 @@ int launch_finalize(const uint64_t *keys, int64_t n, const unsigned long long *n
 int launch_fill_tail(uint64_t *keys, const unsigned long long *n_dev, uint64_t cap, hipStream_t st);
 int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t *src_start, const int64_t *dst_off,
                    int64_t R, int64_t n_out, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st);
+int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, int4 *blkinfo, hipStream_t st);
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
 int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                        int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st);

@@ -95,15 +95,16 @@ __device__ __forceinline__ void stage_flush(HitStage &st, const HitOut &H) {
     __syncthreads();
 }
 
+// floor32: FieldMeta::floor32, the raw-sum floor of test_and_emit rounded DOWN to a float (it came with the field's record: windows
+// that cannot be hits read nothing more); the rest of the test reads {max_raw, cutoff} side by side
 __device__ __forceinline__ void test_and_stage(HitStage &st, const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
-                                               double fwd, double rev, int strand_mask) {
-    const double2 fm = *reinterpret_cast<const double2 *>(Pw.thresh + 4 * (size_t) motif);      // {raw_floor, max_raw}: one read
-    const double floor_ = fm.x;                              // see test_and_emit
+                                               double fwd, double rev, int strand_mask, float floor32) {
+    const double floor_ = (double) floor32;
     const bool try_f = (strand_mask & 1) && !(fwd < floor_);
     const bool try_r = (strand_mask & 2) && !(rev < floor_);
     if (!try_f && !try_r) return;
-    const double max_raw = fm.y;
-    const double cutoff = Pw.thresh[4 * (size_t) motif + 2];
+    const double2 mc = *reinterpret_cast<const double2 *>(Pw.thresh + 4 * (size_t) motif);      // {max_raw, cutoff}: one read
+    const double max_raw = mc.x, cutoff = mc.y;
     if (try_f) {
         const double s = fwd / max_raw;
         if (s - cutoff >= -1e-10) stage_hit(st, H, motif, g, 0u, s);
@@ -767,8 +768,9 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             live[u] = i0 + u * per_sub < n;
             c[u] = live[u] ? cand[i0 + u * per_sub] : 0;
         }
-        // independent of each other: region hint, sequence words, N words, the first flagged field's motif / width / table (one read)
-        int64_t g[U], lo[U];
+        // independent of each other: the region's place (one read), sequence words, N words, the first flagged field's motif / width / table (one read)
+        int64_t g[U];
+        int4 bi[U];
         uint64_t cw[U];
         uint32_t nw[U], flags[U];
         int32_t group[U];
@@ -779,19 +781,25 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
             group[u] = (int32_t) ((c[u] >> 16) & 0x3FFFu);
             const uint32_t f = (uint32_t) c[u] & 0xFFFFu;              // bit n = field n
             flags[u] = both ? (f | (f >> 1)) & 0x5555u : f;             // a motif's two strands are re-scored together anyway
-            lo[u] = S.blk2reg[g[u] >> 6];
+            bi[u] = S.blkinfo[g[u] >> 6];
             cw[u] = code_window(S.codes, g[u]);
             nw[u] = n_window(S.nmask, g[u]);
             fm[u] = flags[u] ? meta4[group[u] * kGroupFields + (__ffs((int) flags[u]) - 1)] : make_int4(-1, 0, 0, 0);
         }
-        // second hop: the region's bounds
+        // the region's bounds: out of the block's record; only tiny regions (a third region start within the block's reach) and
+        // starts beyond 32 bits need the offsets themselves
         int64_t r[U], beg[U], end[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t o0 = S.offsets[lo[u]], o1 = S.offsets[lo[u] + 1];
-            const int64_t o2 = lo[u] + 2 <= S.R ? S.offsets[lo[u] + 2] : o1;
-            if (g[u] < o1) { r[u] = lo[u]; beg[u] = o0; end[u] = o1; }
-            else if (g[u] < o2) { r[u] = lo[u] + 1; beg[u] = o1; end[u] = o2; }
+            const int64_t base = g[u] & ~(int64_t) 63;
+            int64_t lo = bi[u].x, o0 = base + bi[u].y, o1 = base + bi[u].z, o2 = base + bi[u].w;
+            if (bi[u].x < 0) {
+                lo = S.blk2reg[g[u] >> 6];
+                o0 = S.offsets[lo]; o1 = S.offsets[lo + 1];
+                o2 = lo + 2 <= S.R ? S.offsets[lo + 2] : o1;
+            }
+            if (g[u] < o1) { r[u] = lo; beg[u] = o0; end[u] = o1; }
+            else if (g[u] < o2) { r[u] = lo + 1; beg[u] = o1; end[u] = o2; }
             else { r[u] = find_region(S, g[u]); beg[u] = S.offsets[r[u]]; end[u] = S.offsets[r[u] + 1]; }      // tiny regions
         }
 #pragma unroll
@@ -812,7 +820,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
                 double fwd, rev;
                 if (w <= 32 && Pw.tab32) score_window32(Pw.tab2, (uint32_t) f4.z, Pw.zero_bytes, w, cw[u], nw[u], fwd, rev);     // non-ACGT bases add nothing (cscore.c:345-353)
                 else score_window(S, Pw.tab2 + Pw.tab_off[m], w, g[u], fwd, rev);
-                test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask);
+                test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask, __int_as_float(f4.w));
             }
         }
         __syncthreads();
@@ -1212,12 +1220,19 @@ __global__ void __launch_bounds__(256) extract_kernel(const uint32_t *__restrict
 
 // ------------------------------------------------------------------- region hints --
 
-// blk2reg[b] = region that holds position 64*b (part of the extraction stage, next to pack_kernel)
+// blk2reg[b] = region that holds position 64*b (part of the extraction stage, next to pack_kernel); blkinfo[b] = the same region with
+// its own and the next two regions' starts RELATIVE to 64*b as 32-bit numbers -- everything rescore_kernel needs to place a position,
+// in one 16-byte read (the fp64 stage pays per vector-memory instruction); region -1: a start lies more than 2^31 bases away, look it up
 __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict__ offsets, int64_t R, int64_t n_blocks,
-                                                      int32_t *__restrict__ blk2reg) {
+                                                      int32_t *__restrict__ blk2reg, int4 *__restrict__ blkinfo) {
     const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
-    blk2reg[b] = (int32_t) find_region_bsearch(offsets, R, b * 64);
+    const int64_t r = find_region_bsearch(offsets, R, b * 64);
+    blk2reg[b] = (int32_t) r;
+    const int64_t base = b * 64;
+    const int64_t o0 = offsets[r] - base, o1 = offsets[r + 1 <= R ? r + 1 : R] - base, o2 = offsets[r + 2 <= R ? r + 2 : (r + 1 <= R ? r + 1 : R)] - base;
+    const bool fits = o0 > -(1LL << 31) && o1 < (1LL << 31) && o2 < (1LL << 31) && o1 > -(1LL << 31) && o2 > -(1LL << 31) && r < (1LL << 31);
+    blkinfo[b] = fits ? make_int4((int) r, (int) o0, (int) o1, (int) o2) : make_int4(-1, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------- compact copy-out --
@@ -1255,10 +1270,10 @@ int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t
     return MS_OK;
 }
 
-int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, hipStream_t st) {
+int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, int4 *blkinfo, hipStream_t st) {
     const int64_t n_blocks = (n_bases + 63) / 64 + 1;
     hipLaunchKernelGGL(blk2reg_kernel, dim3((unsigned) ((n_blocks + 255) / 256)), dim3(256), 0, st, offsets, R, n_blocks,
-                       blk2reg);
+                       blk2reg, blkinfo);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
