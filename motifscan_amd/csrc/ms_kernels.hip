@@ -1364,25 +1364,39 @@ __global__ void __launch_bounds__(256) sort_fixup_kernel(uint64_t *__restrict__ 
     if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }
     const int64_t i0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;     // four consecutive hits per thread: two 16-byte reads
     if (i0 >= n) return;
+    uint64_t k[4] = {0, 0, 0, 0};
     uint64_t hi[6];                                                               // the high bits of hits i0 - 1 ... i0 + 4 (all-ones: none)
     hi[0] = i0 > 0 ? keys[i0 - 1] >> kSortLowBits : ~0ULL;
     if (i0 + 4 <= n) {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(keys + i0), b = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
-        hi[1] = a.x >> kSortLowBits; hi[2] = a.y >> kSortLowBits; hi[3] = b.x >> kSortLowBits; hi[4] = b.y >> kSortLowBits;
+        k[0] = a.x; k[1] = a.y; k[2] = b.x; k[3] = b.y;
     } else {
-        for (int q = 0; q < 4; q++) hi[1 + q] = i0 + q < n ? keys[i0 + q] >> kSortLowBits : ~0ULL;
+        for (int q = 0; q < 4; q++) k[q] = i0 + q < n ? keys[i0 + q] : ~0ULL;
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) hi[1 + q] = i0 + q < n ? k[q] >> kSortLowBits : ~0ULL;
     hi[5] = i0 + 4 < n ? keys[i0 + 4] >> kSortLowBits : ~0ULL;
     // (the high bits of a run's members do not change while another thread sorts the run: what is compared here is stable)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int64_t i = i0 + q;
-        if (i >= n || hi[1 + q] == hi[q] || hi[1 + q] != hi[2 + q]) continue;   // not the first of a run of two or more
-        if (i + 1 >= n) continue;
+        if (i + 1 >= n || hi[1 + q] == hi[q] || hi[1 + q] != hi[2 + q]) continue;   // not the first of a run of two or more
+        if (q < 3 && hi[3 + q] != hi[1 + q]) {
+            // a run of exactly two, both in this thread's registers (a motif's two strands at one position: nearly every run):
+            // half of them are in order already and touch nothing more
+            if (k[q] > k[q + 1]) {
+                keys[i] = k[q + 1];
+                keys[i + 1] = k[q];
+                const double v0 = vals[i], v1 = vals[i + 1];
+                vals[i] = v1;
+                vals[i + 1] = v0;
+            }
+            continue;
+        }
         const uint64_t h = hi[1 + q];
         int64_t len = 2;
         while (i + len < n && len < ((int64_t) 1 << kSortLowBits) && (keys[i + len] >> kSortLowBits) == h) len++;
-        for (int64_t a = 1; a < len; a++) {                                      // insertion sort: runs of 2 ... 4 in practice
+        for (int64_t a = 1; a < len; a++) {                                      // insertion sort: short runs
             const uint64_t ka = keys[i + a];
             const double va = vals[i + a];
             int64_t b = a;
