@@ -471,7 +471,8 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     units = float(wl["units"])
 
     def timed(fn, passes):
-        fn()                                            # warm: pools, pinned blocks
+        fn()                                            # warm: pools, pinned blocks (they take two passes to reach their steady sizes:
+        fn()                                            # tools/e2e_phases.py -- 195, 93, 63, 62, 60 ms for passes 0 ... 4)
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
