@@ -1224,7 +1224,7 @@ __global__ void __launch_bounds__(256) extract_kernel(const uint32_t *__restrict
 // its own and the next two regions' starts RELATIVE to 64*b as 32-bit numbers -- everything rescore_kernel needs to place a position,
 // in one 16-byte read (the fp64 stage pays per vector-memory instruction); region -1: a start lies more than 2^31 bases away, look it up
 __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict__ offsets, int64_t R, int64_t n_blocks,
-                                                      int32_t *__restrict__ blk2reg, int4 *__restrict__ blkinfo) {
+                                                      int32_t *__restrict__ blk2reg, int4 *__restrict__ blkinfo, int all_far) {
     const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     const int64_t r = find_region_bsearch(offsets, R, b * 64);
@@ -1232,7 +1232,7 @@ __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict_
     const int64_t base = b * 64;
     const int64_t o0 = offsets[r] - base, o1 = offsets[r + 1 <= R ? r + 1 : R] - base, o2 = offsets[r + 2 <= R ? r + 2 : (r + 1 <= R ? r + 1 : R)] - base;
     const bool fits = o0 > -(1LL << 31) && o1 < (1LL << 31) && o2 < (1LL << 31) && o1 > -(1LL << 31) && o2 > -(1LL << 31) && r < (1LL << 31);
-    blkinfo[b] = fits ? make_int4((int) r, (int) o0, (int) o1, (int) o2) : make_int4(-1, 0, 0, 0);
+    blkinfo[b] = fits && !all_far ? make_int4((int) r, (int) o0, (int) o1, (int) o2) : make_int4(-1, 0, 0, 0);     // (all_far: a test aid, MS_BLKINFO_FAR)
 }
 
 // ---------------------------------------------------------------- compact copy-out --
@@ -1272,8 +1272,9 @@ int launch_extract(const uint32_t *gcodes, const uint32_t *gnmask, const int64_t
 
 int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *blk2reg, int4 *blkinfo, hipStream_t st) {
     const int64_t n_blocks = (n_bases + 63) / 64 + 1;
+    const int all_far = measure_env("MS_BLKINFO_FAR") ? 1 : 0;          // test aid: every block record says "look the region up" (starts beyond 32 bits)
     hipLaunchKernelGGL(blk2reg_kernel, dim3((unsigned) ((n_blocks + 255) / 256)), dim3(256), 0, st, offsets, R, n_blocks,
-                       blk2reg, blkinfo);
+                       blk2reg, blkinfo, all_far);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

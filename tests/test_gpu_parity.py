@@ -346,6 +346,7 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
                                  {"MS_PF_PAIR": "0"},                                           # plain rows only (one field per matrix row)
                                  {"MS_SORT_FULL": "1"},                                         # every key bit by radix passes (no fix-up kernel)
                                  {"MS_SORT_FIXUP_MIN": "0"},                                    # ... and the four-pass + fix-up form on short hit lists too (the default from 2^20 hits)
+                                 {"MS_BLKINFO_FAR": "1"},                                       # every 64-base block record says "region starts beyond 32 bits": the fp64 stage looks regions up
                                  ])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
     """Number of LDS tiles, blocks per tile, the hit-key form, the parking space and paired rows are tuning
