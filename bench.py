@@ -525,7 +525,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
             "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s},
             "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "max_batch_regions": a.max_batch_regions, "batch_sizes": [int(len(o) - 1) for _, o in batches], "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
             "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
-            "cu_partition": "while a stream is live the copy / pack kernels own 1 CU of every 32 (CU masks), the scan the other 31",
+            "cu_partition": "off: the copy / pack kernels share the device with the scan (CU masks -- 1 CU of every 32 for the copy streams -- exist behind MS_MEASURE=1 MS_CU_PARTITION=1 and measured slower end to end, profiles/r02_cu_partition_ab.log)",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "
                           "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 16 bytes per hit "
                           "(coord word + fp64 score), 'pipelined_25B' the four plain arrays, 'serial' runs the stages of one batch after another"}
