@@ -23,7 +23,7 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
         }                                                                                   \
     } while (0)
 
-// Measurement switches (MS_PF_NOEMIT, MS_PF_CLOCK, MS_PF_MAX_BLOCKS, MS_SORT_FULL, MS_SORT_FIXUP_MIN, MS_BLKINFO_FAR, MS_HIT_COORD, MS_CU_PARTITION) are honoured only when
+// Measurement switches (MS_PF_NOEMIT, MS_PF_CLOCK, MS_PF_MAX_BLOCKS, MS_SORT_FULL, MS_SORT_FIXUP_MIN, MS_RESCORE_SORTED_MIN, MS_BLKINFO_FAR, MS_HIT_COORD, MS_CU_PARTITION) are honoured only when
 // MS_MEASURE=1 is set as well: a stray variable in the environment must never change what the product does (tests/ and tools/
 // opt in explicitly).
 inline const char *measure_env(const char *name) {

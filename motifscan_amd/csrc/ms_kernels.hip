@@ -64,16 +64,20 @@ __device__ __forceinline__ void test_and_emit(const HitOut &H, const DevPwm &Pw,
 // Block-level staging of hits in LDS: one global atomicAdd per ~2000 hits instead of one per wave
 // (all hit writers of the chip share ONE counter word; it sustains only ~90 M atomics/s).
 constexpr int kHitStage = 2048;
-struct HitStage {
-    uint64_t keys[kHitStage];
-    double vals[kHitStage];
+template <int N>
+struct HitStageN {
+    static constexpr int kCap = N;
+    uint64_t keys[N];
+    double vals[N];
     unsigned int n;
     unsigned long long base;
 };
+typedef HitStageN<kHitStage> HitStage;
 
-__device__ __forceinline__ void stage_hit(HitStage &st, const HitOut &H, uint32_t motif, int64_t g, uint32_t sbit, double score) {
+template <class ST>
+__device__ __forceinline__ void stage_hit(ST &st, const HitOut &H, uint32_t motif, int64_t g, uint32_t sbit, double score) {
     const unsigned int i = atomicAdd(&st.n, 1u);
-    if (i < (unsigned int) kHitStage) {
+    if (i < (unsigned int) ST::kCap) {
         st.keys[i] = ((uint64_t) motif << (H.gbits + 1)) | ((uint64_t) g << 1) | sbit;
         st.vals[i] = score;
     } else {
@@ -82,9 +86,10 @@ __device__ __forceinline__ void stage_hit(HitStage &st, const HitOut &H, uint32_
 }
 
 // all threads of the block, at a block-uniform point
-__device__ __forceinline__ void stage_flush(HitStage &st, const HitOut &H) {
+template <class ST>
+__device__ __forceinline__ void stage_flush(ST &st, const HitOut &H) {
     __syncthreads();
-    const unsigned int n = st.n < (unsigned int) kHitStage ? st.n : (unsigned int) kHitStage;
+    const unsigned int n = st.n < (unsigned int) ST::kCap ? st.n : (unsigned int) ST::kCap;
     if (threadIdx.x == 0 && n > 0) st.base = atomicAdd(H.n_hits, (unsigned long long) n);
     __syncthreads();
     const unsigned long long base = st.base;
@@ -97,7 +102,8 @@ __device__ __forceinline__ void stage_flush(HitStage &st, const HitOut &H) {
 
 // floor32: FieldMeta::floor32, the raw-sum floor of test_and_emit rounded DOWN to a float (it came with the field's record: windows
 // that cannot be hits read nothing more); the rest of the test reads {max_raw, cutoff} side by side
-__device__ __forceinline__ void test_and_stage(HitStage &st, const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
+template <class ST>
+__device__ __forceinline__ void test_and_stage(ST &st, const HitOut &H, const DevPwm &Pw, uint32_t motif, int64_t g,
                                                double fwd, double rev, int strand_mask, float floor32) {
     const double floor_ = (double) floor32;
     const bool try_f = (strand_mask & 1) && !(fwd < floor_);
@@ -831,6 +837,146 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
     stage_flush(st, H);
 }
 
+// The same for LONG candidate lists, a block taking the list in chunks of kRcChunk records that it first brings into (table group,
+// field) order in LDS (a counting sort on a hash of the record's group and first flagged field -- no memory read).  Why: a scattered
+// read costs the texture addressers ~1.9 cycles per distinct 64-byte line its 64 lanes touch (tools/ubench/gather_rate.hip: 122 cycles
+// for 64 lines, 22 for 8, whatever the width), and ~16 of the ~21 reads per candidate are table entries -- one line per (motif, column).
+// In list order a wave's lanes hold ~16 different motifs; 8192 records in motif order hold ~14 of each, so a wave's lanes share ~5.
+// (2048-record chunks -- 3.5 per motif -- changed nothing: profiles/r03s_rescore_chunk_sorted.log.)
+constexpr int kRcThreads = 1024;
+constexpr int kRcPerThread = 8;
+constexpr int kRcChunk = kRcThreads * kRcPerThread;       // 8192 records, 64 KB of LDS
+constexpr int kRcBins = 4096;
+constexpr int kRcStage = 4096;                            // hits a half chunk may stage (it yields ~3300)
+typedef HitStageN<kRcStage> RcStage;
+
+__global__ void __launch_bounds__(kRcThreads) rescore_sorted_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
+                                                                    const unsigned long long *__restrict__ n_cand, uint64_t n_static, uint64_t cand_cap,
+                                                                    const FieldMeta *__restrict__ field_meta, int strand_mask, const HitOut H) {
+    extern __shared__ uint4 rc_lds4[];
+    uint64_t *sorted = reinterpret_cast<uint64_t *>(rc_lds4);                               // [kRcChunk]
+    uint32_t *bins = reinterpret_cast<uint32_t *>(sorted + kRcChunk);                       // [kRcBins]
+    uint32_t *wave_tot = bins + kRcBins;                                                    // [16]
+    RcStage &st = *reinterpret_cast<RcStage *>(wave_tot + 32);
+    if (threadIdx.x == 0) st.n = 0;
+    unsigned long long n = n_static + *n_cand;
+    if (n > cand_cap) n = cand_cap;
+    constexpr int U = kRescoreU;
+    const bool both = strand_mask == 3;
+    const int4 *__restrict__ meta4 = reinterpret_cast<const int4 *>(field_meta);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long n_chunks = (n + kRcChunk - 1) / kRcChunk;
+    for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        // ---- the chunk into (group, field) order
+        for (uint32_t i = threadIdx.x; i < (uint32_t) kRcBins; i += kRcThreads) bins[i] = 0;
+        __syncthreads();
+        {
+            uint64_t rec[kRcPerThread];
+            uint32_t key[kRcPerThread], rank[kRcPerThread];
+#pragma unroll
+            for (int k = 0; k < kRcPerThread; k++) {
+                const unsigned long long i = ch * kRcChunk + (unsigned long long) k * kRcThreads + threadIdx.x;
+                rec[k] = i < n ? cand[i] : 0ULL;
+                const uint32_t f = (uint32_t) rec[k] & 0xFFFFu;
+                const uint32_t fl = both ? (f | (f >> 1)) & 0x5555u : f;
+                key[k] = fl ? ((((uint32_t) (rec[k] >> 16) & 0x3FFFu) << 4) | (uint32_t) (__ffs((int) fl) - 1)) & (uint32_t) (kRcBins - 1) : (uint32_t) (kRcBins - 1);
+            }
+#pragma unroll
+            for (int k = 0; k < kRcPerThread; k++) rank[k] = atomicAdd(&bins[key[k]], 1u);
+            __syncthreads();
+            {   // exclusive prefix over the bins: four per thread, wave scans, wave totals
+                const uint32_t b0 = bins[4 * threadIdx.x], b1 = bins[4 * threadIdx.x + 1], b2 = bins[4 * threadIdx.x + 2], b3 = bins[4 * threadIdx.x + 3];
+                const uint32_t tot = b0 + b1 + b2 + b3;
+                uint32_t v = tot;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(v, d);
+                    if ((int) lane >= d) v += o;
+                }
+                if (lane == 63u) wave_tot[wave] = v;
+                __syncthreads();
+                uint32_t base = 0;
+                for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+                const uint32_t excl = base + v - tot;
+                bins[4 * threadIdx.x] = excl;
+                bins[4 * threadIdx.x + 1] = excl + b0;
+                bins[4 * threadIdx.x + 2] = excl + b0 + b1;
+                bins[4 * threadIdx.x + 3] = excl + b0 + b1 + b2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kRcPerThread; k++) sorted[bins[key[k]] + rank[k]] = rec[k];
+        }
+        __syncthreads();
+        // ---- two halves of U records per thread; a wave's lanes = 64 consecutive records of the order
+        for (int half = 0; half < kRcPerThread / U; half++) {
+            uint64_t c[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                c[u] = sorted[(half * U + u) * kRcThreads + threadIdx.x];
+                live[u] = ((uint32_t) c[u] & 0xFFFFu) != 0u;
+            }
+        // independent of each other: the region's place (one read), sequence words, N words, the first flagged field's motif / width / table (one read)
+            int64_t g[U];
+            int4 bi[U];
+            uint64_t cw[U];
+            uint32_t nw[U], flags[U];
+            int32_t group[U];
+            int4 fm[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                g[u] = (int64_t) (c[u] >> 30);
+                group[u] = (int32_t) ((c[u] >> 16) & 0x3FFFu);
+                const uint32_t f = (uint32_t) c[u] & 0xFFFFu;              // bit n = field n
+                flags[u] = both ? (f | (f >> 1)) & 0x5555u : f;             // a motif's two strands are re-scored together anyway
+                bi[u] = S.blkinfo[g[u] >> 6];
+                cw[u] = code_window(S.codes, g[u]);
+                nw[u] = n_window(S.nmask, g[u]);
+                fm[u] = flags[u] ? meta4[group[u] * kGroupFields + (__ffs((int) flags[u]) - 1)] : make_int4(-1, 0, 0, 0);
+            }
+            // the region's bounds: out of the block's record; only tiny regions (a third region start within the block's reach) and
+            // starts beyond 32 bits need the offsets themselves
+            int64_t r[U], beg[U], end[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t base = g[u] & ~(int64_t) 63;
+                int64_t lo = bi[u].x, o0 = base + bi[u].y, o1 = base + bi[u].z, o2 = base + bi[u].w;
+                if (bi[u].x < 0) {
+                    lo = S.blk2reg[g[u] >> 6];
+                    o0 = S.offsets[lo]; o1 = S.offsets[lo + 1];
+                    o2 = lo + 2 <= S.R ? S.offsets[lo + 2] : o1;
+                }
+                if (g[u] < o1) { r[u] = lo; beg[u] = o0; end[u] = o1; }
+                else if (g[u] < o2) { r[u] = lo + 1; beg[u] = o1; end[u] = o2; }
+                else { r[u] = find_region(S, g[u]); beg[u] = S.offsets[r[u]]; end[u] = S.offsets[r[u] + 1]; }      // tiny regions
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!live[u]) continue;
+                const int64_t gk = H.pbits ? (int64_t) (((uint64_t) r[u] << H.pbits) | (uint64_t) (g[u] - beg[u])) : g[u];
+                bool first = true;
+                while (flags[u]) {
+                    const int field = __ffs((int) flags[u]) - 1;
+                    flags[u] &= flags[u] - 1u;
+                    int4 f4 = fm[u];
+                    if (!first) f4 = meta4[group[u] * kGroupFields + field];           // further motifs of the group: rare
+                    first = false;
+                    const int32_t m = f4.x;
+                    const int w = f4.y;
+                    if (m < 0) continue;
+                    if (g[u] + w > end[u]) continue;                         // window runs past its region (cscore.c:340)
+                    double fwd, rev;
+                    if (w <= 32 && Pw.tab32) score_window32(Pw.tab2, (uint32_t) f4.z, Pw.zero_bytes, w, cw[u], nw[u], fwd, rev);     // non-ACGT bases add nothing (cscore.c:345-353)
+                    else score_window(S, Pw.tab2 + Pw.tab_off[m], w, g[u], fwd, rev);
+                    test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask, __int_as_float(f4.w));
+                }
+            }
+            stage_flush(st, H);               // (barriers inside; half a chunk's hits leave with one global atomic)
+        }
+    }
+}
+
 // ----------------------------------------------------------------------- finalize --
 
 // n_dev != nullptr: the number of hits is only known on the device (a scan whose sizes were predicted, scan_locked): n is then
@@ -1319,6 +1465,19 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
         hipLaunchKernelGGL(exact_all_kernel, grid, dim3(256), 0, st, S, Pw, motifs + m0, strand_mask, H);
         MS_HIP(hipGetLastError());
     }
+    return MS_OK;
+}
+
+size_t rescore_sorted_lds_bytes() { return (size_t) kRcChunk * 8 + (size_t) kRcBins * 4 + 32 * 4 + sizeof(RcStage) + 64; }
+int rescore_sorted_set_lds() {
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) rescore_sorted_lds_bytes()));
+    return MS_OK;
+}
+int launch_rescore_sorted(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
+                          uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(rescore_sorted_kernel, dim3((unsigned) n_blocks), dim3(kRcThreads), rescore_sorted_lds_bytes(), st, S, Pw, cand, n_cand, n_static,
+                       cand_cap, field_meta, strand_mask, H);
+    MS_HIP(hipGetLastError());
     return MS_OK;
 }
 

@@ -346,6 +346,9 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
                                  {"MS_PF_PAIR": "0"},                                           # plain rows only (one field per matrix row)
                                  {"MS_SORT_FULL": "1"},                                         # every key bit by radix passes (no fix-up kernel)
                                  {"MS_SORT_FIXUP_MIN": "0"},                                    # ... and the four-pass + fix-up form on short hit lists too (the default from 2^20 hits)
+                                 {"MS_RESCORE_SORTED_MIN": "0"},                                # the chunk-ordered fp64 stage on short lists too (the default for long ones)
+                                 {"MS_RESCORE_SORTED_MIN": "0", "MS_PF_LDS_BUDGET": "24576"},
+                                 {"MS_RESCORE_SORTED_MIN": "1e30"},                             # ... and the list-order form throughout
                                  {"MS_BLKINFO_FAR": "1"},                                       # every 64-base block record says "region starts beyond 32 bits": the fp64 stage looks regions up
                                  ])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
@@ -490,7 +493,7 @@ def test_edge_shapes_vs_oracle(oracle):
         cscore.c_scan_motif(ml[:1], [0.1], ["ACGT"], 4, 1)
 
 
-@pytest.mark.parametrize("env", [{}, {"MS_PF_RARE_CAP": "16"}, {"MS_SORT_FIXUP_MIN": "0"}])
+@pytest.mark.parametrize("env", [{}, {"MS_PF_RARE_CAP": "16"}, {"MS_SORT_FIXUP_MIN": "0"}, {"MS_RESCORE_SORTED_MIN": "0"}])
 def test_low_complexity_sequences_flood_the_candidate_path(oracle, monkeypatch, env):
     """Homopolymers and short tandem repeats: whole waves flag the same motif at every position, so a wave's parking space fills
     within one row tile (the event parks in pieces, the class comes back to the row tile after every decode), the candidate blocks
