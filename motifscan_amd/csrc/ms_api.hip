@@ -1129,12 +1129,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         (void) hipEventRecord(ev[1], c->stream);
         if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)
         {
-            // long lists: chunks of 8192 records in motif order (fewer cache lines per table read); short ones: list order, many small blocks
+            // long lists: chunks of 4096 candidates in motif order with their windows carried along (fewer cache lines per read); short ones: list order, many small blocks
             double rs_min = 2.0e6;
             if (const char *e = measure_env("MS_RESCORE_SORTED_MIN")) rs_min = atof(e);       // test aid / A-B: 0 = always, 1e30 = never
             if (1.5e-4 * (double) fast_windows >= rs_min) {
-                if (!c->rc_lds_set) { if ((rc = rescore_sorted_set_lds())) return rc; c->rc_lds_set = true; }
-                if ((rc = launch_rescore_sorted(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_field_meta, strand_mask, H, c->n_cu, c->stream))) return rc;
+                if (!c->rc_lds_set) { if ((rc = rescore_carry_set_lds())) return rc; c->rc_lds_set = true; }
+                if ((rc = launch_rescore_carry(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_field_meta, strand_mask, H, c->n_cu, c->stream))) return rc;
             } else if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_field_meta, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
         }
         if (!plan.exact_motifs.empty())

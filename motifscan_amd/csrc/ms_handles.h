@@ -69,7 +69,7 @@ struct DeviceCtx {
     int n_cu_copy = 0;                       // CUs the copy streams own while the device is partitioned (0: masks unavailable)
     std::atomic<int> n_streams{0};           // live batch streams on this device
     size_t lds_max = 0;
-    bool rc_lds_set = false;                // rescore_sorted_kernel's dynamic-LDS attribute raised
+    bool rc_lds_set = false;                // rescore_carry_kernel's dynamic-LDS attribute raised
     size_t lds_set[128] = {};               // dynamic-LDS attribute already raised to this, per kernel variant (+64: measurement instantiation)
     Scratch sc;
     std::mutex mu;               // one scan at a time per device (shared scratch)

@@ -92,10 +92,10 @@ int prefilter_set_lds(bool wide, bool meas, size_t bytes);
 int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
-// the same for long lists: chunks of the list in motif order (rescore_sorted_kernel); one 1024-thread block per CU
-int rescore_sorted_set_lds();
-int launch_rescore_sorted(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
-                          uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st);
+// the same for long lists: chunks of the list in motif order, the window carried along (rescore_carry_kernel); one 1024-thread block per CU
+int rescore_carry_set_lds();
+int launch_rescore_carry(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
+                         uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st);
 int launch_rescore(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
                    uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks,
                    hipStream_t st);

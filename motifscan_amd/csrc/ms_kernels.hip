@@ -837,146 +837,6 @@ __global__ void __launch_bounds__(256) rescore_kernel(const DevSeq S, const DevP
     stage_flush(st, H);
 }
 
-// The same for LONG candidate lists, a block taking the list in chunks of kRcChunk records that it first brings into (table group,
-// field) order in LDS (a counting sort on a hash of the record's group and first flagged field -- no memory read).  Why: a scattered
-// read costs the texture addressers ~1.9 cycles per distinct 64-byte line its 64 lanes touch (tools/ubench/gather_rate.hip: 122 cycles
-// for 64 lines, 22 for 8, whatever the width), and ~16 of the ~21 reads per candidate are table entries -- one line per (motif, column).
-// In list order a wave's lanes hold ~16 different motifs; 8192 records in motif order hold ~14 of each, so a wave's lanes share ~5.
-// (2048-record chunks -- 3.5 per motif -- changed nothing: profiles/r03s_rescore_chunk_sorted.log.)
-constexpr int kRcThreads = 1024;
-constexpr int kRcPerThread = 8;
-constexpr int kRcChunk = kRcThreads * kRcPerThread;       // 8192 records, 64 KB of LDS
-constexpr int kRcBins = 4096;
-constexpr int kRcStage = 4096;                            // hits a half chunk may stage (it yields ~3300)
-typedef HitStageN<kRcStage> RcStage;
-
-__global__ void __launch_bounds__(kRcThreads) rescore_sorted_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
-                                                                    const unsigned long long *__restrict__ n_cand, uint64_t n_static, uint64_t cand_cap,
-                                                                    const FieldMeta *__restrict__ field_meta, int strand_mask, const HitOut H) {
-    extern __shared__ uint4 rc_lds4[];
-    uint64_t *sorted = reinterpret_cast<uint64_t *>(rc_lds4);                               // [kRcChunk]
-    uint32_t *bins = reinterpret_cast<uint32_t *>(sorted + kRcChunk);                       // [kRcBins]
-    uint32_t *wave_tot = bins + kRcBins;                                                    // [16]
-    RcStage &st = *reinterpret_cast<RcStage *>(wave_tot + 32);
-    if (threadIdx.x == 0) st.n = 0;
-    unsigned long long n = n_static + *n_cand;
-    if (n > cand_cap) n = cand_cap;
-    constexpr int U = kRescoreU;
-    const bool both = strand_mask == 3;
-    const int4 *__restrict__ meta4 = reinterpret_cast<const int4 *>(field_meta);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long n_chunks = (n + kRcChunk - 1) / kRcChunk;
-    for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        // ---- the chunk into (group, field) order
-        for (uint32_t i = threadIdx.x; i < (uint32_t) kRcBins; i += kRcThreads) bins[i] = 0;
-        __syncthreads();
-        {
-            uint64_t rec[kRcPerThread];
-            uint32_t key[kRcPerThread], rank[kRcPerThread];
-#pragma unroll
-            for (int k = 0; k < kRcPerThread; k++) {
-                const unsigned long long i = ch * kRcChunk + (unsigned long long) k * kRcThreads + threadIdx.x;
-                rec[k] = i < n ? cand[i] : 0ULL;
-                const uint32_t f = (uint32_t) rec[k] & 0xFFFFu;
-                const uint32_t fl = both ? (f | (f >> 1)) & 0x5555u : f;
-                key[k] = fl ? ((((uint32_t) (rec[k] >> 16) & 0x3FFFu) << 4) | (uint32_t) (__ffs((int) fl) - 1)) & (uint32_t) (kRcBins - 1) : (uint32_t) (kRcBins - 1);
-            }
-#pragma unroll
-            for (int k = 0; k < kRcPerThread; k++) rank[k] = atomicAdd(&bins[key[k]], 1u);
-            __syncthreads();
-            {   // exclusive prefix over the bins: four per thread, wave scans, wave totals
-                const uint32_t b0 = bins[4 * threadIdx.x], b1 = bins[4 * threadIdx.x + 1], b2 = bins[4 * threadIdx.x + 2], b3 = bins[4 * threadIdx.x + 3];
-                const uint32_t tot = b0 + b1 + b2 + b3;
-                uint32_t v = tot;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(v, d);
-                    if ((int) lane >= d) v += o;
-                }
-                if (lane == 63u) wave_tot[wave] = v;
-                __syncthreads();
-                uint32_t base = 0;
-                for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
-                const uint32_t excl = base + v - tot;
-                bins[4 * threadIdx.x] = excl;
-                bins[4 * threadIdx.x + 1] = excl + b0;
-                bins[4 * threadIdx.x + 2] = excl + b0 + b1;
-                bins[4 * threadIdx.x + 3] = excl + b0 + b1 + b2;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kRcPerThread; k++) sorted[bins[key[k]] + rank[k]] = rec[k];
-        }
-        __syncthreads();
-        // ---- two halves of U records per thread; a wave's lanes = 64 consecutive records of the order
-        for (int half = 0; half < kRcPerThread / U; half++) {
-            uint64_t c[U];
-            bool live[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                c[u] = sorted[(half * U + u) * kRcThreads + threadIdx.x];
-                live[u] = ((uint32_t) c[u] & 0xFFFFu) != 0u;
-            }
-        // independent of each other: the region's place (one read), sequence words, N words, the first flagged field's motif / width / table (one read)
-            int64_t g[U];
-            int4 bi[U];
-            uint64_t cw[U];
-            uint32_t nw[U], flags[U];
-            int32_t group[U];
-            int4 fm[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                g[u] = (int64_t) (c[u] >> 30);
-                group[u] = (int32_t) ((c[u] >> 16) & 0x3FFFu);
-                const uint32_t f = (uint32_t) c[u] & 0xFFFFu;              // bit n = field n
-                flags[u] = both ? (f | (f >> 1)) & 0x5555u : f;             // a motif's two strands are re-scored together anyway
-                bi[u] = S.blkinfo[g[u] >> 6];
-                cw[u] = code_window(S.codes, g[u]);
-                nw[u] = n_window(S.nmask, g[u]);
-                fm[u] = flags[u] ? meta4[group[u] * kGroupFields + (__ffs((int) flags[u]) - 1)] : make_int4(-1, 0, 0, 0);
-            }
-            // the region's bounds: out of the block's record; only tiny regions (a third region start within the block's reach) and
-            // starts beyond 32 bits need the offsets themselves
-            int64_t r[U], beg[U], end[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int64_t base = g[u] & ~(int64_t) 63;
-                int64_t lo = bi[u].x, o0 = base + bi[u].y, o1 = base + bi[u].z, o2 = base + bi[u].w;
-                if (bi[u].x < 0) {
-                    lo = S.blk2reg[g[u] >> 6];
-                    o0 = S.offsets[lo]; o1 = S.offsets[lo + 1];
-                    o2 = lo + 2 <= S.R ? S.offsets[lo + 2] : o1;
-                }
-                if (g[u] < o1) { r[u] = lo; beg[u] = o0; end[u] = o1; }
-                else if (g[u] < o2) { r[u] = lo + 1; beg[u] = o1; end[u] = o2; }
-                else { r[u] = find_region(S, g[u]); beg[u] = S.offsets[r[u]]; end[u] = S.offsets[r[u] + 1]; }      // tiny regions
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (!live[u]) continue;
-                const int64_t gk = H.pbits ? (int64_t) (((uint64_t) r[u] << H.pbits) | (uint64_t) (g[u] - beg[u])) : g[u];
-                bool first = true;
-                while (flags[u]) {
-                    const int field = __ffs((int) flags[u]) - 1;
-                    flags[u] &= flags[u] - 1u;
-                    int4 f4 = fm[u];
-                    if (!first) f4 = meta4[group[u] * kGroupFields + field];           // further motifs of the group: rare
-                    first = false;
-                    const int32_t m = f4.x;
-                    const int w = f4.y;
-                    if (m < 0) continue;
-                    if (g[u] + w > end[u]) continue;                         // window runs past its region (cscore.c:340)
-                    double fwd, rev;
-                    if (w <= 32 && Pw.tab32) score_window32(Pw.tab2, (uint32_t) f4.z, Pw.zero_bytes, w, cw[u], nw[u], fwd, rev);     // non-ACGT bases add nothing (cscore.c:345-353)
-                    else score_window(S, Pw.tab2 + Pw.tab_off[m], w, g[u], fwd, rev);
-                    test_and_stage(st, H, Pw, (uint32_t) m, gk, fwd, rev, strand_mask, __int_as_float(f4.w));
-                }
-            }
-            stage_flush(st, H);               // (barriers inside; half a chunk's hits leave with one global atomic)
-        }
-    }
-}
-
 // ----------------------------------------------------------------------- finalize --
 
 // n_dev != nullptr: the number of hits is only known on the device (a scan whose sizes were predicted, scan_locked): n is then
@@ -1468,14 +1328,154 @@ int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, i
     return MS_OK;
 }
 
-size_t rescore_sorted_lds_bytes() { return (size_t) kRcChunk * 8 + (size_t) kRcBins * 4 + 32 * 4 + sizeof(RcStage) + 64; }
-int rescore_sorted_set_lds() {
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) rescore_sorted_lds_bytes()));
+// ---- the fp64 stage for LONG candidate lists: chunks of the list in motif order, the window carried through the sort.
+// A scattered read costs the texture addressers ~1.9 cycles per distinct 64-byte line its 64 lanes touch, whatever its width
+// (tools/ubench/gather_rate.hip: 122 cycles for 64 lines, 22 for 8), and ~16 of the ~21 reads per candidate are table entries -- one
+// line per (motif, column).  In list order a wave's lanes hold ~16 different motifs; in motif order far fewer -- but then the three
+// position-bound reads (block record, code words, mask words), whose lanes sit in one or two pre-filter units in list order, would
+// touch 64 lines each.  So a block takes 4096 candidates, reads the position-bound data in LIST order, packs what the scoring needs
+// into 24 bytes per candidate -- the window's 32 codes, its mask bits, (group, flags), the hit coordinate and how much room the region
+// leaves -- brings THAT into (table group, first flagged field) order with a counting sort in LDS on a hash of the record (no memory
+// read), and the scoring pass reads only per-motif data.  profiles/r03z_rescore_sorted.log: 2.01 ms per 500 Mbase against 2.73 in list
+// order (rescore_kernel, which short lists keep: a chunk per block leaves most of the device idle below ~2e6 candidates).
+constexpr int kRwThreads = 1024;
+constexpr int kRwPerThread = 4;
+constexpr int kRwChunk = kRwThreads * kRwPerThread;       // 4096 candidates: 96 KB of LDS
+constexpr int kRwBins = 4096;
+typedef HitStageN<2048> RwStage;
+
+__global__ void __launch_bounds__(kRwThreads) rescore_carry_kernel(const DevSeq S, const DevPwm Pw, const uint64_t *__restrict__ cand,
+                                                                   const unsigned long long *__restrict__ n_cand, uint64_t n_static, uint64_t cand_cap,
+                                                                   const FieldMeta *__restrict__ field_meta, int strand_mask, const HitOut H) {
+    extern __shared__ uint4 rw_lds4[];
+    uint64_t *s_cw = reinterpret_cast<uint64_t *>(rw_lds4);                                 // [kRwChunk] the window's codes
+    uint64_t *s_gk = s_cw + kRwChunk;                                                       // [kRwChunk] hit coordinate << 8 | room (bases to the region's end, <= 255)
+    uint32_t *s_nw = reinterpret_cast<uint32_t *>(s_gk + kRwChunk);                         // [kRwChunk] the window's non-ACGT bits
+    uint32_t *s_gf = s_nw + kRwChunk;                                                       // [kRwChunk] group << 16 | flags (0: nothing)
+    uint32_t *bins = s_gf + kRwChunk;                                                       // [kRwBins]
+    uint32_t *wave_tot = bins + kRwBins;                                                    // [16]
+    RwStage &st = *reinterpret_cast<RwStage *>(wave_tot + 32);
+    if (threadIdx.x == 0) st.n = 0;
+    unsigned long long n = n_static + *n_cand;
+    if (n > cand_cap) n = cand_cap;
+    const bool both = strand_mask == 3;
+    const int4 *__restrict__ meta4 = reinterpret_cast<const int4 *>(field_meta);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t pmask = H.pbits ? ((1ULL << H.pbits) - 1ULL) : 0ULL;
+    const unsigned long long n_chunks = (n + kRwChunk - 1) / kRwChunk;
+    for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t) kRwBins; i += kRwThreads) bins[i] = 0;
+        __syncthreads();
+        {
+            // ---- list order: everything that depends on the POSITION
+            uint64_t cw[kRwPerThread], gk[kRwPerThread];
+            uint32_t nw[kRwPerThread], gf[kRwPerThread], key[kRwPerThread], rank[kRwPerThread];
+            int64_t g[kRwPerThread];
+            int4 bi[kRwPerThread];
+#pragma unroll
+            for (int k = 0; k < kRwPerThread; k++) {
+                const unsigned long long i = ch * kRwChunk + (unsigned long long) k * kRwThreads + threadIdx.x;
+                const uint64_t rec = i < n ? cand[i] : 0ULL;
+                g[k] = (int64_t) (rec >> 30);
+                gf[k] = (uint32_t) rec & 0x3FFFFFFFu;                                       // group << 16 | flags
+                if (!(gf[k] & 0xFFFFu)) { gf[k] = 0; g[k] = 0; }
+                bi[k] = S.blkinfo[g[k] >> 6];
+                cw[k] = code_window(S.codes, g[k]);
+                nw[k] = n_window(S.nmask, g[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < kRwPerThread; k++) {
+                const int64_t base = g[k] & ~(int64_t) 63;
+                int64_t lo = bi[k].x, o0 = base + bi[k].y, o1 = base + bi[k].z, o2 = base + bi[k].w, r, beg, end;
+                if (bi[k].x < 0) {
+                    lo = S.blk2reg[g[k] >> 6];
+                    o0 = S.offsets[lo]; o1 = S.offsets[lo + 1];
+                    o2 = lo + 2 <= S.R ? S.offsets[lo + 2] : o1;
+                }
+                if (g[k] < o1) { r = lo; beg = o0; end = o1; }
+                else if (g[k] < o2) { r = lo + 1; beg = o1; end = o2; }
+                else { r = find_region(S, g[k]); beg = S.offsets[r]; end = S.offsets[r + 1]; }      // tiny regions
+                const uint64_t coord = H.pbits ? (((uint64_t) r << H.pbits) | (uint64_t) (g[k] - beg)) : (uint64_t) g[k];
+                const int64_t room = end - g[k];
+                gk[k] = (coord << 8) | (uint64_t) (room > 255 ? 255 : (room < 0 ? 0 : room));
+                const uint32_t f = gf[k] & 0xFFFFu;
+                const uint32_t fl = both ? (f | (f >> 1)) & 0x5555u : f;
+                key[k] = fl ? (((gf[k] >> 16) << 4) | (uint32_t) (__ffs((int) fl) - 1)) & (uint32_t) (kRwBins - 1) : (uint32_t) (kRwBins - 1);
+            }
+#pragma unroll
+            for (int k = 0; k < kRwPerThread; k++) rank[k] = atomicAdd(&bins[key[k]], 1u);
+            __syncthreads();
+            {   // exclusive prefix over the bins: four per thread, wave scans, wave totals
+                const uint32_t b0 = bins[4 * threadIdx.x], b1 = bins[4 * threadIdx.x + 1], b2 = bins[4 * threadIdx.x + 2], b3 = bins[4 * threadIdx.x + 3];
+                const uint32_t tot = b0 + b1 + b2 + b3;
+                uint32_t v = tot;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(v, d);
+                    if ((int) lane >= d) v += o;
+                }
+                if (lane == 63u) wave_tot[wave] = v;
+                __syncthreads();
+                uint32_t base = 0;
+                for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+                const uint32_t excl = base + v - tot;
+                bins[4 * threadIdx.x] = excl;
+                bins[4 * threadIdx.x + 1] = excl + b0;
+                bins[4 * threadIdx.x + 2] = excl + b0 + b1;
+                bins[4 * threadIdx.x + 3] = excl + b0 + b1 + b2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kRwPerThread; k++) {
+                const uint32_t at = bins[key[k]] + rank[k];
+                s_cw[at] = cw[k]; s_gk[at] = gk[k]; s_nw[at] = nw[k]; s_gf[at] = gf[k];
+            }
+        }
+        __syncthreads();
+        // ---- motif order: two rounds of two candidates per thread, per-motif reads only
+        for (int round = 0; round < 2; round++) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t at = (uint32_t) (round * 2 + u) * kRwThreads + threadIdx.x;
+                const uint32_t gfu = s_gf[at];
+                const uint32_t f = gfu & 0xFFFFu;
+                uint32_t flags = both ? (f | (f >> 1)) & 0x5555u : f;
+                if (!flags) continue;
+                const uint64_t cwu = s_cw[at], gku = s_gk[at];
+                const uint32_t nwu = s_nw[at];
+                const int32_t group = (int32_t) (gfu >> 16);
+                const int room = (int) (gku & 0xFFu);
+                const int64_t coord = (int64_t) (gku >> 8);
+                while (flags) {
+                    const int field = __ffs((int) flags) - 1;
+                    flags &= flags - 1u;
+                    const int4 f4 = meta4[group * kGroupFields + field];
+                    const int32_t m = f4.x;
+                    const int w = f4.y;
+                    if (m < 0) continue;
+                    if (w > room) continue;                                  // window runs past its region (cscore.c:340)
+                    double fwd, rev;
+                    if (w <= 32 && Pw.tab32) score_window32(Pw.tab2, (uint32_t) f4.z, Pw.zero_bytes, w, cwu, nwu, fwd, rev);
+                    else {
+                        const int64_t gpos = H.pbits ? S.offsets[coord >> H.pbits] + (int64_t) ((uint64_t) coord & pmask) : coord;
+                        score_window(S, Pw.tab2 + Pw.tab_off[m], w, gpos, fwd, rev);
+                    }
+                    test_and_stage(st, H, Pw, (uint32_t) m, coord, fwd, rev, strand_mask, __int_as_float(f4.w));
+                }
+            }
+            stage_flush(st, H);
+        }
+    }
+}
+
+size_t rescore_carry_lds_bytes() { return (size_t) kRwChunk * 24 + (size_t) kRwBins * 4 + 32 * 4 + sizeof(RwStage) + 64; }
+int rescore_carry_set_lds() {
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_carry_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) rescore_carry_lds_bytes()));
     return MS_OK;
 }
-int launch_rescore_sorted(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
-                          uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st) {
-    hipLaunchKernelGGL(rescore_sorted_kernel, dim3((unsigned) n_blocks), dim3(kRcThreads), rescore_sorted_lds_bytes(), st, S, Pw, cand, n_cand, n_static,
+int launch_rescore_carry(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,
+                         uint64_t cand_cap, const FieldMeta *field_meta, int strand_mask, const HitOut &H, int n_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(rescore_carry_kernel, dim3((unsigned) n_blocks), dim3(kRwThreads), rescore_carry_lds_bytes(), st, S, Pw, cand, n_cand, n_static,
                        cand_cap, field_meta, strand_mask, H);
     MS_HIP(hipGetLastError());
     return MS_OK;
