@@ -5,6 +5,6 @@ _lib.set_device(0)
 wl = synth.workload("c4shard")
 sq = _lib.SeqSet(*wl["sets"][0])
 pw = _lib.PwmSet(wl["pwm_values"], wl["widths"], wl["cutoffs"])
-for _ in range(3):
+for _ in range(8):
     r = _lib.scan(pw, sq, 3); st = r.stats(); r.close()
 print({k: st[k] for k in st if k.startswith("n_") or k.startswith("ms_")})
