@@ -15,7 +15,10 @@
 //                     fp6 x fp4 one-hot product on the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4); emits candidates
 //   exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take
 //   rescore_kernel    fp64 scoring of the candidates, in the reference's order of operations,
-//                     and the reference's hit test (cscore.c:356-358, 373-375)
+//                     and the reference's hit test (cscore.c:356-358, 373-375); short candidate lists
+//   rescore_carry_kernel   the same for long lists: chunks of the list in motif order, the windows read in list order and
+//                     carried through an in-LDS counting sort (few cache lines per read either way)
+//   sort_fixup_kernel the radix sort covers the key bits above the low eight; this orders the short runs that agree in them
 //   finalize_kernel   sorted keys -> (seq_idx, pos, strand), per-motif offsets, region counts
 //   score_kernel      c_score: first W bases of every sequence    (cscore.c:191-224)
 //   gather_ranks_kernel   the rank pick of the cutoff builder    (motif/__init__.py:393-399)
