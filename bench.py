@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=list(WORKLOAD_TEXT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the value_api leg (Scanner.scan_motifs at configs[1] and configs[2])")
     ap.add_argument("--no-batch-ramp", action="store_true", help="end-to-end passes: equal batches (default: small first and last batches)")
     ap.add_argument("--min-warm-seconds", type=float, default=2.0, help="untimed warm-up steps continue until this much wall time has passed (DVFS steady state)")
     ap.add_argument("--regions-per-set", type=int, default=None, help="c4 only: shrink the workload (development aid; the line then says so)")
@@ -352,14 +353,18 @@ def main():
         # per rank: its own ms per step, the collective's own time, and 2000 of its regions checked against the oracle
         ps = rank_parity_sample(wl, pw, strand=strand_mask)
         ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1)
-        mine = torch.tensor([own_elapsed / a.steps * 1e3, ar_ms, float(ps["regions"]), float(ps["hits"]), 1.0 if ps["identical"] else 0.0],
-                            dtype=torch.float64, device=dev)
+        mine = torch.tensor([own_elapsed / a.steps * 1e3, ar_ms, float(ps["regions"]), float(ps["hits"]), 1.0 if ps["identical"] else 0.0,
+                             float(wl["shard"][0]), float(wl["shard"][1])], dtype=torch.float64, device=dev)
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
         tab = torch.stack(per_rank).cpu().numpy()
         ranks_report = {"ms_per_step_min": float(tab[:, 0].min()), "ms_per_step_max": float(tab[:, 0].max()),
                         "ms_per_step_by_rank": [round(float(x), 3) for x in tab[:, 0]],
                         "allreduce_ms_mean_by_rank": [round(float(x), 4) for x in tab[:, 1]],
+                        # every rank's [r0, r1) of each region set: contiguous, in rank order, together the whole set
+                        "shard_by_rank": [[int(x), int(y)] for x, y in tab[:, 5:7]],
+                        "shards_tile_every_set": bool(tab[0, 5] == 0 and tab[-1, 6] == wl["n_regions_total"]
+                                                      and all(tab[k, 6] == tab[k + 1, 5] for k in range(world - 1))),
                         "parity_sample": {"regions_per_rank": int(tab[:, 2].min()), "hits_checked": int(tab[:, 3].sum()),
                                           "ranks_identical_to_oracle": int(tab[:, 4].sum()), "ranks": world,
                                           "checker": "oracle/cscore_oracle.c (liboracle.so), first regions of every rank's own shard"}}
@@ -431,6 +436,8 @@ def main():
                                   for k in ("ms_prefilter", "ms_exact", "ms_sort", "ms_finalize", "ms_total")},
             "hits_per_scan": sum(s["n_hits"] for s in all_stats) / n_launch,
             "candidates_per_scan": sum(s["n_candidates"] for s in all_stats) / n_launch,
+            # the path's one collective per step, slowest rank's mean (device events around dist.all_reduce); 0 at N = 1: no collective runs
+            "allreduce_ms": max(ranks_report["allreduce_ms_mean_by_rank"]) if ranks_report is not None else 0.0,
         }
         if counts_check is not None:
             line["counts_check"] = counts_check
@@ -440,10 +447,31 @@ def main():
         if world == 1 and not a.no_cpu_baseline and wl["sets"] and not side:
             line["cpu_baseline"], sample = cpu_baseline(wl)
             line["parity_sample"] = parity_sample(wl, pw, sample)
+        if world == 1 and not a.no_api and not side:
+            line["value_api"] = api_leg()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def api_leg():
+    """The drop-in at the API north_star names: Scanner(genome, regions).scan_motifs(pwms) -> the lazy nested view, and the
+    reference consumers' access pattern on it (tools/api_time.py), at BASELINE configs[1] and configs[2].  Wall time of the
+    Python call, host strings in, everything the call does inside (marshalling, upload, pack, scan, de-dup, copy-out)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import api_time
+    out = {"unit": "bp*motifs/s", "definition": "region_bp x n_motifs / wall time of Scanner.scan_motifs(pwms) (host strings in, lazy "
+           "MotifSites view out, de-dup on); writer_pattern = io/__init__.py:23-33's len(sites[idx]) / max(site.score) double loop",
+           "reference_in_build_container": "profiles/r04_api_time_reference.json (real Scanner.scan_motifs, configs[1], 8 threads)"}
+    for key, name, regs in (("configs1", "c2", 2000), ("configs2", "c3", 500)):
+        m = api_time.measure(name, writer_regions=regs)
+        out[key] = {"value": m["value_api"], "scan_motifs_s": m["scan_motifs_s"], "scan_motifs_again_s": m["scan_motifs_again_s"],
+                    "scanner_ctor_s": m["scanner_ctor_s"], "n_sites": m["n_sites"], "python_heap_bytes": m["scan_motifs_python_heap_bytes"],
+                    "writer_ns_per_motif_region": m["writer_pattern"]["ns_per_motif_region"],
+                    "writer_all_regions_s": m["writer_pattern"]["extrapolated_all_regions_s"],
+                    "stats_all_motifs_s": m["stats_pattern"]["extrapolated_all_motifs_s"], "vectorised_tables_s": m["vectorised_tables_s"]}
+    return out
 
 
 def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
@@ -589,6 +617,7 @@ def main_sweep(a, world, rank, local_rank):
         chroms = {ch: pb.array for ch, pb in pinned.items()}
         del genome
         counts = torch.zeros(P, dtype=torch.int64, device=dev)
+        local_counts = torch.zeros(P, dtype=torch.int64, device=dev)
         my_units = float(sum(sp[4] for sp in mine)) * window * P
         modes = {"counts_only": (_lib.MS_STREAM_NO_HITS, False), "hits_packed": (0, True)}
         out = {}
@@ -605,6 +634,7 @@ def main_sweep(a, world, rank, local_rank):
                 st["ms_prefilter"] += s["ms_prefilter"]; st["ms_total"] += s["ms_total"]; st["n"] += 1
                 res.close()
             counts.copy_(torch.from_numpy(c))
+            local_counts.copy_(counts)
             if world > 1:
                 dist.all_reduce(counts, op=dist.ReduceOp.SUM)
             return sites, st
@@ -636,6 +666,21 @@ def main_sweep(a, world, rank, local_rank):
                          "prefilter_ms_per_step": st["ms_prefilter"], "device_ms_per_step": st["ms_total"],
                          "hbm_pool_timed": {k: pool1[k] - pool0[k] for k in ("hits", "misses", "driver_frees", "driver_ms")},
                          "stage_ms_last_pass": {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in st["stages"].items()}}
+        counts_check = None
+        if world > 1:                                  # the collective and the span shards, checked (last pass = hits_packed mode)
+            gathered = [torch.zeros_like(local_counts) for _ in range(world)]
+            dist.all_gather(gathered, local_counts)
+            first_last = torch.tensor([float(mine[0][3]) if mine else -1.0, float(mine[-1][3] + mine[-1][4]) if mine else -1.0, float(len(mine))],
+                                      dtype=torch.float64, device=dev)
+            fl = [torch.zeros_like(first_last) for _ in range(world)]
+            dist.all_gather(fl, first_last)
+            fl = [x for x in torch.stack(fl).cpu().numpy().tolist() if x[2] > 0]
+            n_windows_total = int(spans_all[-1][3] + spans_all[-1][4])
+            counts_check = {"allreduce_equals_sum_of_rank_counts": bool(torch.equal(torch.stack(gathered).sum(0), counts)),
+                            "max_windows_with_site": int(counts.max().item()),
+                            "window_ranges_tile_the_sweep": bool(fl and fl[0][0] == 0 and fl[-1][1] == n_windows_total
+                                                                 and all(fl[k][1] == fl[k + 1][0] for k in range(len(fl) - 1))),
+                            "ranks_with_spans": len(fl)}
         if rank == 0:
             line = {"metric": "scanned bp*motifs per second (region_bp x n_motifs), both strands, p=1e-4 cutoffs",
                     "value": out["counts_only"]["value"], "unit": "bp*motifs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -649,6 +694,8 @@ def main_sweep(a, world, rank, local_rank):
                                         "scans every base window / stride = 4 times, the sweep once). value = counts_only mode (per-motif window "
                                         "counts, what the enrichment statistics consume); hits_packed also copies every site to the host",
                     "modes": out}
+            if counts_check is not None:
+                line["counts_check"] = counts_check
             print(json.dumps(line), flush=True)
     else:
         P = wl["n_pwms"]

@@ -388,8 +388,9 @@ class ScanResult:
         self._hits = None
         self._hits_owned = True
 
-    def hits(self, copy=True, packed=False):
-        """dict of numpy arrays: seq_idx, pos, score, strand (1 '+', 2 '-'), motif.
+    def hits(self, copy=True, packed=False, motif=True):
+        """dict of numpy arrays: seq_idx, pos, score, strand (1 '+', 2 '-'), motif (motif=False leaves the per-hit motif
+        index out: it is motif_offsets expanded, 4 bytes per hit that few callers read).
         copy=False returns views of the library's pinned host buffers; the views keep this result alive (they are only
         invalidated by an explicit close() or dedup()).  packed=True moves 16 instead of 25 bytes per hit over the host
         link (ms_result_hits_packed_host) and unpacks on the host -- the arrays are then always fresh copies."""
@@ -407,14 +408,15 @@ class ScanResult:
                     arrs = [a.copy() for a in arrs]
             else:
                 arrs = [np.zeros(0, dtype=t) for t in (np.int64, np.int64, np.float64, np.int8)]
-            motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
-            self._hits = {"seq_idx": arrs[0], "pos": arrs[1], "score": arrs[2], "strand": arrs[3], "motif": motif,
+            self._hits = {"seq_idx": arrs[0], "pos": arrs[1], "score": arrs[2], "strand": arrs[3],
                           "motif_offsets": self.motif_offsets}
             self._hits_owned = copy or n == 0
-            if not self._hits_owned:
-                out, self._hits = self._hits, None       # the views reference this object: caching them here would be a cycle
-                return out
-        return self._hits
+        out = self._hits
+        if motif and "motif" not in out:
+            out["motif"] = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
+        if not self._hits_owned:
+            self._hits = None                            # the views reference this object: caching them here would be a cycle
+        return out
 
     def _hits_packed(self):
         n = self.n_hits

@@ -21,15 +21,13 @@ plus, for inputs where n_pwms x n_regions Python lists are not an option (SURVEY
 """
 import logging
 import os
-from collections import namedtuple
 
 import numpy as np
 
 from . import _lib
+from .sites import MotifSite, MotifSites, RegionSites  # noqa: F401  (MotifSite is part of this module's surface, scanner.py:16)
 
 logger = logging.getLogger(__name__)
-
-MotifSite = namedtuple("MotifSite", ["start", "score", "strand"])
 
 _STRAND_FLAG = {"+": 1, "-": 2, "both": 3}
 
@@ -138,10 +136,8 @@ class Scanner:
         lengths = [pwm.length for pwm in pwms]
         return matrices, np.asarray(cutoffs, dtype=np.float64), lengths
 
-    def scan_motifs_arrays(self, pwms, with_tables=False):
-        """Flat result: dict with motif, region, start (genome coordinate), score, strand (1/2),
-        motif_offsets -- ordered exactly like the nested lists scan_motifs returns.  with_tables adds
-        the dense per-(motif, region) site count and maximum score (NaN = no site)."""
+    def _scan(self, pwms, with_tables=False):
+        """One device scan (+ de-dup): (hits dict of the library's pinned arrays, n_regions_with_site, tables or None)."""
         matrices, cutoffs, lengths = self._marshal(pwms)
         logger.debug("Scanning motif PWMs")
         pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
@@ -161,7 +157,7 @@ class Scanner:
         try:
             if self.remove_dup:
                 res.dedup(pw)                      # scanner.py:156-193 on the device, order preserved
-            h = res.hits(copy=False)               # views of the library's pinned host buffers (kept alive below)
+            h = res.hits(copy=False, motif=False)  # views of the library's pinned host buffers (they keep `res` alive)
             region_counts = res.region_counts()
             tables = res.site_tables(len(self.seq_starts)) if with_tables else None
         except BaseException:
@@ -171,8 +167,16 @@ class Scanner:
             if sq is not None:
                 sq.close()
             pw.close()
+        return h, region_counts, tables, res
+
+    def scan_motifs_arrays(self, pwms, with_tables=False):
+        """Flat result: dict with motif, region, start (genome coordinate), score, strand (1/2),
+        motif_offsets -- ordered exactly like the nested lists scan_motifs returns.  with_tables adds
+        the dense per-(motif, region) site count and maximum score (NaN = no site)."""
+        h, region_counts, tables, res = self._scan(pwms, with_tables)
         starts = np.asarray(self.seq_starts, dtype=np.int64)
-        out = {"motif": h["motif"], "region": h["seq_idx"],
+        n_pwms = len(h["motif_offsets"]) - 1
+        out = {"motif": np.repeat(np.arange(n_pwms, dtype=np.int32), np.diff(h["motif_offsets"])), "region": h["seq_idx"],
                "start": (starts[h["seq_idx"]] + h["pos"]) if len(h["pos"]) else h["pos"],
                "score": h["score"], "strand": h["strand"], "motif_offsets": h["motif_offsets"],
                "n_regions_with_site": region_counts,      # de-dup never empties a region
@@ -222,14 +226,12 @@ class Scanner:
             pw.close()
 
     def scan_motifs(self, pwms):
-        pwms = list(pwms)
-        a = self.scan_motifs_arrays(pwms)
-        n_regions = len(self.seq_starts)
-        motif_sites = [[[] for _ in range(n_regions)] for _ in pwms]
-        for m, r, st, sc, sd in zip(a["motif"].tolist(), a["region"].tolist(), a["start"].tolist(),
-                                    a["score"].tolist(), a["strand"].tolist()):
-            motif_sites[m][r].append(MotifSite(st, sc, "+" if sd == 1 else "-"))
-        return motif_sites
+        """motif_sites[n_pwms][n_regions] -> list[MotifSite] (scanner.py:89-132), as a read-only nested view over the
+        device's flat hit arrays: a region's list is built when it is indexed (motifscan_amd/sites.py), so the call costs
+        the scan + the copy-out whatever n_pwms x n_regions is.  `.to_lists()` gives the reference's real lists."""
+        h, region_counts, _, res = self._scan(list(pwms))
+        return MotifSites(h["motif_offsets"], h["seq_idx"], h["pos"], h["score"], h["strand"], self.seq_starts,
+                          n_regions_with_site=region_counts, owner=res)
 
 
 def make_motif_sites(sites, seq_starts):

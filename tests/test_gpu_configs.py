@@ -628,6 +628,44 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert line["roofline"]["kernel"] == "prefilter_f6_kernel"
 
 
+def _bench_ranks_on_one_gpu(args, timeout=1500):
+    env = dict(os.environ, MS_BENCH_BACKEND="gloo", MS_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_world_of_eight_on_one_gpu():
+    """The shape the driver's 8-GPU SCALE run has -- eight fresh ranks, eight shards of both region sets of configs[3] (here 160k
+    regions per set), 8 stream pipelines (24 host threads) and 8 block pools, one all-reduce per step -- on the one GPU of this box
+    over gloo: n_gpus = 8, the all-reduced vector == the sum of the ranks' vectors, the eight shards tile both sets in rank order,
+    and 2000 regions of EVERY rank's own shard are bit-identical to the oracle."""
+    line = _bench_ranks_on_one_gpu(["--gpus", "8", "--regions-per-set", "160000", "--steps", "3", "--warmup", "1", "--min-warm-seconds", "0"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["counts_check"]["allreduce_equals_sum_of_rank_counts"] is True
+    rk = line["ranks"]
+    assert rk["shards_tile_every_set"] is True and len(rk["shard_by_rank"]) == 8
+    assert [b - a for a, b in rk["shard_by_rank"]] == [20_000] * 8
+    ps = rk["parity_sample"]
+    assert ps["ranks"] == 8 and ps["ranks_identical_to_oracle"] == 8 and ps["regions_per_rank"] == 2000 and ps["hits_checked"] > 100_000
+    assert line["allreduce_ms"] >= 0 and len(rk["allreduce_ms_mean_by_rank"]) == 8
+    e2e = line["value_end_to_end"]
+    assert e2e["pipelined"] > 0 and e2e["hits_per_pass_per_gpu"] > 0
+
+
+def test_bench_sweep_world_of_eight_on_one_gpu():
+    """configs[4] (host-streamed sweep) with the spans sharded over eight ranks on one GPU: the ranks' window ranges tile the
+    sweep, the all-reduced per-motif window counts == the sum of the ranks' own."""
+    line = _bench_ranks_on_one_gpu(["--gpus", "8", "--workload", "c5", "--genome-mbp", "240", "--steps", "1", "--warmup", "1",
+                                    "--min-warm-seconds", "0"])
+    assert line["n_gpus"] == 8 and line["value"] > 0
+    cc = line["counts_check"]
+    assert cc["allreduce_equals_sum_of_rank_counts"] is True and cc["window_ranges_tile_the_sweep"] is True and cc["ranks_with_spans"] == 8
+    assert line["modes"]["hits_packed"]["sites_per_step_per_gpu"] > 0
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """--gpus N with N > visible devices: one line, non-zero exit, nothing spawned (and nothing generated)."""
     import time

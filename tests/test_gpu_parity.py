@@ -166,6 +166,12 @@ def test_g4_scanner_with_and_without_dedup(rnd):
     nested = sc.scan_motifs(pw[:5])
     assert len(nested) == 5 and all(len(per) == 7 for per in nested)
     assert all(isinstance(s, scanner.MotifSite) for per in nested for ss in per for s in ss)
+    # the lazy view == real lists built from the flat arrays, and == its own eager form
+    a = sc.scan_motifs_arrays(pw[:5])
+    eager = [[[] for _ in range(7)] for _ in range(5)]
+    for m, r, st, sco, sd in zip(a["motif"].tolist(), a["region"].tolist(), a["start"].tolist(), a["score"].tolist(), a["strand"].tolist()):
+        eager[m][r].append(scanner.MotifSite(st, sco, "+" if sd == 1 else "-"))
+    assert nested == eager and nested.to_lists() == eager and sum(len(x) for per in eager for x in per) > 0
 
 
 def test_device_dedup_and_site_tables(oracle, rnd):
@@ -313,17 +319,62 @@ def test_cutoff_builder_matches_reference(rnd):
 # ------------------------------------------------------------- seeded inputs vs the oracle --
 
 def test_c2_config_bit_exact_vs_oracle(oracle):
-    """BASELINE.json configs[1] shape, reduced in region count so the CPU checker takes seconds:
-    2000 x 500 bp, 50 JASPAR-width PWMs, both strands, N runs + soft-masking."""
-    vals, widths, cutoffs = synth.load_motif_set(50)
-    bases, offsets = synth.make_regions(2000, 500, seed=1, frac_n=0.02)
-    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    """BASELINE.json configs[1] IN FULL ("10k x 500 bp synthetic regions, 50 JASPAR-width PWMs, 1 MI355X, bit-exact vs CPU"):
+    synth.workload("c2") -- the set bench.py --workload c2 scans -- against the oracle on every region, both strands."""
+    wl = synth.workload("c2")
+    vals, widths, cutoffs = wl["pwm_values"], wl["widths"], wl["cutoffs"]
+    bases, offsets = wl["sets"][0]
+    assert len(offsets) - 1 == 10_000 and len(widths) == 50 and int(offsets[-1]) == 5_000_000
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, min(50, os.cpu_count() or 1))
     pw, sq = _lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets)
     res = _lib.scan(pw, sq, 3)
     assert_same_hits(res.hits(), want)
     st = res.stats()
-    assert st["n_windows"] == sum(max(500 - int(w) + 1, 0) for w in widths) * 2000
-    assert len(want["pos"]) > 1000
+    assert st["n_windows"] == sum(max(500 - int(w) + 1, 0) for w in widths) * 10_000
+    assert len(want["pos"]) > 10_000
+
+
+def test_c2_config_through_the_scanner_lazy_result_vs_oracle(oracle):
+    """The same configs[1] set through the drop-in north_star names -- Scanner(...).scan_motifs(pwms) -- with de-dup on and off:
+    the lazy nested view (motifscan_amd/sites.py) == the oracle's make_motif_sites / deduplicate_motif_sites lists
+    (scanner.py:135-193) on every (motif, region), read the way the reference's writers and statistics read it."""
+    wl = synth.workload("c2")
+    vals, widths, cutoffs = wl["pwm_values"], wl["widths"], wl["cutoffs"]
+    bases, offsets = wl["sets"][0]
+    n = 2500                                                            # regions through the Python-level comparison (all 10k above)
+    raw = bases[:int(offsets[n])].tobytes()
+    seqs = [raw[int(offsets[i]):int(offsets[i + 1])].decode() for i in range(n)]
+    mats = synth.matrices_of(vals, widths)
+
+    class G:
+        chrom_sizes = {"c": len(raw)}
+
+        @staticmethod
+        def fetch_sequence(chrom, start, end):
+            return raw[start:end].decode()
+
+    class Reg:
+        def __init__(self, i):
+            self.chrom, self.start, self.end = "c", int(offsets[i]), int(offsets[i + 1])
+            self.summit = (self.start + self.end) // 2
+
+    class P:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = m, {"1e-4": c}, m.shape[1]
+
+    regs, pwms = [Reg(i) for i in range(n)], [P(m, c) for m, c in zip(mats, cutoffs)]
+    pooled = oracle.c_scan_motif([m.tolist() for m in mats], cutoffs.tolist(), seqs, 3, 8)
+    nested = oracle.make_motif_sites(pooled, [r.start for r in regs])
+    for dup, want in ((False, nested), (True, oracle.deduplicate_motif_sites(nested, [int(w) for w in widths]))):
+        sc = scanner.Scanner(G, regs, window_size=0, p_value="1e-4", remove_dup=dup)
+        got = sc.scan_motifs(pwms)
+        assert isinstance(got, scanner.MotifSites) and len(got) == 50 and len(got[0]) == n
+        assert [[tuple(s) for s in x] for x in got[7]] == [[tuple(s) for s in x] for x in want[7]]
+        assert got == [[[scanner.MotifSite(*s) for s in x] for x in per] for per in want]
+        assert got.to_lists() == [[[scanner.MotifSite(*s) for s in x] for x in per] for per in want]
+        assert np.array_equal(got.site_counts(), [[len(x) for x in per] for per in want])
+        assert np.array_equal(got.n_regions_with_site, [sum(len(x) > 0 for x in per) for per in want])   # stats.py:29-31
+        assert sum(len(x) for per in want for x in per) > 2000
 
 
 @pytest.mark.parametrize("pkey", ["1e-2", "1e-3", "1e-5"])
