@@ -281,11 +281,18 @@ class SeqSet:
 
     @classmethod
     def from_strings(cls, seqs, keep_ascii=False):
-        bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in seqs]
-        offsets = np.zeros(len(bs) + 1, dtype=np.int64)
-        if bs:
-            offsets[1:] = np.cumsum([len(b) for b in bs])
-        return cls(b"".join(bs), offsets, keep_ascii)
+        seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
+        offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+        try:                                      # ONE join + ONE encode (plain-ASCII strings: a base is a byte)
+            raw = "".join(seqs).encode("ascii")
+            if seqs:
+                np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)), out=offsets[1:])
+        except (TypeError, UnicodeEncodeError):   # bytes among them, or non-ASCII text (every such byte scores as 'N', cscore.c:92-111)
+            bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in seqs]
+            if bs:
+                offsets[1:] = np.cumsum([len(b) for b in bs])
+            raw = b"".join(bs)
+        return cls(raw, offsets, keep_ascii)
 
     @classmethod
     def from_device(cls, device_ptr, offsets):

@@ -9,10 +9,8 @@
 // so that batch i's copy-out, batch i+1's scan and batch i+2's upload run together.  Results leave in submission order.
 // The reference has no counterpart (its Scanner holds every sequence as a Python str and makes one c_scan_motif call,
 // scanner.py:71-87, 125); the batches' concatenation is what that one call returns.
-#include <atomic>
-#include <chrono>
-
 #include "ms_handles.h"
+#include "ms_pipeline.h"
 
 using namespace ms;
 
@@ -34,61 +32,6 @@ struct Job {
     std::string err;
 };
 
-class JobQueue {
-public:
-    explicit JobQueue(size_t cap) : cap_(cap) {}
-    void push(Job *j) {
-        std::unique_lock<std::mutex> lk(mu_);
-        not_full_.wait(lk, [&] { return q_.size() < cap_; });
-        q_.push_back(j);
-        not_empty_.notify_one();
-    }
-    // true: *out is a job, or nullptr when the queue is closed and drained; false: nothing there right now
-    bool try_pop(Job **out) {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (q_.empty()) {
-            if (!closed_) return false;
-            *out = nullptr;
-            return true;
-        }
-        *out = q_.front();
-        q_.pop_front();
-        not_full_.notify_one();
-        return true;
-    }
-    Job *pop() {                      // nullptr = closed and drained
-        std::unique_lock<std::mutex> lk(mu_);
-        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
-        if (q_.empty()) return nullptr;
-        Job *j = q_.front();
-        q_.pop_front();
-        not_full_.notify_one();
-        return j;
-    }
-    void close() {
-        std::lock_guard<std::mutex> lk(mu_);
-        closed_ = true;
-        not_empty_.notify_all();
-    }
-
-private:
-    std::mutex mu_;
-    std::condition_variable not_full_, not_empty_;
-    std::deque<Job *> q_;
-    size_t cap_;
-    bool closed_ = false;
-};
-
-double now_s() {
-    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// Where a stage's thread spends its time: working, waiting for input, waiting for room downstream
-struct StageClock {
-    std::atomic<uint64_t> work_us{0}, wait_in_us{0}, wait_out_us{0}, jobs{0};
-    static void add(std::atomic<uint64_t> &a, double s) { a.fetch_add((uint64_t) (s * 1e6)); }
-};
-
 void fail_job(Job *j, int rc) {
     j->rc = rc;
     j->err = ms_last_error();         // the failing call left its message on THIS worker thread
@@ -96,48 +39,27 @@ void fail_job(Job *j, int rc) {
 
 }  // namespace
 
+// The stream is the pipeline's Ops (ms_pipeline.h): the three stage bodies below are all that touches the device; the queues,
+// the threads and the scan stage's one-scan-ahead loop live in the host-only header (and run under TSan with stub stages).
 struct ms_stream {
     ms_pwmset *pwms = nullptr;
     int strand = 3;
     uint32_t flags = 0;
     int device = 0;
     int depth = 2;
-    int capacity = 0;
-    std::atomic<int> in_flight{0};
-    std::unique_ptr<JobQueue> q_in, q_up, q_scan, q_done;
-    std::thread th_up, th_scan, th_down;
-    StageClock clk[3];                // uploader, scanner, downloader
+    std::unique_ptr<StagePipeline<Job, ms_stream>> pipe;
 
-    // one stage: pop -> work -> push, each leg timed
-    template <class F>
-    void run_stage(int k, JobQueue &in, JobQueue &out, F &&work) {
+    void bind_thread() {
         set_current_device(device);
         (void) hipSetDevice(device);
-        for (;;) {
-            const double t0 = now_s();
-            Job *j = in.pop();
-            const double t1 = now_s();
-            if (!j) break;
-            work(j);
-            const double t2 = now_s();
-            out.push(j);
-            const double t3 = now_s();
-            StageClock::add(clk[k].wait_in_us, t1 - t0);
-            StageClock::add(clk[k].work_us, t2 - t1);
-            StageClock::add(clk[k].wait_out_us, t3 - t2);
-            clk[k].jobs.fetch_add(1);
-        }
-        out.close();
     }
 
-    void uploader() {
-        run_stage(0, *q_in, *q_up, [](Job *j) {
-            if (j->rc != MS_OK) return;
-            // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
-            const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
-                                        : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
-            if (rc) fail_job(j, rc);
-        });
+    void upload(Job *j) {
+        if (j->rc != MS_OK) return;
+        // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
+        const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
+                                    : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+        if (rc) fail_job(j, rc);
     }
 
     // The scan stage keeps ONE scan queued behind the one it is waiting for: a plain batch whose sizes can be predicted
@@ -145,10 +67,16 @@ struct ms_stream {
     // waits for the first -- the device goes from one batch's last kernel straight into the next batch's first.  Sweep spans
     // and de-duplicated batches need their result at once and run to the end as before.
     PendingScan pend_slot[2];
-    bool pend_ok = false;
 
-    // returns true if the job's scan is pending (finish with scan_finish), false if the job is done (or failed)
-    bool scan_start(Job *j, PendingScan *slot) {
+    bool scanner_begin() { return pending_scan_init(&pend_slot[0]) == MS_OK && pending_scan_init(&pend_slot[1]) == MS_OK; }
+    void scanner_end() {
+        // (a slot whose init failed was left empty by pending_scan_init: destroying it is a no-op)
+        pending_scan_destroy(&pend_slot[0]);
+        pending_scan_destroy(&pend_slot[1]);
+    }
+
+    // returns true if the job's scan is pending in pend_slot[slot] (finish with scan_finish), false if the job is done (or failed)
+    bool scan_start(Job *j, int slot) {
         if (j->rc != MS_OK) return false;
         DeviceCtx *c = nullptr;
         int rc = get_ctx(device, &c);
@@ -159,8 +87,8 @@ struct ms_stream {
             const bool simple = j->kind != 1 && !(flags & MS_STREAM_DEDUP);
             const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) |
                                 ((simple && (flags & MS_STREAM_PACKED) && !(flags & MS_STREAM_NO_HITS)) ? MS_SCAN_PACK_INTERNAL : 0u);
-            const bool plain = simple && pend_ok && slot;
-            rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? slot : nullptr);
+            const bool plain = simple && slot >= 0;
+            rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? &pend_slot[slot] : nullptr);
             if (rc == MS_SCAN_PENDING) { rc = MS_OK; pending = true; }
             if (!rc && !pending && j->kind == 1) {
                 ms_result *r1 = j->res;
@@ -174,13 +102,13 @@ struct ms_stream {
         return pending;
     }
 
-    void scan_finish(Job *j, PendingScan *slot) {
+    void scan_finish(Job *j, int slot) {
         DeviceCtx *c = nullptr;
         int rc = get_ctx(device, &c);
         if (!rc) {
             {
                 std::lock_guard<std::mutex> lk_pwm(pwms->mu);
-                rc = scan_complete(c, pwms, slot, &j->res);
+                rc = scan_complete(c, pwms, &pend_slot[slot], &j->res);
             }
             if (rc == MS_SCAN_RETRY) {                       // the predicted sizes were too small: once more, exactly sized
                 std::lock_guard<std::mutex> lk_dev(c->mu);
@@ -194,54 +122,19 @@ struct ms_stream {
         if (j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
     }
 
-    void scanner() {
-        set_current_device(device);
-        (void) hipSetDevice(device);
-        pend_ok = pending_scan_init(&pend_slot[0]) == MS_OK && pending_scan_init(&pend_slot[1]) == MS_OK;
-        JobQueue &in = *q_up, &out = *q_scan;
-        Job *waiting = nullptr;                               // its scan is queued on the device, not yet waited for
-        int wslot = 0;
-        bool drained = false;
-        auto span = [&](std::atomic<uint64_t> &acc, auto &&fn) { const double t0 = now_s(); fn(); StageClock::add(acc, now_s() - t0); };
-        while (!drained || waiting) {
-            Job *j = nullptr;
-            if (!drained) {
-                bool have = true;
-                span(clk[1].wait_in_us, [&] {
-                    if (waiting) have = in.try_pop(&j);              // a scan is in flight: take the next batch only if it is already there
-                    else j = in.pop();
-                });
-                if (have && !j) drained = true;
-            }
-            bool j_pending = false;
-            if (j) span(clk[1].work_us, [&] { j_pending = scan_start(j, &pend_slot[wslot ^ 1]); });   // queued BEHIND the waiting scan (or run to the end)
-            if (waiting) {
-                span(clk[1].work_us, [&] { scan_finish(waiting, &pend_slot[wslot]); });
-                span(clk[1].wait_out_us, [&] { out.push(waiting); });
-                clk[1].jobs.fetch_add(1);
-                waiting = nullptr;
-            }
-            if (j) {
-                if (j_pending) { waiting = j; wslot ^= 1; }
-                else {
-                    span(clk[1].wait_out_us, [&] { out.push(j); });
-                    clk[1].jobs.fetch_add(1);
-                }
-            }
-        }
-        out.close();
-        if (pend_ok) { pending_scan_destroy(&pend_slot[0]); pending_scan_destroy(&pend_slot[1]); }
-    }
-
-    void downloader() {
-        run_stage(2, *q_scan, *q_done, [this](Job *j) {
-            if (j->rc != MS_OK || (flags & MS_STREAM_NO_HITS)) return;
-            const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
-                                                      : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
-            if (rc) fail_job(j, rc);
-        });
+    void download(Job *j) {
+        if (j->rc != MS_OK || (flags & MS_STREAM_NO_HITS)) return;
+        const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
+                                                  : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
+        if (rc) fail_job(j, rc);
     }
 };
+
+static void drop_job(Job *j) {
+    if (j->res) ms_result_free(j->res);
+    if (j->seqs) ms_seqset_free(j->seqs);
+    delete j;
+}
 
 extern "C" {
 
@@ -262,22 +155,12 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     st->flags = flags;
     st->device = c->device;
     st->depth = depth;
-    st->capacity = 4 * depth + 3;                        // three bounded queues + one job inside each stage + done results
     try {
-        st->q_in.reset(new JobQueue((size_t) depth));
-        st->q_up.reset(new JobQueue((size_t) depth));
-        st->q_scan.reset(new JobQueue((size_t) depth));
-        st->q_done.reset(new JobQueue((size_t) st->capacity + 1));      // never blocks: in_flight <= capacity
-        ms_stream *raw = st.get();
-        st->th_up = std::thread([raw] { raw->uploader(); });
-        st->th_scan = std::thread([raw] { raw->scanner(); });
-        st->th_down = std::thread([raw] { raw->downloader(); });
+        st->pipe.reset(new StagePipeline<Job, ms_stream>(st.get(), depth));
+        st->pipe->start();
     } catch (const std::exception &e) {
         set_error("could not start the stream's threads: %s", e.what());
-        if (st->q_in) st->q_in->close();
-        if (st->th_up.joinable()) st->th_up.join();
-        if (st->th_scan.joinable()) st->th_scan.join();
-        if (st->th_down.joinable()) st->th_down.join();
+        if (st->pipe) st->pipe->shutdown(drop_job);
         return MS_ERR_RUNTIME;
     }
     {
@@ -289,12 +172,11 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
 }
 
 static int stream_enqueue(ms_stream *st, std::unique_ptr<Job> j) {
-    if (st->in_flight.load() >= st->capacity) {
-        set_error("%d batches are in flight: collect results with ms_stream_next first", st->capacity);
+    if (!st->pipe->submit(j.get())) {                    // (may wait for the uploader; never for the consumer)
+        set_error("%d batches are in flight: collect results with ms_stream_next first", st->pipe->capacity());
         return MS_ERR_INVALID;
     }
-    st->in_flight.fetch_add(1);
-    st->q_in->push(j.release());                         // may wait for the uploader; never for the consumer
+    j.release();
     return MS_OK;
 }
 
@@ -347,10 +229,9 @@ int ms_stream_submit_span(ms_stream *st, const char *bases, int64_t n_bases, int
 int ms_stream_next(ms_stream *st, ms_result **out) {
     if (!st || !out) { set_error("NULL argument"); return MS_ERR_INVALID; }
     *out = nullptr;
-    if (st->in_flight.load() == 0) return MS_OK;
-    std::unique_ptr<Job> j(st->q_done->pop());
+    if (st->pipe->in_flight() == 0) return MS_OK;
+    std::unique_ptr<Job> j(st->pipe->next());
     if (!j) { set_error("stream is closed"); return MS_ERR_RUNTIME; }
-    st->in_flight.fetch_sub(1);
     if (j->rc != MS_OK) {
         set_error("%s", j->err.c_str());
         if (j->res) ms_result_free(j->res);
@@ -362,37 +243,31 @@ int ms_stream_next(ms_stream *st, ms_result **out) {
 
 int ms_stream_in_flight(const ms_stream *st, int *n) {
     if (!st || !n) { set_error("NULL argument"); return MS_ERR_INVALID; }
-    *n = st->in_flight.load();
+    *n = st->pipe->in_flight();
     return MS_OK;
 }
 
 int ms_stream_stats(const ms_stream *st, double out[12]) {
     if (!st || !out) { set_error("NULL argument"); return MS_ERR_INVALID; }
     for (int k = 0; k < 3; k++) {
-        out[4 * k + 0] = (double) st->clk[k].jobs.load();
-        out[4 * k + 1] = st->clk[k].work_us.load() * 1e-3;
-        out[4 * k + 2] = st->clk[k].wait_in_us.load() * 1e-3;
-        out[4 * k + 3] = st->clk[k].wait_out_us.load() * 1e-3;
+        const StageClock &clk = st->pipe->clock(k);
+        out[4 * k + 0] = (double) clk.jobs.load();
+        out[4 * k + 1] = clk.work_us.load() * 1e-3;
+        out[4 * k + 2] = clk.wait_in_us.load() * 1e-3;
+        out[4 * k + 3] = clk.wait_out_us.load() * 1e-3;
     }
     return MS_OK;
 }
 
 int ms_stream_capacity(const ms_stream *st, int *n) {
     if (!st || !n) { set_error("NULL argument"); return MS_ERR_INVALID; }
-    *n = st->capacity;
+    *n = st->pipe->capacity();
     return MS_OK;
 }
 
 void ms_stream_free(ms_stream *st) {
     if (!st) return;
-    st->q_in->close();
-    if (st->th_up.joinable()) st->th_up.join();
-    if (st->th_scan.joinable()) st->th_scan.join();
-    if (st->th_down.joinable()) st->th_down.join();
-    while (Job *j = st->q_done->pop()) {                 // closed by the downloader: drains, then nullptr
-        if (j->res) ms_result_free(j->res);
-        delete j;
-    }
+    st->pipe->shutdown(drop_job);
     DeviceCtx *c = nullptr;
     if (get_ctx(st->device, &c) == MS_OK) {
         std::lock_guard<std::mutex> lk_dev(c->mu);

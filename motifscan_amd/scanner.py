@@ -50,6 +50,7 @@ class Scanner:
         self.n_threads = max(1, min(n_threads, n_cpu))
         self.seq_starts, self.seq_ends, self._sequences = [], [], []
         self._resident = None                # (ResidentGenome, chromosome indices) when extraction is on the device
+        self._sq = None                      # the regions as a packed device set (0.375 B/base), kept between scan_motifs calls
         self._extract_seq(genome, regions)
 
     @property
@@ -88,10 +89,21 @@ class Scanner:
             self._sequences = None
 
     def _seqset(self):
-        if self._resident is not None:
-            g, idx = self._resident
-            return g.extract(idx, self.seq_starts, self.seq_ends)
-        return _lib.SeqSet.from_strings(self._sequences)
+        """The regions as a device sequence set (convert_seq, cscore.c:81-114: 2-bit codes + non-ACGT mask), made on the first scan
+        and kept for the scanner's life -- the reference converts its strings again on every c_scan_motif call."""
+        if self._sq is None:
+            if self._resident is not None:
+                g, idx = self._resident
+                self._sq = g.extract(idx, self.seq_starts, self.seq_ends)
+            else:
+                self._sq = _lib.SeqSet.from_strings(self._sequences)
+        return self._sq
+
+    def close(self):
+        """Release the device copy of the regions (also done when the scanner is collected)."""
+        if self._sq is not None:
+            self._sq.close()
+            self._sq = None
 
     def _as_sweep(self):
         """(genome, chromosome index, begin, end, window, stride) if the regions are the windows of ONE fixed-stride
@@ -145,15 +157,12 @@ class Scanner:
         overlapping = self._as_overlapping() if sweep is None else None
         if sweep is not None:
             g, chrom, begin, end, window, stride = sweep
-            sq = None
             res = _lib.scan_sweep(pw, g, chrom, begin, end, window, stride, _STRAND_FLAG[self.strand])
         elif overlapping is not None:
             g, idx = overlapping
-            sq = None
             res = _lib.scan_regions_once(pw, g, idx, self.seq_starts, self.seq_ends, _STRAND_FLAG[self.strand])
         else:
-            sq = self._seqset()
-            res = _lib.scan(pw, sq, _STRAND_FLAG[self.strand])
+            res = _lib.scan(pw, self._seqset(), _STRAND_FLAG[self.strand])
         try:
             if self.remove_dup:
                 res.dedup(pw)                      # scanner.py:156-193 on the device, order preserved
@@ -164,8 +173,6 @@ class Scanner:
             res.close()
             raise
         finally:
-            if sq is not None:
-                sq.close()
             pw.close()
         return h, region_counts, tables, res
 

@@ -45,7 +45,9 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(so):
+        if os.environ.get("ORACLE_SO"):                    # e.g. liboracle_asan.so (`make -C oracle asan`; tests/test_sanitizers.py)
+            so = os.environ["ORACLE_SO"]
+        elif not os.path.exists(so):
             build()
         L = ctypes.CDLL(so)
         pd, pi32, pi64 = (ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32),
