@@ -312,6 +312,36 @@ __device__ __forceinline__ bool rare_park2(MfWave &W, PfResume &R, const f32x16 
     return false;
 }
 
+// The common case of an event, straight-line: BOTH operands' candidate lanes ranked at once (operand 0's lanes first, as rare_park2
+// orders them) and parked with two exec-masked store sequences -- no resumable state, one branch.  Only an event that does not fit
+// the free entries (or a class re-entered in the middle of one, R.op / R.skip set) takes rare_park2's piecewise form.  Round 4:
+// profiles/r03zz_class_clock.log put the hand-off at ~5.7 k of a wave's ~24.5 k cycles per 64-window pass, ~600 cycles per event,
+// most of it the dozen taken branches and scalar bookkeeping of the resumable form.
+__device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &c0, const f32x16 &c1, bool hit0, bool hit1, int64_t g0,
+                                          int32_t group, uint32_t paired) {
+    const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+    const uint32_t n0 = (uint32_t) __popcll(m0), n1 = (uint32_t) __popcll(m1);
+    if (__builtin_expect((R.op | R.skip) != 0u || W.rq_n + n0 + n1 > W.rq_cap, 0))
+        return rare_park2(W, R, c0, c1, hit0, hit1, g0, group, paired);
+    const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, 0u));
+    const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, n0));
+    const uint32_t hi = (uint32_t) ((uint64_t) g0 >> 32) | ((uint32_t) group << 8) | (paired << 31);     // (g0 + 32 never carries into bit 32: g0 < 2^34 is a multiple-of-64 base plus lane & 31)
+    if (hit0) {
+        uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank0) * (uint32_t) kRareEntryWords);
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c0[4 * j]), __float_as_uint(c0[4 * j + 1]), __float_as_uint(c0[4 * j + 2]), __float_as_uint(c0[4 * j + 3]));
+        *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g0, hi);
+    }
+    if (hit1) {
+        uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank1) * (uint32_t) kRareEntryWords);
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c1[4 * j]), __float_as_uint(c1[4 * j + 1]), __float_as_uint(c1[4 * j + 2]), __float_as_uint(c1[4 * j + 3]));
+        *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g0 + 32u, hi);
+    }
+    W.rq_n += n0 + n1;
+    return false;
+}
+
 // Decode and queue the n parked entries of a wave (lane i takes entry i).  All lanes of the wave, at a wave-uniform point.  NOT
 // inlined, and everything it needs comes through two LDS addresses: its registers are its own business.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -454,22 +484,22 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, 127, 0, 127);
         }
     };
-    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) -> bool {        // true: the parking space ran full inside this row tile
-        const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0))
-            // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
-            return rare_park2(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u);
-        return false;
-    };
     // one row tile in flight per wave: with paired rows most instructions belong to four-instruction row tiles, and a second set of
     // 32 accumulators (round 2's two tiles in flight for the narrow classes) costs the whole kernel its registers
+    // (ONE loop exit: a class that must leave early -- the parking space ran full inside row tile t: come back to it; or runs low:
+    // come back to t + 1 -- sets `back` and ends the loop through its counter, so the hot path is product, inspection, one branch)
+    int back = n_row_tiles;
     for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
         f32x16 c0, c1;
         product(p, c0, c1);
-        if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
-        if (__builtin_expect(W.rq_n >= W.rq_flush, 0)) { R.t = t + 1; return; }
+        const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
+        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
+            // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
+            const bool full = park_both(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u);
+            if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_row_tiles; }
+        }
     }
-    R.t = n_row_tiles;
+    R.t = back;
 }
 
 // All row tiles of one class of PAIRED rows (ms_internal.h): NK half-blocks of 8 columns, k-half 0 = field X, k-half 1 = field Y (block
@@ -527,22 +557,20 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1[kb], c1, 2, 4, 0, scale1, 0, 127);
         }
     };
-    auto test = [&](const f32x16 &c0, const f32x16 &c1, int t) -> bool {        // true: the parking space ran full inside this row tile
-        const uint32_t x0 = or16(c0), x1 = or16(c1);
-        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0))
-            // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
-            return rare_park2(W, R, c0, c1, live0 && (x0 & kPairMask) != 0u, live1 && (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
-                              first_group + 4 * t + 2 * (int32_t) h, 1u);
-        return false;
-    };
+    int back = n_row_tiles;                                                         // (one loop exit: see f6_class)
     for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
         // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
         f32x16 c0, c1;
         product(p, c0, c1);
-        if (__builtin_expect(test(c0, c1, t), 0)) { R.t = t; return; }
-        if (__builtin_expect(W.rq_n >= W.rq_flush, 0)) { R.t = t + 1; return; }
+        const uint32_t x0 = or16(c0), x1 = or16(c1);
+        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0)) {
+            // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
+            const bool full = park_both(W, R, c0, c1, live0 && (x0 & kPairMask) != 0u, live1 && (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
+                                        first_group + 4 * t + 2 * (int32_t) h, 1u);
+            if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_row_tiles; }
+        }
     }
-    R.t = n_row_tiles;
+    R.t = back;
 }
 
 // grid = (blocks per tile, tiles); ONE 1024-thread block per CU (16 waves per CU, <= 128 VGPRs): its waves never meet at a barrier
