@@ -488,15 +488,18 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     // 32 accumulators (round 2's two tiles in flight for the narrow classes) costs the whole kernel its registers
     // (ONE loop exit: a class that must leave early -- the parking space ran full inside row tile t: come back to it; or runs low:
     // come back to t + 1 -- sets `back` and ends the loop through its counter, so the hot path is product, inspection, one branch)
+    int n_run = n_row_tiles;
+    if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }                          // measurement: the per-pass and per-class set-up alone
     int back = n_row_tiles;
-    for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
+    for (int t = R.t; t < n_run; t++, p += kStep) {
         f32x16 c0, c1;
         product(p, c0, c1);
+        if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }      // measurement: operand reads + products, no inspection
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
         if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
             // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
             const bool full = park_both(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u);
-            if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_row_tiles; }
+            if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }
     R.t = back;
@@ -557,17 +560,20 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1[kb], c1, 2, 4, 0, scale1, 0, 127);
         }
     };
+    int n_run = n_row_tiles;
+    if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
     int back = n_row_tiles;                                                         // (one loop exit: see f6_class)
-    for (int t = R.t; t < n_row_tiles; t++, p += kStep) {
+    for (int t = R.t; t < n_run; t++, p += kStep) {
         // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
         f32x16 c0, c1;
         product(p, c0, c1);
+        if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
         if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0)) {
             // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
             const bool full = park_both(W, R, c0, c1, live0 && (x0 & kPairMask) != 0u, live1 && (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
                                         first_group + 4 * t + 2 * (int32_t) h, 1u);
-            if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_row_tiles; }
+            if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }
     R.t = back;
@@ -610,6 +616,16 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             for (int c = 0; c < 4; c++) w |= 2ULL << (4 * (4 * c + (int) ((i >> (2 * c)) & 3u)));
             lut2[i] = make_uint2((uint32_t) w, (uint32_t) (w >> 32));
         }
+    }
+    // The tile's class descriptors into LDS, 32 bytes apiece behind the B-operand table: a pass reads them from there, the next class's
+    // while the current one runs.  (From global memory they came through VECTOR loads, each followed by s_waitcnt vmcnt(0) -- a wait that
+    // also covers the next pass's sequence words in flight.  Measured: no difference in time on the benchmark set, profiles/r04_pf_account.log;
+    // kept because the pass loop then holds no vector-memory wait but the staging's own.)
+    int *cls_lds = reinterpret_cast<int *>(lut4 + 256 * 8 / 16);
+    if (threadIdx.x < (uint32_t) kMaxClasses * 8u) {
+        const uint32_t ci = threadIdx.x >> 3, f = threadIdx.x & 7u;
+        static_assert(sizeof(ClassDesc) == 20, "ClassDesc layout");
+        cls_lds[threadIdx.x] = f < 5u ? reinterpret_cast<const int *>(&T->cls[ci])[f] : 0;
     }
     __syncthreads();
     const char *lds = reinterpret_cast<const char *>(lds4);
@@ -679,8 +695,17 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             live1 = live1 && !dead1;
             if (!__any(live0 || live1)) return;
         }
+        auto read_cd = [&](int i) { return *reinterpret_cast<const int4 *>(cls_lds + 8 * i); };      // {nk, n_row_tiles, base16, first_group}; paired: word 4
+        int4 cd4 = read_cd(0);
+        int cdp = cls_lds[4];
         for (int i = 0; i < n_classes; i++) {
-            const ClassDesc cd = T->cls[i];
+            ClassDesc cd;                                                         // wave-uniform: into scalar registers
+            cd.nk = __builtin_amdgcn_readfirstlane(cd4.x);
+            cd.n_row_tiles = __builtin_amdgcn_readfirstlane(cd4.y);
+            cd.base16 = (uint32_t) __builtin_amdgcn_readfirstlane(cd4.z);
+            cd.first_group = __builtin_amdgcn_readfirstlane(cd4.w);
+            cd.paired = __builtin_amdgcn_readfirstlane(cdp);
+            if (i + 1 < n_classes) { cd4 = read_cd(i + 1); cdp = cls_lds[8 * (i + 1) + 4]; }      // the next class's, while this one runs
             const uint32_t off = cd.base16 * 16u;
             PfResume R{0, 0u, 0u};
             unsigned long long tc0 = 0;
@@ -721,19 +746,26 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         PassWords words = v < units_g ? fetch((v * K + g) * wave_passes) : PassWords{0u, 0u};
         while (v < units_g) {
             uint32_t next = 0xFFFFFFFFu;
-            if (dyn) {                                                            // asked for before this unit is scanned
-                unsigned int u = 0;
-                if (lane == 0) u = atomicAdd(word, 1u);
-                next = waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
-            }
+            // the next unit: asked for before this one is scanned, looked at in its last pass.  The instruction by name: hipcc's atomicAdd is
+            // followed at once by s_waitcnt vmcnt(0) (its wave-aggregated form broadcasts the result), which exposed the counter's round
+            // trip once per unit
+            unsigned int u = 0;
             const uint32_t uid = v * K + g;                                       // the unit: window starts [uid, uid + 1) * 64 * wave_passes
             const uint32_t p0 = uid * wave_passes;
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
                 if (lane < 12) stg[lane] = lane < 8 ? words.c : words.n;          // (the wave's LDS operations execute in order: no barrier)
+                // (behind the staging, which waits for every vector-memory operation in flight)
+                if (j == 0 && dyn && lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(u) : "v"(word), "v"(1u) : "memory");
                 // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
                 // flight while this pass is scanned
                 if (j + 1 < wave_passes) words = fetch(p0 + j + 1);
-                else if (next < units_g) words = fetch((next * K + g) * wave_passes);
+                else {
+                    if (dyn) {
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(u) : : "memory");     // (the compiler does not know the atomic is in flight)
+                        next = waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+                    }
+                    if (next < units_g) words = fetch((next * K + g) * wave_passes);
+                }
                 scan_pass((int64_t) (p0 + j) * 64);
             }
             v = next;
