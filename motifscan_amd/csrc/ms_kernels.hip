@@ -429,6 +429,49 @@ __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, i
     return __builtin_amdgcn_alignbit(stg[9 + i], stg[8 + i], r);
 }
 
+// The matrix work of a row tile of TWO blocks, by name (round 4).  The three 16-byte reads of the lane's two A operands -- planes
+// (0, 1) of block 0, (plane 2 of block 0, plane 0 of block 1), planes (1, 2) of block 1: `ds_read2st64_b64` pairs -- land in TWELVE
+// CONSECUTIVE registers, of which the first six are one operand and the last six the other.  hipcc cannot place two 6-register operands
+// on one run (its operands are separate 8-wide values) and moved four registers per row tile into place: 76 of a pass's ~940 vector
+// instructions (profiles/r04_isa_account.md).  Registers v[112:123] are this block's alone (clobbered); the waits are the compiler's
+// own pattern -- `lgkmcnt(1)` before the first operand's two reads are needed, `lgkmcnt(0)` before the second's, and the 11 wait
+// states the 8-pass instruction asks for before a vector instruction reads its result.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
+                                                  f32x16 &c0, f32x16 &c1) {
+    const int one = 127;
+    asm volatile("ds_read2st64_b64 v[112:115], %[pa] offset1:1\n\t"
+                 "ds_read2st64_b64 v[116:119], %[pa] offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b64 v[120:123], %[pa] offset0:4 offset1:5\n\t"
+                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_nop 10"
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one)
+                 : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+}
+// ... and of plain rows: accumulators from 0, both block scales 2^0
+__device__ __forceinline__ void plain_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
+    const int one = 127;
+    asm volatile("ds_read2st64_b64 v[112:115], %[pa] offset1:1\n\t"
+                 "ds_read2st64_b64 v[116:119], %[pa] offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b64 v[120:123], %[pa] offset0:4 offset1:5\n\t"
+                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0, %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0, %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_nop 10"
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s1] "v"(one)
+                 : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+}
+
 // All row tiles of one class of plain rows (NK k-blocks each).
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
@@ -491,9 +534,16 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }                          // measurement: the per-pass and per-class set-up alone
     int back = n_row_tiles;
-    for (int t = R.t; t < n_run; t++, p += kStep) {
+    [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;       // the row tile's LDS address
+    [[maybe_unused]] i32x4 bq[4];
+    if constexpr (NK == 2) {
+        bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
+        bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
+    }
+    for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        product(p, c0, c1);
+        if constexpr (NK == 2) plain_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], c0, c1);
+        else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }      // measurement: operand reads + products, no inspection
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
         if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
@@ -563,10 +613,17 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
     int back = n_row_tiles;                                                         // (one loop exit: see f6_class)
-    for (int t = R.t; t < n_run; t++, p += kStep) {
+    [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;       // the row tile's LDS address
+    [[maybe_unused]] i32x4 bq[4];
+    if constexpr (NK == 2) {
+        bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
+        bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
+    }
+    for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
         f32x16 c0, c1;
-        product(p, c0, c1);
+        if constexpr (NK == 2) pair_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
+        else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
         if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0)) {
