@@ -55,6 +55,13 @@ WORKLOAD_TEXT = {
 }
 
 
+def kernel_source_sha16():
+    """First 16 hex digits of the SHA-256 of the kernels' source: what a recorded PMC traffic figure is valid for."""
+    import hashlib
+    with open(os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def visible_gpus():
     """Devices this process could use, WITHOUT initialising the GPU (on this image torch.cuda.device_count() only reads the
     driver's device list; no context is created, so starting child ranks afterwards stays legal)."""
@@ -383,12 +390,14 @@ def main():
         achieved = alg_bytes / (pf_ms * 1e-3)
         # HBM bytes per launch from a recorded PMC pass (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes: profiles/): only
         # an entry recorded for THIS kernel on THIS workload and configuration counts, anything else prints null
+        # (tools/pmc_traffic_update.py writes the entry "<workload>_current" from the evidence pass's FETCH_SIZE / WRITE_SIZE summaries together
+        # with a hash of the kernel source it was taken on: a kernel changed since then prints null, not a stale number)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile) and not side:
             try:
-                ent = json.load(open(tfile)).get(a.workload + "_r03", {})
-                if PF_KERNEL in ent.get("kernel", ""):
+                ent = json.load(open(tfile)).get(a.workload + "_current", {})
+                if PF_KERNEL in ent.get("kernel", "") and ent.get("kernel_source_sha16") == kernel_source_sha16():
                     traffic = ent.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
