@@ -117,6 +117,9 @@ class RegionSites(Sequence):
     def __repr__(self):
         return f"<RegionSites motif {self._m}: {self._hi - self._lo} sites in {self._p.n_regions} regions>"
 
+    def __reduce__(self):
+        return (list, (list(self),))
+
     # ---- without per-site objects ----
     @property
     def n_sites(self):
@@ -210,3 +213,8 @@ class MotifSites(Sequence):
     def to_lists(self):
         """The reference's eager form: real nested lists (n_pwms x n_regions list objects)."""
         return [list(v) for v in self]
+
+    def __reduce__(self):
+        """Pickles (multiprocessing, caches) as what the reference returns: plain nested lists -- the view itself sits on library-owned
+        pinned memory that does not travel."""
+        return (list, (self.to_lists(),))

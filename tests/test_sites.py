@@ -87,6 +87,10 @@ def test_the_writers_and_the_statistics_read_it_like_lists():
     # an item read twice in a row is one list (the writer reads len() then max()); a caller that edits it sees its own edit, like a list
     first = ms[2][eager[2].index(next(x for x in eager[2] if x))]
     assert first and ms[2][eager[2].index(first)] is first
+    # it pickles as what the reference returns: plain nested lists
+    import pickle
+    back = pickle.loads(pickle.dumps(ms))
+    assert type(back) is list and back == eager and pickle.loads(pickle.dumps(ms[3])) == eager[3]
 
 
 def test_nothing_of_size_pwms_x_regions_is_built_up_front():
