@@ -1939,8 +1939,8 @@ int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *
         const uint8_t *tab = bytes + gi.tab_off;
         // column c of the field: plain rows -- column c % 16 of k-block c / 16; paired rows -- column c % 8 of half-block c / 8 in k-half `sel`
         auto entry = [&](int row, int c, int b) {
-            return gi.paired ? f6_value(f6_get(tab, c / kPairCols, row, kPairCols * gi.sel + c % kPairCols, b))
-                             : f6_value(f6_get(tab, c / kF6Cols, row, c % kF6Cols, b));
+            return gi.paired ? f6_value(f6_get(tab, gi.nk, c / kPairCols, row, kPairCols * gi.sel + c % kPairCols, b))
+                             : f6_value(f6_get(tab, gi.nk, c / kF6Cols, row, c % kF6Cols, b));
         };
         if (group_kb) group_kb[q] = gi.nk;
         if (group_cols) group_cols[q] = n_cols;

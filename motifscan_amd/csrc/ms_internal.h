@@ -190,27 +190,33 @@ inline bool pair_bias_entries(int total, int u[4]) {
         }
     return false;
 }
-inline size_t f6_bit_index(int kb, int row, int col_in_kb, int base, int *bit_in_lane) {   // byte offset of the lane's plane 0 word inside a row tile
-    const int khalf = col_in_kb >> 3;
-    *bit_in_lane = 6 * ((col_in_kb & 7) * 4 + base);
-    return (size_t) kb * kF6BytesPerKb + (size_t) (khalf * 32 + row) * 8;
+// Byte offset, inside a row tile of nk blocks, of plane `plane` (0 ... 2) of the 8-byte word that `lane` reads for block kb.  Tiles of one
+// block (and of 3 or 4) are plane-major -- [block][plane][lane]: a lane's three words lie 512 bytes apart --, tiles of TWO blocks
+// lane-major, 48 bytes per lane (the lane's three words of block 0, then of block 1): the kernel reads them with three 16-byte
+// reads at the LDS array's full rate (ds_read_b128: 4 cycles; the strided pair read ds_read2st64_b64 takes 8 for the same bytes).
+inline size_t f6_word_off(int nk, int kb, int lane, int plane) {
+    return nk == 2 ? (size_t) lane * 48 + (size_t) (kb * 3 + plane) * 8 : (size_t) kb * kF6BytesPerKb + (size_t) plane * 512 + (size_t) lane * 8;
 }
-inline void f6_put(uint8_t *tile, int kb, int row, int col_in_kb, int base, uint32_t code) {
-    int bit;
-    const size_t lane_off = f6_bit_index(kb, row, col_in_kb, base, &bit);
+inline int f6_bit_index(int row, int col_in_kb, int base, int *lane) {                      // bit of the code's LSB inside the lane's 192 bits of the block
+    *lane = (col_in_kb >> 3) * 32 + row;
+    return 6 * ((col_in_kb & 7) * 4 + base);
+}
+inline void f6_put(uint8_t *tile, int nk, int kb, int row, int col_in_kb, int base, uint32_t code) {
+    int lane;
+    const int bit = f6_bit_index(row, col_in_kb, base, &lane);
     for (int i = 0; i < 6; i++) {
         const int bb = bit + i;                 // plane bb / 64, bit bb % 64 of that plane's 8-byte word
-        uint8_t *byte = tile + lane_off + (size_t) (bb >> 6) * 512 + (size_t) ((bb & 63) >> 3);
+        uint8_t *byte = tile + f6_word_off(nk, kb, lane, bb >> 6) + (size_t) ((bb & 63) >> 3);
         if ((code >> i) & 1u) *byte |= (uint8_t) (1u << (bb & 7)); else *byte &= (uint8_t) ~(1u << (bb & 7));
     }
 }
-inline uint32_t f6_get(const uint8_t *tile, int kb, int row, int col_in_kb, int base) {
-    int bit;
-    const size_t lane_off = f6_bit_index(kb, row, col_in_kb, base, &bit);
+inline uint32_t f6_get(const uint8_t *tile, int nk, int kb, int row, int col_in_kb, int base) {
+    int lane;
+    const int bit = f6_bit_index(row, col_in_kb, base, &lane);
     uint32_t code = 0;
     for (int i = 0; i < 6; i++) {
         const int bb = bit + i;
-        const uint8_t byte = tile[lane_off + (size_t) (bb >> 6) * 512 + (size_t) ((bb & 63) >> 3)];
+        const uint8_t byte = tile[f6_word_off(nk, kb, lane, bb >> 6) + (size_t) ((bb & 63) >> 3)];
         code |= (uint32_t) ((byte >> (bb & 7)) & 1u) << i;
     }
     return code;

@@ -429,20 +429,23 @@ __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, i
     return __builtin_amdgcn_alignbit(stg[9 + i], stg[8 + i], r);
 }
 
-// The matrix work of a row tile of TWO blocks, by name (round 4).  The three 16-byte reads of the lane's two A operands -- planes
-// (0, 1) of block 0, (plane 2 of block 0, plane 0 of block 1), planes (1, 2) of block 1: `ds_read2st64_b64` pairs -- land in TWELVE
-// CONSECUTIVE registers, of which the first six are one operand and the last six the other.  hipcc cannot place two 6-register operands
-// on one run (its operands are separate 8-wide values) and moved four registers per row tile into place: 76 of a pass's ~940 vector
-// instructions (profiles/r04_isa_account.md).  Registers v[112:123] are this block's alone (clobbered); the waits are the compiler's
-// own pattern -- `lgkmcnt(1)` before the first operand's two reads are needed, `lgkmcnt(0)` before the second's, and the 11 wait
-// states the 8-pass instruction asks for before a vector instruction reads its result.
+// The matrix work of a row tile of TWO blocks, by name (round 4).  Such a tile lies in LDS lane-major, 48 bytes per lane (ms_internal.h,
+// f6_word_off): three 16-byte reads land in TWELVE CONSECUTIVE registers, of which the first six are the block-0 operand and the last
+// six the block-1 operand.  hipcc cannot place two 6-register operands on one run (its operands are separate 8-wide values) and moved
+// four registers per row tile into place: 76 of a pass's ~940 vector instructions (profiles/r04_isa_account.md).  The reads are
+// ds_read_b128 because the LDS array is this kernel's second-busiest unit (SQ_LDS_IDX_ACTIVE ~70 % of the CU's cycles): the same 48
+// bytes per lane as three strided pair reads (ds_read2st64_b64 on a plane-major tile) take the array 24 cycles instead of 12 -- 16.5-16.6
+// against 17.0 ms per 500 Mbase on one box, six ds_read_b64 16.8 (profiles/r04d_a_reads_ab.log).  Registers v[112:123] are this block's
+// alone (clobbered); the waits are the compiler's own pattern -- `lgkmcnt(1)` before the first operand is needed (its six registers are
+// the first two reads'), `lgkmcnt(0)` before the second's, and the 11 wait states the 8-pass instruction asks for before a vector
+// instruction reads its result.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
                                                   f32x16 &c0, f32x16 &c1) {
     const int one = 127;
-    asm volatile("ds_read2st64_b64 v[112:115], %[pa] offset1:1\n\t"
-                 "ds_read2st64_b64 v[116:119], %[pa] offset0:2 offset1:3\n\t"
-                 "ds_read2st64_b64 v[120:123], %[pa] offset0:4 offset1:5\n\t"
+    asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
+                 "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
                  "s_waitcnt lgkmcnt(1)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
@@ -457,9 +460,9 @@ __device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00,
 // ... and of plain rows: accumulators from 0, both block scales 2^0
 __device__ __forceinline__ void plain_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
     const int one = 127;
-    asm volatile("ds_read2st64_b64 v[112:115], %[pa] offset1:1\n\t"
-                 "ds_read2st64_b64 v[116:119], %[pa] offset0:2 offset1:3\n\t"
-                 "ds_read2st64_b64 v[120:123], %[pa] offset0:4 offset1:5\n\t"
+    asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
+                 "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
                  "s_waitcnt lgkmcnt(1)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0, %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0, %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
@@ -483,7 +486,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     // R.t: the row tile to start at; the class returns early, with the row tile to come back to in R, when the wave's parking space
     // runs low or full (the caller has the parked entries decoded -- ONE call site for all classes -- and comes back)
     constexpr int kStep = NK * kF6BytesPerKb;
-    const char *p = lds + byte_off + lane * 8u + (uint32_t) R.t * (uint32_t) kStep;
+    const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;
     constexpr int NW = NK > 2 ? 3 : 2;
     uint64_t cw[NW];
     cw[0] = Q.cw[0];
@@ -565,7 +568,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
                                               int64_t pass0, bool live0, bool live1, PfResume &R) {
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     constexpr int kStep = NK * kF6BytesPerKb;
-    const char *p = lds + byte_off + lane * 8u + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
+    const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
     // B operands: half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
     i32x8 b0[NK], b1[NK];
 #pragma unroll

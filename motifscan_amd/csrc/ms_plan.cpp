@@ -267,8 +267,8 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                         if (c == n_cols - 1) u = rt.paired ? pb[b] : (fs ? fs->bias : -1);
                         else if (fs && c < fast[j].W) u = fs->u[c][b];
                         // plain: column c of k-block c / 16; paired: column c % 8 of half-block c / 8, in k-half `sel`
-                        if (rt.paired) f6_put(tab, c / kPairCols, row, kPairCols * sel + c % kPairCols, b, f6_code(u));
-                        else f6_put(tab, c / kF6Cols, row, c % kF6Cols, b, f6_code(u));
+                        if (rt.paired) f6_put(tab, rt.nk, c / kPairCols, row, kPairCols * sel + c % kPairCols, b, f6_code(u));
+                        else f6_put(tab, rt.nk, c / kF6Cols, row, c % kF6Cols, b, f6_code(u));
                     }
                 if (fs) plan->group_fields[grp * kGroupFields + n] = fast[j].id;
             }

@@ -163,7 +163,7 @@ static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, 
     const int trips = 40000;
     printf("%-52s\n", what);
     struct Cfg { int blocks, threads; const char *name; } cfgs[] = {
-        {256, 512, "2 waves/SIMD"}, {256, 1024, "4 waves/SIMD"}, {512, 512, "2 x 512 per CU (4 waves/SIMD)"}};
+        {256, 512, "2 waves/SIMD"}, {256, 768, "3 waves/SIMD"}, {256, 1024, "4 waves/SIMD"}, {512, 512, "2 x 512 per CU (4 waves/SIMD)"}};
     for (const Cfg &c : cfgs) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -184,7 +184,7 @@ static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, 
         double mhz = 0; int n = 0;
         for (int b = 0; b < c.blocks; b++) if (h[2 * b + 1]) { mhz += 100.0 * (double) h[2 * b] / (double) h[2 * b + 1]; n++; }
         mhz /= n ? n : 1;
-        const int wps = c.blocks * c.threads / 64 / 1024;
+        const double wps = (double) c.blocks * c.threads / 64 / 1024;
         const double cyc = ms * 1e-3 * mhz * 1e6 / ((double) trips * wps);
         printf("    %-32s %8.3f ms  clock %6.0f MHz  %6.1f cycles per row tile per SIMD\n", c.name, ms, mhz, cyc);
     }
