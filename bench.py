@@ -542,6 +542,30 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
             return n
         return run
 
+    # the same batches as ONE stream kept full over `reps` consecutive passes (a sweep over many region sets, configs[4]'s shape: the
+    # ramp of small batches only at the very beginning and the very end, full-size batches in between): what a pass costs when its
+    # first upload and last copy-out overlap the neighbouring passes' work
+    def sustained_batches(reps):
+        out = []
+        for rep in range(reps):
+            for k, (bases, offsets) in enumerate(wl["sets"]):
+                for r0, r1 in msdist.batch_bounds(len(offsets) - 1, a.batch_regions, ramp=not a.no_batch_ramp, max_batch=a.max_batch_regions,
+                                                  ramp_up=rep == 0 and k == 0, ramp_down=rep == reps - 1 and k == n_sets - 1):
+                    lo, hi = int(offsets[r0]), int(offsets[r1])
+                    out.append((pins[k].array[lo:hi], np.ascontiguousarray(offsets[r0:r1 + 1] - lo)))
+        return out
+
+    def sustained(reps):
+        bl = sustained_batches(reps)
+
+        def run():
+            n = 0
+            for res in _lib.scan_stream(pw, iter(bl), strand_mask, 0, depth=2, packed=True):
+                n += res.n_hits
+                res.close()
+            return n
+        return run
+
     def serial():
         n = 0
         for b, o in batches:
@@ -556,16 +580,23 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     v_p16, ms_p16, hits = timed(pipelined(True), passes)
     v_p25, ms_p25, _ = timed(pipelined(False), passes)
     v_s, ms_s, _ = timed(serial, passes)
+    reps = 4
+    v_su, ms_su, hits_su = timed(sustained(reps), 1)
+    v_su, ms_su = v_su * reps, ms_su / reps                     # timed() counts one call as one pass; the call holds `reps` of them
     for pin in pins:
         pin.close()
-    return {"pipelined": v_p16, "pipelined_25B": v_p25, "serial": v_s, "unit": "bp*motifs/s",
-            "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s},
+    return {"pipelined": v_p16, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
+            "ms_per_pass": {"pipelined": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
+            "sustained_passes_per_stream": reps, "sustained_hits_check": bool(hits_su == hits * reps),
             "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "max_batch_regions": a.max_batch_regions, "batch_sizes": [int(len(o) - 1) for _, o in batches], "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
             "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
             "cu_partition": "off: the copy / pack kernels share the device with the scan (CU masks -- 1 CU of every 32 for the copy streams -- exist behind MS_MEASURE=1 MS_CU_PARTITION=1 and measured slower end to end, profiles/r02_cu_partition_ab.log)",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "
                           "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 16 bytes per hit "
-                          "(coord word + fp64 score), 'pipelined_25B' the four plain arrays, 'serial' runs the stages of one batch after another"}
+                          "(coord word + fp64 score), 'pipelined_25B' the four plain arrays, 'serial' runs the stages of one batch after another; "
+                          "'pipelined' opens and drains a stream for every pass (one pass = the job), 'pipelined_sustained' keeps ONE stream full over "
+                          "several consecutive passes and divides by their number (a sweep over many region sets: the per-pass rate once the first "
+                          "upload and the last copy-out overlap the neighbouring passes)"}
 
 
 def main_sweep(a, world, rank, local_rank):

@@ -653,6 +653,7 @@ def test_bench_world_of_eight_on_one_gpu():
     assert line["allreduce_ms"] >= 0 and len(rk["allreduce_ms_mean_by_rank"]) == 8
     e2e = line["value_end_to_end"]
     assert e2e["pipelined"] > 0 and e2e["hits_per_pass_per_gpu"] > 0
+    assert e2e["pipelined_sustained"] > 0 and e2e["sustained_hits_check"] is True      # one stream over four passes: four times the hits
 
 
 def test_bench_sweep_world_of_eight_on_one_gpu():

@@ -49,6 +49,27 @@ __global__ void __launch_bounds__(1024) probe(int trips, int n_active, int sprea
     if (lane == 0) { clk[2 * (blockIdx.x * 16 + wave)] = t1 - t0; clk[2 * (blockIdx.x * 16 + wave) + 1] = r1 - r0; }
 }
 
+// the same event through VECTOR-MEMORY stores into a per-wave ring in global memory (L2-resident: 3.6 KB per wave): 4 x global_store_dwordx4
+// + 1 x global_store_dwordx2 under the mask; every 48th event the wave waits for its stores (s_waitcnt vmcnt(0)) as a flush would
+__global__ void __launch_bounds__(1024) vprobe(int trips, int n_active, int spread, u32x4 *ring, unsigned long long *clk) {
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool on = spread ? (lane % (64 / n_active) == 0) : ((int) lane < n_active);
+    u32x4 *mine = ring + ((size_t) (blockIdx.x * 16 + wave) * 48) * 5;          // 48 entries of 80 bytes per wave
+    u32x4 v = {lane, wave, lane * 3u, 7u};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (on) {
+        for (int t = 0; t < trips; t++) {
+            u32x4 *e = mine + (size_t) ((t % 48) * 5);                            // one entry per event (the lanes of an event share it here:
+            asm volatile("" : "+v"(v));                                          //  the address pattern is not the question, the issue cost is)
+            e[0] = v; e[1] = v; e[2] = v; e[3] = v;
+            *reinterpret_cast<u32x2 *>(e + 4) = u32x2{v.x, v.y};
+            if (t % 48 == 47) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) { clk[2 * (blockIdx.x * 16 + wave)] = t1 - t0; clk[2 * (blockIdx.x * 16 + wave) + 1] = 0; }
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     unsigned int *d_sink; unsigned long long *d_clk;
@@ -72,6 +93,24 @@ int main() {
                 cyc /= cnt;
                 // all 16 waves of the CU run the loop side by side: the CU completes 16 events in (cyc / trips) cycles
                 printf("    %2d active lanes (%s): %7.1f cycles per event and wave = %6.1f cycles of the CU's LDS pipe per event\n",
+                       n, spread ? "spread over the wave" : "the first lanes    ", cyc / trips, cyc / trips / 16.0);
+            }
+    }
+    {
+        u32x4 *d_ring;
+        CK(hipMalloc(&d_ring, (size_t) 256 * 16 * 48 * 80));
+        printf("global_store: 4 x dwordx4 + 1 x dwordx2 per event into a per-wave ring, 16 waves per CU, 256 CUs\n");
+        for (int spread = 0; spread < 2; spread++)
+            for (int n : {1, 2, 4, 16, 64}) {
+                if (spread && n == 64) continue;
+                for (int w = 0; w < 2; w++) hipLaunchKernelGGL(vprobe, dim3(256), dim3(1024), 0, 0, trips, n, spread, d_ring, d_clk);
+                CK(hipDeviceSynchronize());
+                std::vector<unsigned long long> h(256 * 16 * 2);
+                CK(hipMemcpy(h.data(), d_clk, h.size() * 8, hipMemcpyDeviceToHost));
+                double cyc = 0;
+                for (int i = 0; i < 256 * 16; i++) cyc += (double) h[2 * i];
+                cyc /= 256 * 16;
+                printf("    %2d active lanes (%s): %7.1f cycles per event and wave = %6.1f cycles of the CU per event\n",
                        n, spread ? "spread over the wave" : "the first lanes    ", cyc / trips, cyc / trips / 16.0);
             }
     }
