@@ -29,7 +29,7 @@ $T python tools/pf_account.py 1e-3 2>&1 | grep -v amdgpu.ids >> $OUT/pf_account.
 $T python tools/pf_class_clock.py 3 1e-4 2>&1 | grep -v amdgpu.ids > $OUT/class_clock.log
 $T python tools/e2e_bounds.py 2>&1 | grep -v amdgpu.ids > $OUT/e2e_bounds.log
 for i in 1 2; do
-if [ -d tools/ab/r04base ]; then (cd tools/ab/r04base && $T python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/round 3's final kernels (db17ac6): /") >> $OUT/full_size_stage_times.log; fi
+if [ -d tools/ab/r04base ]; then (cd tools/ab/r04base && $T python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/before the lane-major A tiles (ae3f7da..HEAD~3, 1bcced0d3ba556ed): /") >> $OUT/full_size_stage_times.log; fi
 $T python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/this build: /" >> $OUT/full_size_stage_times.log
 done
 $T python tools/ab_full.py 1 1e-4 2>&1 | grep Mbase >> $OUT/full_size_stage_times.log

@@ -158,6 +158,72 @@ __global__ void __launch_bounds__(1024) twice_kernel(const i32x8 *ab, int trips,
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// modes 10 / 11: the kernel's by-name row tile of two half-blocks (three ds_read_b128 on a lane-major tile, four matrix instructions,
+// the compiler's inspection) -- 10 as the kernel has it, 11 with the NEXT row tile's three reads issued right behind this one's matrix
+// instructions, into the same twelve registers (the reads' latency then lies under the inspection instead of in front of the next products)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <bool PREFETCH>
+__global__ void __launch_bounds__(1024) asm_kernel(const i32x8 *ab, int trips, unsigned int *sink, unsigned long long *clk) {
+    __shared__ unsigned long long tab[17 * 2 * 3 * 64];
+    for (int i = threadIdx.x; i < 17 * 2 * 3 * 64; i += blockDim.x) {
+        const i32x8 v = ab[i & 63];
+        const int pl = (i >> 6) % 3;
+        tab[i] = ((unsigned long long) (unsigned int) v[2 * pl + 1] << 32) | (unsigned int) v[2 * pl];
+    }
+    __syncthreads();
+    const unsigned int lane = threadIdx.x & 63;
+    const i32x8 b0 = ab[64 + lane], b1 = ab[128 + lane], b2 = ab[256 + lane], b3 = ab[320 + lane];
+    i32x4 bq0 = {b0[0], b0[1], b0[2], b0[3]}, bq1 = {b1[0], b1[1], b1[2], b1[3]}, bq2 = {b2[0], b2[1], b2[2], b2[3]}, bq3 = {b3[0], b3[1], b3[2], b3[3]};
+    const int scale0 = lane < 32 ? 121 : 109, scale1 = scale0 - 1, one = 127;
+    const unsigned int base = (unsigned int) (uintptr_t) (__attribute__((address_space(3))) const char *) tab + lane * 48u;
+    unsigned int found = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (PREFETCH)
+        asm volatile("ds_read_b128 v[112:115], %0\n\tds_read_b128 v[116:119], %0 offset:16\n\tds_read_b128 v[120:123], %0 offset:32" : : "v"(base)
+                     : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+    for (int t = 0; t < trips; t++) {
+        asm volatile("" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3));
+        const unsigned int pa = base + (unsigned int) (t & 15) * 3072u, pn = base + (unsigned int) ((t + 1) & 15) * 3072u;
+        f32x16 c0, c1;
+        if constexpr (!PREFETCH)
+            asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
+                         "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
+                         "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
+                         "s_waitcnt lgkmcnt(1)\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "s_nop 10"
+                         : [c0] "=&v"(c0), [c1] "=&v"(c1)
+                         : [pa] "v"(pa), [b00] "v"(bq0), [b10] "v"(bq1), [b01] "v"(bq2), [b11] "v"(bq3), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one)
+                         : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(1)\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                         "ds_read_b128 v[112:115], %[pn]\n\t"
+                         "ds_read_b128 v[116:119], %[pn] offset:16\n\t"
+                         "ds_read_b128 v[120:123], %[pn] offset:32\n\t"
+                         "s_nop 7"
+                         : [c0] "=&v"(c0), [c1] "=&v"(c1)
+                         : [pn] "v"(pn), [b00] "v"(bq0), [b10] "v"(bq1), [b01] "v"(bq2), [b11] "v"(bq3), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one)
+                         : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+        unsigned int x = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) x = __builtin_amdgcn_bitop3_b32(x, (unsigned int) __float_as_int(c0[i]), (unsigned int) __float_as_int(c1[i]), 0xFE);
+        if (__builtin_expect(__any((x & kHitMask) != 0u), 0)) found += x;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (found == 0x12345u) sink[0] = found;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int MODE>
 static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, unsigned long long *d_clk) {
     const int trips = 40000;
@@ -170,6 +236,8 @@ static void run_cost(const char *what, const i32x8 *d_ab, unsigned int *d_sink, 
         auto launch = [&]() {
             if constexpr (MODE == 8) hipLaunchKernelGGL((twice_kernel<2>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips / 2, d_sink, d_clk);
             else if constexpr (MODE == 9) hipLaunchKernelGGL((twice_kernel<1>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips / 2, d_sink, d_clk);
+            else if constexpr (MODE == 10) hipLaunchKernelGGL((asm_kernel<false>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
+            else if constexpr (MODE == 11) hipLaunchKernelGGL((asm_kernel<true>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
             else hipLaunchKernelGGL((cost_kernel<MODE>), dim3(c.blocks), dim3(c.threads), 0, 0, d_ab, trips, d_sink, d_clk);
         };
         for (int w = 0; w < 3; w++) launch();
@@ -295,5 +363,7 @@ int main() {
     run_cost<7>("mode 7: mode 3 with the A operands read from LDS each trip", d_ab, d_sink, d_clk);
     run_cost<8>("mode 8: mode 6, one A read for TWO 64-window halves (per 64 windows)", d_ab, d_sink, d_clk);
     run_cost<9>("mode 9: mode 5, one A read for TWO 64-window halves (per 64 windows)", d_ab, d_sink, d_clk);
+    run_cost<10>("mode 10: the kernel's by-name row tile (lane-major tile, 3 x ds_read_b128, 4 MFMA), OR chain", d_ab, d_sink, d_clk);
+    run_cost<11>("mode 11: mode 10 with the NEXT row tile's reads issued behind this one's MFMAs (same 12 registers)", d_ab, d_sink, d_clk);
     return 0;
 }
