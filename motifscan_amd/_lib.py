@@ -283,11 +283,19 @@ class SeqSet:
     def from_strings(cls, seqs, keep_ascii=False):
         seqs = seqs if isinstance(seqs, (list, tuple)) else list(seqs)
         offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
-        try:                                      # ONE join + ONE encode (plain-ASCII strings: a base is a byte)
-            raw = "".join(seqs).encode("ascii")
+        try:
+            lens = np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs))
             if seqs:
-                np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)), out=offsets[1:])
-        except (TypeError, UnicodeEncodeError):   # bytes among them, or non-ASCII text (every such byte scores as 'N', cscore.c:92-111)
+                np.cumsum(lens, out=offsets[1:])
+            if seqs and lens[0] > 0 and (lens == lens[0]).all():
+                # regions of ONE length (the reference's fixed window around the summit, scanner.py:70-79): numpy encodes the list into one
+                # fixed-width byte matrix in a single C loop -- 2.6x faster than join + encode for 100 000 x 1 kb
+                raw = np.array(seqs, dtype="S%d" % int(lens[0])).view(np.uint8).reshape(-1)
+                if raw.size != int(offsets[-1]):
+                    raise TypeError("not a flat list of strings")
+            else:                                 # ONE join + ONE encode (plain-ASCII strings: a base is a byte)
+                raw = "".join(seqs).encode("ascii")
+        except (TypeError, ValueError, UnicodeEncodeError):   # bytes among them, or non-ASCII text (every such byte scores as 'N', cscore.c:92-111)
             bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in seqs]
             if bs:
                 offsets[1:] = np.cumsum([len(b) for b in bs])

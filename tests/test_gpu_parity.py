@@ -483,6 +483,31 @@ def test_pwm_with_minus_inf_entries_vs_oracle(oracle):
     assert np.array_equal(np.array(sc_g), np.array(sc_w), equal_nan=True)
 
 
+def test_seqset_from_strings_every_input_form_vs_oracle(oracle):
+    """SeqSet.from_strings: regions of one length take the fixed-width numpy path, ragged lists the join, bytes / non-ASCII text the
+    per-item path -- all three hold the same bases (lower case, N, other IUPAC letters, a NUL byte, a non-ASCII letter all score as the
+    reference's convert_seq has them, cscore.c:81-114) and give the oracle's hits."""
+    rng = np.random.default_rng(31)
+    mats = [rng.normal(size=(4, w)) for w in (6, 11, 19)]
+    ml = [m.tolist() for m in mats]
+    cuts = [0.4] * len(mats)
+    equal = ["".join(rng.choice(list("ACGTacgtNRY"), size=120)) for _ in range(40)]
+    equal[3] = equal[3][:50] + "\0" + equal[3][51:]
+    for seqs in (equal, equal + ["ACGT" * 10, ""], [s.encode() for s in equal], equal[:5] + [equal[5][:60] + "\u00c4" + equal[5][61:]]):
+        as_text = [s.decode() if isinstance(s, bytes) else s for s in seqs]
+        want = oracle.c_scan_motif(ml, cuts, as_text, 3, 4)
+        pw = _lib.PwmSet.from_matrices(mats, cuts)
+        sq = _lib.SeqSet.from_strings(seqs)
+        want_bytes = b"".join(s.encode("utf-8") for s in as_text)
+        assert sq.n_bases == len(want_bytes) and sq.n_seqs == len(seqs)
+        h = _lib.scan(pw, sq, 3).hits()
+        got = [[] for _ in mats]
+        for m, r, p_, sc, st in zip(h["motif"], h["seq_idx"], h["pos"], h["score"], h["strand"]):
+            got[int(m)].append((int(r), int(p_), float(sc), int(st)))
+        flat_want = [[tuple(x) for x in per] for per in want]
+        assert [[(a, b, c, d) for a, b, c, d in per] for per in got] == [[(int(a), int(b), float(c), int(d)) for a, b, c, d in per] for per in flat_want]
+
+
 def test_integration_stub_of_the_reference_side_binding(oracle, small, tmp_path):
     """INTEGRATION.md section 1 is the module a MotifScan maintainer would add as motifscan/motif/cscore_amd.py (replacing the
     import at scanner.py:12 / cli/motif.py:24).  The text of that code block is extracted, written out and EXECUTED here: the
