@@ -510,6 +510,15 @@ def test_host_streamed_multi_chromosome_sweep_equals_oracle(oracle, jaspar579, w
     # a rank's share of the spans: contiguous, complete, disjoint
     shares = [dist.span_shard(spans, r, 3) for r in range(3)]
     assert sum(shares, []) == spans and all(shares)
+    # a sweep that stopped after k spans is resumed from span k (the span list is a pure function of the chromosome lengths, a span's
+    # result carries its first window): the two runs' parts together are the whole sweep, in a fresh stream and a fresh PWM handle
+    k = len(spans) // 2
+    parts3 = list(parts[:k])
+    pw2 = _lib.PwmSet(vals, widths, cutoffs)
+    for sp, res in _lib.sweep_stream(pw2, chroms, window, stride, max_span, 3, spans=spans[k:]):
+        parts3.append((res.hits(), sp[3]))
+        res.close()
+    assert_same_hits(_lib.merge_hits(parts3, len(widths)), want)
 
 
 def test_sweep_hands_out_more_than_2_to_the_32_sites_arithmetic():
