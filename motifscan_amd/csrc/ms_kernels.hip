@@ -318,7 +318,7 @@ __device__ __forceinline__ bool rare_park2(MfWave &W, PfResume &R, const f32x16 
 // profiles/r03zz_class_clock.log put the hand-off at ~5.7 k of a wave's ~24.5 k cycles per 64-window pass, ~600 cycles per event,
 // most of it the dozen taken branches and scalar bookkeeping of the resumable form.
 __device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &c0, const f32x16 &c1, bool hit0, bool hit1, int64_t g0,
-                                          int32_t group, uint32_t paired) {
+                                          int32_t group, uint32_t paired, bool no_stores = false) {      // no_stores: measurement only (MS_PF_NOEMIT=5)
     const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
     const uint32_t n0 = (uint32_t) __popcll(m0), n1 = (uint32_t) __popcll(m1);
     if (__builtin_expect((R.op | R.skip) != 0u || W.rq_n + n0 + n1 > W.rq_cap, 0))
@@ -326,13 +326,13 @@ __device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &
     const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, 0u));
     const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, n0));
     const uint32_t hi = (uint32_t) ((uint64_t) g0 >> 32) | ((uint32_t) group << 8) | (paired << 31);     // (g0 + 32 never carries into bit 32: g0 < 2^34 is a multiple-of-64 base plus lane & 31)
-    if (hit0) {
+    if (hit0 && !no_stores) {
         uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank0) * (uint32_t) kRareEntryWords);
 #pragma unroll
         for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c0[4 * j]), __float_as_uint(c0[4 * j + 1]), __float_as_uint(c0[4 * j + 2]), __float_as_uint(c0[4 * j + 3]));
         *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g0, hi);
     }
-    if (hit1) {
+    if (hit1 && !no_stores) {
         uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank1) * (uint32_t) kRareEntryWords);
 #pragma unroll
         for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c1[4 * j]), __float_as_uint(c1[4 * j + 1]), __float_as_uint(c1[4 * j + 2]), __float_as_uint(c1[4 * j + 3]));
@@ -549,9 +549,11 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }      // measurement: operand reads + products, no inspection
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit), 0)) {
+        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
             // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
-            const bool full = park_both(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u);
+            const bool full = park_both(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u,
+                                        MEAS && A.no_emit == 5);
+            if constexpr (MEAS) { if (A.no_emit >= 4) W.rq_n = 0; }              // measurement: the events run, their entries are dropped (4), nor stored at all (5): no decode
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }
@@ -629,10 +631,11 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
-        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit), 0)) {
+        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
             // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
             const bool full = park_both(W, R, c0, c1, live0 && (x0 & kPairMask) != 0u, live1 && (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
-                                        first_group + 4 * t + 2 * (int32_t) h, 1u);
+                                        first_group + 4 * t + 2 * (int32_t) h, 1u, MEAS && A.no_emit == 5);
+            if constexpr (MEAS) { if (A.no_emit >= 4) W.rq_n = 0; }
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }

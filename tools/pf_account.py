@@ -2,6 +2,7 @@
 """Where the pre-filter's time goes, by subtraction (measurement instantiation of the kernel, MS_MEASURE=1):
     MS_PF_NOEMIT=0  the product's work                                   MS_PF_NOEMIT=1  no candidate hand-off (events skipped)
     MS_PF_NOEMIT=3  operand reads + matrix instructions, no inspection   MS_PF_NOEMIT=2  per-pass / per-class set-up only (no row tiles)
+    MS_PF_NOEMIT=4  events run and park, the entries are dropped (no decode)   MS_PF_NOEMIT=5  ... and not stored either (the events' control code alone)
 each with the kernel's own clock stamps (cycles per wave and 64-window pass).  Usage (GPU box): python tools/pf_account.py [p-value] [full]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +17,7 @@ sq = _lib.SeqSet(*wl["sets"][0])
 os.environ["MS_MEASURE"] = "1"
 os.environ["MS_PF_CLOCK"] = "1"
 passes_per_wave = sq.n_bases / 64 / 4096
-for mode, what in ((0, "product work"), (1, "no hand-off"), (3, "reads + matrix instructions only"), (2, "set-up only"), (0, "product work (again)")):
+for mode, what in ((0, "product work"), (4, "events park, nothing decoded"), (5, "events without their stores"), (1, "no hand-off"), (3, "reads + matrix instructions only"), (2, "set-up only"), (0, "product work (again)")):
     os.environ["MS_PF_NOEMIT"] = str(mode)
     best = None
     for _ in range(6):
