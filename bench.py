@@ -376,6 +376,12 @@ def main():
                                           "ranks_identical_to_oracle": int(tab[:, 4].sum()), "ranks": world,
                                           "checker": "oracle/cscore_oracle.c (liboracle.so), first regions of every rank's own shard"}}
 
+    # ---- the drop-in at the Python API (before the streamed legs: they leave the library's block pools holding a few dozen GB-sized
+    # blocks, and the first small scan behind them once paid a 40 ms driver call for that: r04f_bench_c4.json against r04e_) ----
+    api = None
+    if rank == 0 and world == 1 and not a.no_api and not side:
+        api = api_leg()
+
     # ---- SURVEY.md 8(d) end-to-end: host ASCII (pinned) -> hit arrays in pinned host memory, through the batch stream ----
     e2e = None
     if not a.no_end_to_end:
@@ -456,8 +462,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline and wl["sets"] and not side:
             line["cpu_baseline"], sample = cpu_baseline(wl)
             line["parity_sample"] = parity_sample(wl, pw, sample)
-        if world == 1 and not a.no_api and not side:
-            line["value_api"] = api_leg()
+        if api is not None:
+            line["value_api"] = api
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
