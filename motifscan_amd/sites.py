@@ -12,7 +12,9 @@ motif, region, position, '+' before '-'; `motif_offsets[P+1]`), and builds a reg
 that region is indexed:
 
     MotifSites[m]            -> RegionSites (per-motif view; len == n_regions)
-    MotifSites[m][r]         -> list[MotifSite]  (a fresh plain list, genome coordinates, '+' / '-')
+    MotifSites[m][r]         -> list[MotifSite]  (a plain list built on access, genome coordinates, '+' / '-'; asking for the SAME region
+                                again right away returns the same list object -- `len(sites[idx])` then `max(... sites[idx])` --, any
+                                other access builds a new one: the view is read-only, `to_lists()` is the mutable form)
     len(), iteration, negative indices, slices (-> plain lists of the items), == against plain nested lists
 
 A motif's region index (`uint32[n_regions + 1]`, one bincount + cumsum over the motif's hits) is built the first time
