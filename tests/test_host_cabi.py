@@ -390,6 +390,34 @@ def test_matrix_pipeline_matches_reference_values(small):
         assert float(pwm.score(s)) == v
 
 
+def test_motif_set_pipeline_in_one_pass_equals_the_reference_made_579(jaspar579):
+    """The database-wide form (one [4, sum W] array, one numpy pass per stage) against the values the REFERENCE's
+    per-motif objects produced: motifscan_amd/data/synth_jaspar579.npz was written by tests/golden/make_golden.py::make_579
+    through PositionFrequencyMatrix.to_ppm().to_pwm(bg) (matrix.py:74-171) from this very seeded count stream."""
+    rng = np.random.default_rng(20250310)
+    widths = np.clip(np.rint(rng.gamma(shape=7.5, scale=1.55, size=579)), 5, 30).astype(np.int32)
+    widths[0], widths[1] = 30, 5
+    assert np.array_equal(widths, jaspar579["widths"])
+    counts = []
+    for w in widths:
+        depth = rng.integers(20, 3001)
+        c = np.rint(rng.dirichlet(0.3 * np.ones(4), size=int(w)).T * depth).astype(np.int64)
+        c[:, c.sum(axis=0) == 0] = 1
+        counts.append(c)
+    pfms = matrix.MotifSet.from_matrices("pfm", counts, ids=[f"M{i}" for i in range(579)])
+    pwms = pfms.to_ppm().to_pwm(dict(zip("ACGT", jaspar579["bg"])))
+    vals, w = pwms.flat()
+    assert np.array_equal(w, widths) and np.array_equal(vals, jaspar579["pwm_values"])          # bit for bit
+    # a Motif is a window onto the set; the one-motif factories give the same numbers
+    one = matrix.PositionFrequencyMatrix(counts[7]).to_ppm().to_pwm(dict(zip("ACGT", jaspar579["bg"])))
+    assert np.array_equal(one.matrix, pwms[7].matrix) and pwms[7].length == widths[7] and pwms[-1].matrix_id == "M578"
+    mx, mn = pwms.raw_extrema()
+    assert float(mx[7]) == float(one.max_raw_score) == float(one.matrix.max(axis=0).sum()) and float(mn[7]) == float(one.min_raw_score)
+    assert np.array_equal(pwms.max_raw_c(), _lib.PwmSet(vals, w, None).max_raw())               # cscore.c:36-48, the library's own
+    with pytest.raises(ValueError):
+        matrix.MotifSet.from_matrices("pfm", counts[:3] + [np.zeros((4, 2), dtype=np.int64)])
+
+
 def test_matrix_errors_like_reference():
     """/root/reference/tests/test_motif_matrix.py:9-60,106-112"""
     with pytest.raises(ValueError):
