@@ -85,20 +85,20 @@ typedef struct ms_scan_stats {
     int64_t n_candidates;       /* windows x strands that passed the integer pre-filter              */
     int64_t n_hits;
     int32_t n_pwms;
-    int32_t n_pwms_exact;       /* PWMs routed to the all-fp64 path (W > 32, degenerate values)      */
+    int32_t n_pwms_exact;       /* PWMs routed to the all-fp64 path (W > 63, max_raw <= 0, non-finite entries, a cutoff below the quantiser's floor) */
     int32_t n_tiles;            /* LDS tiles of pre-filter operand tables                            */
     int32_t n_passes;           /* 1, or 2 when a buffer had to grow and the scan was re-run         */
     double  ms_prefilter;       /* device time of the pre-filter kernel (dominant kernel)            */
-    double  ms_exact;           /* fp64 kernels: N-overlapping windows + candidate re-scoring        */
+    double  ms_exact;           /* fp64 kernels: candidate re-scoring + the motifs of the all-fp64 path */
     double  ms_sort;            /* ordering of the hit list                                          */
     double  ms_finalize;        /* coordinates, per-motif offsets, region counts                     */
     double  ms_total;           /* first launch -> last kernel done                                  */
     int64_t lds_bytes_read;     /* bytes the pre-filter reads from LDS (operand tables)              */
     int64_t hbm_bytes_algorithmic; /* codes + mask + offsets + PWMs + 16 B/hit + 8 B/PWM */
     double  pf_clock_mhz;       /* shader clock held inside the pre-filter kernel; 0 unless MS_PF_CLOCK=1 */
-    int64_t mfma_ops;           /* multiply-adds x 2 the pre-filter issues on the matrix cores (0: LDS-lookup engine) */
+    int64_t mfma_ops;           /* multiply-adds x 2 the pre-filter issues on the matrix cores (one-hot zeros and width padding included) */
     int64_t mfma_ops_algorithmic; /* 2 x windows x strands x W: the adds the reference performs */
-    int32_t pf_engine;          /* 3: fp6 x fp4 one-hot product on the matrix cores (default); 1 / 2: int8 forms; 0: packed 2-mer LDS lookups */
+    int32_t pf_engine;          /* always 3: the fp6 x fp4 one-hot product on the matrix cores (the int8 / LDS-lookup engines left the library in round 3) */
     int32_t reserved;
 } ms_scan_stats;
 

@@ -1069,6 +1069,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             counter_used = false;
         }
         pf_wave_passes = wp;
+        if (counter_used && pf_wave_passes < 2) {                     // the kernel's hand-written atomic needs a second pass before its value is read (ms_kernels.hip)
+            set_error("internal: a dynamic hand-out of single-pass units (wave_passes %lld)", (long long) pf_wave_passes);
+            return MS_ERR_RUNTIME;
+        }
     }
 
     // counters: [0] candidate record slots, [1] hits

@@ -437,7 +437,7 @@ __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, i
 // bytes per lane as three strided pair reads (ds_read2st64_b64 on a plane-major tile) take the array 24 cycles instead of 12 -- 16.5-16.6
 // against 17.0 ms per 500 Mbase on one box, six ds_read_b64 16.8 (profiles/r04d_a_reads_ab.log).  Registers v[112:123] are this block's
 // alone (clobbered); the waits are the compiler's own pattern -- `lgkmcnt(1)` before the first operand is needed (its six registers are
-// the first two reads'), `lgkmcnt(0)` before the second's, and the 11 wait states the 8-pass instruction asks for before a vector
+// the first two reads'), `lgkmcnt(0)` before the second's, and the 12 wait states (`s_nop 11`: hipcc's own pattern for this instruction in this binary) an 8-pass matrix instruction needs before a vector
 // instruction reads its result.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
@@ -452,7 +452,7 @@ __device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00,
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
-                 "s_nop 10"
+                 "s_nop 11"
                  : [c0] "=&v"(c0), [c1] "=&v"(c1)
                  : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one)
                  : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
@@ -469,7 +469,7 @@ __device__ __forceinline__ void plain_product2_asm(uint32_t pa, const i32x4 &b00
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
-                 "s_nop 10"
+                 "s_nop 11"
                  : [c0] "=&v"(c0), [c1] "=&v"(c1)
                  : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s1] "v"(one)
                  : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
@@ -818,7 +818,15 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
                 if (lane < 12) stg[lane] = lane < 8 ? words.c : words.n;          // (the wave's LDS operations execute in order: no barrier)
                 // (behind the staging, which waits for every vector-memory operation in flight)
-                if (j == 0 && dyn && lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(u) : "v"(word), "v"(1u) : "memory");
+                // INVARIANT: the compiler believes `u` is ready at once, the value arrives with the atomic's return.  Nothing may read,
+                // copy or spill u's register before a vmcnt(0) wait has retired the atomic: with wave_passes >= 2 that is pass 1's staging wait
+                // (every later copy is then harmless), and pass 0's scan must not touch the register -- checked on the built code object by
+                // tests/test_host_cabi.py::test_prefilter_isa_resources_and_the_atomic_register.  The host never launches wave_passes == 1 with
+                // the counters on (scan_locked refuses it); if it ever did, the compiler's own atomicAdd (waited for at once) takes over.
+                if (j == 0 && dyn && lane == 0) {
+                    if (wave_passes >= 2) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(u) : "v"(word), "v"(1u) : "memory");
+                    else u = atomicAdd(word, 1u);
+                }
                 // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
                 // flight while this pass is scanned
                 if (j + 1 < wave_passes) words = fetch(p0 + j + 1);

@@ -32,6 +32,18 @@ logger = logging.getLogger(__name__)
 _STRAND_FLAG = {"+": 1, "-": 2, "both": 3}
 
 
+class _Frozen(list):
+    """The scanner's region lists: real lists to read (==, len, index, slices), but the regions are FROZEN after construction --
+    the packed device copy made on the first scan is kept for the scanner's life, so an edit would be silently ignored by
+    scan_motifs while scan_batches re-encodes the strings.  Every mutating method raises instead."""
+    __slots__ = ()
+
+    def _refuse(self, *a, **k):
+        raise TypeError("a Scanner's regions are frozen after construction (its packed device copy is cached): build a new Scanner")
+
+    __setitem__ = __delitem__ = __iadd__ = __imul__ = append = extend = insert = pop = remove = clear = sort = reverse = _refuse
+
+
 class Scanner:
     def __init__(self, genome, regions, window_size=0, strand="both", p_value="1e-4", remove_dup=True,
                  n_threads=1):
@@ -48,10 +60,23 @@ class Scanner:
         if n_threads > n_cpu:
             logger.warning(f"Threads number exceed the number of CPUs, using {n_cpu} instead")
         self.n_threads = max(1, min(n_threads, n_cpu))
-        self.seq_starts, self.seq_ends, self._sequences = [], [], []
+        self._starts, self._ends, self._sequences = [], [], []
         self._resident = None                # (ResidentGenome, chromosome indices) when extraction is on the device
         self._sq = None                      # the regions as a packed device set (0.375 B/base), kept between scan_motifs calls
         self._extract_seq(genome, regions)
+        # frozen from here on: see _Frozen (the attributes are read-only properties, their lists refuse edits)
+        self._starts, self._ends = _Frozen(self._starts), _Frozen(self._ends)
+        if self._sequences is not None:
+            self._sequences = _Frozen(self._sequences)
+
+    @property
+    def seq_starts(self):
+        """0-based start of every scanned sequence on its chromosome (scanner.py:66)."""
+        return self._starts
+
+    @property
+    def seq_ends(self):
+        return self._ends
 
     @property
     def sequences(self):
@@ -59,8 +84,8 @@ class Scanner:
         materialised on demand (and only if the genome kept a host copy)."""
         if self._sequences is None:
             g, idx = self._resident
-            self._sequences = [g.fetch_sequence(g.names[c], lo, hi)
-                               for c, lo, hi in zip(idx, self.seq_starts, self.seq_ends)]
+            self._sequences = _Frozen(g.fetch_sequence(g.names[c], lo, hi)
+                                      for c, lo, hi in zip(idx, self.seq_starts, self.seq_ends))
         return self._sequences
 
     def _extract_seq(self, genome, regions):
@@ -78,8 +103,8 @@ class Scanner:
             else:
                 lo = max(region.summit - self.extend, 0)
                 hi = min(region.summit + self.extend, genome.chrom_sizes[region.chrom])
-            self.seq_starts.append(lo)
-            self.seq_ends.append(hi)
+            self._starts.append(lo)
+            self._ends.append(hi)
             if resident:
                 chrom_idx.append(genome.index[region.chrom])
             else:
@@ -90,7 +115,8 @@ class Scanner:
 
     def _seqset(self):
         """The regions as a device sequence set (convert_seq, cscore.c:81-114: 2-bit codes + non-ACGT mask), made on the first scan
-        and kept for the scanner's life -- the reference converts its strings again on every c_scan_motif call."""
+        and kept for the scanner's life -- the reference converts its strings again on every c_scan_motif call.  The regions are
+        frozen after construction (`_Frozen`), so the cached set cannot go stale; `close()` releases it."""
         if self._sq is None:
             if self._resident is not None:
                 g, idx = self._resident
@@ -252,28 +278,52 @@ def make_motif_sites(sites, seq_starts):
     return out
 
 
+def _walk_strand_in_given_order(sites, length):
+    """One strand's sites of one region in the order the CALLER gave them: the survivor of each comparison meets the next
+    site of the list; `next.start - current.start < length` also holds for a site that lies to the LEFT of the current one
+    (scanner.py:156-168 does not sort).  Returns the kept sites in list order."""
+    kept, cur = [], None
+    for s in sites:
+        if cur is None:
+            cur = s
+        elif s.start - cur.start < length:
+            if not cur.score >= s.score:
+                cur = s                                             # the later one scores strictly higher: it replaces the current site
+        else:
+            kept.append(cur)
+            cur = s
+    if cur is not None:
+        kept.append(cur)
+    return kept
+
+
 def deduplicate_motif_sites(motif_sites, lengths):
-    """Drop the lower-scoring one of two same-strand sites closer than the motif length (greedy,
-    left to right, ties keep the earlier site); strands are handled separately, the result is
-    ordered by start with '+' before '-'.  Works on the nested lists through the same C routine
-    (ms_dedup_hits) the array path uses."""
-    motif, region, start, score, strand, sizes = [], [], [], [], [], []
-    for m, per_pwm in enumerate(motif_sites):
+    """Drop the lower-scoring one of two same-strand sites closer than the motif length (greedy walk over each strand's sites IN
+    THE ORDER GIVEN, ties keep the earlier site); the result is ordered by start with '+' before '-' (scanner.py:156-193).
+    Regions whose strands are start-sorted -- everything a scan produces -- go through the C routine the array path uses
+    (ms_dedup_hits), all of them in one call; a region handed over in any other order is walked here, in its own order."""
+    motif, region, start, score, strand = [], [], [], [], []
+    out = [[[] for _ in per_pwm] for per_pwm in motif_sites]
+    for m, (per_pwm, length) in enumerate(zip(motif_sites, lengths)):
         for r, sites in enumerate(per_pwm):
-            sizes.append(len(sites))
-            # the C routine wants (start asc, '+' first) inside a region: stable sort by that key
-            for s in sorted(sites, key=lambda s: (s.start, 0 if s.strand == "+" else 1)):
-                motif.append(m)
-                region.append(r)
-                start.append(s.start)
-                score.append(s.score)
-                strand.append(1 if s.strand == "+" else 2)
+            fwd = [s for s in sites if s.strand == "+"]
+            rev = [s for s in sites if s.strand != "+"]
+            if all(a.start <= b.start for part in (fwd, rev) for a, b in zip(part, part[1:])):
+                # (start asc, '+' first) inside a region is what the C routine wants; the stable merge keeps each strand's own order
+                for s in sorted(fwd + rev, key=lambda s: s.start):
+                    motif.append(m)
+                    region.append(r)
+                    start.append(s.start)
+                    score.append(s.score)
+                    strand.append(1 if s.strand == "+" else 2)
+            else:
+                kept = _walk_strand_in_given_order(fwd, length) + _walk_strand_in_given_order(rev, length)
+                out[m][r] = sorted(kept, key=lambda s: s.start)
     n_pwms = len(motif_sites)
     offsets = np.concatenate([[0], np.cumsum(np.bincount(np.asarray(motif, dtype=np.int64), minlength=n_pwms))]) \
         if n_pwms else np.zeros(1)
     keep = _lib.dedup_keep(offsets, list(lengths), region, start, np.asarray(score, dtype=np.float64), strand) \
         if motif else np.zeros(0, dtype=bool)
-    out = [[[] for _ in per_pwm] for per_pwm in motif_sites]
     for k in np.nonzero(keep)[0].tolist():
         out[motif[k]][region[k]].append(MotifSite(start[k], score[k], "+" if strand[k] == 1 else "-"))
     return out

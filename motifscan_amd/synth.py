@@ -214,6 +214,33 @@ def c5_genome(chroms, lens, workers=None, out=None):
     return res
 
 
+def _c5_block_to_file(args):
+    path, ch, k, n, off = args
+    mm = np.memmap(path, dtype=np.uint8, mode="r+")
+    mm[off:off + n] = _c5_block((ch, k, n))
+    mm.flush()
+    return n
+
+
+def c5_genome_to_dir(dirpath, lens, chroms=None, workers=None):
+    """The same chromosomes as c5_genome() (block for block, seed for seed), written straight into one flat uint8 file per
+    chromosome under dirpath (chr<i>.u8): the workers fill disjoint slices of a shared mapping, nothing is pickled back.  Meant to
+    run in a FRESH python process (a test that has already initialised the GPU starts it as a child, never forks itself).
+    Returns the file paths by chromosome index."""
+    chroms = list(range(len(lens))) if chroms is None else list(chroms)
+    jobs, paths = [], {}
+    for ch in chroms:
+        L, B = int(lens[ch]), C5["block_bp"]
+        path = os.path.join(dirpath, f"chr{ch}.u8")
+        np.memmap(path, dtype=np.uint8, mode="w+", shape=(max(L, 1),)).flush()
+        paths[ch] = path
+        jobs += [(path, ch, k, min(B, L - k * B), k * B) for k in range((L + B - 1) // B)]
+    if workers is None:
+        workers = min(32, os.cpu_count() or 1)
+    _pool_map(_c5_block_to_file, jobs, workers)
+    return paths
+
+
 def workload(name, rank=0):
     """Returns dict(pwm_values, widths, cutoffs, sets=[(bases, offsets), ...], units) for a named
     workload; rank shifts the sequence seeds so every GPU scans different regions."""

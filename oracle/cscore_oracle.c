@@ -5,8 +5,10 @@
  * algorithm in the reference's only native component,
  * /root/reference/motifscan/motif/cscore.c.  It exists so that the HIP path in
  * motifscan_amd/csrc can be checked bit-for-bit on any box (the reference tree
- * does not travel to the GPU box) and so bench.py has a CPU baseline
- * ("cpu_baseline.kind" = "port").  Only tests/, __graft_entry__.smoke() and
+ * does not travel to the GPU box) and so bench.py has a CPU baseline when
+ * oracle/_ref (the real cscore.c, built in the build container and shipped as a
+ * binary) is absent: "cpu_baseline.kind" is "reference" when bench.py timed
+ * oracle/_ref and "port" only when it had to fall back to this file.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load this library; the product path
  * (motifscan_amd/) must never call it.
  *

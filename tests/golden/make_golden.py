@@ -211,25 +211,41 @@ def make_small(R):
     }
 
     # de-dup semantics (tests/test_scanner.py:57-73 plus ties / chains)
-    MS = sc.MotifSite
-    cases = []
-    for name, sites, length in (
-            ("reference_test", [(1, 1, "+"), (3, 0.8, "+"), (1, 1, "-"), (2, 3, "-"), (5, 1, "+")], 3),
-            ("tie_keeps_earlier", [(1, 0.5, "+"), (2, 0.5, "+"), (3, 0.5, "+"), (10, 0.5, "+")], 3),
-            ("chain_rising", [(1, 0.1, "+"), (2, 0.2, "+"), (3, 0.3, "+"), (4, 0.4, "+"), (9, 0.1, "+")], 4),
-            ("chain_falling", [(1, 0.4, "-"), (2, 0.3, "-"), (3, 0.2, "-"), (6, 0.9, "-")], 4),
-            ("interleaved_strands", [(1, 0.4, "+"), (1, 0.9, "-"), (2, 0.5, "+"), (2, 0.1, "-"), (8, 1, "+")], 5)):
-        ms = [[[MS(*s) for s in sites]]]
-        res = sc.deduplicate_motif_sites(ms, [length])
-        cases.append({"name": name, "sites": [list(s) for s in sites], "length": length,
-                      "out": [[s.start, s.score, s.strand] for s in res[0][0]]})
-    out["dedup"] = cases
+    out["dedup"] = dedup_cases(sc)
 
     out["N4"] = make_formats(R, genome, GR, toy, chroms)
 
     with open(os.path.join(HERE, "ref_small.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote ref_small.json")
+
+
+def dedup_cases(sc):
+    """scanner.py:156-193 run on hand-made lists -- start-sorted ones (what a scan produces) and lists in ARBITRARY order (what a
+    caller may hand over: the reference walks each strand's sites in the order given, so a negative distance also counts as
+    'closer than the motif length')."""
+    MS = sc.MotifSite
+    rng = np.random.default_rng(77)
+    shuffled = []
+    for k in range(6):
+        n = int(rng.integers(5, 40))
+        sites = [(int(rng.integers(0, 60)), float(np.round(rng.random(), 3)), "+-"[int(rng.integers(0, 2))]) for _ in range(n)]
+        shuffled.append((f"unsorted_random_{k}", sites, int(rng.integers(2, 12))))
+    cases = []
+    for name, sites, length in (
+            ("reference_test", [(1, 1, "+"), (3, 0.8, "+"), (1, 1, "-"), (2, 3, "-"), (5, 1, "+")], 3),
+            ("tie_keeps_earlier", [(1, 0.5, "+"), (2, 0.5, "+"), (3, 0.5, "+"), (10, 0.5, "+")], 3),
+            ("chain_rising", [(1, 0.1, "+"), (2, 0.2, "+"), (3, 0.3, "+"), (4, 0.4, "+"), (9, 0.1, "+")], 4),
+            ("chain_falling", [(1, 0.4, "-"), (2, 0.3, "-"), (3, 0.2, "-"), (6, 0.9, "-")], 4),
+            ("interleaved_strands", [(1, 0.4, "+"), (1, 0.9, "-"), (2, 0.5, "+"), (2, 0.1, "-"), (8, 1, "+")], 5),
+            ("unsorted_descending", [(9, 0.2, "+"), (7, 0.9, "+"), (1, 0.5, "+"), (3, 0.1, "-"), (2, 0.8, "-")], 3),
+            ("unsorted_far_apart_backwards", [(50, 0.3, "+"), (10, 0.2, "+"), (30, 0.9, "+"), (31, 0.1, "+")], 4),
+            ("unsorted_equal_starts", [(5, 0.1, "-"), (5, 0.7, "-"), (4, 0.7, "-"), (20, 0.2, "+"), (5, 0.3, "+")], 2)) + tuple(shuffled):
+        ms = [[[MS(*s) for s in sites]]]
+        res = sc.deduplicate_motif_sites(ms, [length])
+        cases.append({"name": name, "sites": [list(s) for s in sites], "length": length,
+                      "out": [[s.start, s.score, s.strand] for s in res[0][0]]})
+    return cases
 
 
 def make_formats(R, genome, GR, toy, chroms):
@@ -466,9 +482,19 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-579", action="store_true")
     ap.add_argument("--only-579", action="store_true")
+    ap.add_argument("--only-dedup", action="store_true", help="refresh only the de-dup cases of ref_small.json (everything else stays byte for byte)")
     ap.add_argument("--n-kmers", type=int, default=1000000)
     a = ap.parse_args()
     R = import_reference()
+    if a.only_dedup:
+        path = os.path.join(HERE, "ref_small.json")
+        with open(path) as fh:
+            small = json.load(fh)
+        small["dedup"] = dedup_cases(R["scanner"])
+        with open(path, "w") as fh:
+            json.dump(small, fh, indent=1)
+        print("refreshed the de-dup cases of ref_small.json:", len(small["dedup"]))
+        sys.exit(0)
     if not a.only_579:
         make_small(R)
         make_random(R)

@@ -196,6 +196,98 @@ def test_host_streamed_sweep_with_the_default_span(oracle):
     assert np.array_equal(last["score"], want["score"]) and np.array_equal(last["strand"].astype(np.int32), want["strand"])
 
 
+def test_c5_full_size_three_gbp_host_streamed_sweep(oracle):
+    """BASELINE configs[4] AT ITS FULL SIZE: a 3 Gbp / 24-chromosome genome on the host (synth.c5_chrom_lengths / c5_genome's
+    blocks), swept as 200 bp windows stride 50 (60M windows) x 579 PWMs through the product's span stream.
+      1. the span plan tiles every window of every chromosome exactly once and every base of the genome is scanned once;
+      2. counts-only pass over ALL spans (what stats.py:29-31 consumes): per-motif window counts;
+      3. a second pass WITH hits over the spans of three chromosomes: order, ranges, and the window counts recounted from the
+         hit arrays == the counts-only pass's vectors for those spans;
+      4. the last 400 windows of three different chromosomes bit for bit against the oracle
+         (window extraction scanner.py:71-87, scoring cscore.c:336-390).
+    The genome is generated by a fresh child process (32+ numpy workers writing into /dev/shm files): this process has a GPU
+    context and never forks workers itself."""
+    import shutil, subprocess, tempfile
+    window, stride, max_span = synth.C5["window"], synth.C5["stride"], 375_000_000
+    lens = synth.c5_chrom_lengths()
+    assert int(lens.sum()) == 3_000_000_000 and len(lens) == 24
+    tmp = tempfile.mkdtemp(prefix="ms_c5_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    pins = {}
+    try:
+        code = ("import sys; sys.path.insert(0, %r); from motifscan_amd import synth; "
+                "synth.c5_genome_to_dir(%r, synth.c5_chrom_lengths(), workers=min(48, __import__('os').cpu_count() or 1))" % (ROOT, tmp))
+        subprocess.run([sys.executable, "-c", code], check=True, timeout=600)
+        chroms = {}
+        for ch in range(24):
+            pb = _lib.PinnedBuffer(int(lens[ch]))
+            pb.array[:] = np.fromfile(os.path.join(tmp, f"chr{ch}.u8"), dtype=np.uint8)
+            os.unlink(os.path.join(tmp, f"chr{ch}.u8"))
+            pins[ch] = pb
+            chroms[ch] = pb.array
+        vals, widths, cutoffs = synth.load_motif_set(579)
+        P = len(widths)
+        pw = _lib.PwmSet(vals, widths, cutoffs)
+        # 1. the plan
+        spans = _lib.sweep_spans(lens, window, stride, max_span)
+        n_win = [(int(L) - window) // stride + 1 for L in lens]
+        assert sum(n_win) == 59_999_916 and spans[-1][3] + spans[-1][4] == sum(n_win)           # configs[4]'s 60M windows
+        nxt, per_chrom = 0, {}
+        for ch, b0, b1, w0, nw in spans:
+            assert w0 == nxt and nw > 0 and b1 - b0 <= max_span and (nw - 1) * stride + window == b1 - b0 and b0 % stride == 0
+            first_of_chrom = sum(n_win[:ch])
+            assert b0 == (w0 - first_of_chrom) * stride                  # the span starts at its first window
+            per_chrom[ch] = per_chrom.get(ch, 0) + nw
+            nxt += nw
+        assert [per_chrom[ch] for ch in range(24)] == n_win
+        # every base once: consecutive spans of a chromosome overlap by window - stride, nothing else is uploaded twice
+        bases_uploaded = sum(b1 - b0 for _, b0, b1, _, _ in spans)
+        assert bases_uploaded == sum((n - 1) * stride + window for n in n_win) + (len(spans) - 24) * (window - stride)
+        # 2. counts only, all spans
+        counts_by_span, n_sites_counts, bases_scanned = [], 0, 0
+        for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, _lib.MS_STREAM_NO_HITS, spans=spans):
+            counts_by_span.append(res.region_counts().copy())
+            st = res.stats()
+            bases_scanned += st["n_bases"]
+            n_sites_counts += res.n_hits
+            res.close()
+        assert len(counts_by_span) == len(spans) and bases_scanned == bases_uploaded
+        total = np.sum(counts_by_span, axis=0)
+        assert (total > 0).all() and (total <= sum(n_win)).all()
+        # 3. + 4. hits for three chromosomes of different sizes
+        picked = [5, 14, 23]
+        sub = [sp for sp in spans if sp[0] in picked]
+        tails = {}
+        for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, spans=sub, packed=True):
+            h = res.hits(copy=False)
+            assert len(h["pos"]) == res.n_hits > 1_000_000 and order_key_increasing(h, 8)
+            assert (h["seq_idx"] >= 0).all() and (h["seq_idx"] < sp[4]).all()
+            assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= window).all()
+            assert np.array_equal(recount_regions(h, P), counts_by_span[spans.index(sp)])          # == the counts-only pass
+            assert np.array_equal(res.region_counts(), counts_by_span[spans.index(sp)])
+            if sp[3] + sp[4] == sum(n_win[:sp[0] + 1]):                                                # the chromosome's last span
+                keep = h["seq_idx"] >= sp[4] - 400
+                t = {k: h[k][keep].copy() for k in ("seq_idx", "pos", "score", "strand", "motif")}
+                t["seq_idx"] -= sp[4] - 400
+                tails[sp[0]] = t
+            res.close()
+        assert sorted(tails) == picked
+        for ch in picked:
+            b = chroms[ch]
+            k0 = n_win[ch] - 400
+            wins = np.concatenate([b[k * stride:k * stride + window] for k in range(k0, k0 + 400)])
+            want = oracle.scan_arrays(vals, widths, cutoffs, wins.tobytes(), np.arange(401, dtype=np.int64) * window, 3, 8)
+            wm = np.repeat(np.arange(P), np.diff(want["motif_offsets"]))
+            got = tails[ch]
+            assert len(want["pos"]) == len(got["pos"]) > 1000
+            assert np.array_equal(got["motif"], wm) and np.array_equal(got["seq_idx"], want["seq_idx"]) and np.array_equal(got["pos"], want["pos"])
+            assert np.array_equal(got["score"], want["score"]) and np.array_equal(got["strand"].astype(np.int32), want["strand"])
+        pw.close()
+    finally:
+        for pb in pins.values():
+            pb.close()
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # ------------------------------------------------------------- configs[4]: the sweep shard --
 
 def test_c5shard_sweep_all_579_motifs(oracle):

@@ -553,6 +553,73 @@ def test_bench_refuses_more_ranks_than_gpus_before_spawning():
     assert out.returncode != 0 and "nothing was started" in out.stderr and not out.stdout.strip()
 
 
+def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
+    """Build-time checks on the gfx950 code object of the pre-filter: what the hand-written
+    asm blocks of ms_kernels.hip rest on, read from the disassembly of the object the library was linked from.
+      * <= 128 vector registers (four waves per SIMD), no scalar spills, and no scratch traffic between the first and the last
+        matrix instruction (the compiler's three spilled registers live in the unit hand-out around the passes);
+      * the work hand-out's `global_atomic_add vN ... sc0` (issued without a wait): vN is named by no instruction of the pass body
+        (first to last matrix instruction) and by nothing in pf_flush, the one real call inside it -- the value arrives while pass 0
+        runs and is first read after pass 1's staging wait;
+      * every hand-written two-block product is followed by `s_nop 11` (12 wait states before a vector read of its result)."""
+    import re, shutil, subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    obj = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("no ROCm llvm tools / object file here (the build container has both)")
+    shutil.copy(obj, tmp_path / "k.o")
+    subprocess.run([objdump, "--offloading", "k.o"], cwd=tmp_path, check=True, capture_output=True)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1
+    asm = subprocess.run([objdump, "-d", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+    notes = subprocess.run([readelf, "--notes", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+    funcs, name = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            name = m.group(1)
+            funcs[name] = []
+        elif name and line.startswith("\t"):
+            funcs[name].append(line.split("//")[0].strip())
+    flush = [k for k in funcs if "pf_flush" in k]
+    assert len(flush) == 1
+    kernels = [k for k in funcs if "prefilter_f6_kernel" in k]
+    assert len(kernels) == 4                                          # <2|4 k-blocks> x <product | measurement>
+    for k in kernels:
+        meta = notes[notes.index(".name:           " + k + "\n"):]
+        meta = meta[:meta.index(".wavefront_size")]
+        num = {f: int(re.search(rf"\.{f}:\s+(\d+)", meta).group(1)) for f in ("vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size")}
+        assert num["vgpr_count"] <= 128, (k, num)
+        body = funcs[k]
+        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+        assert len(mf) >= 12
+        product = "ILi2ELb0" in k                                  # the kernel every JASPAR-like set runs on (the 3/4-k-block one spills in its rare paths)
+        if product:
+            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 4 and num["private_segment_fixed_size"] <= 32, (k, num)
+            assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("scratch_")], "spill traffic inside the pass body"
+        # the hand-out's atomic: the one that is NOT waited for at once
+        cand = [i for i, l in enumerate(body) if l.startswith("global_atomic_add") and "sc0" in l
+                and not any(x.startswith("s_waitcnt vmcnt(0)") for x in body[i + 1:i + 4])]
+        assert len(cand) == 1, (k, cand)
+        reg = re.match(r"global_atomic_add (v\d+),", body[cand[0]]).group(1)
+        named = re.compile(rf"\b{reg}\b|\bv\[(\d+):(\d+)\]")
+
+        def names(line):
+            for m in named.finditer(line):
+                if m.group(1) is None or int(m.group(1)) <= int(reg[1:]) <= int(m.group(2)):
+                    return True
+            return False
+        assert cand[0] < mf[0], "the atomic is issued before the pass body"
+        if product:
+            assert not [l for l in body[mf[0]:mf[-1] + 1] if names(l)], f"{reg} is touched while the atomic may be in flight"
+            assert not [l for l in funcs[flush[0]] if names(l)], f"pf_flush touches {reg}"
+        # the two-block products by name: three 16-byte reads into v[112:123], four matrix instructions, s_nop 11
+        for i, l in enumerate(body):
+            if l.startswith("ds_read_b128 v[112:115]"):
+                blk = body[i:i + 10]
+                assert sum(x.startswith("v_mfma_scale_f32_32x32x64_f8f6f4") for x in blk) == 4 and blk[9] == "s_nop 11", blk
+
+
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
     """measurement variables alone must not change what the library does; the retired engine / variant / tail switches
     of rounds 1-2 change nothing at all (host-visible part: the plan)."""

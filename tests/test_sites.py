@@ -6,7 +6,7 @@ import tracemalloc
 import numpy as np
 import pytest
 
-from motifscan_amd.sites import MotifSite, MotifSites, RegionSites
+from motifscan_amd.sites import LazyRegionSites, MotifSite, MotifSites, RegionRow, RegionSites
 
 
 def _random_result(rng, P, R, n, max_pos=400):
@@ -35,12 +35,12 @@ def test_lazy_view_equals_nested_lists(P, R, n):
     for m in range(P):
         for r in range(R):
             got = ms[m][r]
-            assert type(got) is list and got == eager[m][r]
+            assert type(got) is tuple and list(got) == eager[m][r]
             assert all(type(s) is MotifSite and type(s.start) is int and type(s.score) is float and s.strand in "+-" for s in got)
     if P and R:
-        assert ms[-1][-1] == eager[-1][-1] and ms[0][np.int64(R - 1)] == eager[0][R - 1]
-        assert ms[0][1:4] == eager[0][1:4] and ms[0][::-2] == eager[0][::-2]
-        assert [list(v) for v in ms[1:3]] == eager[1:3]
+        assert list(ms[-1][-1]) == eager[-1][-1] and list(ms[0][np.int64(R - 1)]) == eager[0][R - 1]
+        assert [list(x) for x in ms[0][1:4]] == eager[0][1:4] and [list(x) for x in ms[0][::-2]] == eager[0][::-2]
+        assert [[list(x) for x in v] for v in ms[1:3]] == eager[1:3] and all(v == e for v, e in zip(ms[1:3], eager[1:3]))
         with pytest.raises(IndexError):
             ms[P]
         with pytest.raises(IndexError):
@@ -84,9 +84,15 @@ def test_the_writers_and_the_statistics_read_it_like_lists():
     assert table(ms, 40) == table(eager, 40) and bed(ms, 40) == bed(eager, 40) and enrich(ms) == enrich(eager)
     for a, b in zip(ms, eager):                                  # zip(pwms, motif_sites, motif_sites_control): stats.py:24
         assert a == b
-    # an item read twice in a row is one list (the writer reads len() then max()); a caller that edits it sees its own edit, like a list
-    first = ms[2][eager[2].index(next(x for x in eager[2] if x))]
-    assert first and ms[2][eager[2].index(first)] is first
+    # an item read twice in a row is one object (the writer reads len() then max()); region items are TUPLES: an edit fails loudly
+    # instead of being lost (the view is read-only; to_lists() is the mutable form)
+    r_first = eager[2].index(next(x for x in eager[2] if x))
+    first = ms[2][r_first]
+    assert first and ms[2][r_first] is first and type(first) is tuple
+    with pytest.raises(AttributeError):
+        first.append(None)
+    with pytest.raises(AttributeError):
+        ms[2][eager[2].index([])].append(None)
     # it pickles as what the reference returns: plain nested lists
     import pickle
     back = pickle.loads(pickle.dumps(ms))
@@ -109,7 +115,68 @@ def test_nothing_of_size_pwms_x_regions_is_built_up_front():
     built = tracemalloc.get_traced_memory()[0]
     assert built < 1 << 20, built
     want = [MotifSite(int(starts[region[k]] + pos[k]), float(score[k]), "+-"[strand[k] - 1]) for k in range(mo[17], mo[18]) if region[k] == 4242]
-    assert ms[17][4242] == want                                  # one motif's index: 4 bytes per region
+    assert list(ms[17][4242]) == want                                  # one motif's index: 4 bytes per region
     assert tracemalloc.get_traced_memory()[0] - built < 3 * R * 4 + (1 << 16)
     tracemalloc.stop()
     assert sum(len(x) > 0 for x in ms[3]) == len(np.unique(region[mo[3]:mo[4]]))
+
+
+def test_iteration_hands_out_real_lists_and_indexing_stays_lazy():
+    """`for sites in motif_sites` (io/__init__.py:26, stats.py:24) gets RegionRow objects -- real lists, so `sites[idx]` is the C list
+    subscript -- built per motif on the first pass and kept; `motif_sites[m]` before any iteration is the lazy view; both compare
+    equal to the reference's nested lists; when the rows would not fit the budget, iteration hands out the lazy views."""
+    ms, eager = _random_result(np.random.default_rng(11), 9, 70, 900)
+    assert type(ms[4]) is LazyRegionSites
+    it = iter(ms)
+    first = next(it)
+    assert type(first) is RegionRow and isinstance(first, list) and isinstance(first, RegionSites) and type(ms[1]) is LazyRegionSites
+    assert first == eager[0] and not (first != eager[0]) and first != eager[1]
+    rest = list(it)
+    assert all(type(r) is RegionRow for r in rest) and [first] + rest == eager
+    assert all(a is b for a, b in zip(ms, [first] + rest))                  # the second pass: the same row objects, a plain list iterator
+    assert type(iter(ms)).__name__ == "list_iterator"
+    empty = next(x for x in first if not x)
+    assert sum(x is empty for x in first) == sum(not x for x in eager[0])   # one shared empty tuple
+    assert np.array_equal(first.site_counts(), [len(x) for x in eager[0]]) and first.n_sites == sum(len(x) for x in eager[0])
+    assert ms == eager and ms.to_lists() == eager and type(ms.to_lists()[0][0]) is list
+    small = MotifSites.row_budget_bytes
+    try:
+        MotifSites.row_budget_bytes = 100
+        ms2, eager2 = _random_result(np.random.default_rng(11), 9, 70, 900)
+        assert all(type(v) is LazyRegionSites for v in ms2) and ms2 == eager2
+    finally:
+        MotifSites.row_budget_bytes = small
+
+
+def test_no_reference_cycle_and_close_releases_the_owner():
+    """the views must not keep their container (and through it the scan result's pinned / device blocks) alive until
+    the cycle collector runs.  Without gc: dropping the MotifSites drops the owner; close() does it while views are still held."""
+    import weakref
+
+    class Owner:
+        pass
+
+    rng = np.random.default_rng(3)
+    ms, _ = _random_result(rng, 4, 20, 100)
+    own = Owner()
+    ref = weakref.ref(own)
+    ms2 = MotifSites(ms._h.motif_offsets, ms._h.region, ms._h.pos, ms._h.score, ms._h.strand, ms._h.seq_starts, owner=own)
+    del own
+    gc.disable()
+    try:
+        rows = list(ms2)
+        view = ms2[0]
+        assert ref() is not None
+        ms2.close()
+        assert ref() is None and len(ms2) == 0                           # released with views and rows still referenced
+        ms3 = MotifSites(ms._h.motif_offsets, ms._h.region, ms._h.pos, ms._h.score, ms._h.strand, ms._h.seq_starts, owner=Owner())
+        r3 = weakref.ref(ms3._h.owner)
+        list(ms3)
+        del ms3
+        assert r3() is None                                                # no cycle: plain reference counting frees it
+        with MotifSites(ms._h.motif_offsets, ms._h.region, ms._h.pos, ms._h.score, ms._h.strand, ms._h.seq_starts) as m4:
+            assert len(m4) == 4
+        assert len(m4) == 0
+    finally:
+        gc.enable()
+    del rows, view
