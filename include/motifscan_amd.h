@@ -208,6 +208,10 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
 /* Queue one batch of regions (same arguments as ms_seqset_create).  offsets is copied; bases is BORROWED until
  * ms_stream_next has returned this batch.  Fails with MS_ERR_INVALID when ms_stream_capacity batches are in flight. */
 int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs);
+/* The same for a batch of which only the per-motif region counts will be read (MS_STREAM_NO_HITS for this batch alone): what the
+ * reference does with the control regions -- cli/scan.py:81-89 scans them, stats.py:29-31 counts the regions with >= 1 site, no
+ * writer ever sees their sites -- while the input regions' batches of the same stream carry their hits out. */
+int ms_stream_submit_counts_only(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs);
 /* Queue one span of a window sweep: n_bases of ONE chromosome starting at a window start; the result is what
  * ms_scan_sweep gives for it (seq_idx = window index inside the span: add ms_span.first_window). */
 int ms_stream_submit_span(ms_stream *st, const char *bases, int64_t n_bases, int32_t window, int32_t stride);

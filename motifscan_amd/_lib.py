@@ -117,6 +117,7 @@ def lib():
         "ms_host_free": (None, [vp]),
         "ms_stream_create": (c_int, [vp, c_int, c_u32, c_int, pvp]),
         "ms_stream_submit": (c_int, [vp, vp, pi64, c_i64]),
+        "ms_stream_submit_counts_only": (c_int, [vp, vp, pi64, c_i64]),
         "ms_stream_submit_span": (c_int, [vp, vp, c_i64, c_i32, c_i32]),
         "ms_stream_submit_regions": (c_int, [vp, vp, pi32, pi64, pi64, c_i64]),
         "ms_stream_next": (c_int, [vp, pvp]),
@@ -559,12 +560,13 @@ class Stream:
         check(lib().ms_stream_in_flight(self.h, ctypes.byref(n)))
         return n.value
 
-    def submit(self, bases, offsets):
+    def submit(self, bases, offsets, counts_only=False):
         bases = np.ascontiguousarray(bases, dtype=np.uint8) if isinstance(bases, np.ndarray) else np.frombuffer(bytes(bases), dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         if offsets.ndim != 1 or offsets.size < 1 or int(offsets[0]) != 0 or int(offsets[-1]) != bases.size:
             raise ValueError("offsets must run from 0 to the number of bases")
-        check(lib().ms_stream_submit(self.h, ctypes.c_void_p(bases.ctypes.data), ptr(offsets, ctypes.c_int64), offsets.size - 1))
+        fn = lib().ms_stream_submit_counts_only if counts_only else lib().ms_stream_submit
+        check(fn(self.h, ctypes.c_void_p(bases.ctypes.data), ptr(offsets, ctypes.c_int64), offsets.size - 1))
         self._keep.append(bases)
 
     def submit_regions(self, genome, chrom_idx, starts, ends):
@@ -641,7 +643,9 @@ def merge_hits(parts, n_pwms):
 
 def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None):
     """Generator: push (bases, offsets) batches -- or (ResidentGenome, chrom_idx, starts, ends) batches of a genome that sits in
-    HBM -- through a Stream, yield each batch's ScanResult in order (the caller closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end."""
+    HBM -- through a Stream, yield each batch's ScanResult in order (the caller closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end.
+    A (bases, offsets, True) batch is COUNTS ONLY (ms_stream_submit_counts_only): its hits stay on the device, only the per-motif
+    region counts are read -- what the reference does with the control regions (cli/scan.py:81-89 -> stats.py:29-31)."""
     st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
     try:
         for batch in batches:                             # (bases, offsets), or (ResidentGenome, chrom_idx, starts, ends)
@@ -650,7 +654,7 @@ def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, st
             if len(batch) == 4:
                 st.submit_regions(*batch)
             else:
-                st.submit(*batch)
+                st.submit(*batch)                         # (bases, offsets) or (bases, offsets, counts_only)
         while st.in_flight:
             yield st.next()
         if stage_stats is not None:

@@ -26,6 +26,7 @@ struct Job {
     int64_t n_seqs = 0;
     int32_t window = 0, stride = 0;
     int64_t n_windows = 0;
+    uint32_t flags = 0;               // the stream's flags | this batch's own (ms_stream_submit_counts_only adds MS_STREAM_NO_HITS)
     ms_seqset *seqs = nullptr;
     ms_result *res = nullptr;
     int rc = MS_OK;
@@ -78,6 +79,7 @@ struct ms_stream {
     // returns true if the job's scan is pending in pend_slot[slot] (finish with scan_finish), false if the job is done (or failed)
     bool scan_start(Job *j, int slot) {
         if (j->rc != MS_OK) return false;
+        const uint32_t flags = j->flags;
         DeviceCtx *c = nullptr;
         int rc = get_ctx(device, &c);
         bool pending = false;
@@ -103,6 +105,7 @@ struct ms_stream {
     }
 
     void scan_finish(Job *j, int slot) {
+        const uint32_t flags = j->flags;
         DeviceCtx *c = nullptr;
         int rc = get_ctx(device, &c);
         if (!rc) {
@@ -123,6 +126,7 @@ struct ms_stream {
     }
 
     void download(Job *j) {
+        const uint32_t flags = j->flags;
         if (j->rc != MS_OK || (flags & MS_STREAM_NO_HITS)) return;
         const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
                                                   : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
@@ -171,7 +175,8 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     return MS_OK;
 }
 
-static int stream_enqueue(ms_stream *st, std::unique_ptr<Job> j) {
+static int stream_enqueue(ms_stream *st, std::unique_ptr<Job> j, uint32_t batch_flags = 0) {
+    j->flags = st->flags | batch_flags;
     if (!st->pipe->submit(j.get())) {                    // (may wait for the uploader; never for the consumer)
         set_error("%d batches are in flight: collect results with ms_stream_next first", st->pipe->capacity());
         return MS_ERR_INVALID;
@@ -180,7 +185,15 @@ static int stream_enqueue(ms_stream *st, std::unique_ptr<Job> j) {
     return MS_OK;
 }
 
-int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs) {
+static int submit_batch(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t batch_flags);
+
+int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs) { return submit_batch(st, bases, offsets, n_seqs, 0); }
+
+int ms_stream_submit_counts_only(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs) {
+    return submit_batch(st, bases, offsets, n_seqs, MS_STREAM_NO_HITS);
+}
+
+static int submit_batch(ms_stream *st, const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t batch_flags) {
     if (!st) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (n_seqs < 0 || !offsets) { set_error("bad offsets / n_seqs"); return MS_ERR_INVALID; }
     if (offsets[n_seqs] > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
@@ -190,7 +203,7 @@ int ms_stream_submit(ms_stream *st, const char *bases, const int64_t *offsets, i
     catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
     j->bases = bases;
     j->n_seqs = n_seqs;
-    return stream_enqueue(st, std::move(j));
+    return stream_enqueue(st, std::move(j), batch_flags);
 }
 
 int ms_stream_submit_regions(ms_stream *st, const ms_genome *genome, const int32_t *chrom, const int64_t *start, const int64_t *end, int64_t n_regions) {

@@ -141,6 +141,11 @@ def _pool_map(fn, jobs, workers):
         raise
 
 
+def default_workers(world):
+    """Generator processes ONE rank may start so that `world` ranks together stay within the box's cores (at most 16 each)."""
+    return min(16, max(1, (os.cpu_count() or 1) // max(int(world), 1)))
+
+
 def c4_shard(rank=0, world=1, workers=None, regions_per_set=None):
     """Rank's contiguous share of the full configs[3] workload: dict like workload() with sets = [(bases, offsets)] of the
     rank's regions [r0, r1) of each set, plus "shard" = (r0, r1).  Only the blocks the share overlaps are generated."""
@@ -150,7 +155,7 @@ def c4_shard(rank=0, world=1, workers=None, regions_per_set=None):
     blocks = list(range(r0 // B, (r1 + B - 1) // B)) if r1 > r0 else []
     jobs = [(s, b) for s in range(C4["n_sets"]) for b in blocks]
     if workers is None:
-        workers = min(16, max(1, (os.cpu_count() or 1) // max(world, 1)))
+        workers = default_workers(world)
     made = dict(zip(jobs, _pool_map(_c4_block, jobs, workers)))
     vals, widths, cutoffs = load_motif_set(C4["n_pwms"])
     sets = []

@@ -385,6 +385,22 @@ def test_stream_counts_only_errors_and_pinned_input(oracle):
         r.close()
     assert st.next() is None
     assert np.array_equal(c, want.region_counts()) and n == want.n_hits
+    # the reference-shaped job in ONE stream (cli/scan.py:81-89): input batches with their hits out (compact form), control batches
+    # counts only (ms_stream_submit_counts_only) -- same counts, same hits for the batches that carry them
+    half = int(offsets[1500])
+    mixed = [(pin.array[:half], offsets[:1501], False), (pin.array[half:], offsets[1500:] - half, True),
+             (pin.array[:half], offsets[:1501], True), (pin.array[half:], offsets[1500:] - half, False)]
+    got = list(_lib.scan_stream(pw, iter(mixed), 3, packed=True))
+    wa = _lib.scan(pw, _lib.SeqSet(bases[:half], offsets[:1501]), 3)
+    wb = _lib.scan(pw, _lib.SeqSet(bases[half:], offsets[1500:] - half), 3)
+    for r, w, counts_only in zip(got, (wa, wb, wa, wb), (False, True, True, False)):
+        assert r.n_hits == w.n_hits and np.array_equal(r.region_counts(), w.region_counts())
+        if not counts_only:
+            hp, hw = r.hits(packed=True), w.hits()
+            for k in ("motif_offsets", "seq_idx", "pos", "score"):
+                assert np.array_equal(hp[k], hw[k])
+        r.close()
+    wa.close(); wb.close()
     # a bad batch fails at next(), in order, with the library's message; the stream stays usable
     st.submit(bases[:600], np.array([0, 300, 600], dtype=np.int64))
     with pytest.raises(ValueError):
