@@ -209,20 +209,27 @@ void pool_free(DeviceCtx *c, void *p, size_t bytes) {
         c->pool.bytes += bytes;
         return;
     }
-    // full: give the driver the SMALLEST cached block (or this one), the large ones are the dear ones to make again
-    size_t small = (size_t) -1;
-    for (size_t i = 0; i < c->pool.free_.size(); i++)
-        if (c->pool.free_[i].second < bytes && (small == (size_t) -1 || c->pool.free_[i].second < c->pool.free_[small].second)) small = i;
-    void *victim = p;
-    if (small != (size_t) -1 && c->pool.bytes - c->pool.free_[small].second + bytes <= c->pool.max_bytes) {
-        victim = c->pool.free_[small].first;
-        c->pool.bytes += bytes - c->pool.free_[small].second;
-        c->pool.free_[small] = {p, bytes};
+    // full: the blocks that have sat in the cache UNUSED for the longest leave (free_ is in order of return -- a block that is handed
+    // out is taken from the middle, one that comes back is appended -- so its front is the stalest).  A steady workload keeps
+    // recycling its own blocks and never reaches the front; the blocks of a PREVIOUS workload age out.  (Round 4 evicted the smallest
+    // block instead: after a 3 Gbp sweep had filled the cache with 64 large blocks, every block of a later stream of small batches
+    // went back to the driver and came from hipMalloc again, forever -- tests/test_gpu_configs.py found it.)
+    std::vector<void *> victims;
+    while (!c->pool.free_.empty() && (c->pool.bytes + bytes > c->pool.max_bytes || c->pool.free_.size() >= BlockPool::kMaxBlocks)) {
+        victims.push_back(c->pool.free_.front().first);
+        c->pool.bytes -= c->pool.free_.front().second;
+        c->pool.free_.erase(c->pool.free_.begin());
     }
-    c->pool.n_driver_free++;
+    if (c->pool.bytes + bytes <= c->pool.max_bytes) {
+        c->pool.free_.emplace_back(p, bytes);
+        c->pool.bytes += bytes;
+    } else {
+        victims.push_back(p);                                   // larger than the whole cache may be
+    }
+    c->pool.n_driver_free += victims.size();
     lk.unlock();
     const uint64_t t0 = now_ns();
-    (void) hipFree(victim);
+    for (void *v : victims) (void) hipFree(v);
     lk.lock();
     c->pool.ns_driver += now_ns() - t0;
 }

@@ -478,14 +478,73 @@ def make_579(R, n_kmers):
     print(f"wrote synth_jaspar579.npz  (mean width {widths.mean():.2f}, keys {keys})")
 
 
+# ------------------------------------------------------------- 579, JASPAR-like information --
+
+def column_with_information(rng, bits):
+    """A probability column whose information content (against a uniform background) is `bits`: one dominant base, the rest of
+    the mass spread unevenly over the other three (bisection on the dominant base's probability)."""
+    w = rng.dirichlet(np.ones(3))                                   # how the rest is split
+    lo, hi = 0.25, 1.0 - 1e-9
+    for _ in range(60):
+        p = 0.5 * (lo + hi)
+        q = np.concatenate([[p], (1 - p) * w])
+        info = 2.0 + float((q * np.log2(np.maximum(q, 1e-300))).sum())
+        lo, hi = (p, hi) if info < bits else (lo, p)
+    col = np.concatenate([[p], (1 - p) * w])
+    return col[rng.permutation(4)]
+
+
+def make_579_realistic(R, n_kmers):
+    """a second 579-motif set whose per-column information follows a JASPAR-like profile -- an informative core
+    (1.2 ... 1.8 bits per column) between low-information flanks (0.1 ... 0.4 bits), 10 % weak motifs (< 6 bits in total) -- built
+    through the reference's own to_ppm().to_pwm() (matrix.py:74-171) with cutoffs from its c_score + get_score_cutoffs
+    (motif/__init__.py:378-401).  The benchmark set (make_579: Dirichlet(0.3) columns, every column informative) is the one
+    BASELINE's numbers are quoted on; this one is a side workload for the filter's candidate ratio and the truncation decision."""
+    rng = np.random.default_rng(20261004)
+    bg = {"A": 0.295, "C": 0.205, "G": 0.205, "T": 0.295}
+    bgp = np.array([bg[b] for b in "ACGT"])
+    P = 579
+    widths = np.clip(np.rint(rng.gamma(shape=7.5, scale=1.55, size=P)), 5, 30).astype(np.int32)
+    widths[0], widths[1] = 30, 5
+    mats, infos = [], []
+    for w in widths:
+        w = int(w)
+        depth = int(rng.integers(20, 3001))
+        weak = rng.random() < 0.10
+        n_core = max(3, int(round(w * rng.uniform(0.45, 0.7))))
+        c0 = int(rng.integers(0, w - n_core + 1))
+        bits = np.where((np.arange(w) >= c0) & (np.arange(w) < c0 + n_core), rng.uniform(1.2, 1.8, size=w), rng.uniform(0.1, 0.4, size=w))
+        if weak:
+            bits *= min(1.0, rng.uniform(3.5, 5.9) / bits.sum())
+        cols = np.stack([column_with_information(rng, b) for b in bits], axis=1)              # 4 x W
+        counts = np.rint(cols * depth).astype(np.int64)
+        counts[:, counts.sum(axis=0) == 0] = 1
+        mats.append(R["PFM"](counts).to_ppm().to_pwm(bg).matrix)
+        infos.append(float(bits.sum()))
+    cuts, _ = reference_cutoffs(R, mats, rng, bgp, n_kmers, 8)
+    keys = sorted(cuts[0].keys())
+    np.savez_compressed(os.path.join(HERE, "..", "..", "motifscan_amd", "data", "synth_jaspar579_lowinfo.npz"),
+                        reference_version=np.array(R["version"]), n_kmers=np.array(n_kmers),
+                        widths=widths, pwm_values=np.concatenate([m.ravel() for m in mats]),
+                        cutoff_keys=np.array(keys),
+                        cutoffs=np.array([[c[k] for k in keys] for c in cuts]),
+                        bg=bgp, information_bits=np.array(infos))
+    print(f"wrote synth_jaspar579_lowinfo.npz  (mean width {widths.mean():.2f}, mean information {np.mean(infos):.1f} bits, "
+          f"{int((np.array(infos) < 6).sum())} motifs under 6 bits)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-579", action="store_true")
     ap.add_argument("--only-579", action="store_true")
+    ap.add_argument("--only-lowinfo", action="store_true", help="only the JASPAR-like-information 579-motif side set")
     ap.add_argument("--only-dedup", action="store_true", help="refresh only the de-dup cases of ref_small.json (everything else stays byte for byte)")
     ap.add_argument("--n-kmers", type=int, default=1000000)
     a = ap.parse_args()
     R = import_reference()
+    if a.only_lowinfo:
+        make_579_realistic(R, a.n_kmers)
+        sys.exit(0)
     if a.only_dedup:
         path = os.path.join(HERE, "ref_small.json")
         with open(path) as fh:
