@@ -239,10 +239,12 @@ def main():
     ap.add_argument("--p-value", default="1e-4", choices=["1e-2", "1e-3", "1e-4", "1e-5", "1e-6"],
                     help="cutoff column of the motif set (the reference's -p, cli/main.py:520-521); anything but 1e-4 is a builder-run side workload, the line says so")
     ap.add_argument("--strand", default="both", choices=["both", "+", "-"], help="the reference's --strand (cli/main.py:543); default both")
+    ap.add_argument("--motif-set", default="benchmark", choices=["benchmark", "lowinfo"],
+                    help="lowinfo: the JASPAR-like-information side set (informative core, weak flanks, 10 %% weak motifs); a side workload, the line says so")
     ap.add_argument("--extra-widths", default="", help="comma list: append one synthetic motif of each of these widths (side workload: motifs wider than the set holds)")
     a = ap.parse_args()
     strand_mask = {"both": 3, "+": 1, "-": 2}[a.strand]
-    side = a.p_value != "1e-4" or a.strand != "both" or bool(a.extra_widths)
+    side = a.p_value != "1e-4" or a.strand != "both" or bool(a.extra_widths) or a.motif_set != "benchmark"
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)                             # never returns
@@ -259,7 +261,7 @@ def main():
     wl = load_workload(a.workload, rank, world, a)
     if side:
         from motifscan_amd import synth
-        vals, widths, cutoffs = synth.load_motif_set(wl["n_pwms"], a.p_value)
+        vals, widths, cutoffs = synth.load_motif_set(wl["n_pwms"], a.p_value, a.motif_set)
         mats = [m for m in synth.matrices_of(vals, widths)]
         cuts = list(cutoffs)
         for w in [int(x) for x in a.extra_widths.split(",") if x]:
@@ -482,7 +484,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[a.workload] + (f" [SHRUNK to {a.regions_per_set} regions per set: development run]" if shrunk else ""),
                        "regions_total": wl["n_regions_total"] * n_sets, "regions_per_gpu": wl["n_regions"] * n_sets,
-                       "region_bp": wl["length"], "n_pwms": P, "strands": a.strand, "p_value": a.p_value,
+                       "region_bp": wl["length"], "n_pwms": P, "strands": a.strand, "p_value": a.p_value, "motif_set": a.motif_set,
                        "motif_widths": f"{int(np.min(wl['widths']))}..{int(np.max(wl['widths']))}",
                        "sharding": f"{wl['n_regions_total']} + {wl['n_regions_total']} regions split contiguously over {world} GPU(s)"
                                    if n_sets == 2 else f"{wl['n_regions_total']} regions split contiguously over {world} GPU(s)",

@@ -32,9 +32,14 @@ WORKLOADS = {
 C5_SHARD = {"genome_bp": 375_000_000, "window": 200, "stride": 50, "n_pwms": 579}
 
 
-def load_motif_set(n_pwms=579, p_value="1e-4"):
-    """(pwm_values, widths, cutoffs) of the first n_pwms synthetic JASPAR-like motifs."""
-    d = np.load(MOTIF_SET)
+MOTIF_SETS = {"benchmark": "synth_jaspar579.npz",          # Dirichlet(0.3) columns: every column informative (BASELINE's numbers are quoted on it)
+              "lowinfo": "synth_jaspar579_lowinfo.npz"}     # JASPAR-like information profile: informative core, weak flanks, 10 % weak motifs (side workload)
+
+
+def load_motif_set(n_pwms=579, p_value="1e-4", which="benchmark"):
+    """(pwm_values, widths, cutoffs) of the first n_pwms synthetic JASPAR-like motifs (both sets: built through the reference's own
+    to_ppm().to_pwm() and cutoff pick, tests/golden/make_golden.py)."""
+    d = np.load(MOTIF_SET if which == "benchmark" else os.path.join(os.path.dirname(MOTIF_SET), MOTIF_SETS[which]))
     widths = d["widths"][:n_pwms].astype(np.int32)
     n_vals = 4 * int(widths.sum())
     keys = [str(k) for k in d["cutoff_keys"]]
