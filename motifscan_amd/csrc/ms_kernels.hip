@@ -619,13 +619,14 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     }
     // The two products of a row tile start from DIFFERENT constants, C and C / 2, with block scales one binade apart: the same mantissa
     // layout either way (an inline constant shared by two instructions is put into 16 registers by hipcc, eight v_mov per row tile)
-    const int scale0 = h ? kPairScaleY : kPairScaleX, scale1 = scale0 - 1;
-    [[maybe_unused]] f32x16 cc0, cc1;
+    const int scale0 = h ? kPairScaleY : kPairScaleX;
+    [[maybe_unused]] const int scale1 = scale0 - 1;
+    [[maybe_unused]] f32x16 cc0;                                                  // one half-block: BOTH products start from these 16 registers, at the same scale
     if constexpr (NK == 1) {
         constexpr float kC3 = kPairC + (float) kDeltaC0 * (1.0f / 512.0f) + (float) kDeltaC0 * (1.0f / 2097152.0f);     // exact: a multiple of 2^-21 below 8
         const float c = delta ? kC3 : kPairC;
 #pragma unroll
-        for (int j = 0; j < 16; j++) { cc0[j] = c; cc1[j] = 0.5f * c; }
+        for (int j = 0; j < 16; j++) cc0[j] = c;
     }
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
@@ -640,7 +641,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             const i32x8 a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
             const i32x8 b0 = i32x8{bq[0][0], bq[0][1], bq[0][2], bq[0][3], 0, 0, 0, 0}, b1 = i32x8{bq[1][0], bq[1][1], bq[1][2], bq[1][3], 0, 0, 0, 0};
             c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, cc0, 2, 4, 0, scale0, 0, 127);
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, cc1, 2, 4, 0, scale1, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, cc0, 2, 4, 0, scale0, 0, 127);
         }
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);

@@ -621,8 +621,8 @@ def test_bench_refuses_more_ranks_than_gpus_before_spawning():
 def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
     """Build-time checks on the gfx950 code object of the pre-filter: what the hand-written
     asm blocks of ms_kernels.hip rest on, read from the disassembly of the object the library was linked from.
-      * <= 128 vector registers (four waves per SIMD), no scalar spills, and no scratch traffic between the first and the last
-        matrix instruction (the registers the compiler spills live in the unit hand-out and the pass set-up around the classes);
+      * <= 128 vector registers (four waves per SIMD), NO vector register spilled to scratch memory, no scratch traffic at all in the
+        product kernel;
       * the work hand-out's `global_atomic_add vN ... sc0` (issued without a wait): vN is named by no instruction of the pass body
         (first to last matrix instruction) and by nothing in pf_flush, the one real call inside it -- the value arrives while pass 0
         runs and is first read after pass 1's staging wait;
@@ -660,7 +660,9 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
         assert len(mf) >= 12
         product = "ILi2ELb0" in k                                  # the kernel every JASPAR-like set runs on (the 3/4-k-block one spills in its rare paths)
         if product:
-            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 24 and num["private_segment_fixed_size"] <= 96, (k, num)
+            # no vector register in scratch memory (round 5: at -O3 hipcc spilled 10 ... 18 of them into the per-pass set-up, +1.2 ms per 500 Mbase;
+            # the kernels are built at -O2, csrc/Makefile); a few scalar registers parked in a vector register's lanes cost nothing
+            assert num["vgpr_spill_count"] == 0 and num["private_segment_fixed_size"] == 0 and num["sgpr_spill_count"] <= 8, (k, num)
             assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("scratch_")], "spill traffic inside the pass body"
         # the hand-out's atomic: the one that is NOT waited for at once
         cand = [i for i, l in enumerate(body) if l.startswith("global_atomic_add") and "sc0" in l
