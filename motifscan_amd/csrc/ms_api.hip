@@ -1962,20 +1962,20 @@ int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *
         if (group_paired) group_paired[q] = gi.paired == 2 ? 3 + gi.sel : (gi.paired ? 1 + gi.sel : 0);
         if (gi.paired == 2) {
             // delta rows (ms_internal.h): k-slot s of half-block kb, k-half sel = entry (column 8 sel + s / 4, base s % 4) of block kb.  What
-            // base b adds at column c: nothing for A, the slot's entry for C, G, T; the bias: the half-blocks' slots 15 / 31 times the
-            // B operand's constants there, + kDeltaC0 from the accumulator's start value (one half-block), less the field offset
+            // base b adds at column c: nothing for A, the slot's entry for C, G, T; the bias: the row's four bias slots times the B operand's
+            // constants there (delta_bias_slots), less the field offset
             auto slot_entry = [&](int row, int kb, int sl) { return f6_value(f6_get(tab, gi.nk, kb, row, 8 * gi.sel + sl / 4, sl % 4)); };
             for (int f = 0; f < kGroupFields; f++) {
                 const int row = mfma_row_of(gi.h, f);
-                int b0 = -kPairOffset + (gi.nk == 1 ? kDeltaC0 : 0);
-                for (int kb = 0; kb < gi.nk; kb++)
-                    b0 += delta_bias_weight(gi.nk, kb, 0) * slot_entry(row, kb, 15) + delta_bias_weight(gi.nk, kb, 1) * slot_entry(row, kb, 31);
+                int b0 = -kPairOffset;
+                const DeltaBiasSlot *bs = delta_bias_slots(gi.nk);
+                for (int k = 0; k < 4; k++) b0 += bs[k].weight * slot_entry(row, bs[k].kb, bs[k].slot);
                 if (bias) bias[q * kGroupFields + f] = b0;
                 if (rows)
                     for (int c = 0; c < kF6Cols * kF6MaxKb; c++)
                         for (int b = 0; b < 4; b++)
                             rows[((q * kGroupFields + f) * (kF6Cols * kF6MaxKb) + c) * 4 + b] =
-                                (int16_t) (c < n_cols && b > 0 ? slot_entry(row, c / kDeltaCols, delta_slot(c % kDeltaCols, b)) : 0);
+                                (int16_t) (c < (gi.nk == 1 ? kDeltaCols1 : n_cols) && b > 0 ? slot_entry(row, c / kDeltaCols, delta_slot(c % kDeltaCols, b)) : 0);
             }
             continue;
         }

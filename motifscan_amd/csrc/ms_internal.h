@@ -116,32 +116,39 @@ constexpr int kPairBiasW[4] = {6, 6, 6, 1};
 // BE the all-zero column: the row's bias takes A's value of every column and the slots for C, G, T hold what the base adds ON TOP of A,
 //     acc = [56 - sum_c dq_c(A)] + sum_c delta_c(code_c),   delta_c(b) = dq_c(A) - dq_c(b)  (0 for A),
 // the same number as the one-hot form's 56 - sum_c dq_c(code_c).  A half-block (one k-half of a paired-style row: field X in k-half 0 at
-// block scale 2^-6, field Y in k-half 1 at 2^-18, exactly as above) then holds TEN columns -- 30 k-slots -- and two bias slots: k-slots
-// 0 ... 14 = bases 0 ... 4 of the half-block x (C, G, T), slot 15 bias, slots 16 ... 30 = bases 5 ... 9, slot 31 bias.  Motifs of <= 10
-// columns cost one half-block (one-hot: <= 7), of <= 20 columns two (one-hot: <= 15; 16 ... 20 were plain rows at twice the price): 64
-// matrix instructions per 64 windows on the benchmark set instead of 82.  The deltas must lie on the signed e2m3 grid, so the quantiser
-// (ms_plan.cpp, quantize_strand_d3) picks dq'_c(A) <= floor(d_c(A) s) and the largest dq'_c(b) = dq'_c(A) - g <= floor(d_c(b) s) with g
-// on the grid: an upper bound of the score like the one-hot rows (every dq' is at or below the true scaled deficit), 1.7 % more
-// candidates on the benchmark set (tools/delta_quant_sim.py).  The B operand comes from a 1024-entry table (five 2-bit codes -> fifteen
-// fp4 k-slots, + the constant 6.0 in slot 15); the k-half's second word pair is the same table's entry for bases 5 ... 9, with slot 31
-// turned into 1.0 where the layout says so.  Bias: rows of two half-blocks have four bias slots with B constants (6, 1, 6, 6) [half-block
-// 0: slots 15, 31; half-block 1: slots 15, 31] carrying 1024 + b0 like the paired rows' bias column; rows of ONE half-block have two
-// (6, 1) = 6 u0 + u1, every integer of +-375 -- not enough for 1024 + b0, so kDeltaC0 = 780 levels of both fields ride on the
-// accumulator's START VALUE (4.0 + 780 (2^-9 + 2^-21): a register constant instead of the inline 4.0).
+// block scale 2^-6, field Y in k-half 1 at 2^-18, exactly as above) has room for TEN columns -- 30 k-slots -- and two bias slots: k-slots
+// 0 ... 14 = bases 0 ... 4 of the half-block x (C, G, T), slot 15 bias, slots 16 ... 30 = bases 5 ... 9, slot 31 bias.  The bias must carry
+// 1024 + b0 (<= 1080) in e2m3 entries times B constants of at most 6.0, i.e. four bias slots: rows of TWO half-blocks (motifs of 10 ... 20
+// columns; one-hot: <= 15, and 16 ... 20 were plain rows at twice the price) have them -- B constants (6, 1) in half-block 0 and (6, 6) in
+// half-block 1 --, rows of ONE half-block give up their tenth column for them (motifs of <= 9 columns; one-hot: <= 7): bias slots 15, 28,
+// 29, 30 with B constants (6, 6, 6, 1).  (A tenth column with the offset riding on the accumulator's start value instead was built first:
+// the sixteen registers of that constant cost the kernel twenty spilled registers.)  68 matrix instructions per 64 windows on the
+// benchmark set instead of 82.  The deltas must lie on the signed e2m3 grid, so the quantiser (ms_plan.cpp, quantize_strand_d3) picks
+// dq'_c(A) <= floor(d_c(A) s) and the largest dq'_c(b) = dq'_c(A) - g <= floor(d_c(b) s) with g on the grid: an upper bound of the score
+// like the one-hot rows (every dq' is at or below the true scaled deficit), 1.7 % more candidates on the benchmark set
+// (tools/delta_quant_sim.py).  The B operand comes from a 1024-entry table (five 2-bit codes -> fifteen fp4 k-slots, + the constant 6.0
+// in slot 15); the k-half's second word pair is the same table's entry for the next five (four) bases, with the bias constants put in.
 // Windows WITH non-ACGT bases cannot use these rows (A's column is not "adds nothing"): a pass whose 96 bases hold one -- wave-uniform,
 // rare -- runs the one-hot classes instead; every class says which kind of pass it serves (ClassDesc::family).  All sums stay exact:
 // every partial sum of a field is below 2048 levels in magnitude (positive deltas are bounded by the dq(A) the bias was lowered by).
-constexpr int kDeltaCols = 10;                  // columns per half-block of a delta row
+constexpr int kDeltaCols = 10;                  // columns per half-block of a two-half-block delta row
+constexpr int kDeltaCols1 = 9;                  // ... of a one-half-block delta row (the tenth column's slots carry the bias)
 constexpr int kDeltaMaxWidth = 2 * kDeltaCols;
-constexpr int kDeltaC0 = 780;                   // levels both fields of a ONE-half-block delta row get from the accumulator's start value
 constexpr int kDeltaMaxSum = 1080;              // a field's deficits may add up to this: X + 1024 = 1080 - sum stays >= 0
 constexpr size_t kDeltaLutBytes = 1024 * 8;     // five 2-bit codes -> 15 fp4 k-slots + the bias constant in slot 15
-constexpr uint32_t kDeltaFlip31 = 0x50000000u;  // xor into the k-half's last word: slot 31 from 6.0 (0x7) to 1.0 (0x2)
+constexpr uint32_t kDeltaFlip31 = 0x50000000u;  // two half-blocks: xor into half-block 0's last word: slot 31 from 6.0 (0x7) to 1.0 (0x2)
+constexpr uint32_t kDeltaBias1 = 0x02770000u;   // one half-block: or into the last word: slots 28, 29, 30 = 6.0, 6.0, 1.0
 constexpr int kFamilyN = 1, kFamilyClean = 2;   // ClassDesc::family bits: the class runs in passes WITH / WITHOUT non-ACGT bases
-inline int delta_kb_of_width(int W) { return (W + kDeltaCols - 1) / kDeltaCols; }
+inline int delta_kb_of_width(int W) { return W <= kDeltaCols1 ? 1 : 2; }     // (W <= kDeltaMaxWidth)
 inline int delta_slot(int c, int b) { return (c < 5 ? 0 : 16) + 3 * (c % 5) + (b - 1); }   // column c (0 ... 9) of a half-block, base b (1 ... 3)
-// B-operand constant at (half-block kb of nk, bias slot 15 / 31), as a weight in units of the A entry
-inline int delta_bias_weight(int nk, int kb, int slot31) { return (slot31 && kb == 0) ? 1 : 6; }
+// the bias slots of half-block kb of a delta row of nk half-blocks, in the order pair_bias_entries' u[0 ... 3] fills them, and the B
+// operand's constant there (a weight in units of the A entry): u[0 ... 2] ride the 6.0 slots, u[3] the 1.0 slot
+struct DeltaBiasSlot { int kb, slot, weight, u; };
+inline const DeltaBiasSlot *delta_bias_slots(int nk) {
+    static const DeltaBiasSlot one[4] = {{0, 15, 6, 0}, {0, 28, 6, 1}, {0, 29, 6, 2}, {0, 30, 1, 3}};
+    static const DeltaBiasSlot two[4] = {{0, 15, 6, 0}, {0, 31, 1, 3}, {1, 15, 6, 1}, {1, 31, 6, 2}};
+    return nk == 1 ? one : two;
+}
 
 inline int f6_kb_of_width(int W) { return W / kF6Cols + 1; }
 inline int pair_kb_of_width(int W) { return W / kPairCols + 1; }
@@ -221,17 +228,6 @@ inline bool pair_bias_entries(int total, int u[4]) {
                 if (rest >= -60 && rest <= 60 && f6_representable(rest)) { u[0] = a; u[1] = b; u[2] = c; u[3] = rest; return true; }
             }
         }
-    return false;
-}
-// the two bias entries (units of 1/8, on the signed e2m3 grid) of a one-half-block delta row: 6 u0 + u1 = total; false if there are none
-inline bool delta_bias_entries2(int total, int u[2]) {
-    for (int m = 0; m <= 60; m++) {
-        if (!f6_representable(m)) continue;
-        for (int sg = 1; sg >= -1; sg -= 2) {
-            const int rest = total - 6 * sg * m;
-            if (rest >= -60 && rest <= 60 && f6_representable(rest)) { u[0] = sg * m; u[1] = rest; return true; }
-        }
-    }
     return false;
 }
 // Byte offset, inside a row tile of nk blocks, of plane `plane` (0 ... 2) of the 8-byte word that `lane` reads for block kb.  Tiles of one

@@ -566,11 +566,10 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 // body per kind cost the kernel its registers (84 spilled) -- and differ in how the B operand is made, once per class and pass:
 //   paired (one-hot, 8 columns per half-block): two reads of the 256-entry table per half-block; non-ACGT bases cleared to all-zero columns;
 //       the bias column's (last column of the last half-block) B slots are the constants (6, 6, 6, 1);
-//   delta (round 5; 10 columns per half-block at three k-slots each; only passes WITHOUT a non-ACGT base run them -- the caller looks at
-//       Q.any_n): two reads of the 1024-entry table per half-block (bases 0 ... 4 and 5 ... 9; slot 15 of an entry is the bias constant 6.0),
-//       the second entry's slot 15 -- the k-half's slot 31 -- turned into 1.0 in half-block 0.
-// Accumulators: two half-blocks -- the inline constants 4.0 / 2.0 inside the product by name; one half-block -- a register constant, 4.0 for
-// paired rows and 4.0 + kDeltaC0 levels of both fields for delta rows (2.0 + ... at the second product's halved scale: the same mantissa).
+//   delta (round 5; three k-slots per column: 10 columns per half-block of a two-half-block row, 9 in a one-half-block row; only passes
+//       WITHOUT a non-ACGT base run them -- the caller looks at Q.any_n): two reads of the 1024-entry table per half-block (bases 0 ... 4 and
+//       5 ... 9 / 5 ... 8; slot 15 of an entry is the bias constant 6.0), the bias constants of the k-half's last slots put in.
+// Accumulators start from the inline constants 4.0 / 2.0 in either kind.
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut, const bool delta,
                                               uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
@@ -587,8 +586,9 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
 #pragma unroll
             for (int o = 0; o < 2; o++) {
                 const uint32_t twenty = (uint32_t) (Q.cw[o] >> (20 * kb));      // the half-block's ten bases, 2 bits each
-                const int2 lo = *reinterpret_cast<const int2 *>(lut5 + ((twenty & 0x3FFu) << 3)), hi = *reinterpret_cast<const int2 *>(lut5 + (((twenty >> 10) & 0x3FFu) << 3));
-                bq[2 * kb + o] = i32x4{lo.x, lo.y, hi.x, kb == 0 ? (int) ((uint32_t) hi.y ^ kDeltaFlip31) : hi.y};
+                const uint32_t second = NK == 1 ? (twenty >> 10) & 0xFFu : (twenty >> 10) & 0x3FFu;     // one half-block: nine columns, the tenth's slots carry the bias
+                const int2 lo = *reinterpret_cast<const int2 *>(lut5 + ((twenty & 0x3FFu) << 3)), hi = *reinterpret_cast<const int2 *>(lut5 + (second << 3));
+                bq[2 * kb + o] = i32x4{lo.x, lo.y, hi.x, NK == 1 ? (int) ((uint32_t) hi.y | kDeltaBias1) : (kb == 0 ? (int) ((uint32_t) hi.y ^ kDeltaFlip31) : hi.y)};
             }
         }
     } else {
@@ -619,14 +619,11 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     }
     // The two products of a row tile start from DIFFERENT constants, C and C / 2, with block scales one binade apart: the same mantissa
     // layout either way (an inline constant shared by two instructions is put into 16 registers by hipcc, eight v_mov per row tile)
-    const int scale0 = h ? kPairScaleY : kPairScaleX;
-    [[maybe_unused]] const int scale1 = scale0 - 1;
-    [[maybe_unused]] f32x16 cc0;                                                  // one half-block: BOTH products start from these 16 registers, at the same scale
+    const int scale0 = h ? kPairScaleY : kPairScaleX, scale1 = scale0 - 1;
+    [[maybe_unused]] f32x16 cc0, cc1;
     if constexpr (NK == 1) {
-        constexpr float kC3 = kPairC + (float) kDeltaC0 * (1.0f / 512.0f) + (float) kDeltaC0 * (1.0f / 2097152.0f);     // exact: a multiple of 2^-21 below 8
-        const float c = delta ? kC3 : kPairC;
 #pragma unroll
-        for (int j = 0; j < 16; j++) cc0[j] = c;
+        for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
     }
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
@@ -641,7 +638,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             const i32x8 a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
             const i32x8 b0 = i32x8{bq[0][0], bq[0][1], bq[0][2], bq[0][3], 0, 0, 0, 0}, b1 = i32x8{bq[1][0], bq[1][1], bq[1][2], bq[1][3], 0, 0, 0, 0};
             c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, cc0, 2, 4, 0, scale0, 0, 127);
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, cc0, 2, 4, 0, scale0, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, cc1, 2, 4, 0, scale1, 0, 127);
         }
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);

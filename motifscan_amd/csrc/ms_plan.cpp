@@ -330,7 +330,7 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                 if (fm) plan->group_fields[grp * kGroupFields + n] = fm->id;
                 if (rt.kind == 2) {
                     // delta row: (C, G, T) of column c in k-slots delta_slot(c % 10, b) of half-block c / 10, k-half `sel`; the bias in the
-                    // half-blocks' slots 15 / 31 (+ kDeltaC0 from the accumulator's start value in the one-half-block class)
+                    // row's four bias slots (delta_bias_slots)
                     const D3Strand *ds = fm && !fm->d3[sd].dead ? &fm->d3[sd] : nullptr;
                     if (ds)
                         for (int c = 0; c < fm->W; c++)
@@ -339,21 +339,13 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                                 f6_put(tab, rt.nk, c / kDeltaCols, row, 8 * sel + sl / 4, sl % 4, f6_code(ds->delta[c][b - 1]));
                             }
                     const int tot = kPairOffset + (ds ? kF6Levels - ds->a_sum : -1);          // empty / dead field: acc = -1/8, never a candidate
-                    int u4[4] = {0, 0, 0, 0}, u2[2] = {0, 0};
-                    if (rt.nk == 1 ? !delta_bias_entries2(tot - kDeltaC0, u2) : !pair_bias_entries(tot, u4)) {
+                    int u4[4] = {0, 0, 0, 0};
+                    if (!pair_bias_entries(tot, u4)) {
                         set_error("internal: no delta bias entries for %d", tot);
                         return MS_ERR_RUNTIME;
                     }
-                    // (slot 15 = column 3 base 3 of the k-half's 8 x 4 slot grid, slot 31 = column 7 base 3)
-                    if (rt.nk == 1) {
-                        f6_put(tab, 1, 0, row, 8 * sel + 3, 3, f6_code(u2[0]));             // x 6
-                        f6_put(tab, 1, 0, row, 8 * sel + 7, 3, f6_code(u2[1]));             // x 1
-                    } else {
-                        f6_put(tab, rt.nk, 0, row, 8 * sel + 3, 3, f6_code(u4[0]));         // x 6
-                        f6_put(tab, rt.nk, 0, row, 8 * sel + 7, 3, f6_code(u4[3]));         // x 1
-                        f6_put(tab, rt.nk, 1, row, 8 * sel + 3, 3, f6_code(u4[1]));         // x 6
-                        f6_put(tab, rt.nk, 1, row, 8 * sel + 7, 3, f6_code(u4[2]));         // x 6
-                    }
+                    const DeltaBiasSlot *bs = delta_bias_slots(rt.nk);                       // (k-slot s = column s / 4, base s % 4 of the k-half's 8 x 4 grid)
+                    for (int k = 0; k < 4; k++) f6_put(tab, rt.nk, bs[k].kb, row, 8 * sel + bs[k].slot / 4, bs[k].slot % 4, f6_code(u4[bs[k].u]));
                     continue;
                 }
                 const F6Strand *fs = fm ? (fm->use_wide ? &fm->f6w[sd] : &fm->f6[sd]) : nullptr;
