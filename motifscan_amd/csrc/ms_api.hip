@@ -375,10 +375,8 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
                        int device) {
     const char *pe = measure_env("MS_PF_PAIR");                          // measurement only: "0" = no paired rows
     const bool pair_rows = !(pe && pe[0] == '0');
-    const char *de = measure_env("MS_PF_DELTA");                         // measurement only: "0" = no delta rows (every pass runs the one-hot classes)
-    const bool delta_rows = pair_rows && !(de && de[0] == '0');
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
-                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_pair != pair_rows || p->plan_delta != delta_rows;
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_pair != pair_rows;
     if (stale) {
         if (exact_only) {
             p->plan = PrefilterPlan();
@@ -386,12 +384,11 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
             int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(), p->max_raw.data(),
-                                p->P, strand_mask, lds_budget, pair_rows, &p->plan, delta_rows);
+                                p->P, strand_mask, lds_budget, pair_rows, &p->plan);
             if (rc) return rc;
         }
         p->plan_strand = strand_mask;
         p->plan_pair = pair_rows;
-        p->plan_delta = delta_rows;
         p->plan_cutoff_version = p->cutoff_version;
         p->plan_lds = lds_budget;
         p->plan_exact_only = exact_only;
@@ -1930,8 +1927,7 @@ int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_bud
 // int16 = what the product adds for that base at that column, units of 1/8 (the bias column reads 0 here), bias [n_groups][16]
 // = the entry of the field's last column (MS_ERR_RUNTIME if its four bases disagree), group_kb [n_groups] matrix instructions
 // per row tile, group_cols [n_groups] columns of the group's fields incl. the bias column (16 per instruction, paired rows: 8),
-// group_paired [n_groups] 0 = plain row, 1 / 2 = field X / Y of a paired row, 3 / 4 = field X / Y of a DELTA row (rows[..][c][0] = 0: base A adds nothing
-// there, its share is in the bias; such rows are only evaluated for windows without non-ACGT bases), exact_motifs [n_exact], tile_first_group [n_tiles + 1].
+// group_paired [n_groups] 0 = plain row, 1 / 2 = field X / Y of a paired row, exact_motifs [n_exact], tile_first_group [n_tiles + 1].
 int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *rows, int32_t *bias, int32_t *group_kb,
                        int32_t *group_cols, int32_t *group_paired, int32_t *exact_motifs, int32_t *tile_first_group) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
@@ -1959,26 +1955,7 @@ int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *
         };
         if (group_kb) group_kb[q] = gi.nk;
         if (group_cols) group_cols[q] = n_cols;
-        if (group_paired) group_paired[q] = gi.paired == 2 ? 3 + gi.sel : (gi.paired ? 1 + gi.sel : 0);
-        if (gi.paired == 2) {
-            // delta rows (ms_internal.h): k-slot s of half-block kb, k-half sel = entry (column 8 sel + s / 4, base s % 4) of block kb.  What
-            // base b adds at column c: nothing for A, the slot's entry for C, G, T; the bias: the row's four bias slots times the B operand's
-            // constants there (delta_bias_slots), less the field offset
-            auto slot_entry = [&](int row, int kb, int sl) { return f6_value(f6_get(tab, gi.nk, kb, row, 8 * gi.sel + sl / 4, sl % 4)); };
-            for (int f = 0; f < kGroupFields; f++) {
-                const int row = mfma_row_of(gi.h, f);
-                int b0 = -kPairOffset;
-                const DeltaBiasSlot *bs = delta_bias_slots(gi.nk);
-                for (int k = 0; k < 4; k++) b0 += bs[k].weight * slot_entry(row, bs[k].kb, bs[k].slot);
-                if (bias) bias[q * kGroupFields + f] = b0;
-                if (rows)
-                    for (int c = 0; c < kF6Cols * kF6MaxKb; c++)
-                        for (int b = 0; b < 4; b++)
-                            rows[((q * kGroupFields + f) * (kF6Cols * kF6MaxKb) + c) * 4 + b] =
-                                (int16_t) (c < (gi.nk == 1 ? kDeltaCols1 : n_cols) && b > 0 ? slot_entry(row, c / kDeltaCols, delta_slot(c % kDeltaCols, b)) : 0);
-            }
-            continue;
-        }
+        if (group_paired) group_paired[q] = gi.paired ? 1 + gi.sel : 0;
         for (int f = 0; f < kGroupFields; f++) {
             const int row = mfma_row_of(gi.h, f);
             int b0 = entry(row, n_cols - 1, 0);

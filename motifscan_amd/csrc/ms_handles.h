@@ -149,7 +149,6 @@ struct ms_pwmset {
     size_t plan_lds = 0;
     bool plan_exact_only = false;
     bool plan_pair = true;                        // paired rows in the plan (always, but for MS_MEASURE=1 MS_PF_PAIR=0)
-    bool plan_delta = true;               // delta rows in the cached plan (MS_PF_DELTA=0 under MS_MEASURE builds one without)
     int plan_device = -1;
     uint4 *d_tables = nullptr;
     ms::TileDesc *d_tiles = nullptr;

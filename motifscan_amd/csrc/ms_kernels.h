@@ -8,7 +8,7 @@ constexpr int kPfThreads = 1024;      // pre-filter block: 16 waves, one block p
 constexpr int kPfBlocksPerCu = 1;     // after the tables are loaded, so the block shape only decides how many copies of the tables a CU's LDS holds
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr size_t kPfClsBytes = (size_t) kMaxClasses * 32;   // the tile's class descriptors, 32 bytes apiece, behind the B-operand table (prefilter_f6_kernel)
-constexpr size_t kF6LutBytes = 256 * 8 + kPfClsBytes + kDeltaLutBytes;       // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables; + the class descriptors; + the delta rows' table (five codes -> 15 k-slots + bias constant)
+constexpr size_t kF6LutBytes = 256 * 8 + kPfClsBytes;       // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables; + the class descriptors
 constexpr int kPfStageWords = 16;            // per wave: 8 code words + 4 non-ACGT words of the current pass (+ 4 spare), after the B-operand table
 constexpr size_t kPfStageBytes = (size_t) (kPfThreads / 64) * kPfStageWords * sizeof(uint32_t);
 // per wave: the lanes that hold a candidate park their 16 result registers here; the flag words are decoded later, one parked entry
