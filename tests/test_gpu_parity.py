@@ -387,6 +387,21 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
     assert_same_hits(res.hits(), want)
 
 
+@pytest.mark.parametrize("pkey", ["1e-3", "1e-4"])
+def test_low_information_motif_set_vs_oracle(oracle, pkey):
+    """the side set with a JASPAR-like information profile (informative core between weak flanks, 10 % weak motifs;
+    built through the reference's own to_ppm().to_pwm() and cutoff pick, tests/golden/make_golden.py::make_579_realistic) -- all 579
+    motifs, both strands, sequences with non-ACGT bases, bit for bit against the oracle; and the filter stays selective on it."""
+    vals, widths, cutoffs = synth.load_motif_set(579, pkey, "lowinfo")
+    bases, offsets = synth.make_regions(160, 600, seed=17, frac_n=0.05, ragged=True)
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), 3)
+    assert_same_hits(res.hits(), want)
+    st = res.stats()
+    assert st["n_pwms_exact"] == 0 and st["n_hits"] == len(want["pos"]) > 1000
+    assert st["n_candidates"] <= 3 * st["n_hits"] + 64 * 4096        # (records incl. the waves' unused block rests)
+
+
 @pytest.mark.parametrize("env", [{},
                                  {"MS_PF_LDS_BUDGET": "24576"},                                 # several LDS tiles (grid.y), as a very large motif set has
                                  {"MS_PF_LDS_BUDGET": "12288", "MS_HIT_COORD": "global"},

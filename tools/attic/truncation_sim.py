@@ -19,7 +19,7 @@ sys.path.insert(0, ".")
 from motifscan_amd import _lib, synth
 
 pkey = sys.argv[1] if len(sys.argv) > 1 else "1e-4"
-vals, widths, cutoffs = synth.load_motif_set(579, pkey)
+vals, widths, cutoffs = synth.load_motif_set(579, pkey, sys.argv[2] if len(sys.argv) > 2 else "benchmark")
 pw = _lib.PwmSet(vals, widths, cutoffs)
 plan = pw.plan(3)
 BG = synth.BG

@@ -1,6 +1,6 @@
 # Round evidence on the GPU box: tests, bench lines, profiles.  Usage: bash tools/evidence_round.sh <tag> [quick]
 # Everything lands in gpurun_out/evidence_<tag>/ (scratch); what is to be judged is copied into profiles/ afterwards (profiles/INDEX.md).
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
 T="timeout 900"
@@ -23,13 +23,17 @@ $T python bench.py --no-cpu-baseline --no-end-to-end --p-value 1e-3 > $OUT/bench
 $T python bench.py --no-cpu-baseline --no-end-to-end --p-value 1e-5 > $OUT/bench_c4_p1e-5.json 2> /dev/null
 $T python bench.py --no-cpu-baseline --no-end-to-end --p-value 1e-2 --regions-per-set 125000 --steps 3 > $OUT/bench_c4shard_p1e-2.json 2> /dev/null
 $T python bench.py --no-cpu-baseline --no-end-to-end --strand + > $OUT/bench_c4_strand_plus.json 2> /dev/null
+# the side set with a JASPAR-like information profile: candidates per hit, fp64-stage ms
+$T python bench.py --no-cpu-baseline --no-end-to-end --no-api --motif-set lowinfo > $OUT/bench_c4_lowinfo.json 2> /dev/null
+# end to end with other batch schedules (8 equal batches of 250k; batches of 62.5k ... 125k)
+$T python bench.py --no-cpu-baseline --no-api --no-scale-projection --batch-regions 250000 --max-batch-regions 250000 --no-batch-ramp --steps 4 > $OUT/bench_c4_e2e_8_equal_batches.json 2> /dev/null
+$T python bench.py --no-cpu-baseline --no-api --no-scale-projection --batch-regions 62500 --max-batch-regions 125000 --steps 4 > $OUT/bench_c4_e2e_small_batches.json 2> /dev/null
 $T python bench.py --no-cpu-baseline --no-end-to-end --extra-widths 33,40 > $OUT/bench_c4_plus_w33_w40.json 2> /dev/null
 $T python tools/pf_account.py 1e-4 full 2>&1 | grep -v amdgpu.ids > $OUT/pf_account.log
 $T python tools/pf_account.py 1e-3 2>&1 | grep -v amdgpu.ids >> $OUT/pf_account.log
 $T python tools/pf_class_clock.py 3 1e-4 2>&1 | grep -v amdgpu.ids > $OUT/class_clock.log
 $T python tools/e2e_bounds.py 2>&1 | grep -v amdgpu.ids > $OUT/e2e_bounds.log
 for i in 1 2; do
-if [ -d tools/ab/r04base ]; then (cd tools/ab/r04base && $T python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/before the lane-major A tiles (ae3f7da..HEAD~3, 1bcced0d3ba556ed): /") >> $OUT/full_size_stage_times.log; fi
 $T python tools/ab_full.py 3 1e-4 2>&1 | grep Mbase | sed "s/^/this build: /" >> $OUT/full_size_stage_times.log
 done
 $T python tools/ab_full.py 1 1e-4 2>&1 | grep Mbase >> $OUT/full_size_stage_times.log
