@@ -129,12 +129,29 @@ int main(void) {
         ms_result *none = (ms_result *) 1;
         CHECK(ms_stream_next(st, &none));
         if (none != NULL) return 1;
+        /* the control-set form (cli/scan.py:81-89 -> stats.py:29-31): the same batch counts-only -- its per-motif region counts and hit
+         * number are those of the batch that carried its hits out */
+        {
+            int64_t c_hits[P], c_only[P], n_hits = 0, n_only = 0;
+            ms_result *r1 = NULL, *r2 = NULL;
+            CHECK(ms_stream_submit(st, pin, boff[0], cut[1] - cut[0]));
+            CHECK(ms_stream_submit_counts_only(st, pin, boff[0], cut[1] - cut[0]));
+            CHECK(ms_stream_next(st, &r1));
+            CHECK(ms_stream_next(st, &r2));
+            if (!r1 || !r2) return 1;
+            CHECK(ms_result_region_counts(r1, c_hits));
+            CHECK(ms_result_region_counts(r2, c_only));
+            CHECK(ms_result_num_hits(r1, &n_hits));
+            CHECK(ms_result_num_hits(r2, &n_only));
+            if (n_hits != n_only || memcmp(c_hits, c_only, sizeof(c_hits)) != 0) { fprintf(stderr, "counts-only batch differs\n"); return 1; }
+            ms_result_free(r1); ms_result_free(r2);
+        }
         double stage[12];
         uint64_t pool[6];
         CHECK(ms_stream_stats(st, stage));
         CHECK(ms_device_pool_stats(pool));
         for (int k = 0; k < 3; k++)
-            if (stage[4 * k] != 3.0 || stage[4 * k + 1] < 0.0) { fprintf(stderr, "stream: stage %d saw %.0f batches\n", k, stage[4 * k]); return 1; }
+            if (stage[4 * k] != 5.0 || stage[4 * k + 1] < 0.0) { fprintf(stderr, "stream: stage %d saw %.0f batches\n", k, stage[4 * k]); return 1; }
         if (pool[0] + pool[1] == 0) { fprintf(stderr, "block pool saw no request\n"); return 1; }
         ms_stream_free(st);
         ms_host_free(pin);

@@ -1,6 +1,6 @@
 # Short refresh of the evidence a kernel-source change invalidates (the traffic record is stamped with the source hash): GPU suite, the
 # driver-style line, rocprofv3 kernel stats and the two HBM-traffic PMC passes.  Usage: bash tools/evidence_refresh.sh <tag>
-TAG=${1:-r04f}
+TAG=${1:-r05b}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
 T="timeout 900"
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export MS_SYNTH_WORKERS=1
 P=$OUT/prof
 mkdir -p $P
-B="python3 bench.py --no-cpu-baseline --no-end-to-end --no-api"
+B="python3 bench.py --no-cpu-baseline --no-end-to-end --no-api --no-scale-projection"      # (the projection adds shrunk launches: every average here is over full-size launches only)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $B --steps 5 --warmup 2 > $P/bench_under_rocprof.json 2> $P/stats.err
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/write.err

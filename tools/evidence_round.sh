@@ -49,7 +49,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export MS_SYNTH_WORKERS=1      # no forked workers under rocprofv3 (a forked child once hung in the tool's signal handler: 46 minutes)
 P=$OUT/prof
 mkdir -p $P
-B="python3 bench.py --no-cpu-baseline --no-end-to-end --no-api"
+B="python3 bench.py --no-cpu-baseline --no-end-to-end --no-api --no-scale-projection"      # (the projection adds shrunk launches: every average here is over full-size launches only)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $B --steps 5 --warmup 2 > $P/bench_under_rocprof.json 2> $P/stats.err
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $P/sq1 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq1.err
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F8 SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $P/sq2 -- $B --steps 2 --warmup 1 --min-warm-seconds 0 > /dev/null 2> $P/sq2.err
