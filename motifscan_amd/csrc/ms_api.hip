@@ -1134,9 +1134,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 A.clk = d_clk;
             }
             const int64_t n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
-            const int bpt2 = two_launch ? (int) std::min<int64_t>(std::min(bpt, 32), n_chunks) : 0;      // the second launch: a few blocks per tile
+            const int bpt2 = two_launch ? (int) std::min<int64_t>(bpt, n_chunks) : 0;                   // the second launch: the same grid (each wave takes a few listed passes)
             const uint64_t static1 = (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
-            cand_static = static1 + (uint64_t) bpt2 * n_tiles * (kPfThreads / 64) * cand_block;
+            const uint32_t cand_block2 = 64;                                      // the second launch's waves find few candidates: small blocks of their own
+            cand_static = static1 + (uint64_t) bpt2 * n_tiles * (kPfThreads / 64) * cand_block2;
             A.cand_static = cand_static;
             A.cand_static_base = 0;
             A.pass_list = nullptr; A.n_list = nullptr; A.list_mode = 0;
@@ -1171,6 +1172,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 B.list_mode = 1;
                 B.use_counters = 0;
                 B.cand_static_base = static1;
+                B.cand_block = cand_block2;
                 B.lut_off16 = (uint32_t) (lds_bytes_full / 16);
                 B.stage_off16 = B.lut_off16 + (uint32_t) (kF6LutBytes / 16);
                 B.emit_off16 = B.stage_off16 + (uint32_t) (kPfStageBytes / 16);

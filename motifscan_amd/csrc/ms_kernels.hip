@@ -560,40 +560,39 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     R.t = back;
 }
 
-// All row tiles of one class of PAIRED rows or of DELTA rows (ms_internal.h): NK half-blocks, k-half 0 = field X, k-half 1 = field Y (block
-// scales 2^-6 / 2^-18), both k-halves of the B operand = the same bases of the window.  A row tile answers for 32 motifs x 2 strands with the
-// 32 result registers that answer for 16 in a plain row tile.  The two kinds share this one body -- the row tile loop is the same code, and a
-// body per kind cost the kernel its registers (84 spilled) -- and differ in how the B operand is made, once per class and pass:
-//   paired (one-hot, 8 columns per half-block): two reads of the 256-entry table per half-block; non-ACGT bases cleared to all-zero columns;
-//       the bias column's (last column of the last half-block) B slots are the constants (6, 6, 6, 1);
-//   delta (round 5; three k-slots per column: 10 columns per half-block of a two-half-block row, 9 in a one-half-block row; only passes
-//       WITHOUT a non-ACGT base run them -- the caller looks at Q.any_n): two reads of the 1024-entry table per half-block (bases 0 ... 4 and
-//       5 ... 9 / 5 ... 8; slot 15 of an entry is the bias constant 6.0), the bias constants of the k-half's last slots put in.
-// Accumulators start from the inline constants 4.0 / 2.0 in either kind.
+// All row tiles of one class of PAIRED rows (ms_internal.h): NK half-blocks of 8 columns, k-half 0 = field X, k-half 1 = field Y (block
+// scales 2^-6 / 2^-18), both k-halves of the B operand = the same 8 bases, accumulators started at the inline constant 4.0, the bias
+// column's B slots constant.  A row tile answers for 32 motifs x 2 strands with the 32 result registers that answer for 16 in a
+// plain row tile.
+// DELTA (round 5; ms_internal.h): the same body for DELTA rows -- three k-slots per column, base A the all-zero column: 10 columns per
+// half-block of a two-half-block row, 9 in a one-half-block row.  They differ from the paired rows only in how the B operand is made: two
+// reads of the 1024-entry table per half-block (five 2-bit codes -> fifteen fp4 k-slots; slot 15 of an entry is the bias constant 6.0),
+// the bias constants of the k-half's last slots put in.  Only the kernel of the passes WITHOUT non-ACGT bases runs them.
 template <int NK, bool MEAS, bool DELTA>
 __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                               uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
                                               int64_t pass0, bool live0, bool live1, PfResume &R) {
-    static_assert(NK == 1 || NK == 2, "paired / delta rows have one or two half-blocks");
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     constexpr int kStep = NK * kF6BytesPerKb;
     const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
-    i32x4 bq[2 * NK];                                                            // [2 kb + operand]: half-block kb of the windows at g0 / at g0 + 32
+    // B operands: half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
+    i32x8 b0[NK], b1[NK];
     if constexpr (DELTA) {
+        static_assert(NK <= 2, "delta rows have one or two half-blocks");
         const char *lut5 = lut + 256 * 8 + kPfClsBytes;
 #pragma unroll
         for (int kb = 0; kb < NK; kb++) {
-#pragma unroll
-            for (int o = 0; o < 2; o++) {
-                const uint32_t twenty = (uint32_t) (Q.cw[o] >> (20 * kb));      // the half-block's ten bases, 2 bits each
-                const uint32_t second = NK == 1 ? (twenty >> 10) & 0xFFu : (twenty >> 10) & 0x3FFu;     // one half-block: nine columns, the tenth's slots carry the bias
-                const int2 lo = *reinterpret_cast<const int2 *>(lut5 + ((twenty & 0x3FFu) << 3)), hi = *reinterpret_cast<const int2 *>(lut5 + (second << 3));
-                bq[2 * kb + o] = i32x4{lo.x, lo.y, hi.x, NK == 1 ? (int) ((uint32_t) hi.y | kDeltaBias1) : (kb == 0 ? (int) ((uint32_t) hi.y ^ kDeltaFlip31) : hi.y)};
-            }
+            const uint32_t t0 = (uint32_t) (Q.cw[0] >> (20 * kb)), t1 = (uint32_t) (Q.cw[1] >> (20 * kb));      // the half-block's ten bases, 2 bits each
+            const uint32_t m2 = NK == 1 ? 0xFFu : 0x3FFu;                          // one half-block: nine columns, the tenth's slots carry the bias
+            const int2 l0 = *reinterpret_cast<const int2 *>(lut5 + ((t0 & 0x3FFu) << 3)), h0 = *reinterpret_cast<const int2 *>(lut5 + (((t0 >> 10) & m2) << 3));
+            const int2 l1 = *reinterpret_cast<const int2 *>(lut5 + ((t1 & 0x3FFu) << 3)), h1 = *reinterpret_cast<const int2 *>(lut5 + (((t1 >> 10) & m2) << 3));
+            uint32_t y0 = (uint32_t) h0.y, y1 = (uint32_t) h1.y;
+            if (NK == 1) { y0 |= kDeltaBias1; y1 |= kDeltaBias1; }                 // slots 28 ... 30: the bias constants 6.0, 6.0, 1.0
+            else if (kb == 0) { y0 ^= kDeltaFlip31; y1 ^= kDeltaFlip31; }          // slot 31: the 1.0 bias slot
+            b0[kb] = i32x8{l0.x, l0.y, h0.x, (int) y0, 0, 0, 0, 0};
+            b1[kb] = i32x8{l1.x, l1.y, h1.x, (int) y1, 0, 0, 0, 0};
         }
     } else {
-        // half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
-        i32x8 b0[NK], b1[NK];
 #pragma unroll
         for (int kb = 0; kb < NK; kb++) {
             b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[0] >> (16 * kb)) & 0xFFFFu);
@@ -611,35 +610,46 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
         // the bias column (last column of the last half-block): constant k-slots in place of the base's one-hot image
         b0[NK - 1][3] = (int) (((uint32_t) b0[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
         b1[NK - 1][3] = (int) (((uint32_t) b1[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            bq[2 * kb] = i32x4{b0[kb][0], b0[kb][1], b0[kb][2], b0[kb][3]};
-            bq[2 * kb + 1] = i32x4{b1[kb][0], b1[kb][1], b1[kb][2], b1[kb][3]};
-        }
     }
-    // The two products of a row tile start from DIFFERENT constants, C and C / 2, with block scales one binade apart: the same mantissa
-    // layout either way (an inline constant shared by two instructions is put into 16 registers by hipcc, eight v_mov per row tile)
+    // The two products of a row tile start from DIFFERENT inline constants, 4.0 and 2.0, with block scales one binade apart: the same
+    // mantissa layout either way (a constant shared by two instructions is put into 16 registers by hipcc, eight v_mov per row tile)
     const int scale0 = h ? kPairScaleY : kPairScaleX, scale1 = scale0 - 1;
-    [[maybe_unused]] f32x16 cc0, cc1;
-    if constexpr (NK == 1) {
+    f32x16 cc0, cc1;
 #pragma unroll
-        for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
-    }
+    for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
+    auto load_a = [&](const char *q, int kb) {
+        const int2 w0 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb);
+        const int2 w1 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 512);
+        const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
+        return i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+    };
+    auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
+        // (three half-blocks: the A operands are read one or two at a time -- 6 B operands of 4 registers, 3 A operands of 6 and the
+        // 32 results do not fit beside the rest)
+        i32x8 a = load_a(q, 0);
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0[0], cc0, 2, 4, 0, scale0, 0, 127);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1[0], cc1, 2, 4, 0, scale1, 0, 127);
+#pragma unroll
+        for (int kb = 1; kb < NK; kb++) {
+            a = load_a(q, kb);
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0[kb], c0, 2, 4, 0, scale0, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1[kb], c1, 2, 4, 0, scale1, 0, 127);
+        }
+    };
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
     int back = n_row_tiles;                                                         // (one loop exit: see f6_class)
     [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;       // the row tile's LDS address
+    [[maybe_unused]] i32x4 bq[4];
+    if constexpr (NK == 2) {
+        bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
+        bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
+    }
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
         f32x16 c0, c1;
         if constexpr (NK == 2) pair_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
-        else {
-            const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
-            const i32x8 a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
-            const i32x8 b0 = i32x8{bq[0][0], bq[0][1], bq[0][2], bq[0][3], 0, 0, 0, 0}, b1 = i32x8{bq[1][0], bq[1][1], bq[1][2], bq[1][3], 0, 0, 0, 0};
-            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, cc0, 2, 4, 0, scale0, 0, 127);
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, cc1, 2, 4, 0, scale1, 0, 127);
-        }
+        else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
         if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
@@ -699,7 +709,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // while the current one runs.  (From global memory they came through VECTOR loads, each followed by s_waitcnt vmcnt(0) -- a wait that
     // also covers the next pass's sequence words in flight.  Measured: no difference in time on the benchmark set, profiles/r04_pf_account.log;
     // kept because the pass loop then holds no vector-memory wait but the staging's own.)
-    {
+    if constexpr (DELTA) {
         // five 2-bit codes -> fifteen fp4 k-slots of a delta row's B operand: slot 3 j + code_j - 1 = 1.0 for C, G, T, nothing for A (its share
         // rides in the row's bias); slot 15 = the bias constant 6.0 (e2m1 code 0x7)
         uint2 *lut5w = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(lut4) + 256 * 8 + kPfClsBytes);
@@ -717,7 +727,9 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     if (threadIdx.x < (uint32_t) kMaxClasses * 8u) {
         const uint32_t ci = threadIdx.x >> 3, f = threadIdx.x & 7u;
         static_assert(sizeof(ClassDesc) == 24, "ClassDesc layout");
-        cls_lds[threadIdx.x] = f < 6u ? reinterpret_cast<const int *>(&T->cls[ci])[f] : 0;
+        // (word 4 of the LDS copy = paired / delta kind | family << 8: one read, one scalar)
+        const int *cdw = reinterpret_cast<const int *>(&T->cls[ci]);
+        cls_lds[threadIdx.x] = f < 4u ? cdw[f] : (f == 4u ? (cdw[4] | (cdw[5] << 8)) : 0);
     }
     __syncthreads();
     const char *lds = reinterpret_cast<const char *>(lds4);
@@ -798,18 +810,18 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         }
         auto read_cd = [&](int i) { return *reinterpret_cast<const int4 *>(cls_lds + 8 * i); };      // {nk, n_row_tiles, base16, first_group}; paired: word 4
         int4 cd4 = read_cd(0);
-        int2 cdp = *reinterpret_cast<const int2 *>(cls_lds + 4);                 // {paired / delta, family}
-        constexpr int my_family = DELTA ? kFamilyClean : kFamilyN;              // which rows this kernel's passes run
+        int cdp = cls_lds[4];
         for (int i = 0; i < n_classes; i++) {
             ClassDesc cd;                                                         // wave-uniform: into scalar registers
             cd.nk = __builtin_amdgcn_readfirstlane(cd4.x);
             cd.n_row_tiles = __builtin_amdgcn_readfirstlane(cd4.y);
             cd.base16 = (uint32_t) __builtin_amdgcn_readfirstlane(cd4.z);
             cd.first_group = __builtin_amdgcn_readfirstlane(cd4.w);
-            cd.paired = __builtin_amdgcn_readfirstlane(cdp.x);
-            cd.family = __builtin_amdgcn_readfirstlane(cdp.y);
-            if (i + 1 < n_classes) { cd4 = read_cd(i + 1); cdp = *reinterpret_cast<const int2 *>(cls_lds + 8 * (i + 1) + 4); }      // the next class's, while this one runs
-            if (!(cd.family & my_family)) continue;
+            const int kf = __builtin_amdgcn_readfirstlane(cdp);
+            cd.paired = kf & 0xFF;                                                // 0 plain, 1 paired, 2 delta
+            cd.family = kf >> 8;
+            if (i + 1 < n_classes) { cd4 = read_cd(i + 1); cdp = cls_lds[8 * (i + 1) + 4]; }      // the next class's, while this one runs
+            if (!(cd.family & (DELTA ? kFamilyClean : kFamilyN))) continue;        // the other kernel's rows
             const uint32_t off = cd.base16 * 16u;
             PfResume R{0, 0u, 0u};
             unsigned long long tc0 = 0;
@@ -820,7 +832,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                     else f6_pair_class<2, MEAS, DELTA>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
                 } else {
                     switch (cd.nk) {
-                        case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;     // (only without paired rows: MS_PF_PAIR=0, measurement)
+                        case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
                         case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
                         case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); else R.t = cd.n_row_tiles; break;
                         case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); else R.t = cd.n_row_tiles; break;
