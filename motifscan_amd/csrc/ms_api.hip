@@ -1134,7 +1134,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 A.clk = d_clk;
             }
             const int64_t n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
-            const int bpt2 = two_launch ? (int) std::min<int64_t>(bpt, n_chunks) : 0;                   // the second launch: the same grid (each wave takes a few listed passes)
+            int bpt2 = two_launch ? (int) std::min<int64_t>(bpt, n_chunks) : 0;                         // the second launch: the same grid (each wave takes a few listed passes)
+            if (const char *e = measure_env("MS_PF_L2_BLOCKS")) bpt2 = two_launch ? std::max(1, std::min(bpt2, atoi(e))) : 0;
             const uint64_t static1 = (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
             const uint32_t cand_block2 = 64;                                      // the second launch's waves find few candidates: small blocks of their own
             cand_static = static1 + (uint64_t) bpt2 * n_tiles * (kPfThreads / 64) * cand_block2;
