@@ -228,9 +228,7 @@ class PwmSet:
         group_fields [groups][16] motif of the field (-1 empty; both strands: field n = slot n >> 1, even forward, odd reverse;
         one strand: field n = slot n), rows [groups][16][64 columns][4 bases] and bias [groups][16] in units of 1/8,
         group_kb [groups] matrix instructions per row tile, group_cols [groups] columns of the group's fields incl. the bias
-        column (16 per instruction; paired rows: 8; delta rows: 10, no bias column), group_paired [groups] 0 = plain row, 1 / 2 = field X / Y
-        of a paired row, 3 / 4 = field X / Y of a delta row (base A adds nothing there; evaluated for windows without non-ACGT bases only),
-        delta: the plan has delta rows (passes without non-ACGT bases run them instead of the paired rows)."""
+        column (16 per instruction; paired rows: 8), group_paired [groups] 0 = plain row, 1 / 2 = field X / Y of a paired row."""
         L = lib()
         nf, ne, nq, nt = (ctypes.c_int32() for _ in range(4))
         check(L.ms_debug_plan_dims(self.h, strand_mask, lds_budget, ctypes.byref(nf), ctypes.byref(ne),
@@ -247,7 +245,7 @@ class PwmSet:
                                    ptr(kb, ctypes.c_int32), ptr(cols, ctypes.c_int32), ptr(paired, ctypes.c_int32),
                                    ptr(ex, ctypes.c_int32), ptr(tf, ctypes.c_int32)))
         return {"n_fast": nf.value, "n_exact": ne.value, "n_tiles": nt.value, "strand_mask": strand_mask, "group_fields": gf,
-                "rows": rows, "bias": bias, "group_kb": kb, "group_cols": cols, "group_paired": paired, "delta": bool((paired >= 3).any()),
+                "rows": rows, "bias": bias, "group_kb": kb, "group_cols": cols, "group_paired": paired,
                 "exact_motifs": ex[:ne.value], "tile_first_group": tf}
 
     def close(self):

@@ -375,10 +375,8 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
                        int device) {
     const char *pe = measure_env("MS_PF_PAIR");                          // measurement only: "0" = no paired rows
     const bool pair_rows = !(pe && pe[0] == '0');
-    const char *de = measure_env("MS_PF_DELTA");                         // measurement only: "0" = no delta rows (every pass runs the one-hot classes)
-    const bool delta_rows = pair_rows && !(de && de[0] == '0');
     const bool stale = p->plan_strand != strand_mask || p->plan_cutoff_version != p->cutoff_version ||
-                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_pair != pair_rows || p->plan_delta != delta_rows;
+                       p->plan_lds != lds_budget || p->plan_exact_only != exact_only || p->plan_pair != pair_rows;
     if (stale) {
         if (exact_only) {
             p->plan = PrefilterPlan();
@@ -386,12 +384,11 @@ static int pwmset_plan(ms_pwmset *p, int strand_mask, size_t lds_budget, bool ex
             for (int32_t i = 0; i < p->P; i++) p->plan.exact_motifs.push_back(i);
         } else {
             int rc = build_plan(p->values.data(), p->val_off.data(), p->widths.data(), p->cutoffs.data(), p->max_raw.data(),
-                                p->P, strand_mask, lds_budget, pair_rows, &p->plan, delta_rows);
+                                p->P, strand_mask, lds_budget, pair_rows, &p->plan);
             if (rc) return rc;
         }
         p->plan_strand = strand_mask;
         p->plan_pair = pair_rows;
-        p->plan_delta = delta_rows;
         p->plan_cutoff_version = p->cutoff_version;
         p->plan_lds = lds_budget;
         p->plan_exact_only = exact_only;
@@ -1029,15 +1026,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
 
     const DevSeq S = dev_seq(seqs);
     const DevPwm Pw = dev_pwm(pwms);
-    // Two-launch plans (delta rows): the FIRST launch -- every pass without non-ACGT bases -- loads only the clean prefix of a tile (delta
-    // rows + plain rows of > 20 columns); the second -- round 4's one-hot kernel over the few passes the first set aside -- the whole tile
-    // with the smallest parking space.  Everything below sizes the first (or only) launch; the second's layout is derived where it is made.
-    const bool two_launch = plan.delta;
-    size_t lds_bytes = 0, lds_bytes_full = 0;
-    for (const TileDesc &t : plan.tiles) {
-        lds_bytes = std::max(lds_bytes, (size_t) (two_launch ? t.clean_len16 : t.table_len16) * 16);
-        lds_bytes_full = std::max(lds_bytes_full, (size_t) t.table_len16 * 16);
-    }
+    size_t lds_bytes = 0;
+    for (const TileDesc &t : plan.tiles) lds_bytes = std::max(lds_bytes, (size_t) t.table_len16 * 16);
     const uint32_t lut_off16 = (uint32_t) (lds_bytes / 16);
     lds_bytes += lds_fixed;
     // the waves' candidate parking space takes what the tables leave of the block's LDS: kRareCapMin ... kRareCapMax entries per wave
@@ -1133,55 +1123,19 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
                 (void) hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * kPfClkWords * clk_blocks, c->stream);
                 A.clk = d_clk;
             }
-            const int64_t n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
-            int bpt2 = two_launch ? (int) std::min<int64_t>(bpt, n_chunks) : 0;                         // the second launch: the same grid (each wave takes a few listed passes)
-            if (const char *e = measure_env("MS_PF_L2_BLOCKS")) bpt2 = two_launch ? std::max(1, std::min(bpt2, atoi(e))) : 0;
-            const uint64_t static1 = (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
-            const uint32_t cand_block2 = 64;                                      // the second launch's waves find few candidates: small blocks of their own
-            cand_static = static1 + (uint64_t) bpt2 * n_tiles * (kPfThreads / 64) * cand_block2;
-            A.cand_static = cand_static;
-            A.cand_static_base = 0;
-            A.pass_list = nullptr; A.n_list = nullptr; A.list_mode = 0;
-            if (two_launch) {
-                const size_t need = (size_t) ((S.n_bases + 63) / 64) + 32;         // room for every pass of the input
-                if (need > sc.pass_list_cap) {
-                    dev_free(sc.pass_list);
-                    sc.pass_list_cap = 0;
-                    if ((rc = dev_alloc(&sc.pass_list, need + need / 4))) return rc;
-                    sc.pass_list_cap = need + need / 4;
-                }
-                he = hipMemsetAsync(sc.pass_list, 0, 64, c->stream);
-                if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
-                A.n_list = reinterpret_cast<unsigned int *>(sc.pass_list);
-                A.pass_list = sc.pass_list + 16;
+            {
+                const int64_t n_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
+                cand_static = (uint64_t) std::min<int64_t>(bpt, n_chunks) * n_tiles * (kPfThreads / 64) * cand_block;
+                A.cand_static = cand_static;
             }
             bool wide = false;
             for (const TileDesc &t : plan.tiles) wide = wide || t.max_nk > 2;
-            auto launch = [&](const PfArgs &Ax, bool delta, int blocks, size_t lds) -> int {
-                const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0) + (delta ? 4 : 0);
-                if (lds > c->lds_set[li]) {
-                    if (int r = prefilter_set_lds(wide, pf_meas, delta, lds)) return r;
-                    c->lds_set[li] = lds;
-                }
-                return launch_prefilter(Ax, wide, pf_meas, delta, blocks, n_tiles, lds, c->stream);
-            };
-            if ((rc = launch(A, two_launch, bpt, lds_bytes))) return rc;
-            if (two_launch) {
-                // the passes with non-ACGT bases, through round 4's kernel: the whole tile in LDS, the smallest parking space, its waves' own
-                // candidate blocks behind the first launch's
-                PfArgs B = A;
-                B.list_mode = 1;
-                B.use_counters = 0;
-                B.cand_static_base = static1;
-                B.cand_block = cand_block2;
-                B.lut_off16 = (uint32_t) (lds_bytes_full / 16);
-                B.stage_off16 = B.lut_off16 + (uint32_t) (kF6LutBytes / 16);
-                B.emit_off16 = B.stage_off16 + (uint32_t) (kPfStageBytes / 16);
-                B.rare_off16 = B.emit_off16 + (uint32_t) (kPfEmitBytes / 16);
-                B.rare_cap = (uint32_t) kRareCapMin;
-                B.clk = nullptr;
-                if ((rc = launch(B, false, bpt2, lds_bytes_full + lds_fixed))) return rc;
+            const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0);
+            if (lds_bytes > c->lds_set[li]) {
+                if ((rc = prefilter_set_lds(wide, pf_meas, lds_bytes))) return rc;
+                c->lds_set[li] = lds_bytes;
             }
+            if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return rc;
         }
         (void) hipEventRecord(ev[1], c->stream);
         if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)
@@ -1973,8 +1927,7 @@ int ms_debug_plan_dims(const ms_pwmset *pwms_c, int strand_mask, int64_t lds_bud
 // int16 = what the product adds for that base at that column, units of 1/8 (the bias column reads 0 here), bias [n_groups][16]
 // = the entry of the field's last column (MS_ERR_RUNTIME if its four bases disagree), group_kb [n_groups] matrix instructions
 // per row tile, group_cols [n_groups] columns of the group's fields incl. the bias column (16 per instruction, paired rows: 8),
-// group_paired [n_groups] 0 = plain row, 1 / 2 = field X / Y of a paired row, 3 / 4 = field X / Y of a DELTA row (rows[..][c][0] = 0: base A adds nothing
-// there, its share is in the bias; such rows are only evaluated for windows without non-ACGT bases), exact_motifs [n_exact], tile_first_group [n_tiles + 1].
+// group_paired [n_groups] 0 = plain row, 1 / 2 = field X / Y of a paired row, exact_motifs [n_exact], tile_first_group [n_tiles + 1].
 int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *rows, int32_t *bias, int32_t *group_kb,
                        int32_t *group_cols, int32_t *group_paired, int32_t *exact_motifs, int32_t *tile_first_group) {
     if (!pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
@@ -2002,26 +1955,7 @@ int ms_debug_plan_rows(const ms_pwmset *pwms_c, int32_t *group_fields, int16_t *
         };
         if (group_kb) group_kb[q] = gi.nk;
         if (group_cols) group_cols[q] = n_cols;
-        if (group_paired) group_paired[q] = gi.paired == 2 ? 3 + gi.sel : (gi.paired ? 1 + gi.sel : 0);
-        if (gi.paired == 2) {
-            // delta rows (ms_internal.h): k-slot s of half-block kb, k-half sel = entry (column 8 sel + s / 4, base s % 4) of block kb.  What
-            // base b adds at column c: nothing for A, the slot's entry for C, G, T; the bias: the row's four bias slots times the B operand's
-            // constants there (delta_bias_slots), less the field offset
-            auto slot_entry = [&](int row, int kb, int sl) { return f6_value(f6_get(tab, gi.nk, kb, row, 8 * gi.sel + sl / 4, sl % 4)); };
-            for (int f = 0; f < kGroupFields; f++) {
-                const int row = mfma_row_of(gi.h, f);
-                int b0 = -kPairOffset;
-                const DeltaBiasSlot *bs = delta_bias_slots(gi.nk);
-                for (int k = 0; k < 4; k++) b0 += bs[k].weight * slot_entry(row, bs[k].kb, bs[k].slot);
-                if (bias) bias[q * kGroupFields + f] = b0;
-                if (rows)
-                    for (int c = 0; c < kF6Cols * kF6MaxKb; c++)
-                        for (int b = 0; b < 4; b++)
-                            rows[((q * kGroupFields + f) * (kF6Cols * kF6MaxKb) + c) * 4 + b] =
-                                (int16_t) (c < (gi.nk == 1 ? kDeltaCols1 : n_cols) && b > 0 ? slot_entry(row, c / kDeltaCols, delta_slot(c % kDeltaCols, b)) : 0);
-            }
-            continue;
-        }
+        if (group_paired) group_paired[q] = gi.paired ? 1 + gi.sel : 0;
         for (int f = 0; f < kGroupFields; f++) {
             const int row = mfma_row_of(gi.h, f);
             int b0 = entry(row, n_cols - 1, 0);
@@ -2053,9 +1987,8 @@ int ms_debug_release_scratch(void) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
     Scratch &sc = c->sc;
-    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.chunk_counters); dev_free(sc.pass_list);
+    dev_free(sc.cand); dev_free(sc.keys); dev_free(sc.vals); dev_free(sc.keys_sorted); dev_free(sc.chunk_counters);
     sc.chunk_counters_cap = 0;
-    sc.pass_list_cap = 0;
     if (sc.sort_tmp) (void) hipFree(sc.sort_tmp);
     sc.sort_tmp = nullptr;
     sc.cand_cap = sc.hit_cap = sc.sort_tmp_bytes = 0;

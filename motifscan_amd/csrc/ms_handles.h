@@ -20,7 +20,6 @@ struct Scratch {                 // grow-only work buffers of the scan pipeline
     uint64_t *keys = nullptr;     double *vals = nullptr;   uint64_t *keys_sorted = nullptr;  size_t hit_cap = 0;
     void *sort_tmp = nullptr;     size_t sort_tmp_bytes = 0;
     unsigned int *chunk_counters = nullptr;    size_t chunk_counters_cap = 0;   // per LDS tile: the pre-filter's chunk dispenser
-    uint32_t *pass_list = nullptr;             size_t pass_list_cap = 0;        // two-launch plans: [0] the count, [16 ...] the passes with non-ACGT bases
     unsigned long long *counters = nullptr;      // 8 words, see scan_locked
     unsigned long long *h_counters = nullptr;    // pinned
 };
@@ -150,7 +149,6 @@ struct ms_pwmset {
     size_t plan_lds = 0;
     bool plan_exact_only = false;
     bool plan_pair = true;                        // paired rows in the plan (always, but for MS_MEASURE=1 MS_PF_PAIR=0)
-    bool plan_delta = true;               // delta rows in the cached plan (MS_PF_DELTA=0 under MS_MEASURE builds one without)
     int plan_device = -1;
     uint4 *d_tables = nullptr;
     ms::TileDesc *d_tiles = nullptr;

@@ -94,7 +94,7 @@ constexpr int kF6MaxKb = 4;
 constexpr int kF6BytesPerKb = 3 * 64 * 8;       // 1536
 constexpr int kF6Levels = 56;
 constexpr int kGroupFields = 16;                // fields per table group = result registers per lane
-constexpr int kMaxClasses = 8;                  // paired 1 / 2 half-blocks, delta 1 / 2 half-blocks, plain rows of 16 ... 20 columns, plain 2 ... 4 k-blocks
+constexpr int kMaxClasses = 6;                  // paired 1 / 2 half-blocks, plain 1 ... 4 k-blocks
 constexpr int kPairCols = 8;                    // columns per half-block of a paired row
 constexpr int kPairMaxWidth = 2 * kPairCols - 1;
 // Motifs of 16 ... 23 columns COULD ride paired rows of three half-blocks at 36 budget levels (deficits of 40 and more stored as 40:
@@ -112,44 +112,6 @@ constexpr uint32_t kPairMask = (1u << 22) | (1u << 10);
 constexpr uint32_t kPairBiasB = 0x2777u;        // the bias column of the B operand: k-slots (6.0, 6.0, 6.0, 1.0) in fp4 (e2m1), low nibble first
 constexpr int kPairBiasW[4] = {6, 6, 6, 1};
 
-// DELTA ROWS (round 5): three k-slots per column instead of four.  A window without non-ACGT bases needs no all-zero column, so base A can
-// BE the all-zero column: the row's bias takes A's value of every column and the slots for C, G, T hold what the base adds ON TOP of A,
-//     acc = [56 - sum_c dq_c(A)] + sum_c delta_c(code_c),   delta_c(b) = dq_c(A) - dq_c(b)  (0 for A),
-// the same number as the one-hot form's 56 - sum_c dq_c(code_c).  A half-block (one k-half of a paired-style row: field X in k-half 0 at
-// block scale 2^-6, field Y in k-half 1 at 2^-18, exactly as above) has room for TEN columns -- 30 k-slots -- and two bias slots: k-slots
-// 0 ... 14 = bases 0 ... 4 of the half-block x (C, G, T), slot 15 bias, slots 16 ... 30 = bases 5 ... 9, slot 31 bias.  The bias must carry
-// 1024 + b0 (<= 1080) in e2m3 entries times B constants of at most 6.0, i.e. four bias slots: rows of TWO half-blocks (motifs of 10 ... 20
-// columns; one-hot: <= 15, and 16 ... 20 were plain rows at twice the price) have them -- B constants (6, 1) in half-block 0 and (6, 6) in
-// half-block 1 --, rows of ONE half-block give up their tenth column for them (motifs of <= 9 columns; one-hot: <= 7): bias slots 15, 28,
-// 29, 30 with B constants (6, 6, 6, 1).  (A tenth column with the offset riding on the accumulator's start value instead was built first:
-// the sixteen registers of that constant cost the kernel twenty spilled registers.)  68 matrix instructions per 64 windows on the
-// benchmark set instead of 82.  The deltas must lie on the signed e2m3 grid, so the quantiser (ms_plan.cpp, quantize_strand_d3) picks
-// dq'_c(A) <= floor(d_c(A) s) and the largest dq'_c(b) = dq'_c(A) - g <= floor(d_c(b) s) with g on the grid: an upper bound of the score
-// like the one-hot rows (every dq' is at or below the true scaled deficit), 1.7 % more candidates on the benchmark set
-// (tools/delta_quant_sim.py).  The B operand comes from a 1024-entry table (five 2-bit codes -> fifteen fp4 k-slots, + the constant 6.0
-// in slot 15); the k-half's second word pair is the same table's entry for the next five (four) bases, with the bias constants put in.
-// Windows WITH non-ACGT bases cannot use these rows (A's column is not "adds nothing"): a pass whose 96 bases hold one -- wave-uniform,
-// rare -- runs the one-hot classes instead; every class says which kind of pass it serves (ClassDesc::family).  All sums stay exact:
-// every partial sum of a field is below 2048 levels in magnitude (positive deltas are bounded by the dq(A) the bias was lowered by).
-constexpr int kDeltaCols = 10;                  // columns per half-block of a two-half-block delta row
-constexpr int kDeltaCols1 = 9;                  // ... of a one-half-block delta row (the tenth column's slots carry the bias)
-constexpr int kDeltaMaxWidth = 2 * kDeltaCols;
-constexpr int kDeltaMaxSum = 1080;              // a field's deficits may add up to this: X + 1024 = 1080 - sum stays >= 0
-constexpr size_t kDeltaLutBytes = 1024 * 8;     // five 2-bit codes -> 15 fp4 k-slots + the bias constant in slot 15
-constexpr uint32_t kDeltaFlip31 = 0x50000000u;  // two half-blocks: xor into half-block 0's last word: slot 31 from 6.0 (0x7) to 1.0 (0x2)
-constexpr uint32_t kDeltaBias1 = 0x02770000u;   // one half-block: or into the last word: slots 28, 29, 30 = 6.0, 6.0, 1.0
-constexpr int kFamilyN = 1, kFamilyClean = 2;   // ClassDesc::family bits: the class runs in passes WITH / WITHOUT non-ACGT bases
-inline int delta_kb_of_width(int W) { return W <= kDeltaCols1 ? 1 : 2; }     // (W <= kDeltaMaxWidth)
-inline int delta_slot(int c, int b) { return (c < 5 ? 0 : 16) + 3 * (c % 5) + (b - 1); }   // column c (0 ... 9) of a half-block, base b (1 ... 3)
-// the bias slots of half-block kb of a delta row of nk half-blocks, in the order pair_bias_entries' u[0 ... 3] fills them, and the B
-// operand's constant there (a weight in units of the A entry): u[0 ... 2] ride the 6.0 slots, u[3] the 1.0 slot
-struct DeltaBiasSlot { int kb, slot, weight, u; };
-inline const DeltaBiasSlot *delta_bias_slots(int nk) {
-    static const DeltaBiasSlot one[4] = {{0, 15, 6, 0}, {0, 28, 6, 1}, {0, 29, 6, 2}, {0, 30, 1, 3}};
-    static const DeltaBiasSlot two[4] = {{0, 15, 6, 0}, {0, 31, 1, 3}, {1, 15, 6, 1}, {1, 31, 6, 2}};
-    return nk == 1 ? one : two;
-}
-
 inline int f6_kb_of_width(int W) { return W / kF6Cols + 1; }
 inline int pair_kb_of_width(int W) { return W / kPairCols + 1; }
 inline int mfma_row_of(int h, int field) { const int j = 15 - field; return (j & 3) + 8 * (j >> 2) + 4 * h; }
@@ -159,15 +121,14 @@ struct ClassDesc {
     int32_t n_row_tiles;
     uint32_t base16;       // offset of the class's tables inside the LDS tile, 16-byte units
     int32_t first_group;   // global index of the class's first table group
-    int32_t paired;        // 0: plain rows; 1: paired rows, 2: delta rows (four table groups per row tile either way)
-    int32_t family;        // kFamilyN | kFamilyClean: which passes run the class
+    int32_t paired;        // != 0: paired rows, four table groups per row tile
 };
 
 // where a table group's fields sit in the operand image (host side: tests decode the physical image through this)
 struct GroupInfo {
     uint32_t tab_off;      // byte offset of the group's row tile in PrefilterPlan::tables
     int8_t nk;             // instructions per row tile
-    int8_t paired;         // 0 plain, 1 paired, 2 delta
+    int8_t paired;
     int8_t h;              // lane half of the group's result registers
     int8_t sel;            // paired rows: 0 = field X (k-half 0, scale 2^12), 1 = field Y
 };
@@ -175,7 +136,6 @@ struct GroupInfo {
 struct TileDesc {
     uint32_t table_off16;   // offset into the table buffer, in 16-byte units
     uint32_t table_len16;   // tile size in 16-byte units
-    uint32_t clean_len16;   // ... of which this prefix holds the rows the passes WITHOUT non-ACGT bases run (delta rows, plain rows of > 20 columns)
     int32_t first_group;    // global index of the tile's first table group
     int32_t n_classes;
     int32_t max_nk;         // widest class of the tile
@@ -194,8 +154,7 @@ struct PrefilterPlan {
     std::vector<uint32_t> tables;        // the operand image, row tile after row tile
     std::vector<TileDesc> tiles;
     int64_t lds_bytes_per_position = 0;  // A-operand bytes read per window start
-    int64_t kb_total = 0;                // k-blocks over the row tiles a pass WITHOUT non-ACGT bases runs (the common pass)
-    bool delta = false;                  // delta rows are in the plan (passes without non-ACGT bases use them)
+    int64_t kb_total = 0;                // k-blocks over all row tiles
     bool alln_can_hit = false;           // some pre-filter motif reports windows made of non-ACGT bases only (threshold <= 0)
 };
 
@@ -265,10 +224,8 @@ inline uint32_t f6_get(const uint8_t *tile, int nk, int kb, int row, int col_in_
 
 // Quantiser + planner (pure host code, ms_plan.cpp).  lds_budget in bytes.
 // pair_rows: motifs of <= kPairMaxWidth columns go to paired rows (the product default; false = measurement only).
-// delta_rows: motifs of <= kDeltaMaxWidth columns ALSO get delta rows, for the passes without non-ACGT bases (needs pair_rows).
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths, const double *cutoffs,
-               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan,
-               bool delta_rows = true);
+               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan);
 
 // Sort (ms_sort.hip): keys ascending over bits [begin_bit, end_bit) (stable).  Query temp size with temp == nullptr.
 constexpr int kSortLowBits = 8;        // a scan's hits are radix-sorted over the key bits above these; sort_fixup_kernel orders the rest

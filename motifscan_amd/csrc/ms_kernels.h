@@ -8,7 +8,7 @@ constexpr int kPfThreads = 1024;      // pre-filter block: 16 waves, one block p
 constexpr int kPfBlocksPerCu = 1;     // after the tables are loaded, so the block shape only decides how many copies of the tables a CU's LDS holds
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr size_t kPfClsBytes = (size_t) kMaxClasses * 32;   // the tile's class descriptors, 32 bytes apiece, behind the B-operand table (prefilter_f6_kernel)
-constexpr size_t kF6LutBytes = 256 * 8 + kPfClsBytes + kDeltaLutBytes;       // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables; + the class descriptors; + the delta rows' table (five codes -> 15 k-slots + bias constant)
+constexpr size_t kF6LutBytes = 256 * 8 + kPfClsBytes;       // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables; + the class descriptors
 constexpr int kPfStageWords = 16;            // per wave: 8 code words + 4 non-ACGT words of the current pass (+ 4 spare), after the B-operand table
 constexpr size_t kPfStageBytes = (size_t) (kPfThreads / 64) * kPfStageWords * sizeof(uint32_t);
 // per wave: the lanes that hold a candidate park their 16 result registers here; the flag words are decoded later, one parked entry
@@ -77,8 +77,7 @@ struct PfArgs {
     unsigned long long *n_cand;   // slots reserved so far
     uint64_t cand_cap;
     uint32_t cand_block;      // >= 64
-    uint64_t cand_static;     // slots [0, cand_static) are the waves' own first blocks (wave w of a launch: cand_static_base + [w, w + 1) * cand_block)
-    uint64_t cand_static_base;   // where THIS launch's waves' own blocks start (two-launch plans: the second launch's lie behind the first's)
+    uint64_t cand_static;     // slots [0, cand_static) are the launch's waves' own first blocks (wave w: [w, w + 1) * cand_block)
     int skip_alln;            // != 0: no motif of the plan reports a window made of non-ACGT bases only: such windows are dropped unseen
     int no_emit;              // measurement only (MEAS instantiations): run the filter, drop the candidates
     int cls_clk;              // measurement only: also time the classes (MS_PF_CLOCK=2: the stamps themselves cost a few per cent)
@@ -86,15 +85,12 @@ struct PfArgs {
     unsigned int *chunk_counter;   // [LDS tiles][kPfCounters] words 64 bytes apart, zeroed: the units behind the waves' own first ones
     int use_counters;              // 0: a small input, one even unit per wave and no atomics
     int wave_passes;               // per-wave hand-out: passes of 64 window starts a wave takes per atomic (scan_locked sizes it)
-    uint32_t *pass_list;           // two-launch plans: the passes (pass0 / 64) that hold non-ACGT bases, set aside by the delta kernel for the one-hot kernel
-    unsigned int *n_list;          // ... and how many (zeroed before the first launch)
-    int list_mode;                 // the one-hot kernel behind a delta kernel: scan the listed passes only
 };
 
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int prefilter_set_lds(bool wide, bool meas, bool delta, size_t bytes);
-int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool delta, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
+int prefilter_set_lds(bool wide, bool meas, size_t bytes);
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 // the same for long lists: chunks of the list in motif order, the window carried along (rescore_carry_kernel); one 1024-thread block per CU

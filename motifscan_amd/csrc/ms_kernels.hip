@@ -564,11 +564,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 // scales 2^-6 / 2^-18), both k-halves of the B operand = the same 8 bases, accumulators started at the inline constant 4.0, the bias
 // column's B slots constant.  A row tile answers for 32 motifs x 2 strands with the 32 result registers that answer for 16 in a
 // plain row tile.
-// DELTA (round 5; ms_internal.h): the same body for DELTA rows -- three k-slots per column, base A the all-zero column: 10 columns per
-// half-block of a two-half-block row, 9 in a one-half-block row.  They differ from the paired rows only in how the B operand is made: two
-// reads of the 1024-entry table per half-block (five 2-bit codes -> fifteen fp4 k-slots; slot 15 of an entry is the bias constant 6.0),
-// the bias constants of the k-half's last slots put in.  Only the kernel of the passes WITHOUT non-ACGT bases runs them.
-template <int NK, bool MEAS, bool DELTA>
+template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                               uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
                                               int64_t pass0, bool live0, bool live1, PfResume &R) {
@@ -577,40 +573,23 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
     // B operands: half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
     i32x8 b0[NK], b1[NK];
-    if constexpr (DELTA) {
-        static_assert(NK <= 2, "delta rows have one or two half-blocks");
-        const char *lut5 = lut + 256 * 8 + kPfClsBytes;
 #pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            const uint32_t t0 = (uint32_t) (Q.cw[0] >> (20 * kb)), t1 = (uint32_t) (Q.cw[1] >> (20 * kb));      // the half-block's ten bases, 2 bits each
-            const uint32_t m2 = NK == 1 ? 0xFFu : 0x3FFu;                          // one half-block: nine columns, the tenth's slots carry the bias
-            const int2 l0 = *reinterpret_cast<const int2 *>(lut5 + ((t0 & 0x3FFu) << 3)), h0 = *reinterpret_cast<const int2 *>(lut5 + (((t0 >> 10) & m2) << 3));
-            const int2 l1 = *reinterpret_cast<const int2 *>(lut5 + ((t1 & 0x3FFu) << 3)), h1 = *reinterpret_cast<const int2 *>(lut5 + (((t1 >> 10) & m2) << 3));
-            uint32_t y0 = (uint32_t) h0.y, y1 = (uint32_t) h1.y;
-            if (NK == 1) { y0 |= kDeltaBias1; y1 |= kDeltaBias1; }                 // slots 28 ... 30: the bias constants 6.0, 6.0, 1.0
-            else if (kb == 0) { y0 ^= kDeltaFlip31; y1 ^= kDeltaFlip31; }          // slot 31: the 1.0 bias slot
-            b0[kb] = i32x8{l0.x, l0.y, h0.x, (int) y0, 0, 0, 0, 0};
-            b1[kb] = i32x8{l1.x, l1.y, h1.x, (int) y1, 0, 0, 0, 0};
-        }
-    } else {
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[0] >> (16 * kb)) & 0xFFFFu);
-            b1[kb] = onehot_f4(lut, (uint32_t) (Q.cw[1] >> (16 * kb)) & 0xFFFFu);
-        }
-        if (Q.any_n) {                                                            // rare, wave-uniform
-            const uint32_t nw0 = staged_nw(Q.stg, lane & 31u, 0), nw1 = staged_nw(Q.stg, lane & 31u, 1);
-#pragma unroll
-            for (int kb = 0; kb < NK; kb++) {
-                const uint32_t keep = kb == NK - 1 ? 0x7Fu : 0xFFu;               // the fields' last column carries the bias: never cleared
-                clear_n(b0[kb], (nw0 >> (8 * kb)) & keep);
-                clear_n(b1[kb], (nw1 >> (8 * kb)) & keep);
-            }
-        }
-        // the bias column (last column of the last half-block): constant k-slots in place of the base's one-hot image
-        b0[NK - 1][3] = (int) (((uint32_t) b0[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
-        b1[NK - 1][3] = (int) (((uint32_t) b1[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
+    for (int kb = 0; kb < NK; kb++) {
+        b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[0] >> (16 * kb)) & 0xFFFFu);
+        b1[kb] = onehot_f4(lut, (uint32_t) (Q.cw[1] >> (16 * kb)) & 0xFFFFu);
     }
+    if (Q.any_n) {                                                                // rare, wave-uniform
+        const uint32_t nw0 = staged_nw(Q.stg, lane & 31u, 0), nw1 = staged_nw(Q.stg, lane & 31u, 1);
+#pragma unroll
+        for (int kb = 0; kb < NK; kb++) {
+            const uint32_t keep = kb == NK - 1 ? 0x7Fu : 0xFFu;                   // the fields' last column carries the bias: never cleared
+            clear_n(b0[kb], (nw0 >> (8 * kb)) & keep);
+            clear_n(b1[kb], (nw1 >> (8 * kb)) & keep);
+        }
+    }
+    // the bias column (last column of the last half-block): constant k-slots in place of the base's one-hot image
+    b0[NK - 1][3] = (int) (((uint32_t) b0[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
+    b1[NK - 1][3] = (int) (((uint32_t) b1[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
     // The two products of a row tile start from DIFFERENT inline constants, 4.0 and 2.0, with block scales one binade apart: the same
     // mantissa layout either way (a constant shared by two instructions is put into 16 registers by hipcc, eight v_mov per row tile)
     const int scale0 = h ? kPairScaleY : kPairScaleX, scale1 = scale0 - 1;
@@ -681,17 +660,13 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
 // one-k-block class only, after tools/ubench/insp_probe.hip modes 6 / 7 promised -7 %: +6 % in the kernel), s_setprio around the
 // matrix instructions, 12 / 20 / 24 waves per CU, 128 windows per wave, a block-wide hand-out behind barriers, one branch per pair
 // of row tiles, a real function call for the rare path.)
-// DELTA (round 5): the kernel of the passes WITHOUT non-ACGT bases -- it loads the clean prefix of the tile (delta rows + plain rows of > 20
-// columns), runs the classes of that family, and a pass that does hold a non-ACGT base (wave-uniform, rare) is not scanned but APPENDED to
-// A.pass_list.  The other instantiation is round 4's kernel (paired one-hot rows + all plain rows); launched behind the first with the list
-// (A.list_mode), its waves take the listed passes one by one instead of units of the whole input.
-template <int MAXNK, bool MEAS, bool DELTA>
+template <int MAXNK, bool MEAS>
 __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArgs A) {
     extern __shared__ uint4 lds4[];
     constexpr int NT = kPfThreads;
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
     const bool wide = MAXNK > 2 && T->max_nk > 2;
-    const uint32_t len16 = DELTA ? T->clean_len16 : T->table_len16;
+    const uint32_t len16 = T->table_len16;
     const uint4 *__restrict__ src = A.tables + T->table_off16;
     for (uint32_t i = threadIdx.x; i < len16; i += NT) lds4[i] = src[i];
     uint4 *lut4 = lds4 + A.lut_off16;
@@ -709,27 +684,11 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // while the current one runs.  (From global memory they came through VECTOR loads, each followed by s_waitcnt vmcnt(0) -- a wait that
     // also covers the next pass's sequence words in flight.  Measured: no difference in time on the benchmark set, profiles/r04_pf_account.log;
     // kept because the pass loop then holds no vector-memory wait but the staging's own.)
-    if constexpr (DELTA) {
-        // five 2-bit codes -> fifteen fp4 k-slots of a delta row's B operand: slot 3 j + code_j - 1 = 1.0 for C, G, T, nothing for A (its share
-        // rides in the row's bias); slot 15 = the bias constant 6.0 (e2m1 code 0x7)
-        uint2 *lut5w = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(lut4) + 256 * 8 + kPfClsBytes);
-        for (uint32_t i = threadIdx.x; i < 1024u; i += NT) {
-            unsigned long long w = 7ULL << 60;
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const uint32_t cde = (i >> (2 * j)) & 3u;
-                if (cde) w |= 2ULL << (4 * (3 * j + (int) cde - 1));
-            }
-            lut5w[i] = make_uint2((uint32_t) w, (uint32_t) (w >> 32));
-        }
-    }
     int *cls_lds = reinterpret_cast<int *>(lut4 + 256 * 8 / 16);
     if (threadIdx.x < (uint32_t) kMaxClasses * 8u) {
         const uint32_t ci = threadIdx.x >> 3, f = threadIdx.x & 7u;
-        static_assert(sizeof(ClassDesc) == 24, "ClassDesc layout");
-        // (word 4 of the LDS copy = paired / delta kind | family << 8: one read, one scalar)
-        const int *cdw = reinterpret_cast<const int *>(&T->cls[ci]);
-        cls_lds[threadIdx.x] = f < 4u ? cdw[f] : (f == 4u ? (cdw[4] | (cdw[5] << 8)) : 0);
+        static_assert(sizeof(ClassDesc) == 20, "ClassDesc layout");
+        cls_lds[threadIdx.x] = f < 5u ? reinterpret_cast<const int *>(&T->cls[ci])[f] : 0;
     }
     __syncthreads();
     const char *lds = reinterpret_cast<const char *>(lds4);
@@ -746,13 +705,13 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     const uint32_t em_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) em;
     const uint32_t rq_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) W.rq;
     if ((threadIdx.x & 63u) == 0) {
-        em->base = A.cand_static_base + ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
+        em->base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
         em->left = A.cand_block;
         em->cand = A.cand; em->n_cand = A.n_cand; em->cand_cap = A.cand_cap; em->cand_static = A.cand_static; em->cand_block = A.cand_block;
     }
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     unsigned long long t0 = 0, r0 = 0;
-    unsigned long long cls_cyc[kMaxClasses] = {};               // measurement only: this wave's cycles inside each class
+    unsigned long long cls_cyc[kMaxClasses] = {0, 0, 0, 0, 0, 0};               // measurement only: this wave's cycles inside each class
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
     // The sequence words of a pass, staged per wave in LDS: the wave's 64 window starts and the 32 (wide tiles: 64) bases behind the
@@ -799,15 +758,6 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             live1 = live1 && !dead1;
             if (!__any(live0 || live1)) return;
         }
-        if constexpr (DELTA) {
-            if (Q.any_n) {                                                        // not this kernel's pass: the one-hot kernel takes it from the list
-                if (lane == 0 && blockIdx.y == 0) {                               // (one entry per pass: every LDS tile of the second launch reads the same list)
-                    const unsigned int k = atomicAdd(A.n_list, 1u);
-                    A.pass_list[k] = (uint32_t) (pass0 >> 6);                     // (the list has room for every pass of the input)
-                }
-                return;
-            }
-        }
         auto read_cd = [&](int i) { return *reinterpret_cast<const int4 *>(cls_lds + 8 * i); };      // {nk, n_row_tiles, base16, first_group}; paired: word 4
         int4 cd4 = read_cd(0);
         int cdp = cls_lds[4];
@@ -817,19 +767,16 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             cd.n_row_tiles = __builtin_amdgcn_readfirstlane(cd4.y);
             cd.base16 = (uint32_t) __builtin_amdgcn_readfirstlane(cd4.z);
             cd.first_group = __builtin_amdgcn_readfirstlane(cd4.w);
-            const int kf = __builtin_amdgcn_readfirstlane(cdp);
-            cd.paired = kf & 0xFF;                                                // 0 plain, 1 paired, 2 delta
-            cd.family = kf >> 8;
+            cd.paired = __builtin_amdgcn_readfirstlane(cdp);
             if (i + 1 < n_classes) { cd4 = read_cd(i + 1); cdp = cls_lds[8 * (i + 1) + 4]; }      // the next class's, while this one runs
-            if (!(cd.family & (DELTA ? kFamilyClean : kFamilyN))) continue;        // the other kernel's rows
             const uint32_t off = cd.base16 * 16u;
             PfResume R{0, 0u, 0u};
             unsigned long long tc0 = 0;
             if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
             while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
                 if (cd.paired) {
-                    if (cd.nk == 1) f6_pair_class<1, MEAS, DELTA>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
-                    else f6_pair_class<2, MEAS, DELTA>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
+                    if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
+                    else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
                 } else {
                     switch (cd.nk) {
                         case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
@@ -844,17 +791,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) cls_cyc[i] += __builtin_amdgcn_s_memtime() - tc0; }
         }
     };
-    if (!DELTA && A.list_mode) {
-        // the passes the first launch set aside, one per wave at a time (a few thousandths of the input: no prefetch, no atomics)
-        const uint32_t n_list = *A.n_list;
-        const uint32_t n_waves = gridDim.x * (NT / 64);
-        for (uint32_t k = blockIdx.x * (NT / 64) + (threadIdx.x >> 6); k < n_list; k += n_waves) {
-            const uint32_t pass = A.pass_list[k];
-            const PassWords w = fetch(pass);
-            if (lane < 12) stg[lane] = lane < 8 ? w.c : w.n;
-            scan_pass((int64_t) pass * 64);
-        }
-    } else {
+    {
         const uint32_t wave_passes = A.wave_passes < 1 ? 8u : (uint32_t) A.wave_passes;
         const uint32_t n_passes_total = (uint32_t) ((A.n_bases + 63) / 64);           // <= 2^28: a set holds <= 2^34 bases
         const uint32_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
@@ -1494,25 +1431,21 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 }
 
 typedef void (*PfKernel)(const PfArgs);
-static PfKernel pf_kernel(bool wide, bool meas, bool delta) {
-    if (delta) {
-        if (wide) return meas ? prefilter_f6_kernel<4, true, true> : prefilter_f6_kernel<4, false, true>;
-        return meas ? prefilter_f6_kernel<2, true, true> : prefilter_f6_kernel<2, false, true>;
-    }
-    if (wide) return meas ? prefilter_f6_kernel<4, true, false> : prefilter_f6_kernel<4, false, false>;
-    return meas ? prefilter_f6_kernel<2, true, false> : prefilter_f6_kernel<2, false, false>;
+static PfKernel pf_kernel(bool wide, bool meas) {
+    if (wide) return meas ? prefilter_f6_kernel<4, true> : prefilter_f6_kernel<4, false>;
+    return meas ? prefilter_f6_kernel<2, true> : prefilter_f6_kernel<2, false>;
 }
 
-int prefilter_set_lds(bool wide, bool meas, bool delta, size_t bytes) {
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas, delta)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+int prefilter_set_lds(bool wide, bool meas, size_t bytes) {
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
 // wide: the plan holds row tiles of 3 or 4 k-blocks
-int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool delta, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
     const int64_t n_chunks = (A.n_bases + kPfThreads - 1) / kPfThreads;
     if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
-    hipLaunchKernelGGL(pf_kernel(wide, meas, delta), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
+    hipLaunchKernelGGL(pf_kernel(wide, meas), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -119,84 +119,19 @@ bool quantize_strand_f6(const double e[4][kMaxFastWidth], int W, double T, int B
     return true;
 }
 
-// A strand as a DELTA row (ms_internal.h): for windows without non-ACGT bases acc = 56 - sum_c dq'_c(code_c) with
-// dq'_c(A) = a_c and dq'_c(b) = a_c - delta_c(b), every delta on the signed e2m3 grid and every dq' at or below the true scaled
-// deficit floor(d_c(b) s) (so a reported hit still has sum dq' <= 56.5, acc >= 0: the proof of the one-hot rows with NS empty).
-struct D3Strand {
-    int8_t delta[kMaxFastWidth][3]; // what C, G, T add on top of A, units of 1/8
-    int32_t a_sum;                  // sum_c dq'_c(A): the bias is 56 - a_sum
-    bool dead;                      // never a candidate (strand not asked for, or no window reaches the threshold)
-};
-
-inline int grid_ceil_signed(int need) {         // the smallest value of the signed e2m3 grid that is >= need (|need| <= 60)
-    for (int g = need; g <= 60; g++)
-        if (f6_representable(g)) return g;
-    return 60;
-}
-
-// false: the strand cannot ride a delta row (only ever for strands quantize_strand_f6 refuses as well)
-bool quantize_strand_d3(const double e[4][kMaxFastWidth], int W, double T, int levels, D3Strand *out) {
-    std::memset(out->delta, 0, sizeof(out->delta));
-    out->a_sum = 0;
-    out->dead = true;
-    double hi[kMaxFastWidth], sum_hi = 0, sum_hi_pos = 0, lowest = 0;
-    for (int c = 0; c < W; c++) {
-        hi[c] = std::max(std::max(e[0][c], e[1][c]), std::max(e[2][c], e[3][c]));
-        sum_hi += hi[c];
-        sum_hi_pos += std::max(hi[c], 0.0);
-        lowest += std::min(std::min(std::min(e[0][c], e[1][c]), std::min(e[2][c], e[3][c])), 0.0);
-    }
-    if (!(sum_hi_pos >= T)) return true;        // dead, as in the one-hot form
-    const double budget = sum_hi - T;
-    if (!(budget >= 0) || !(T > lowest)) return false;
-    const double s = budget > 0 ? ((double) levels + 0.5) / budget : 1e300;
-    const int clamp = std::min(60, kDeltaMaxSum / std::max(W, 1));      // W x clamp <= kDeltaMaxSum: the field never leaves its 11 bits
-    if (clamp <= levels / 2) return false;
-    for (int c = 0; c < W; c++) {
-        int qc[4];
-        for (int b = 0; b < 4; b++) {
-            const double d = hi[c] - e[b][c];
-            double q = d <= 0 ? 0.0 : std::floor(std::min(d * s * (1 - 1e-12) - 1e-7, 1e6));
-            if (!(q >= 0)) q = 0;
-            qc[b] = (int) std::min(q, (double) clamp);
-        }
-        // a = dq'(A) in [0, qc[A]]: the choice that loses the least against the true deficits, a level lost on a near-best base
-        // (what near-hit windows are made of) counting more than one on a base that sinks the window anyway
-        auto weight = [](int q) { return 1.0 / (1.0 + q / 4.0); };
-        double best_loss = -1;
-        int best_a = 0, best_g[3] = {0, 0, 0};
-        for (int a = qc[0]; a >= 0; a--) {
-            double loss = (qc[0] - a) * weight(qc[0]);
-            int g[3];
-            for (int b = 1; b < 4; b++) {
-                g[b - 1] = grid_ceil_signed(a - qc[b]);                 // dq'(b) = a - g <= qc[b], as large as the grid allows
-                loss += (qc[b] - (a - g[b - 1])) * weight(qc[b]);
-            }
-            if (best_loss < 0 || loss < best_loss - 1e-12) { best_loss = loss; best_a = a; best_g[0] = g[0]; best_g[1] = g[1]; best_g[2] = g[2]; }
-        }
-        out->a_sum += best_a;
-        for (int b = 0; b < 3; b++) out->delta[c][b] = (int8_t) best_g[b];
-    }
-    out->dead = false;
-    return true;
-}
-
 struct FastMotif {
     int32_t id;
     int32_t W;
     F6Strand f6[2];                 // 56 levels
     F6Strand f6w[2];                // 36 levels (motifs of 16 ... kPairWideMaxWidth columns that may ride a paired row)
-    D3Strand d3[2];                 // the same strands as delta rows (motifs of <= kDeltaMaxWidth columns)
     bool wide_ok;
     bool use_wide;
-    bool d3_ok;
 };
 
 }  // namespace
 
 int build_plan(const double *values, const int64_t *val_off, const int32_t *widths, const double *cutoffs,
-               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan,
-               bool delta_rows) {
+               const double *max_raw, int32_t n_pwms, int strand_mask, size_t lds_budget, bool pair_rows, PrefilterPlan *plan) {
     *plan = PrefilterPlan();
     plan->strand_mask = strand_mask;
     std::vector<FastMotif> fast;
@@ -213,8 +148,6 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
         for (int sd = 0; sd < 2; sd++) { f6_dead(&fm.f6[sd]); f6_dead(&fm.f6w[sd]); }     // never a candidate unless quantised below
         fm.wide_ok = pair_rows && W > kPairMaxWidth && W <= kPairWideMaxWidth;
         fm.use_wide = false;
-        fm.d3_ok = W <= kDeltaMaxWidth;
-        for (int sd = 0; sd < 2; sd++) { std::memset(fm.d3[sd].delta, 0, sizeof(fm.d3[sd].delta)); fm.d3[sd].a_sum = 0; fm.d3[sd].dead = true; }
         for (int sd = 0; ok && sd < 2; sd++) {
             if (!(strand_mask & (1 << sd))) continue;                    // strand not asked for
             double e[4][kMaxFastWidth];
@@ -223,37 +156,27 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                     e[b][c] = sd == 0 ? m[(int64_t) b * W + c] : m[(int64_t) (3 - b) * W + (W - 1 - c)];   // cscore.c:351
             ok = quantize_strand_f6(e, W, T, kF6Levels, 60, &fm.f6[sd], &alln);
             if (ok && fm.wide_ok) { bool alln2 = false; fm.wide_ok = quantize_strand_f6(e, W, T, kPairWideLevels, 40, &fm.f6w[sd], &alln2); }
-            if (ok && fm.d3_ok) fm.d3_ok = quantize_strand_d3(e, W, T, kF6Levels, &fm.d3[sd]);
         }
         if (ok) { fast.push_back(fm); plan->alln_can_hit = plan->alln_can_hit || alln; }
         else plan->exact_motifs.push_back(p);
     }
-    // Row tiles, in this order: delta rows, plain rows of > 20 columns, paired rows, plain rows of 16 ... 20 columns (narrow to wide within each).  A row tile serves passes WITH
-    // non-ACGT bases (kFamilyN), passes without (kFamilyClean) or both; every motif is covered exactly once in either kind of pass:
-    //   with delta rows:    N passes     = paired rows (<= 15 columns) + plain rows (16 ... 20 columns) + plain rows (wider)
-    //                       clean passes = delta rows (<= 20 columns)                                    + plain rows (wider)
-    //   without:            every pass   = paired rows + plain rows.
-    // Motifs of 16 ... kPairWideMaxWidth columns may go either way in the one-hot family (three half-blocks at 36 levels for 32 motifs,
-    // or two k-blocks at 56 levels for 16): the narrowest n_w of them ride paired rows, n_w chosen for the least instructions.
+    // Paired rows first (narrow to wide), then plain rows (narrow to wide).  Motifs of 16 ... kPairWideMaxWidth columns may go either way
+    // (three half-blocks at 36 levels for 32 motifs, or two k-blocks at 56 levels for 16): the narrowest n_w of them ride paired rows,
+    // n_w chosen so that the plan's instruction count is minimal.
     const bool both = strand_mask == 3;
     const int sd_single = strand_mask == 2 ? 1 : 0;
-    std::stable_sort(fast.begin(), fast.end(), [](const FastMotif &x, const FastMotif &y) { return x.W < y.W; });
-    bool use_delta = delta_rows && pair_rows;
-    for (const FastMotif &fm : fast)
-        if (fm.W <= kDeltaMaxWidth && !fm.d3_ok) use_delta = false;         // (cannot happen for a strand the one-hot form accepts)
-    plan->delta = use_delta;
-    struct RowTile { int kind; int nk; int family; std::vector<int> members; size_t off; };     // kind: 0 plain, 1 paired, 2 delta; members: indices into `fast`
-    auto nk_of = [&](int i, int kind) { return kind == 2 ? delta_kb_of_width(fast[i].W) : (kind == 1 ? pair_kb_of_width(fast[i].W) : f6_kb_of_width(fast[i].W)); };
+    struct RowTile { bool paired; int nk; size_t first, count, off; };
+    auto nk_of = [&](const FastMotif &a, bool pr) { return pr ? pair_kb_of_width(a.W) : f6_kb_of_width(a.W); };
     // Row tiles = runs of consecutive motifs of `v` (sorted by width: a tile pays for its widest), cut so that the instruction count
     // is minimal -- e.g. the last few narrow motifs get a short tile of their own rather than riding a tile of wider ones
-    auto cut = [&](const std::vector<int> &v, int kind, int family, std::vector<RowTile> *out) -> long {
-        const size_t per_rt = (both ? 16 : 32) * (kind ? 2 : 1), n = v.size();
+    auto cut = [&](const std::vector<const FastMotif *> &v, bool pr, size_t base, std::vector<RowTile> *out) -> long {
+        const size_t per_rt = (both ? 16 : 32) * (pr ? 2 : 1), n = v.size();
         std::vector<long> cost(n + 1, 0);
         std::vector<size_t> from(n + 1, 0);
         for (size_t i = 1; i <= n; i++) {
             cost[i] = -1;
             for (size_t j = i > per_rt ? i - per_rt : 0; j < i; j++) {
-                const long cst = cost[j] + 64L * nk_of(v[i - 1], kind) + 1;         // instructions first, then the number of tiles
+                const long cst = cost[j] + 64L * nk_of(*v[i - 1], pr) + 1;         // instructions first, then the number of tiles
                 if (cost[i] < 0 || cst < cost[i]) { cost[i] = cst; from[i] = j; }
             }
         }
@@ -262,110 +185,92 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
             for (size_t i = n; i > 0; i = from[i]) ends.push_back(i);
             size_t j = 0;
             for (size_t k = ends.size(); k-- > 0;) {
-                out->push_back(RowTile{kind, nk_of(v[ends[k] - 1], kind), family, std::vector<int>(v.begin() + (long) j, v.begin() + (long) ends[k]), 0});
+                out->push_back(RowTile{pr, nk_of(*v[ends[k] - 1], pr), base + j, ends[k] - j, 0});
                 j = ends[k];
             }
         }
         return cost[n];
     };
-    std::vector<int> narrow, mid, rest;                                         // <= 15 columns | either way | plain only  (indices, by width)
-    for (int i = 0; i < (int) fast.size(); i++) (pair_rows && fast[i].W <= kPairMaxWidth ? narrow : (fast[i].wide_ok ? mid : rest)).push_back(i);
+    std::stable_sort(fast.begin(), fast.end(), [](const FastMotif &a, const FastMotif &b) { return a.W < b.W; });
+    std::vector<const FastMotif *> narrow, mid, rest;                           // <= 15 columns | either way | plain only
+    for (const FastMotif &fm : fast) (pair_rows && fm.W <= kPairMaxWidth ? narrow : (fm.wide_ok ? mid : rest)).push_back(&fm);
     size_t best_w = 0;
     {
         long best = -1;
         for (size_t n_w = 0; n_w <= mid.size(); n_w++) {
-            std::vector<int> pv(narrow), lv(mid.begin() + (long) n_w, mid.end());
+            std::vector<const FastMotif *> pv(narrow), lv(mid.begin() + (long) n_w, mid.end());
             pv.insert(pv.end(), mid.begin(), mid.begin() + (long) n_w);
             lv.insert(lv.end(), rest.begin(), rest.end());
-            std::stable_sort(lv.begin(), lv.end(), [&](int x, int y) { return fast[x].W < fast[y].W; });
-            const long cst = cut(pv, 1, 0, nullptr) + cut(lv, 0, 0, nullptr);
+            std::stable_sort(lv.begin(), lv.end(), [](const FastMotif *a, const FastMotif *b) { return a->W < b->W; });
+            const long cst = cut(pv, true, 0, nullptr) + cut(lv, false, 0, nullptr);
             if (best < 0 || cst < best) { best = cst; best_w = n_w; }
         }
     }
+    std::vector<FastMotif> ordered;
+    ordered.reserve(fast.size());
+    for (const FastMotif *f : narrow) ordered.push_back(*f);
+    for (size_t i = 0; i < best_w; i++) { ordered.push_back(*mid[i]); ordered.back().use_wide = true; }
+    const size_t n_paired = ordered.size();
+    {
+        std::vector<const FastMotif *> lv(mid.begin() + (long) best_w, mid.end());
+        lv.insert(lv.end(), rest.begin(), rest.end());
+        std::stable_sort(lv.begin(), lv.end(), [](const FastMotif *a, const FastMotif *b) { return a->W < b->W; });
+        for (const FastMotif *f : lv) ordered.push_back(*f);
+    }
+    fast.swap(ordered);
     std::vector<RowTile> rts;
     {
-        std::vector<int> pv(narrow), lv(mid.begin() + (long) best_w, mid.end()), lvA, lvB, dv;
-        for (size_t i = 0; i < best_w; i++) { pv.push_back(mid[i]); fast[mid[i]].use_wide = true; }
-        lv.insert(lv.end(), rest.begin(), rest.end());
-        std::stable_sort(lv.begin(), lv.end(), [&](int x, int y) { return fast[x].W < fast[y].W; });
-        for (int i : lv) (use_delta && fast[i].W <= kDeltaMaxWidth ? lvA : lvB).push_back(i);
-        if (use_delta)
-            for (int i = 0; i < (int) fast.size(); i++)
-                if (fast[i].W <= kDeltaMaxWidth) dv.push_back(i);
-        // the rows of the clean passes FIRST: the kernel that runs those passes loads only that prefix of an LDS tile (TileDesc::clean_len16)
-        (void) cut(dv, 2, kFamilyClean, &rts);
-        (void) cut(lvB, 0, kFamilyN | kFamilyClean, &rts);
-        (void) cut(pv, 1, use_delta ? kFamilyN : (kFamilyN | kFamilyClean), &rts);
-        (void) cut(lvA, 0, kFamilyN, &rts);
+        std::vector<const FastMotif *> pv, lv;
+        for (size_t i = 0; i < fast.size(); i++) (i < n_paired ? pv : lv).push_back(&fast[i]);
+        (void) cut(pv, true, 0, &rts);
+        (void) cut(lv, false, n_paired, &rts);
     }
     const size_t n_rt = rts.size();
     size_t total = 0;
     for (RowTile &rt : rts) {
         rt.off = total;
         total += (size_t) rt.nk * kF6BytesPerKb;
-        if (rt.family & kFamilyClean) {
-            plan->kb_total += rt.nk;
-            plan->lds_bytes_per_position += (int64_t) rt.nk * (int64_t) kF6BytesPerKb / 64;    // A-operand bytes per window start (2 x 32 windows share a read)
-        }
+        plan->kb_total += rt.nk;
+        plan->lds_bytes_per_position += (int64_t) rt.nk * (int64_t) kF6BytesPerKb / 64;        // A-operand bytes per window start (2 x 32 windows share a read)
     }
     std::vector<uint8_t> bytes(total, 0);
     for (size_t t = 0; t < n_rt; t++) {
         const RowTile &rt = rts[t];
         uint8_t *tab = bytes.data() + rt.off;
-        const int cols_per_kb = rt.kind == 2 ? kDeltaCols : (rt.kind == 1 ? kPairCols : kF6Cols);
+        const int cols_per_kb = rt.paired ? kPairCols : kF6Cols;
         const int n_cols = cols_per_kb * rt.nk;
-        const int n_groups = rt.kind ? 4 : 2;
+        const int n_groups = rt.paired ? 4 : 2;
         const size_t per_group = both ? 8 : 16;
         for (int gi = 0; gi < n_groups; gi++) {
-            const int h = rt.kind ? gi >> 1 : gi, sel = rt.kind ? gi & 1 : 0;
+            const int h = rt.paired ? gi >> 1 : gi, sel = rt.paired ? gi & 1 : 0;
             const size_t grp = plan->group_kb.size();
             plan->group_kb.push_back(rt.nk);
             plan->group_cols.push_back(n_cols);
-            plan->group_info.push_back(GroupInfo{(uint32_t) rt.off, (int8_t) rt.nk, (int8_t) rt.kind, (int8_t) h, (int8_t) sel});
+            plan->group_info.push_back(GroupInfo{(uint32_t) rt.off, (int8_t) rt.nk, (int8_t) rt.paired, (int8_t) h, (int8_t) sel});
             plan->group_fields.resize((grp + 1) * kGroupFields, -1);
             for (int n = 0; n < kGroupFields; n++) {
                 const size_t slot = per_group * (size_t) gi + (both ? (size_t) (n >> 1) : (size_t) n);
-                const FastMotif *fm = slot < rt.members.size() ? &fast[rt.members[slot]] : nullptr;
+                const size_t j = rt.first + slot;
                 const int sd = both ? (n & 1) : sd_single;
                 const int row = mfma_row_of(h, n);
-                if (fm) plan->group_fields[grp * kGroupFields + n] = fm->id;
-                if (rt.kind == 2) {
-                    // delta row: (C, G, T) of column c in k-slots delta_slot(c % 10, b) of half-block c / 10, k-half `sel`; the bias in the
-                    // row's four bias slots (delta_bias_slots)
-                    const D3Strand *ds = fm && !fm->d3[sd].dead ? &fm->d3[sd] : nullptr;
-                    if (ds)
-                        for (int c = 0; c < fm->W; c++)
-                            for (int b = 1; b < 4; b++) {
-                                const int sl = delta_slot(c % kDeltaCols, b);
-                                f6_put(tab, rt.nk, c / kDeltaCols, row, 8 * sel + sl / 4, sl % 4, f6_code(ds->delta[c][b - 1]));
-                            }
-                    const int tot = kPairOffset + (ds ? kF6Levels - ds->a_sum : -1);          // empty / dead field: acc = -1/8, never a candidate
-                    int u4[4] = {0, 0, 0, 0};
-                    if (!pair_bias_entries(tot, u4)) {
-                        set_error("internal: no delta bias entries for %d", tot);
-                        return MS_ERR_RUNTIME;
-                    }
-                    const DeltaBiasSlot *bs = delta_bias_slots(rt.nk);                       // (k-slot s = column s / 4, base s % 4 of the k-half's 8 x 4 grid)
-                    for (int k = 0; k < 4; k++) f6_put(tab, rt.nk, bs[k].kb, row, 8 * sel + bs[k].slot / 4, bs[k].slot % 4, f6_code(u4[bs[k].u]));
-                    continue;
-                }
-                const F6Strand *fs = fm ? (fm->use_wide ? &fm->f6w[sd] : &fm->f6[sd]) : nullptr;
+                const F6Strand *fs = slot < rt.count ? (fast[j].use_wide ? &fast[j].f6w[sd] : &fast[j].f6[sd]) : nullptr;
                 // empty field: bias -1/8 and nothing else -> never a candidate; columns past W stay +0; the bias sits in the field's
                 // LAST column for all four bases (the kernel never clears that column for non-ACGT bases)
                 int pb[4] = {0, 0, 0, 0};                                   // paired rows: the bias column also carries the field's offset
-                if (rt.kind == 1 && !pair_bias_entries((fs ? fs->bias : -1) + kPairOffset, pb)) {
+                if (rt.paired && !pair_bias_entries((fs ? fs->bias : -1) + kPairOffset, pb)) {
                     set_error("internal: no bias entries for %d", (fs ? fs->bias : -1) + kPairOffset);
                     return MS_ERR_RUNTIME;
                 }
                 for (int c = 0; c < n_cols; c++)
                     for (int b = 0; b < 4; b++) {
                         int u = 0;
-                        if (c == n_cols - 1) u = rt.kind == 1 ? pb[b] : (fs ? fs->bias : -1);
-                        else if (fs && c < fm->W) u = fs->u[c][b];
+                        if (c == n_cols - 1) u = rt.paired ? pb[b] : (fs ? fs->bias : -1);
+                        else if (fs && c < fast[j].W) u = fs->u[c][b];
                         // plain: column c of k-block c / 16; paired: column c % 8 of half-block c / 8, in k-half `sel`
-                        if (rt.kind == 1) f6_put(tab, rt.nk, c / kPairCols, row, kPairCols * sel + c % kPairCols, b, f6_code(u));
+                        if (rt.paired) f6_put(tab, rt.nk, c / kPairCols, row, kPairCols * sel + c % kPairCols, b, f6_code(u));
                         else f6_put(tab, rt.nk, c / kF6Cols, row, c % kF6Cols, b, f6_code(u));
                     }
+                if (fs) plan->group_fields[grp * kGroupFields + n] = fast[j].id;
             }
         }
     }
@@ -389,8 +294,7 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
             while (q < n_rt) {
                 const size_t need = (size_t) rts[q].nk * kF6BytesPerKb;
                 if (used > 0 && (used + need > budget || used >= target)) break;
-                const bool new_class = t.n_classes == 0 || t.cls[t.n_classes - 1].nk != rts[q].nk || t.cls[t.n_classes - 1].paired != rts[q].kind ||
-                                       t.cls[t.n_classes - 1].family != rts[q].family;
+                const bool new_class = t.n_classes == 0 || t.cls[t.n_classes - 1].nk != rts[q].nk || (t.cls[t.n_classes - 1].paired != 0) != rts[q].paired;
                 if (new_class) {
                     if (t.n_classes == kMaxClasses) break;                   // (cannot happen: the row tiles are sorted by class)
                     ClassDesc &cd = t.cls[t.n_classes++];
@@ -398,14 +302,12 @@ int build_plan(const double *values, const int64_t *val_off, const int32_t *widt
                     cd.n_row_tiles = 0;
                     cd.base16 = (uint32_t) (used / 16);
                     cd.first_group = group;
-                    cd.paired = rts[q].kind;
-                    cd.family = rts[q].family;
+                    cd.paired = rts[q].paired ? 1 : 0;
                 }
                 t.cls[t.n_classes - 1].n_row_tiles++;
-                if (!rts[q].kind) t.max_nk = std::max(t.max_nk, rts[q].nk);
+                if (!rts[q].paired) t.max_nk = std::max(t.max_nk, rts[q].nk);
                 used += need;
-                if (rts[q].family & kFamilyClean) t.clean_len16 = (uint32_t) (used / 16);      // (the clean rows of a tile are a prefix of it: the order above)
-                group += rts[q].kind ? 4 : 2;
+                group += rts[q].paired ? 4 : 2;
                 q++;
             }
             t.table_len16 = (uint32_t) (used / 16);
