@@ -258,6 +258,31 @@ class Scanner:
         finally:
             pw.close()
 
+    def count_regions_with_sites(self, pwms):
+        """int64 [n_pwms]: the number of this scanner's regions that hold >= 1 site of each motif -- what
+        `stats.motif_enrichment` computes from the nested lists (`sum(len(sites_by_region) > 0 ...)`, stats.py:29-31) and ALL the
+        reference ever reads of the CONTROL regions' scan (cli/scan.py:81-89).  The hits stay on the device: no copy-out, no
+        Python object per site.  (De-duplication never empties a region, so the count does not depend on remove_dup.)"""
+        matrices, cutoffs, _ = self._marshal(pwms)
+        pw = _lib.PwmSet.from_matrices(matrices, cutoffs)
+        try:
+            sweep = self._as_sweep()
+            overlapping = self._as_overlapping() if sweep is None else None
+            if sweep is not None:
+                g, chrom, begin, end, window, stride = sweep
+                res = _lib.scan_sweep(pw, g, chrom, begin, end, window, stride, _STRAND_FLAG[self.strand])
+            elif overlapping is not None:
+                g, idx = overlapping
+                res = _lib.scan_regions_once(pw, g, idx, self.seq_starts, self.seq_ends, _STRAND_FLAG[self.strand])
+            else:
+                res = _lib.scan(pw, self._seqset(), _STRAND_FLAG[self.strand])
+            try:
+                return res.region_counts()
+            finally:
+                res.close()
+        finally:
+            pw.close()
+
     def scan_motifs(self, pwms):
         """motif_sites[n_pwms][n_regions] -> list[MotifSite] (scanner.py:89-132), as a read-only nested view over the
         device's flat hit arrays: a region's list is built when it is indexed (motifscan_amd/sites.py), so the call costs

@@ -387,6 +387,41 @@ def test_all_579_motifs_other_cutoffs_vs_oracle(oracle, jaspar579, pkey):
     assert_same_hits(res.hits(), want)
 
 
+def test_scanner_counts_only_is_what_the_enrichment_statistics_read(oracle, rnd):
+    """Scanner.count_regions_with_sites == stats.py:29-31's `sum(len(sites_by_region) > 0 ...)` over the nested result of the same
+    scanner (de-dup on or off), == the oracle's hit list regrouped."""
+    class Genome:
+        chrom_sizes = {"c": 10 ** 9}
+
+        def __init__(self, seqs):
+            self.text, self.pos = "".join(seqs), np.concatenate([[0], np.cumsum([len(x) for x in seqs])])
+
+        def fetch_sequence(self, chrom, start, end):
+            return self.text[start:end]
+
+    class Region:
+        def __init__(self, a, b):
+            self.chrom, self.start, self.end, self.summit = "c", int(a), int(b), int(a + b) // 2
+
+    class Pwm:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = m, {"1e-3": c}, m.shape[1]
+
+    seqs = rnd["seqs"][:300]
+    g = Genome(seqs)
+    regions = [Region(a, b) for a, b in zip(g.pos[:-1], g.pos[1:])]
+    pwms = [Pwm(m, c) for m, c in zip(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])]
+    want = oracle.c_scan_motif([m.tolist() for m in rnd["mats"]], rnd["cutoff_by_key"]["1e-3"].tolist(), seqs, 3, 4)
+    want_counts = [len({h[0] for h in per}) for per in want]
+    for dup in (True, False):
+        sc = scanner.Scanner(g, regions, strand="both", p_value="1e-3", remove_dup=dup)
+        counts = sc.count_regions_with_sites(pwms)
+        nested = sc.scan_motifs(pwms)
+        assert counts.tolist() == want_counts == [sum([len(s) > 0 for s in sites]) for sites in nested]
+        nested.close()
+        sc.close()
+
+
 @pytest.mark.parametrize("pkey", ["1e-3", "1e-4"])
 def test_low_information_motif_set_vs_oracle(oracle, pkey):
     """the side set with a JASPAR-like information profile (informative core between weak flanks, 10 % weak motifs;
