@@ -687,6 +687,70 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
     return MS_OK;
 }
 
+// convert_seq on HOST threads (ms_hostpack.cpp): the packed codes, the mask and the region hints are made in pinned staging memory by
+// n_threads threads and cross the link on the copy engines -- no kernel is launched, so nothing of the set's construction waits for CUs
+// a running scan holds (the batch stream's upload stage, MS_STREAM_HOST_PACK).  The set is identical to ms_seqset_create's.
+int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, ms_seqset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(offsets, n_seqs, s);
+    if (rc) return rc;
+    if (s->n_bases > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    DeviceCtx *c;
+    if ((rc = get_ctx(s->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw))) return fail(rc);
+    const int64_t n_units = (raw->n_bases + 31) / 32, n_blocks = (raw->n_bases + 63) / 64 + 1;
+    const size_t b_codes = (size_t) n_units * 8, b_nmask = (size_t) n_units * 4, b_blk = (size_t) n_blocks * 4, b_info = (size_t) n_blocks * 16;
+    auto up256 = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+    size_t got = 0;
+    char *stage = static_cast<char *>(pinned_alloc(up256(b_codes) + up256(b_nmask) + up256(b_blk) + up256(b_info) + 256, &got));
+    if (!stage) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+    uint32_t *h_codes = reinterpret_cast<uint32_t *>(stage), *h_nmask = reinterpret_cast<uint32_t *>(stage + up256(b_codes));
+    int32_t *h_blk = reinterpret_cast<int32_t *>(stage + up256(b_codes) + up256(b_nmask));
+    int32_t *h_info = reinterpret_cast<int32_t *>(stage + up256(b_codes) + up256(b_nmask) + up256(b_blk));
+    {
+        const bool all_far = measure_env("MS_BLKINFO_FAR") != nullptr;
+        const int64_t *off = raw->offsets.data();
+        const int64_t R = raw->R, nb = raw->n_bases;
+        const int T = (int) std::min<int64_t>(n_threads, std::max<int64_t>(1, n_units / 4096));
+        auto work = [&](int t) {
+            host_pack_units(reinterpret_cast<const uint8_t *>(bases), nb, n_units * t / T, n_units * (t + 1) / T, h_codes, h_nmask);
+            host_region_hints(off, R, n_blocks * t / T, n_blocks * (t + 1) / T, h_blk, h_info, all_far);
+        };
+        std::vector<std::thread> th;
+        try { for (int t = 1; t < T; t++) th.emplace_back(work, t); }
+        catch (const std::exception &) { for (auto &x : th) x.join(); pinned_free(stage, got); set_error("could not start packing threads"); return fail(MS_ERR_RUNTIME); }
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    hipError_t e = hipSuccess;
+    if (b_codes) e = hipMemcpyAsync(raw->d_codes, h_codes, b_codes, hipMemcpyHostToDevice, raw->up);
+    if (e == hipSuccess && b_nmask) e = hipMemcpyAsync(raw->d_nmask, h_nmask, b_nmask, hipMemcpyHostToDevice, raw->up);
+    if (e == hipSuccess) e = hipMemcpyAsync(raw->d_blk2reg, h_blk, b_blk, hipMemcpyHostToDevice, raw->up);
+    if (e == hipSuccess) e = hipMemcpyAsync(raw->d_blkinfo, h_info, b_info, hipMemcpyHostToDevice, raw->up);
+    if (e == hipSuccess) e = hipStreamSynchronize(raw->up);
+    pinned_free(stage, got);
+    if (e != hipSuccess) { set_error("upload of the packed set failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    raw->built = true;
+    *out = raw;
+    return MS_OK;
+}
+
+// the host packer alone, for CPU tests (no device): codes [2 * ceil(n / 32)], nmask [ceil(n / 32)], blk2reg [(n + 63) / 64 + 1], blkinfo [4 x that]
+int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo) {
+    if (!offsets || n_seqs < 0 || !codes || !nmask || !blk2reg || !blkinfo) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const int64_t n = offsets[n_seqs];
+    if (n > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    host_pack_units(reinterpret_cast<const uint8_t *>(bases), n, 0, (n + 31) / 32, codes, nmask);
+    host_region_hints(offsets, n_seqs, 0, (n + 63) / 64 + 1, blk2reg, blkinfo, false);
+    return MS_OK;
+}
+
 int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out) {
     if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
     *out = nullptr;

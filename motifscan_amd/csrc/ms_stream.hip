@@ -48,6 +48,7 @@ struct ms_stream {
     uint32_t flags = 0;
     int device = 0;
     int depth = 2;
+    int pack_threads = 8;             // MS_STREAM_HOST_PACK: host threads of the upload stage (MS_PACK_THREADS overrides)
     std::unique_ptr<StagePipeline<Job, ms_stream>> pipe;
 
     void bind_thread() {
@@ -59,7 +60,8 @@ struct ms_stream {
         if (j->rc != MS_OK) return;
         // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
         const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
-                                    : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+                       : (flags & MS_STREAM_HOST_PACK) ? ms_seqset_create_hostpacked(j->bases, j->offsets.data(), j->n_seqs, pack_threads, &j->seqs)
+                                                       : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
         if (rc) fail_job(j, rc);
     }
 
@@ -148,7 +150,7 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     if (!pwms) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
     if (depth < 1 || depth > 16) { set_error("depth must be in [1, 16]"); return MS_ERR_INVALID; }
-    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
+    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED | MS_STREAM_HOST_PACK)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
     DeviceCtx *c;
     int rc = get_ctx(current_device(), &c);             // no device: fail here, loudly, not in a worker
     if (rc) return rc;
@@ -159,6 +161,7 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     st->flags = flags;
     st->device = c->device;
     st->depth = depth;
+    if (const char *e = getenv("MS_PACK_THREADS")) st->pack_threads = std::max(1, std::min(64, atoi(e)));
     try {
         st->pipe.reset(new StagePipeline<Job, ms_stream>(st.get(), depth));
         st->pipe->start();
