@@ -691,6 +691,12 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
 // n_threads threads and cross the link on the copy engines -- no kernel is launched, so nothing of the set's construction waits for CUs
 // a running scan holds (the batch stream's upload stage, MS_STREAM_HOST_PACK).  The set is identical to ms_seqset_create's.
 int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, ms_seqset **out) {
+    return seqset_create_hostpacked(bases, offsets, n_seqs, n_threads, nullptr, nullptr, out);
+}
+
+// stage / stage_bytes: the caller's grow-only pinned staging block (a batch stream's uploader keeps ONE for its life: page-locking ~90 MB
+// per batch costs tens of milliseconds); nullptr: a block of the call's own.
+int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out) {
     if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
     *out = nullptr;
     std::unique_ptr<ms_seqset> s;
@@ -707,9 +713,23 @@ int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64
     const int64_t n_units = (raw->n_bases + 31) / 32, n_blocks = (raw->n_bases + 63) / 64 + 1;
     const size_t b_codes = (size_t) n_units * 8, b_nmask = (size_t) n_units * 4, b_blk = (size_t) n_blocks * 4, b_info = (size_t) n_blocks * 16;
     auto up256 = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+    const size_t need = up256(b_codes) + up256(b_nmask) + up256(b_blk) + up256(b_info) + 256;
     size_t got = 0;
-    char *stage = static_cast<char *>(pinned_alloc(up256(b_codes) + up256(b_nmask) + up256(b_blk) + up256(b_info) + 256, &got));
-    if (!stage) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+    char *stage = nullptr;
+    if (stage_io) {
+        if (*stage_bytes_io < need) {
+            if (*stage_io) (void) hipHostFree(*stage_io);
+            *stage_io = nullptr; *stage_bytes_io = 0;
+            void *p = nullptr;
+            if (hipHostMalloc(&p, need + need / 8) != hipSuccess) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+            *stage_io = p; *stage_bytes_io = need + need / 8;
+        }
+        stage = static_cast<char *>(*stage_io);
+    } else {
+        stage = static_cast<char *>(pinned_alloc(need, &got));
+        if (!stage) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+    }
+    auto release = [&]() { if (!stage_io) pinned_free(stage, got); };
     uint32_t *h_codes = reinterpret_cast<uint32_t *>(stage), *h_nmask = reinterpret_cast<uint32_t *>(stage + up256(b_codes));
     int32_t *h_blk = reinterpret_cast<int32_t *>(stage + up256(b_codes) + up256(b_nmask));
     int32_t *h_info = reinterpret_cast<int32_t *>(stage + up256(b_codes) + up256(b_nmask) + up256(b_blk));
@@ -724,7 +744,7 @@ int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64
         };
         std::vector<std::thread> th;
         try { for (int t = 1; t < T; t++) th.emplace_back(work, t); }
-        catch (const std::exception &) { for (auto &x : th) x.join(); pinned_free(stage, got); set_error("could not start packing threads"); return fail(MS_ERR_RUNTIME); }
+        catch (const std::exception &) { for (auto &x : th) x.join(); release(); set_error("could not start packing threads"); return fail(MS_ERR_RUNTIME); }
         work(0);
         for (auto &x : th) x.join();
     }
@@ -734,7 +754,7 @@ int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64
     if (e == hipSuccess) e = hipMemcpyAsync(raw->d_blk2reg, h_blk, b_blk, hipMemcpyHostToDevice, raw->up);
     if (e == hipSuccess) e = hipMemcpyAsync(raw->d_blkinfo, h_info, b_info, hipMemcpyHostToDevice, raw->up);
     if (e == hipSuccess) e = hipStreamSynchronize(raw->up);
-    pinned_free(stage, got);
+    release();
     if (e != hipSuccess) { set_error("upload of the packed set failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
     raw->built = true;
     *out = raw;

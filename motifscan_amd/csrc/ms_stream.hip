@@ -49,6 +49,8 @@ struct ms_stream {
     int device = 0;
     int depth = 2;
     int pack_threads = 8;             // MS_STREAM_HOST_PACK: host threads of the upload stage (MS_PACK_THREADS overrides)
+    void *pack_stage = nullptr;       // ... and the uploader's pinned staging block (grow-only, freed with the stream)
+    size_t pack_stage_bytes = 0;
     std::unique_ptr<StagePipeline<Job, ms_stream>> pipe;
 
     void bind_thread() {
@@ -60,7 +62,7 @@ struct ms_stream {
         if (j->rc != MS_OK) return;
         // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
         const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
-                       : (flags & MS_STREAM_HOST_PACK) ? ms_seqset_create_hostpacked(j->bases, j->offsets.data(), j->n_seqs, pack_threads, &j->seqs)
+                       : (flags & MS_STREAM_HOST_PACK) ? seqset_create_hostpacked(j->bases, j->offsets.data(), j->n_seqs, pack_threads, &pack_stage, &pack_stage_bytes, &j->seqs)
                                                        : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
         if (rc) fail_job(j, rc);
     }
@@ -284,6 +286,7 @@ int ms_stream_capacity(const ms_stream *st, int *n) {
 void ms_stream_free(ms_stream *st) {
     if (!st) return;
     st->pipe->shutdown(drop_job);
+    if (st->pack_stage) (void) hipHostFree(st->pack_stage);
     DeviceCtx *c = nullptr;
     if (get_ctx(st->device, &c) == MS_OK) {
         std::lock_guard<std::mutex> lk_dev(c->mu);
