@@ -694,9 +694,11 @@ int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64
     return seqset_create_hostpacked(bases, offsets, n_seqs, n_threads, nullptr, nullptr, out);
 }
 
+}  // extern "C"  (an internal C++ entry follows: the stream's uploader calls it with its own staging block)
+
 // stage / stage_bytes: the caller's grow-only pinned staging block (a batch stream's uploader keeps ONE for its life: page-locking ~90 MB
 // per batch costs tens of milliseconds); nullptr: a block of the call's own.
-int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out) {
+int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out) {
     if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
     *out = nullptr;
     std::unique_ptr<ms_seqset> s;
@@ -760,6 +762,8 @@ int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t 
     *out = raw;
     return MS_OK;
 }
+
+extern "C" {
 
 // the host packer alone, for CPU tests (no device): codes [2 * ceil(n / 32)], nmask [ceil(n / 32)], blk2reg [(n + 63) / 64 + 1], blkinfo [4 x that]
 int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo) {
