@@ -629,7 +629,7 @@ static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr
     return MS_OK;
 }
 
-static int seqset_alloc_packed(ms_seqset *s) {
+static int seqset_alloc_packed(ms_seqset *s, bool pads_by_copy = false) {
     const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
     const size_t b_codes = (2 * n_units + kPadWords) * sizeof(uint32_t);
     const size_t b_nmask = (n_units + kPadWords) * sizeof(uint32_t);
@@ -650,8 +650,10 @@ static int seqset_alloc_packed(ms_seqset *s) {
     // only the pad words behind the packed data need clearing: the kernels write everything else
     // sequence sets are built on the upload stream: a batch can be packed while the previous one is being scanned
     s->up = c->stream_up;                                 // read once: every step of building this set stays on one stream
-    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
-    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    if (!pads_by_copy) {                                  // (a memset is a KERNEL: the host-packed form copies zero pad words along instead)
+        MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+        MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    }
     MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));
     return MS_OK;
 }
@@ -711,9 +713,10 @@ int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int6
     if ((rc = get_ctx(s->device, &c))) return rc;
     ms_seqset *raw = s.release();
     auto fail = [&](int code) { ms_seqset_free(raw); return code; };
-    if ((rc = seqset_alloc_packed(raw))) return fail(rc);
+    if ((rc = seqset_alloc_packed(raw, true))) return fail(rc);
     const int64_t n_units = (raw->n_bases + 31) / 32, n_blocks = (raw->n_bases + 63) / 64 + 1;
-    const size_t b_codes = (size_t) n_units * 8, b_nmask = (size_t) n_units * 4, b_blk = (size_t) n_blocks * 4, b_info = (size_t) n_blocks * 16;
+    // (codes and mask travel WITH their zero pad words: not one kernel -- a memset is one -- is queued on the upload stream)
+    const size_t b_codes = ((size_t) n_units * 2 + kPadWords) * 4, b_nmask = ((size_t) n_units + kPadWords) * 4, b_blk = (size_t) n_blocks * 4, b_info = (size_t) n_blocks * 16;
     auto up256 = [](size_t x) { return (x + 255) & ~(size_t) 255; };
     const size_t need = up256(b_codes) + up256(b_nmask) + up256(b_blk) + up256(b_info) + 256;
     size_t got = 0;
@@ -749,6 +752,8 @@ int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int6
         catch (const std::exception &) { for (auto &x : th) x.join(); release(); set_error("could not start packing threads"); return fail(MS_ERR_RUNTIME); }
         work(0);
         for (auto &x : th) x.join();
+        std::memset(h_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t));
+        std::memset(h_nmask + n_units, 0, kPadWords * sizeof(uint32_t));
     }
     hipError_t e = hipSuccess;
     if (b_codes) e = hipMemcpyAsync(raw->d_codes, h_codes, b_codes, hipMemcpyHostToDevice, raw->up);
