@@ -654,7 +654,7 @@ static int seqset_alloc_packed(ms_seqset *s, bool pads_by_copy = false) {
         MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
         MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
     }
-    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));
+    if (!pads_by_copy) MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));      // (host-packed: the offsets travel in the one copy of the whole block)
     return MS_OK;
 }
 
@@ -715,10 +715,15 @@ int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int6
     auto fail = [&](int code) { ms_seqset_free(raw); return code; };
     if ((rc = seqset_alloc_packed(raw, true))) return fail(rc);
     const int64_t n_units = (raw->n_bases + 31) / 32, n_blocks = (raw->n_bases + 63) / 64 + 1;
-    // (codes and mask travel WITH their zero pad words: not one kernel -- a memset is one -- is queued on the upload stream)
-    const size_t b_codes = ((size_t) n_units * 2 + kPadWords) * 4, b_nmask = ((size_t) n_units + kPadWords) * 4, b_blk = (size_t) n_blocks * 4, b_info = (size_t) n_blocks * 16;
+    // The staging block MIRRORS the set's device block (seqset_alloc_packed: codes + pad | mask + pad | offsets | region of every 64th
+    // position | block records, 256-byte aligned), so that ONE copy moves everything -- no kernel (a memset is one) and no second copy is
+    // queued on the upload stream.
     auto up256 = [](size_t x) { return (x + 255) & ~(size_t) 255; };
-    const size_t need = up256(b_codes) + up256(b_nmask) + up256(b_blk) + up256(b_info) + 256;
+    const size_t o_nmask = (size_t) (reinterpret_cast<char *>(raw->d_nmask) - static_cast<char *>(raw->block));
+    const size_t o_off = (size_t) (reinterpret_cast<char *>(raw->d_offsets) - static_cast<char *>(raw->block));
+    const size_t o_blk = (size_t) (reinterpret_cast<char *>(raw->d_blk2reg) - static_cast<char *>(raw->block));
+    const size_t o_info = (size_t) (reinterpret_cast<char *>(raw->d_blkinfo) - static_cast<char *>(raw->block));
+    const size_t need = up256(o_info + (size_t) n_blocks * 16) + 256;
     size_t got = 0;
     char *stage = nullptr;
     if (stage_io) {
@@ -735,9 +740,9 @@ int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int6
         if (!stage) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
     }
     auto release = [&]() { if (!stage_io) pinned_free(stage, got); };
-    uint32_t *h_codes = reinterpret_cast<uint32_t *>(stage), *h_nmask = reinterpret_cast<uint32_t *>(stage + up256(b_codes));
-    int32_t *h_blk = reinterpret_cast<int32_t *>(stage + up256(b_codes) + up256(b_nmask));
-    int32_t *h_info = reinterpret_cast<int32_t *>(stage + up256(b_codes) + up256(b_nmask) + up256(b_blk));
+    uint32_t *h_codes = reinterpret_cast<uint32_t *>(stage), *h_nmask = reinterpret_cast<uint32_t *>(stage + o_nmask);
+    int32_t *h_blk = reinterpret_cast<int32_t *>(stage + o_blk);
+    int32_t *h_info = reinterpret_cast<int32_t *>(stage + o_info);
     {
         const bool all_far = measure_env("MS_BLKINFO_FAR") != nullptr;
         const int64_t *off = raw->offsets.data();
@@ -754,12 +759,9 @@ int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int6
         for (auto &x : th) x.join();
         std::memset(h_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t));
         std::memset(h_nmask + n_units, 0, kPadWords * sizeof(uint32_t));
+        std::memcpy(stage + o_off, off, ((size_t) R + 1) * sizeof(int64_t));
     }
-    hipError_t e = hipSuccess;
-    if (b_codes) e = hipMemcpyAsync(raw->d_codes, h_codes, b_codes, hipMemcpyHostToDevice, raw->up);
-    if (e == hipSuccess && b_nmask) e = hipMemcpyAsync(raw->d_nmask, h_nmask, b_nmask, hipMemcpyHostToDevice, raw->up);
-    if (e == hipSuccess) e = hipMemcpyAsync(raw->d_blk2reg, h_blk, b_blk, hipMemcpyHostToDevice, raw->up);
-    if (e == hipSuccess) e = hipMemcpyAsync(raw->d_blkinfo, h_info, b_info, hipMemcpyHostToDevice, raw->up);
+    hipError_t e = hipMemcpyAsync(raw->block, stage, o_info + (size_t) n_blocks * 16, hipMemcpyHostToDevice, raw->up);
     if (e == hipSuccess) e = hipStreamSynchronize(raw->up);
     release();
     if (e != hipSuccess) { set_error("upload of the packed set failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
