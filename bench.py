@@ -595,12 +595,12 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
 
     stages = {}
 
-    def pipelined(packed, host_pack=False):
+    def pipelined(packed):
         def run():
             n = 0
-            st = stages.setdefault(("pipelined_hostpack" if host_pack else "pipelined") if packed else "pipelined_25B", {})
+            st = stages.setdefault("pipelined" if packed else "pipelined_25B", {})
             dev_ms = {"prefilter": 0.0, "fp64_stage": 0.0, "sort": 0.0, "finalize": 0.0, "scan_total": 0.0, "clock_mhz_sum": 0.0}
-            for res in _lib.scan_stream(pw, iter(batches), strand_mask, 0, depth=2, packed=packed, stage_stats=st, host_pack=host_pack):
+            for res in _lib.scan_stream(pw, iter(batches), strand_mask, 0, depth=2, packed=packed, stage_stats=st):
                 n += res.n_hits                         # the arrays are already in pinned host memory at this point
                 s_ = res.stats()
                 for k_, f_ in (("prefilter", "ms_prefilter"), ("fp64_stage", "ms_exact"), ("sort", "ms_sort"), ("finalize", "ms_finalize"),
@@ -640,10 +640,10 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     # counted (stats.py:29-31) -- one stream, control batches submitted counts-only (ms_stream_submit_counts_only)
     cli_batches = [(b, o, k > 0) for (b, o), (k, _, _) in zip(batches, cuts)]
 
-    def pipelined_cli(host_pack=False):
+    def pipelined_cli():
         n = 0
-        st = stages.setdefault("pipelined_cli_hostpack" if host_pack else "pipelined_cli", {})
-        for res, (_, _, counts_only) in zip(_lib.scan_stream(pw, iter(cli_batches), strand_mask, 0, depth=2, packed=True, stage_stats=st, host_pack=host_pack), cli_batches):
+        st = stages.setdefault("pipelined_cli", {})
+        for res, (_, _, counts_only) in zip(_lib.scan_stream(pw, iter(cli_batches), strand_mask, 0, depth=2, packed=True, stage_stats=st), cli_batches):
             if not counts_only:
                 n += res.n_hits                         # in pinned host memory
             res.region_counts()
@@ -663,8 +663,6 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     passes = max(1, min(a.steps, 4))
     v_p16, ms_p16, hits = timed(pipelined(True), passes)
     v_cli, ms_cli, hits_cli = timed(pipelined_cli, passes)
-    v_hp, ms_hp, hits_hp = timed(pipelined(True, host_pack=True), passes)
-    v_clihp, ms_clihp, _ = timed(lambda: pipelined_cli(True), passes)
     v_p25, ms_p25, _ = timed(pipelined(False), passes)
     v_s, ms_s, _ = timed(serial, passes)
     reps = 4
@@ -672,9 +670,8 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     v_su, ms_su = v_su * reps, ms_su / reps                     # timed() counts one call as one pass; the call holds `reps` of them
     for pin in pins:
         pin.close()
-    return {"pipelined_hostpack": v_hp, "pipelined_cli_hostpack": v_clihp, "hostpack_hits_check": bool(hits_hp == hits),
-            "pipelined": v_p16, "pipelined_cli": v_cli, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
-            "ms_per_pass": {"pipelined_hostpack": ms_hp, "pipelined_cli_hostpack": ms_clihp, "pipelined": ms_p16, "pipelined_cli": ms_cli, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
+    return {"pipelined": v_p16, "pipelined_cli": v_cli, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
+            "ms_per_pass": {"pipelined": ms_p16, "pipelined_cli": ms_cli, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
             "hits_out_per_pass_cli": int(hits_cli),
             "sustained_passes_per_stream": reps, "sustained_hits_check": bool(hits_su == hits * reps),
             "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "max_batch_regions": a.max_batch_regions, "batch_sizes": [int(len(o) - 1) for _, o in batches], "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),

@@ -131,10 +131,6 @@ void ms_pwmset_free(ms_pwmset *pwms);
  * re-run the extraction/packing kernel (bench.py times it inside the step). */
 int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, int keep_ascii,
                      ms_seqset **out);
-/* The same set with convert_seq done by n_threads HOST threads: the 2-bit codes, the non-ACGT mask and the region hints are made in pinned
- * staging memory and copied over -- no kernel runs, so building the set never waits for CUs a running scan holds (what the batch stream's
- * upload stage does under MS_STREAM_HOST_PACK).  bases is borrowed for the duration of the call. */
-int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, ms_seqset **out);
 /* d_bases: device pointer to the concatenated ASCII (borrowed for the call); offsets on host. */
 int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n_seqs,
                           ms_seqset **out);
@@ -205,7 +201,6 @@ void ms_host_free(void *p);
 #define MS_STREAM_NO_HITS     2u   /* counts only: hit arrays stay on the device (control regions: stats.py:29-31)         */
 #define MS_STREAM_EXACT_ONLY  4u   /* MS_SCAN_EXACT_ONLY for every batch (validation)                                      */
 #define MS_STREAM_PACKED      8u   /* copy the hits out in the compact form of ms_result_hits_packed_host                  */
-#define MS_STREAM_HOST_PACK  16u   /* the upload stage packs on host threads (ms_seqset_create_hostpacked): no kernel beside the scan */
 typedef struct ms_stream ms_stream;
 /* depth: batches that may wait between two stages (>= 1; 2 overlaps all three stages).  The stream is bound to the
  * calling thread's device (ms_set_device).  The PWM set must outlive the stream. */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmotifscan_amd.so")
 
 MS_OK, MS_ERR_INVALID, MS_ERR_NOMEM, MS_ERR_RUNTIME = 0, 1, 2, 3
 MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY = 0, 1
-MS_STREAM_DEDUP, MS_STREAM_NO_HITS, MS_STREAM_EXACT_ONLY, MS_STREAM_PACKED, MS_STREAM_HOST_PACK = 1, 2, 4, 8, 16
+MS_STREAM_DEDUP, MS_STREAM_NO_HITS, MS_STREAM_EXACT_ONLY, MS_STREAM_PACKED = 1, 2, 4, 8
 
 
 class ScanStats(ctypes.Structure):
@@ -96,8 +96,6 @@ def lib():
         "ms_pwmset_max_raw": (c_int, [vp, pd]),
         "ms_pwmset_free": (None, [vp]),
         "ms_seqset_create": (c_int, [ctypes.c_char_p, pi64, c_i64, c_int, pvp]),
-        "ms_seqset_create_hostpacked": (c_int, [ctypes.c_char_p, pi64, c_i64, c_int, pvp]),
-        "ms_debug_host_pack": (c_int, [ctypes.c_char_p, pi64, c_i64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), pi32, pi32]),
         "ms_seqset_from_device": (c_int, [vp, pi64, c_i64, pvp]),
         "ms_seqset_repack": (c_int, [vp]),
         "ms_seqset_size": (c_int, [vp, pi64, pi64]),
@@ -261,8 +259,7 @@ class PwmSet:
 class SeqSet:
     """Device-side packed sequence set (convert_seq, cscore.c:81-114)."""
 
-    def __init__(self, bases, offsets, keep_ascii=False, host_pack_threads=0):
-        """host_pack_threads > 0: convert_seq on that many host threads (ms_seqset_create_hostpacked: no kernel is launched) -- the same set."""
+    def __init__(self, bases, offsets, keep_ascii=False):
         if isinstance(bases, np.ndarray):
             bases = np.ascontiguousarray(bases, dtype=np.uint8)
             buf = bases.ctypes.data_as(ctypes.c_char_p)
@@ -279,11 +276,8 @@ class SeqSet:
         self.n_seqs = self.offsets.size - 1
         self.n_bases = nbytes
         h = ctypes.c_void_p()
-        if host_pack_threads and not keep_ascii:
-            check(lib().ms_seqset_create_hostpacked(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(host_pack_threads), ctypes.byref(h)))
-        else:
-            check(lib().ms_seqset_create(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(bool(keep_ascii)),
-                                         ctypes.byref(h)))
+        check(lib().ms_seqset_create(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(bool(keep_ascii)),
+                                     ctypes.byref(h)))
         self.h = h
 
     @classmethod
@@ -496,20 +490,6 @@ class ScanResult:
     __del__ = close
 
 
-def host_pack(bases, offsets):
-    """The host packer alone (ms_debug_host_pack; no device): (codes uint32 [2 x units], nmask uint32 [units], blk2reg int32 [blocks],
-    blkinfo int32 [blocks][4]) of a sequence set -- the layout the device's pack / hint kernels write."""
-    bases = np.ascontiguousarray(bases, dtype=np.uint8)
-    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-    n = int(offsets[-1])
-    units, blocks = (n + 31) // 32, (n + 63) // 64 + 1
-    codes, nmask = np.zeros(2 * units, dtype=np.uint32), np.zeros(units, dtype=np.uint32)
-    blk, info = np.zeros(blocks, dtype=np.int32), np.zeros((blocks, 4), dtype=np.int32)
-    check(lib().ms_debug_host_pack(bases.ctypes.data_as(ctypes.c_char_p), ptr(offsets, ctypes.c_int64), offsets.size - 1,
-                                   ptr(codes, ctypes.c_uint32), ptr(nmask, ctypes.c_uint32), ptr(blk, ctypes.c_int32), ptr(info, ctypes.c_int32)))
-    return codes, nmask, blk, info
-
-
 def pool_stats():
     """HBM block cache of the calling thread's device (ms_device_pool_stats)."""
     out = (ctypes.c_uint64 * 6)()
@@ -661,13 +641,12 @@ def merge_hits(parts, n_pwms):
     return out
 
 
-def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None, host_pack=False):
+def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None):
     """Generator: push (bases, offsets) batches -- or (ResidentGenome, chrom_idx, starts, ends) batches of a genome that sits in
     HBM -- through a Stream, yield each batch's ScanResult in order (the caller closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end.
     A (bases, offsets, True) batch is COUNTS ONLY (ms_stream_submit_counts_only): its hits stay on the device, only the per-motif
-    region counts are read -- what the reference does with the control regions (cli/scan.py:81-89 -> stats.py:29-31).
-    host_pack: the upload stage packs the batches on host threads (MS_STREAM_HOST_PACK: no kernel beside the scan)."""
-    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0) | (MS_STREAM_HOST_PACK if host_pack else 0), depth)
+    region counts are read -- what the reference does with the control regions (cli/scan.py:81-89 -> stats.py:29-31)."""
+    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
     try:
         for batch in batches:                             # (bases, offsets), or (ResidentGenome, chrom_idx, starts, ends)
             while st.in_flight >= st.capacity:

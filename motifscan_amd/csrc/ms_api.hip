@@ -629,7 +629,7 @@ static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr
     return MS_OK;
 }
 
-static int seqset_alloc_packed(ms_seqset *s, bool pads_by_copy = false) {
+static int seqset_alloc_packed(ms_seqset *s) {
     const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
     const size_t b_codes = (2 * n_units + kPadWords) * sizeof(uint32_t);
     const size_t b_nmask = (n_units + kPadWords) * sizeof(uint32_t);
@@ -650,11 +650,9 @@ static int seqset_alloc_packed(ms_seqset *s, bool pads_by_copy = false) {
     // only the pad words behind the packed data need clearing: the kernels write everything else
     // sequence sets are built on the upload stream: a batch can be packed while the previous one is being scanned
     s->up = c->stream_up;                                 // read once: every step of building this set stays on one stream
-    if (!pads_by_copy) {                                  // (a memset is a KERNEL: the host-packed form copies zero pad words along instead)
-        MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
-        MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
-    }
-    if (!pads_by_copy) MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));      // (host-packed: the offsets travel in the one copy of the whole block)
+    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));
     return MS_OK;
 }
 
@@ -686,99 +684,6 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
     if (!keep_ascii) { pool_free(c, raw->d_ascii, raw->ascii_bytes); raw->d_ascii = nullptr; raw->ascii_bytes = 0; }
     raw->built = true;
     *out = raw;
-    return MS_OK;
-}
-
-// convert_seq on HOST threads (ms_hostpack.cpp): the packed codes, the mask and the region hints are made in pinned staging memory by
-// n_threads threads and cross the link on the copy engines -- no kernel is launched, so nothing of the set's construction waits for CUs
-// a running scan holds (the batch stream's upload stage, MS_STREAM_HOST_PACK).  The set is identical to ms_seqset_create's.
-int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, ms_seqset **out) {
-    return seqset_create_hostpacked(bases, offsets, n_seqs, n_threads, nullptr, nullptr, out);
-}
-
-}  // extern "C"  (an internal C++ entry follows: the stream's uploader calls it with its own staging block)
-
-// stage / stage_bytes: the caller's grow-only pinned staging block (a batch stream's uploader keeps ONE for its life: page-locking ~90 MB
-// per batch costs tens of milliseconds); nullptr: a block of the call's own.
-int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out) {
-    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
-    *out = nullptr;
-    std::unique_ptr<ms_seqset> s;
-    int rc = seqset_common(offsets, n_seqs, s);
-    if (rc) return rc;
-    if (s->n_bases > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
-    if (n_threads < 1) n_threads = 1;
-    if (n_threads > 64) n_threads = 64;
-    DeviceCtx *c;
-    if ((rc = get_ctx(s->device, &c))) return rc;
-    ms_seqset *raw = s.release();
-    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
-    if ((rc = seqset_alloc_packed(raw, true))) return fail(rc);
-    const int64_t n_units = (raw->n_bases + 31) / 32, n_blocks = (raw->n_bases + 63) / 64 + 1;
-    // The staging block MIRRORS the set's device block (seqset_alloc_packed: codes + pad | mask + pad | offsets | region of every 64th
-    // position | block records, 256-byte aligned), so that ONE copy moves everything -- no kernel (a memset is one) and no second copy is
-    // queued on the upload stream.
-    auto up256 = [](size_t x) { return (x + 255) & ~(size_t) 255; };
-    const size_t o_nmask = (size_t) (reinterpret_cast<char *>(raw->d_nmask) - static_cast<char *>(raw->block));
-    const size_t o_off = (size_t) (reinterpret_cast<char *>(raw->d_offsets) - static_cast<char *>(raw->block));
-    const size_t o_blk = (size_t) (reinterpret_cast<char *>(raw->d_blk2reg) - static_cast<char *>(raw->block));
-    const size_t o_info = (size_t) (reinterpret_cast<char *>(raw->d_blkinfo) - static_cast<char *>(raw->block));
-    const size_t need = up256(o_info + (size_t) n_blocks * 16) + 256;
-    size_t got = 0;
-    char *stage = nullptr;
-    if (stage_io) {
-        if (*stage_bytes_io < need) {
-            if (*stage_io) (void) hipHostFree(*stage_io);
-            *stage_io = nullptr; *stage_bytes_io = 0;
-            void *p = nullptr;
-            if (hipHostMalloc(&p, need + need / 8) != hipSuccess) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
-            *stage_io = p; *stage_bytes_io = need + need / 8;
-        }
-        stage = static_cast<char *>(*stage_io);
-    } else {
-        stage = static_cast<char *>(pinned_alloc(need, &got));
-        if (!stage) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
-    }
-    auto release = [&]() { if (!stage_io) pinned_free(stage, got); };
-    uint32_t *h_codes = reinterpret_cast<uint32_t *>(stage), *h_nmask = reinterpret_cast<uint32_t *>(stage + o_nmask);
-    int32_t *h_blk = reinterpret_cast<int32_t *>(stage + o_blk);
-    int32_t *h_info = reinterpret_cast<int32_t *>(stage + o_info);
-    {
-        const bool all_far = measure_env("MS_BLKINFO_FAR") != nullptr;
-        const int64_t *off = raw->offsets.data();
-        const int64_t R = raw->R, nb = raw->n_bases;
-        const int T = (int) std::min<int64_t>(n_threads, std::max<int64_t>(1, n_units / 4096));
-        auto work = [&](int t) {
-            host_pack_units(reinterpret_cast<const uint8_t *>(bases), nb, n_units * t / T, n_units * (t + 1) / T, h_codes, h_nmask);
-            host_region_hints(off, R, n_blocks * t / T, n_blocks * (t + 1) / T, h_blk, h_info, all_far);
-        };
-        std::vector<std::thread> th;
-        try { for (int t = 1; t < T; t++) th.emplace_back(work, t); }
-        catch (const std::exception &) { for (auto &x : th) x.join(); release(); set_error("could not start packing threads"); return fail(MS_ERR_RUNTIME); }
-        work(0);
-        for (auto &x : th) x.join();
-        std::memset(h_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t));
-        std::memset(h_nmask + n_units, 0, kPadWords * sizeof(uint32_t));
-        std::memcpy(stage + o_off, off, ((size_t) R + 1) * sizeof(int64_t));
-    }
-    hipError_t e = hipMemcpyAsync(raw->block, stage, o_info + (size_t) n_blocks * 16, hipMemcpyHostToDevice, raw->up);
-    if (e == hipSuccess) e = hipStreamSynchronize(raw->up);
-    release();
-    if (e != hipSuccess) { set_error("upload of the packed set failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
-    raw->built = true;
-    *out = raw;
-    return MS_OK;
-}
-
-extern "C" {
-
-// the host packer alone, for CPU tests (no device): codes [2 * ceil(n / 32)], nmask [ceil(n / 32)], blk2reg [(n + 63) / 64 + 1], blkinfo [4 x that]
-int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo) {
-    if (!offsets || n_seqs < 0 || !codes || !nmask || !blk2reg || !blkinfo) { set_error("NULL argument"); return MS_ERR_INVALID; }
-    const int64_t n = offsets[n_seqs];
-    if (n > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
-    host_pack_units(reinterpret_cast<const uint8_t *>(bases), n, 0, (n + 31) / 32, codes, nmask);
-    host_region_hints(offsets, n_seqs, 0, (n + 63) / 64 + 1, blk2reg, blkinfo, false);
     return MS_OK;
 }
 

@@ -81,10 +81,6 @@ void set_current_device(int device);  // thread-local only; no HIP call
 
 // Give every cached block of the calling thread's device back to the driver (ms_api.hip); returns the bytes released.
 size_t pool_trim_current_device();
-// ms_hostpack.cpp: convert_seq and the region hints on host threads (units of 32 bases / blocks of 64 positions [u0, u1) / [b0, b1))
-void host_pack_units(const uint8_t *bases, int64_t n_bases, int64_t u0, int64_t u1, uint32_t *codes, uint32_t *nmask);
-void host_region_hints(const int64_t *offsets, int64_t R, int64_t b0, int64_t b1, int32_t *blk2reg, int32_t *info, bool all_far);
-int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out);
 
 template <typename T>
 inline int dev_alloc(T **p, size_t n) {

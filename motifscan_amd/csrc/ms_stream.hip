@@ -48,9 +48,6 @@ struct ms_stream {
     uint32_t flags = 0;
     int device = 0;
     int depth = 2;
-    int pack_threads = 8;             // MS_STREAM_HOST_PACK: host threads of the upload stage (MS_PACK_THREADS overrides)
-    void *pack_stage = nullptr;       // ... and the uploader's pinned staging block (grow-only, freed with the stream)
-    size_t pack_stage_bytes = 0;
     std::unique_ptr<StagePipeline<Job, ms_stream>> pipe;
 
     void bind_thread() {
@@ -62,8 +59,7 @@ struct ms_stream {
         if (j->rc != MS_OK) return;
         // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
         const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
-                       : (flags & MS_STREAM_HOST_PACK) ? seqset_create_hostpacked(j->bases, j->offsets.data(), j->n_seqs, pack_threads, &pack_stage, &pack_stage_bytes, &j->seqs)
-                                                       : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+                                    : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
         if (rc) fail_job(j, rc);
     }
 
@@ -152,7 +148,7 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     if (!pwms) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
     if (depth < 1 || depth > 16) { set_error("depth must be in [1, 16]"); return MS_ERR_INVALID; }
-    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED | MS_STREAM_HOST_PACK)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
+    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
     DeviceCtx *c;
     int rc = get_ctx(current_device(), &c);             // no device: fail here, loudly, not in a worker
     if (rc) return rc;
@@ -163,7 +159,6 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     st->flags = flags;
     st->device = c->device;
     st->depth = depth;
-    if (const char *e = getenv("MS_PACK_THREADS")) st->pack_threads = std::max(1, std::min(64, atoi(e)));
     try {
         st->pipe.reset(new StagePipeline<Job, ms_stream>(st.get(), depth));
         st->pipe->start();
@@ -286,7 +281,6 @@ int ms_stream_capacity(const ms_stream *st, int *n) {
 void ms_stream_free(ms_stream *st) {
     if (!st) return;
     st->pipe->shutdown(drop_job);
-    if (st->pack_stage) (void) hipHostFree(st->pack_stage);
     DeviceCtx *c = nullptr;
     if (get_ctx(st->device, &c) == MS_OK) {
         std::lock_guard<std::mutex> lk_dev(c->mu);

@@ -418,48 +418,6 @@ def test_stream_counts_only_errors_and_pinned_input(oracle):
         _lib.Stream(pw, 3, 0, depth=0)
 
 
-def test_host_packed_sets_and_streams_equal_device_packed_ones(oracle):
-    """ms_seqset_create_hostpacked / MS_STREAM_HOST_PACK: convert_seq and the region hints made by host threads, no kernel in the upload
-    stage.  The set scans to the same hits as the device-packed one (ragged regions incl. empty ones, runs of N, lower case, IUPAC letters,
-    an unaligned tail), and a stream of host-packed batches -- hits out and counts-only mixed -- equals the oracle."""
-    vals, widths, cutoffs = synth.load_motif_set(120)
-    pw = _lib.PwmSet(vals, widths, cutoffs)
-    rng = np.random.default_rng(77)
-    bases, offsets = synth.make_regions(3001, 333, seed=31, frac_n=0.08, ragged=True)
-    bases = bases.copy()
-    for ch in b"RYKMSWryn-*":                                         # letters that "add nothing" (cscore.c:92-111)
-        bases[rng.integers(0, bases.size, 40)] = ch
-    lens = np.diff(offsets)
-    lens[[5, 6, 900]] = 0                                             # empty regions
-    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    bases = bases[:int(offsets[-1])]
-    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
-    for threads in (1, 5):
-        sq = _lib.SeqSet(bases, offsets, host_pack_threads=threads)
-        res = _lib.scan(pw, sq, 3)
-        assert_same_hits(res.hits(), want)
-        res.close(); sq.close()
-    cuts = [0, 1, 700, 700, 2200, 3001]
-    batches = [(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a], k == 3) for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
-    parts, st = [], {}
-    results = list(_lib.scan_stream(pw, iter(batches), 3, packed=True, host_pack=True, stage_stats=st))
-    for (b_, o_, counts_only), (a, _), res in zip(batches, zip(cuts[:-1], cuts[1:]), results):
-        ref = _lib.scan(pw, _lib.SeqSet(b_, o_), 3)
-        assert res.n_hits == ref.n_hits and np.array_equal(res.region_counts(), ref.region_counts())
-        if not counts_only:
-            parts.append((res.hits(packed=True), a))
-        res.close(); ref.close()
-    merged = _lib.merge_hits(parts, len(widths))
-    # (the counts-only batch is regions [700, 2200): its hits stay on the device)
-    sel = (want["seq_idx"] < 700) | (want["seq_idx"] >= 2200)
-    wm = np.repeat(np.arange(len(widths)), np.diff(want["motif_offsets"]))
-    for k in ("seq_idx", "pos", "score"):
-        assert np.array_equal(merged[k], want[k][sel])
-    assert np.array_equal(np.repeat(np.arange(len(widths)), np.diff(merged["motif_offsets"])), wm[sel])
-    assert st["upload"]["batches"] == len(batches)
-    pw.close()
-
-
 def test_stream_stage_clocks_and_block_pool_statistics():
     """ms_stream_stats counts every batch once per stage and its clocks are sane; ms_device_pool_stats: a second pass over the
     same batches is served from the block cache (size classes), not by the driver."""
