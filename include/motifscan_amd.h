@@ -198,7 +198,9 @@ void ms_host_free(void *p);
 
 /* ---- batch streams: upload + pack | scan | copy-out overlapped ------------------------------- */
 #define MS_STREAM_DEDUP       1u   /* de-duplicate every batch on the device (scanner.py:156-193) before the copy-out      */
-#define MS_STREAM_NO_HITS     2u   /* counts only: hit arrays stay on the device (control regions: stats.py:29-31)         */
+#define MS_STREAM_NO_HITS     2u   /* counts only: hit arrays stay on the device (control regions: stats.py:29-31); a sweep span then
+                                      makes ONLY the per-motif window counts and the number of sites (no site is handed out: the hit
+                                      accessors of such a result fail with MS_ERR_INVALID)                                     */
 #define MS_STREAM_EXACT_ONLY  4u   /* MS_SCAN_EXACT_ONLY for every batch (validation)                                      */
 #define MS_STREAM_PACKED      8u   /* copy the hits out in the compact form of ms_result_hits_packed_host                  */
 typedef struct ms_stream ms_stream;

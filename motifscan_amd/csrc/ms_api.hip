@@ -1386,6 +1386,7 @@ int ms_result_motif_offsets(const ms_result *r, int64_t *out) {
 int ms_result_hits(const ms_result *r, int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
     if (r->n_hits == 0) return MS_OK;
     MS_HIP(hipSetDevice(r->device));
     const size_t n = (size_t) r->n_hits;
@@ -1403,6 +1404,7 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
                         const int8_t **strand) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
     const size_t bytes = 25 * n_round + 64;
@@ -1442,6 +1444,7 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
 int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const double **score) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
     const size_t bytes = 16 * n_round + 64;
@@ -1549,6 +1552,7 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     if (!r || !pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     if (pwms->P != r->P) { set_error("result and PWM set disagree on the number of PWMs"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
     if (r->deduped || r->n_hits == 0) { r->deduped = true; return MS_OK; }
     if (r->coord_blk) {                                  // coordinate words of the hits before de-duplication: void
         DeviceCtx *c0;
@@ -1619,6 +1623,7 @@ int ms_result_site_tables(const ms_result *r, int32_t *n_sites, double *max_scor
     if (!r) { set_error("NULL handle"); return MS_ERR_INVALID; }
     const size_t cells = (size_t) r->P * (size_t) r->R;
     if (cells == 0) return MS_OK;
+    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
     if (!n_sites || !max_score) { set_error("NULL output"); return MS_ERR_INVALID; }
     DeviceCtx *c;
     int rc = get_ctx(r->device, &c);
@@ -1663,7 +1668,7 @@ namespace ms {
 
 // r1: the scan of the span as ONE region.  Consumes r1 (also on failure).
 int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *r1, int64_t span_bases, int32_t window, int32_t stride,
-                         int64_t n_windows, ms_result **out) {
+                         int64_t n_windows, ms_result **out, bool counts_only) {
     int rc;
     auto fail = [&](int code) { ms_result_free(r1); return code; };
     // the device copies of the widths may have moved since the scan if the set was used on another device in between
@@ -1690,6 +1695,43 @@ int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *r1, int64_t s
     uint64_t total = 0;
     hipError_t he = hipSuccess;
     (void) hipEventRecord(c->ev[0], c->stream);
+    if (counts_only) {
+        // what a counts-only sweep reads of a span: per motif the windows with >= 1 site, and the number of sites -- one pass over the
+        // span's hit positions, nothing handed out (sweep_countonly_kernel)
+        void *blk = nullptr;
+        size_t got = 0;
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, 0), &blk, &got))) return fail2(rc);
+        raw->block = blk;
+        raw->block_bytes = got;
+        result_carve(raw, blk, 0);
+        raw->counts_only = true;
+        const size_t P1 = (size_t) pwms->P + 1;
+        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);                     // (word P: the number of sites)
+        if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0, 8 * P1, c->stream);
+        if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+        rc = launch_sweep_countonly((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, window, stride, n_windows,
+                                    raw->d_region_counts, raw->d_region_counts + pwms->P, c->stream);
+        if (rc) return fail2(rc);
+        (void) hipEventRecord(c->ev[1], c->stream);
+        unsigned long long n_sites = 0;
+        he = hipMemcpyAsync(&n_sites, raw->d_region_counts + pwms->P, 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { set_error("sweep count failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+        total = n_sites;
+        raw->n_hits = (int64_t) total;
+        float ms01 = 0;
+        (void) hipEventElapsedTime(&ms01, c->ev[0], c->ev[1]);
+        ms_scan_stats &stt = raw->stats;
+        stt.ms_finalize += ms01;
+        stt.ms_total += ms01;
+        stt.n_hits = (int64_t) total;
+        stt.n_bases = span_bases;
+        stt.n_windows = 0;
+        for (int32_t p = 0; p < pwms->P; p++) stt.n_windows += n_windows * std::max<int64_t>(window - pwms->widths[p] + 1, 0);
+        ms_result_free(r1);
+        *out = raw;
+        return MS_OK;
+    }
     if (n1 > 0) {
         size_t tmp_bytes = 0;
         const size_t n8 = (n1 + 31) & ~(size_t) 31;

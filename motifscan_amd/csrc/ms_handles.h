@@ -186,6 +186,7 @@ struct ms_result {
     bool deduped = false;
     int raw_gbits = 0, raw_pbits = 0;                 // MS_SCAN_RAW_INTERNAL: layout of the unordered hit keys left in the device scratch
     bool invalid = false;                             // a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1): stage times only, no hits
+    bool counts_only = false;                         // a sweep span of a counts-only stream: per-motif window counts and the number of sites, NO site arrays
     void *block = nullptr;                            // one device block holding everything below
     size_t block_bytes = 0;
     int64_t *d_seq_idx = nullptr;
@@ -249,8 +250,9 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend = nullptr);
 // Hand the hits of a span scan (one region) to the windows of a fixed-stride sweep, in place of *span_res (ms_api.hip);
 // the caller holds c->mu and pwms->mu.
+// counts_only: only the per-motif window counts and the number of sites are made (ms_result::counts_only: the hit accessors refuse it)
 int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *span_res, int64_t span_bases, int32_t window, int32_t stride,
-                         int64_t n_windows, ms_result **out);
+                         int64_t n_windows, ms_result **out, bool counts_only = false);
 int pwmset_upload(ms_pwmset *p, int device, hipStream_t st);
 // One pooled device block holds everything a result owns: [counts P+1][offsets P+1][seq_idx n][pos n][score n][strand n]
 size_t result_block_bytes(int32_t P, size_t n);

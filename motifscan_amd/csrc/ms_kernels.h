@@ -112,6 +112,8 @@ int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
 int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                        int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st);
+int launch_sweep_countonly(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                           int32_t window, int32_t stride, int64_t n_windows, unsigned long long *region_counts, unsigned long long *n_sites, hipStream_t st);
 int launch_sweep_scatter(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                          const double *score, const int8_t *strand, const uint64_t *dst, int32_t window, int32_t stride,
                          int64_t n_windows, int64_t total, int64_t *seq_idx_out, int64_t *pos_out, double *score_out,

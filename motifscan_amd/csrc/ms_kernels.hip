@@ -1265,6 +1265,50 @@ __global__ void __launch_bounds__(256) sweep_scatter_kernel(int64_t n, const int
     }
 }
 
+// The hand-out of a COUNTS-ONLY sweep (MS_STREAM_NO_HITS; round 5): what the enrichment statistics read of a sweep is, per motif, the number
+// of windows that hold >= 1 site (stats.py:29-31) -- plus, here, the number of sites.  Within a motif the hits are ordered by span
+// position and both ends of a hit's window range are non-decreasing, so hit i is the FIRST site of exactly the windows of its range that
+// the previous hit of the motif does not reach: max(0, hi_i - max(lo_i, prev_hi + 1) + 1).  One read per hit, no site is written
+// (the full hand-out writes 25 bytes per (site, window): 36 GB per pass of a 3 Gbp genome).
+__global__ void __launch_bounds__(256) sweep_countonly_kernel(int64_t n, const int64_t *__restrict__ motif_off, int32_t P,
+                                                              const int32_t *__restrict__ width, const int64_t *__restrict__ pos,
+                                                              int32_t window, int32_t stride, int64_t n_windows,
+                                                              unsigned long long *__restrict__ region_counts, unsigned long long *__restrict__ n_sites) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    int32_t m = -1;
+    int n_first = 0;
+    unsigned long long mine = 0;
+    if (live) {
+        m = motif_of_hit(motif_off, P, i);
+        const int W = width[m];
+        int64_t lo, hi;
+        sweep_window_range(pos[i], W, window, stride, n_windows, lo, hi);
+        if (hi >= lo) {
+            mine = (unsigned long long) (hi - lo + 1);
+            int64_t prev_hi = -1;
+            if (i > motif_off[m]) { int64_t l2; sweep_window_range(pos[i - 1], W, window, stride, n_windows, l2, prev_hi); if (prev_hi < l2) prev_hi = -1; }
+            const int64_t from = lo > prev_hi + 1 ? lo : prev_hi + 1;
+            n_first = hi >= from ? (int) (hi - from + 1) : 0;
+        }
+    }
+    unsigned long long v64 = mine;                              // the wave's sites: one atomic per wave
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v64 += __shfl_xor(v64, o);
+    if ((threadIdx.x & 63) == 0 && v64) atomicAdd(n_sites, v64);
+    unsigned long long todo = __ballot(live && n_first > 0);    // windows with >= 1 site per motif: one atomic per (wave, motif)
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const int32_t mm = __shfl(m, leader);
+        const unsigned long long same = __ballot(live && n_first > 0 && m == mm);
+        int v = (live && m == mm) ? n_first : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((int) (threadIdx.x & 63) == leader) atomicAdd(&region_counts[mm], (unsigned long long) v);
+        todo &= ~same;
+    }
+}
+
 // per-motif offsets of the handed-out sites: where the motif's first hit went
 __global__ void sweep_offsets_kernel(const int64_t *__restrict__ motif_off, int32_t P, int64_t n, const uint64_t *__restrict__ dst,
                                      int64_t total, int64_t *__restrict__ out) {
@@ -1720,6 +1764,15 @@ int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int
     if (n == 0) return MS_OK;
     hipLaunchKernelGGL(sweep_count_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, pos,
                        window, stride, n_windows, cnt);
+    MS_HIP(hipGetLastError());
+    return MS_OK;
+}
+
+int launch_sweep_countonly(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
+                           int32_t window, int32_t stride, int64_t n_windows, unsigned long long *region_counts, unsigned long long *n_sites, hipStream_t st) {
+    if (n == 0) return MS_OK;
+    hipLaunchKernelGGL(sweep_countonly_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, motif_off, P, width, pos,
+                       window, stride, n_windows, region_counts, n_sites);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

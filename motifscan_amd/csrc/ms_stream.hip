@@ -95,7 +95,7 @@ struct ms_stream {
             if (!rc && !pending && j->kind == 1) {
                 ms_result *r1 = j->res;
                 j->res = nullptr;
-                rc = sweep_handout_locked(c, pwms, r1, j->seqs->n_bases, j->window, j->stride, j->n_windows, &j->res);
+                rc = sweep_handout_locked(c, pwms, r1, j->seqs->n_bases, j->window, j->stride, j->n_windows, &j->res, (flags & MS_STREAM_NO_HITS) != 0);
             }
         }
         if (!rc && !pending && (flags & MS_STREAM_DEDUP)) rc = ms_result_dedup(j->res, pwms);

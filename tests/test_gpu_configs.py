@@ -243,14 +243,19 @@ def test_c5_full_size_three_gbp_host_streamed_sweep(oracle):
         bases_uploaded = sum(b1 - b0 for _, b0, b1, _, _ in spans)
         assert bases_uploaded == sum((n - 1) * stride + window for n in n_win) + (len(spans) - 24) * (window - stride)
         # 2. counts only, all spans
-        counts_by_span, n_sites_counts, bases_scanned = [], 0, 0
+        counts_by_span, sites_of_span, n_sites_counts, bases_scanned = [], [], 0, 0
         for sp, res in _lib.sweep_stream(pw, chroms, window, stride, max_span, 3, _lib.MS_STREAM_NO_HITS, spans=spans):
             counts_by_span.append(res.region_counts().copy())
             st = res.stats()
             bases_scanned += st["n_bases"]
             n_sites_counts += res.n_hits
+            sites_of_span.append(res.n_hits)
+            if sp == spans[0]:
+                with pytest.raises(ValueError, match="counts-only"):          # a counts-only span hands no site out: asking for them fails loudly
+                    res.hits()
             res.close()
         assert len(counts_by_span) == len(spans) and bases_scanned == bases_uploaded
+        sites_by_span = dict(zip(spans, sites_of_span))
         total = np.sum(counts_by_span, axis=0)
         assert (total > 0).all() and (total <= sum(n_win)).all()
         # 3. + 4. hits for three chromosomes of different sizes
@@ -264,6 +269,7 @@ def test_c5_full_size_three_gbp_host_streamed_sweep(oracle):
             assert (h["pos"] >= 0).all() and (h["pos"] + widths[h["motif"]] <= window).all()
             assert np.array_equal(recount_regions(h, P), counts_by_span[spans.index(sp)])          # == the counts-only pass
             assert np.array_equal(res.region_counts(), counts_by_span[spans.index(sp)])
+            assert res.n_hits == sites_by_span[sp]                                                     # ... and the same number of sites
             if sp[3] + sp[4] == sum(n_win[:sp[0] + 1]):                                                # the chromosome's last span
                 keep = h["seq_idx"] >= sp[4] - 400
                 t = {k: h[k][keep].copy() for k in ("seq_idx", "pos", "score", "strand", "motif")}
@@ -595,6 +601,15 @@ def test_host_streamed_multi_chromosome_sweep_equals_oracle(oracle, jaspar579, w
         counts += res.region_counts()
         res.close()
     got = _lib.merge_hits(parts, len(widths))
+    # the same sweep counts-only (what stats.py:29-31 reads of it): per-motif window counts and the number of sites of every span equal
+    # those of the span's full hand-out -- made by one pass over the span's hit positions, no site is written
+    per_span = [(int(len(h["pos"])), off) for h, off in parts]
+    counts_only = np.zeros(len(widths), dtype=np.int64)
+    for (sp, res), (n_sites, _) in zip(_lib.sweep_stream(pw, chroms, window, stride, max_span, 3, _lib.MS_STREAM_NO_HITS, spans=spans), per_span):
+        assert res.n_hits == n_sites
+        counts_only += res.region_counts()
+        res.close()
+    assert np.array_equal(counts_only, counts)
     # the oracle over every window as a region of its own
     win_bases, n_win = [], 0
     for b in chroms:
