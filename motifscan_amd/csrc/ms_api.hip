@@ -1700,23 +1700,28 @@ int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *r1, int64_t s
         // span's hit positions, nothing handed out (sweep_countonly_kernel)
         void *blk = nullptr;
         size_t got = 0;
-        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, 0), &blk, &got))) return fail2(rc);
+        if ((size_t) pwms->P > 65536) { set_error("internal: counts-only hand-out with more than 65536 motifs"); return fail2(MS_ERR_RUNTIME); }
+        if ((rc = pool_alloc(c, result_block_bytes(pwms->P, 1), &blk, &got))) return fail2(rc);        // (room for >= 65536 words behind the counts)
         raw->block = blk;
         raw->block_bytes = got;
-        result_carve(raw, blk, 0);
+        result_carve(raw, blk, 1);
         raw->counts_only = true;
         const size_t P1 = (size_t) pwms->P + 1;
-        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);                     // (word P: the number of sites)
+        unsigned long long *d_sites = reinterpret_cast<unsigned long long *>(raw->d_seq_idx);           // per-motif sites, summed on the host
+        he = hipMemsetAsync(raw->d_region_counts, 0, 8 * P1, c->stream);
         if (he == hipSuccess) he = hipMemsetAsync(raw->d_motif_first, 0, 8 * P1, c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(d_sites, 0, 8 * P1, c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
         rc = launch_sweep_countonly((int64_t) n1, r1->d_motif_first, r1->P, pwms->d_width, r1->d_pos, window, stride, n_windows,
-                                    raw->d_region_counts, raw->d_region_counts + pwms->P, c->stream);
+                                    raw->d_region_counts, d_sites, c->stream);
         if (rc) return fail2(rc);
         (void) hipEventRecord(c->ev[1], c->stream);
-        unsigned long long n_sites = 0;
-        he = hipMemcpyAsync(&n_sites, raw->d_region_counts + pwms->P, 8, hipMemcpyDeviceToHost, c->stream);
+        std::vector<unsigned long long> per_motif((size_t) pwms->P, 0ULL);
+        if (pwms->P > 0) he = hipMemcpyAsync(per_motif.data(), d_sites, 8 * (size_t) pwms->P, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("sweep count failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
+        unsigned long long n_sites = 0;
+        for (unsigned long long v : per_motif) n_sites += v;
         total = n_sites;
         raw->n_hits = (int64_t) total;
         float ms01 = 0;
