@@ -209,22 +209,35 @@ void pool_free(DeviceCtx *c, void *p, size_t bytes) {
         c->pool.bytes += bytes;
         return;
     }
-    // full: the blocks that have sat in the cache UNUSED for the longest leave (free_ is in order of return -- a block that is handed
-    // out is taken from the middle, one that comes back is appended -- so its front is the stalest).  A steady workload keeps
-    // recycling its own blocks and never reaches the front; the blocks of a PREVIOUS workload age out.  (Round 4 evicted the smallest
-    // block instead: after a 3 Gbp sweep had filled the cache with 64 large blocks, every block of a later stream of small batches
-    // went back to the driver and came from hipMalloc again, forever -- tests/test_gpu_configs.py found it.)
+    // full.  By BYTES (the cache holds a third of the device): give the driver the SMALLEST cached block that is smaller than this one, or
+    // this one -- the large blocks are the dear ones to make again (~100 ms per GB-sized hipMalloc), and a sweep that cycles through more
+    // result blocks than fit keeps missing the cheap ones, not the dear ones (an LRU rule, tried in round 5, cost the 3 Gbp sweep with all
+    // sites copied out 300 ms of driver time per pass: profiles/r05_bench_c5_3000mbp.json against r04e_).  By COUNT (kMaxBlocks, 512 since
+    // round 5: 64 large blocks of a sweep once filled the list and every block of a later stream of small batches went back to the driver
+    // and came from hipMalloc again, forever): the stalest block leaves -- the list is in order of return, its front is the stalest.
     std::vector<void *> victims;
-    while (!c->pool.free_.empty() && (c->pool.bytes + bytes > c->pool.max_bytes || c->pool.free_.size() >= BlockPool::kMaxBlocks)) {
+    void *keep = p;
+    if (c->pool.free_.size() >= BlockPool::kMaxBlocks) {
         victims.push_back(c->pool.free_.front().first);
         c->pool.bytes -= c->pool.free_.front().second;
         c->pool.free_.erase(c->pool.free_.begin());
     }
-    if (c->pool.bytes + bytes <= c->pool.max_bytes) {
-        c->pool.free_.emplace_back(p, bytes);
+    if (c->pool.bytes + bytes > c->pool.max_bytes) {
+        size_t small = (size_t) -1;
+        for (size_t i = 0; i < c->pool.free_.size(); i++)
+            if (c->pool.free_[i].second < bytes && (small == (size_t) -1 || c->pool.free_[i].second < c->pool.free_[small].second)) small = i;
+        if (small != (size_t) -1 && c->pool.bytes - c->pool.free_[small].second + bytes <= c->pool.max_bytes) {
+            victims.push_back(c->pool.free_[small].first);
+            c->pool.bytes -= c->pool.free_[small].second;
+            c->pool.free_.erase(c->pool.free_.begin() + (long) small);
+        } else {
+            victims.push_back(p);
+            keep = nullptr;
+        }
+    }
+    if (keep) {
+        c->pool.free_.emplace_back(keep, bytes);
         c->pool.bytes += bytes;
-    } else {
-        victims.push_back(p);                                   // larger than the whole cache may be
     }
     c->pool.n_driver_free += victims.size();
     lk.unlock();

@@ -34,7 +34,7 @@ struct BlockPool {
     // chromosomes of a sweep, the batches of a region stream -- reuse each other's blocks instead of going to the driver:
     // hipMalloc maps pages for milliseconds and hipFree waits for the whole device, either stalls every stage of a stream.
     size_t max_bytes = 96ull << 30;                        // cached at most: a third of the device's memory (set in get_ctx from hipMemGetInfo)
-    static constexpr size_t kMaxBlocks = 64;
+    static constexpr size_t kMaxBlocks = 512;
     uint64_t n_hit = 0, n_miss = 0, n_driver_free = 0, ns_driver = 0;
 };
 
