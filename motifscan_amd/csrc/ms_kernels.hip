@@ -194,7 +194,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // What a wave keeps in registers about its candidates: the parking space (below) -- the rest of the hand-off lives in LDS (PfEmit)
 struct MfWave {
-    uint32_t *rq;              // the wave's parking space in LDS: rq_cap entries of kRareEntryWords words
+    uint32_t rq;               // the wave's parking space: its LDS byte address (32-bit address arithmetic: a generic pointer made every entry's address a 64-bit multiply-add); rq_cap entries of kRareEntryWords words
     uint32_t rq_n;             // entries parked (wave-uniform)
     uint32_t rq_cap, rq_flush; // PfArgs::rare_cap; the fill at which the parked entries are decoded
 };
@@ -283,6 +283,10 @@ __device__ __forceinline__ void pair_flags(const f32x16 &c, uint32_t &fx, uint32
 // (not inlined) function: it decodes the parked entries one per lane and queues the records.  An event with more candidate lanes
 // than free entries parks what fits; the class comes back to the same row tile after the flush (PfResume).
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 // Parks the event's candidate lanes number skip, skip + 1, ... while entries are free.  True: all parked (skip is 0 again).
 __device__ __forceinline__ bool rare_park(MfWave &W, const f32x16 &c, bool hit, int64_t g, int32_t group, uint32_t paired, uint32_t &skip) {
     const unsigned long long mask = __ballot(hit);
@@ -290,10 +294,10 @@ __device__ __forceinline__ bool rare_park(MfWave &W, const f32x16 &c, bool hit, 
     const uint32_t n_take = n_new < n_free ? n_new : n_free;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u)) - skip;   // (wraps for the lanes already parked)
     if (hit && rank < n_take) {
-        uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank) * (uint32_t) kRareEntryWords);      // 80-byte entries: four 16-byte stores + one of 8
+        lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) (W.rq + __umul24(W.rq_n + rank, (uint32_t) (kRareEntryWords * 4)));      // 80-byte entries: four 16-byte stores + one of 8
 #pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c[4 * j]), __float_as_uint(c[4 * j + 1]), __float_as_uint(c[4 * j + 2]), __float_as_uint(c[4 * j + 3]));
-        *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g, (uint32_t) ((uint64_t) g >> 32) | ((uint32_t) group << 8) | (paired << 31));
+        for (int j = 0; j < 4; j++) e[j] = u32x4{__float_as_uint(c[4 * j]), __float_as_uint(c[4 * j + 1]), __float_as_uint(c[4 * j + 2]), __float_as_uint(c[4 * j + 3])};
+        *(lds_u32x2 *) (e + 4) = u32x2{(uint32_t) g, (uint32_t) ((uint64_t) g >> 32) | ((uint32_t) group << 8) | (paired << 31)};
     }
     W.rq_n += n_take;
     if (n_take < n_new) { skip += n_take; return false; }
@@ -317,9 +321,16 @@ __device__ __forceinline__ bool rare_park2(MfWave &W, PfResume &R, const f32x16 
 // the free entries (or a class re-entered in the middle of one, R.op / R.skip set) takes rare_park2's piecewise form.  Round 4:
 // profiles/r03zz_class_clock.log put the hand-off at ~5.7 k of a wave's ~24.5 k cycles per 64-window pass, ~600 cycles per event,
 // most of it the dozen taken branches and scalar bookkeeping of the resumable form.
-__device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &c0, const f32x16 &c1, bool hit0, bool hit1, int64_t g0,
+struct PfLive {                 // which of the lane's two windows lie inside the input: the lane's flags, and the wave's masks (scalar registers, made once per pass)
+    bool l0, l1;
+    unsigned long long m0, m1;
+};
+__device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &c0, const f32x16 &c1, const PfLive &L, bool cand0, bool cand1, int64_t g0,
                                           int32_t group, uint32_t paired, bool no_stores = false) {      // no_stores: measurement only (MS_PF_NOEMIT=5)
-    const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+    // (the two conditions' masks ANDed as masks: a ballot of `live && cand` turns the AND into a register of 0 / 1 and compares that again --
+    // four vector instructions per event, found in the ISA in round 5)
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cand0) & L.m0, m1 = __builtin_amdgcn_ballot_w64(cand1) & L.m1;
+    const bool hit0 = L.l0 && cand0, hit1 = L.l1 && cand1;
     const uint32_t n0 = (uint32_t) __popcll(m0), n1 = (uint32_t) __popcll(m1);
     if (__builtin_expect((R.op | R.skip) != 0u || W.rq_n + n0 + n1 > W.rq_cap, 0))
         return rare_park2(W, R, c0, c1, hit0, hit1, g0, group, paired);
@@ -327,16 +338,16 @@ __device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &
     const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, n0));
     const uint32_t hi = (uint32_t) ((uint64_t) g0 >> 32) | ((uint32_t) group << 8) | (paired << 31);     // (g0 + 32 never carries into bit 32: g0 < 2^34 is a multiple-of-64 base plus lane & 31)
     if (hit0 && !no_stores) {
-        uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank0) * (uint32_t) kRareEntryWords);
+        lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) (W.rq + __umul24(W.rq_n + rank0, (uint32_t) (kRareEntryWords * 4)));      // 80-byte entries: four 16-byte stores + one of 8
 #pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c0[4 * j]), __float_as_uint(c0[4 * j + 1]), __float_as_uint(c0[4 * j + 2]), __float_as_uint(c0[4 * j + 3]));
-        *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g0, hi);
+        for (int j = 0; j < 4; j++) e[j] = u32x4{__float_as_uint(c0[4 * j]), __float_as_uint(c0[4 * j + 1]), __float_as_uint(c0[4 * j + 2]), __float_as_uint(c0[4 * j + 3])};
+        *(lds_u32x2 *) (e + 4) = u32x2{(uint32_t) g0, hi};
     }
     if (hit1 && !no_stores) {
-        uint4 *e = reinterpret_cast<uint4 *>(W.rq + (W.rq_n + rank1) * (uint32_t) kRareEntryWords);
+        lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) (W.rq + __umul24(W.rq_n + rank1, (uint32_t) (kRareEntryWords * 4)));      // 80-byte entries: four 16-byte stores + one of 8
 #pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = make_uint4(__float_as_uint(c1[4 * j]), __float_as_uint(c1[4 * j + 1]), __float_as_uint(c1[4 * j + 2]), __float_as_uint(c1[4 * j + 3]));
-        *reinterpret_cast<uint2 *>(e + 4) = make_uint2((uint32_t) g0 + 32u, hi);
+        for (int j = 0; j < 4; j++) e[j] = u32x4{__float_as_uint(c1[4 * j]), __float_as_uint(c1[4 * j + 1]), __float_as_uint(c1[4 * j + 2]), __float_as_uint(c1[4 * j + 3])};
+        *(lds_u32x2 *) (e + 4) = u32x2{(uint32_t) g0 + 32u, hi};
     }
     W.rq_n += n0 + n1;
     return false;
@@ -345,8 +356,6 @@ __device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &
 // Decode and queue the n parked entries of a wave (lane i takes entry i).  All lanes of the wave, at a wave-uniform point.  NOT
 // inlined, and everything it needs comes through two LDS addresses: its registers are its own business.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 __device__ __attribute__((noinline)) void pf_flush(uint32_t em_lds, uint32_t rq_lds, uint32_t n) {
     const uint32_t lane = threadIdx.x & 63u;
     const bool mine = lane < n;
@@ -479,7 +488,7 @@ __device__ __forceinline__ void plain_product2_asm(uint32_t pa, const i32x4 &b00
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                          uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
-                                         int64_t pass0, bool live0, bool live1, PfResume &R) {
+                                         int64_t pass0, const PfLive &L, PfResume &R) {
     // pass0 = the pass's first window start (wave-uniform: scalar registers); this lane's two window starts are pass0 + r and
     // pass0 + r + 32 with r = lane & 31 -- recomputed where needed (rare paths), not carried
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
@@ -551,7 +560,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
         if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
             // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
-            const bool full = park_both(W, R, c0, c1, live0 && (int) x0 >= 0, live1 && (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u,
+            const bool full = park_both(W, R, c0, c1, L, (int) x0 >= 0, (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u,
                                         MEAS && A.no_emit == 5);
             if constexpr (MEAS) { if (A.no_emit >= 4) W.rq_n = 0; }              // measurement: the events run, their entries are dropped (4), nor stored at all (5): no decode
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
@@ -567,7 +576,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                               uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
-                                              int64_t pass0, bool live0, bool live1, PfResume &R) {
+                                              int64_t pass0, const PfLive &L, PfResume &R) {
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
     constexpr int kStep = NK * kF6BytesPerKb;
     const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
@@ -633,7 +642,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
         const uint32_t x0 = or16(c0), x1 = or16(c1);
         if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
             // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
-            const bool full = park_both(W, R, c0, c1, live0 && (x0 & kPairMask) != 0u, live1 && (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
+            const bool full = park_both(W, R, c0, c1, L, (x0 & kPairMask) != 0u, (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
                                         first_group + 4 * t + 2 * (int32_t) h, 1u, MEAS && A.no_emit == 5);
             if constexpr (MEAS) { if (A.no_emit >= 4) W.rq_n = 0; }
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
@@ -697,13 +706,13 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // every wave OWNS a first block of the candidate list (no atomic: 4096 waves reserving their first block on one counter word
     // cost 45 us, the whole fixed cost of a small scan); further blocks come from the counter, behind the static ones
     MfWave W;
-    W.rq = reinterpret_cast<uint32_t *>(lds4 + A.rare_off16) + (threadIdx.x >> 6) * (A.rare_cap * (uint32_t) kRareEntryWords);
+    W.rq = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) (lds4 + A.rare_off16) + (threadIdx.x >> 6) * (A.rare_cap * (uint32_t) (kRareEntryWords * 4));
     W.rq_cap = A.rare_cap;
     W.rq_flush = A.rare_cap - (A.rare_cap > 32u ? A.rare_cap / 4u : 8u);
     W.rq_n = 0;
     PfEmit *em = reinterpret_cast<PfEmit *>(reinterpret_cast<uint32_t *>(lds4 + A.emit_off16) + (threadIdx.x >> 6) * (uint32_t) kPfEmitWords);
     const uint32_t em_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) em;
-    const uint32_t rq_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) W.rq;
+    const uint32_t rq_lds = W.rq;
     if ((threadIdx.x & 63u) == 0) {
         em->base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
         em->left = A.cand_block;
@@ -758,6 +767,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             live1 = live1 && !dead1;
             if (!__any(live0 || live1)) return;
         }
+        const PfLive L{live0, live1, __builtin_amdgcn_ballot_w64(live0), __builtin_amdgcn_ballot_w64(live1)};
         auto read_cd = [&](int i) { return *reinterpret_cast<const int4 *>(cls_lds + 8 * i); };      // {nk, n_row_tiles, base16, first_group}; paired: word 4
         int4 cd4 = read_cd(0);
         int cdp = cls_lds[4];
@@ -775,14 +785,14 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
             while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
                 if (cd.paired) {
-                    if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
-                    else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R);
+                    if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
+                    else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
                 } else {
                     switch (cd.nk) {
-                        case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
-                        case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); break;
-                        case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); else R.t = cd.n_row_tiles; break;
-                        case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, live0, live1, R); else R.t = cd.n_row_tiles; break;
+                        case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
+                        case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
+                        case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
+                        case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
                         default: R.t = cd.n_row_tiles; break;
                     }
                 }
