@@ -954,7 +954,7 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kF6LutBytes + kPfStageBytes + kPfEmitBytes + kPfRareBytesMin;   // the B-operand table, the waves' sequence staging, their PfEmit and (at least) kRareCapMin parking entries follow the tables
+    const size_t lds_fixed = kF6LutBytes + kPfStageBytes + kPfEmitBytes + kPfOnehotBytes + kPfRareBytesMin;   // the B-operand table, the waves' sequence staging, their PfEmit, their one-hot arrays and (at least) kRareCapMin parking entries follow the tables
     // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
     // (profiles/r02_wave_occupancy_ab.log)
     size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
@@ -1111,7 +1111,8 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.codes = S.codes; A.nmask = S.nmask; A.n_bases = S.n_bases; A.no_emit = pf_no_emit; A.skip_alln = plan.alln_can_hit ? 0 : 1;
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16; A.stage_off16 = lut_off16 + (uint32_t) (kF6LutBytes / 16);
             A.emit_off16 = A.stage_off16 + (uint32_t) (kPfStageBytes / 16);
-            A.rare_off16 = A.emit_off16 + (uint32_t) (kPfEmitBytes / 16);
+            A.onehot_off16 = A.emit_off16 + (uint32_t) (kPfEmitBytes / 16);
+            A.rare_off16 = A.onehot_off16 + (uint32_t) (kPfOnehotBytes / 16);
             A.rare_cap = rare_cap;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
             const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart

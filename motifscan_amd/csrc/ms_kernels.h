@@ -18,6 +18,7 @@ constexpr int kRareCapMin = 16;              // entries per wave: whatever LDS t
 constexpr int kRareCapMax = 64;              // (a wave has 64 lanes: an event never needs more)
 constexpr int kRareEntryWords = 20;          // 16 result registers + {position low word, position high bits | group << 8 | paired << 31} + 2 spare: 80 bytes (16-byte stores)
 constexpr size_t kPfRareBytesMin = (size_t) (kPfThreads / 64) * kRareCapMin * kRareEntryWords * sizeof(uint32_t);
+constexpr size_t kPfOnehotBytes = (size_t) (kPfThreads / 64) * 96 * 16;   // per wave: the pass's one-hot array, 96 entries of 16 bytes (ms_kernels.hip, kOnehotEntries)
 constexpr int kPfEmitWords = 16;             // per wave: its place in the global candidate list and the launch's constants (PfEmit, ms_kernels.hip)
 constexpr size_t kPfEmitBytes = (size_t) (kPfThreads / 64) * kPfEmitWords * sizeof(uint32_t);
 
@@ -72,6 +73,7 @@ struct PfArgs {
     uint32_t stage_off16;     // start of the per-wave sequence staging
     uint32_t rare_off16;      // start of the per-wave parking space for candidate lanes' result registers
     uint32_t emit_off16;      // start of the per-wave PfEmit
+    uint32_t onehot_off16;    // start of the per-wave one-hot arrays
     uint32_t rare_cap;        // entries of a wave's parking space; decoded when fewer than 8 (above 32 entries: a quarter) are free
     uint64_t *cand;           // candidate records; a wave reserves blocks of cand_block slots (unused slots are written as 0 = empty)
     unsigned long long *n_cand;   // slots reserved so far
