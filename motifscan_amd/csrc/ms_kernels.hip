@@ -461,39 +461,76 @@ __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, i
 // alone (clobbered); the waits are the compiler's own pattern -- `lgkmcnt(1)` before the first operand is needed (its six registers are
 // the first two reads'), `lgkmcnt(0)` before the second's, and the 12 wait states (`s_nop 11`: hipcc's own pattern for this instruction in this binary) an 8-pass matrix instruction needs before a vector
 // instruction reads its result.
-__device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
-                                                  f32x16 &c0, f32x16 &c1) {
-    const int one = 127;
+// Round 5: the reads of the NEXT row tile's operand are issued inside the same block, right behind the last matrix instruction (which has
+// read v[118:123] long before LDS data can come back), so that their latency -- a third of a wave's cycles were spent parked at
+// s_waitcnt (SQ_WAIT_ANY, profiles/r05b_pmc_sq1.csv) -- runs beside the 12 wait states, the inspection and the loop branch instead of in
+// front of the next products.  In C++ this was measured twice and lost (a second set of operand registers, moves); here the twelve
+// registers are the same ones: the operand is dead once its instructions have issued.  The registers are an OPERAND of the blocks
+// (`areg`, tied to v[112:123]), not a clobber: the compiler must keep them free between the blocks while the reads are in flight, and
+// nothing but these blocks may touch them -- a_reads_begin starts the first row tile's reads, a_reads_drain waits for the last (unused)
+// ones before the class returns and the registers go back to the compiler.  tests/test_host_cabi.py checks the built code for both.
+typedef int i32x12 __attribute__((ext_vector_type(12)));
+__device__ __forceinline__ void a_reads_begin(uint32_t pa, i32x12 &areg) {
     asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
                  "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
-                 "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
-                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:32"
+                 : "={v[112:123]}"(areg) : [pa] "v"(pa) : "memory");
+}
+__device__ __forceinline__ void a_reads_drain(i32x12 &areg) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "={v[112:123]}"(areg) : "0"(areg) : "memory");
+}
+// NEXT = byte distance to the next row tile's operand (the ds_read offset field: 16 bits)
+template <int NEXT>
+__device__ __forceinline__ void pair_product2_noreads_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
+                                                          f32x16 &c0, f32x16 &c1) {      // measurement only (MS_PF_NOEMIT=6): the products of a row tile on whatever the registers hold, no operand reads
+    const int one = 127;
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_nop 11"
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1), "={v[112:123]}"(areg)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one), "2"(areg)
+                 : "memory");
+}
+template <int NEXT>
+__device__ __forceinline__ void pair_product2_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
+                                                  f32x16 &c0, f32x16 &c1) {
+    const int one = 127;
+    asm volatile("s_waitcnt lgkmcnt(1)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "ds_read_b128 v[112:115], %[pa] offset:%[n0]\n\t"
+                 "ds_read_b128 v[116:119], %[pa] offset:%[n1]\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:%[n2]\n\t"
                  "s_nop 11"
-                 : [c0] "=&v"(c0), [c1] "=&v"(c1)
-                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one)
-                 : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1), "={v[112:123]}"(areg)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one), "2"(areg),
+                   [n0] "n"(NEXT), [n1] "n"(NEXT + 16), [n2] "n"(NEXT + 32)
+                 : "memory");
 }
 // ... and of plain rows: accumulators from 0, both block scales 2^0
-__device__ __forceinline__ void plain_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
-    const int one = 127;
-    asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
-                 "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
-                 "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
-                 "s_waitcnt lgkmcnt(1)\n\t"
-                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0, %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
-                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0, %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+template <int NEXT>
+__device__ __forceinline__ void plain_product2_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
+    // (the instruction WITHOUT block scales: the scaled form is two instructions, v_mfma_ld_scale_b32 + the product, 16 bytes of code and two more
+    // register reads, for a scale of 2^0)
+    asm volatile("s_waitcnt lgkmcnt(1)\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0 cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0 cbsz:2 blgp:4\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
-                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s1], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1] cbsz:2 blgp:4\n\t"
+                 "ds_read_b128 v[112:115], %[pa] offset:%[n0]\n\t"
+                 "ds_read_b128 v[116:119], %[pa] offset:%[n1]\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:%[n2]\n\t"
                  "s_nop 11"
-                 : [c0] "=&v"(c0), [c1] "=&v"(c1)
-                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s1] "v"(one)
-                 : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1), "={v[112:123]}"(areg)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), "2"(areg),
+                   [n0] "n"(NEXT), [n1] "n"(NEXT + 16), [n2] "n"(NEXT + 32)
+                 : "memory");
 }
 
 // All row tiles of one class of plain rows (NK k-blocks each).
@@ -558,12 +595,13 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
             const int2 w2 = *reinterpret_cast<const int2 *>(q + kb * kF6BytesPerKb + 1024);
             a[kb] = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
         }
-        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], z, 2, 4, 0, 127, 0, 127);
-        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], z, 2, 4, 0, 127, 0, 127);
+        // (scale operands 0, 0: the compiler emits the instruction without block scales, v_mfma_f32_32x32x64_f8f6f4 -- scale 2^0)
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b0[0], z, 2, 4, 0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b1[0], z, 2, 4, 0, 0, 0, 0);
 #pragma unroll
         for (int kb = 1; kb < NK; kb++) {
-            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b0[kb], c0, 2, 4, 0, 127, 0, 127);
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, 127, 0, 127);
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b0[kb], c0, 2, 4, 0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[kb], b1[kb], c1, 2, 4, 0, 0, 0, 0);
         }
     };
     // one row tile in flight per wave: with paired rows most instructions belong to four-instruction row tiles, and a second set of
@@ -579,13 +617,15 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
         bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
         bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
     }
+    [[maybe_unused]] i32x12 areg;
+    if constexpr (NK == 2) a_reads_begin(pa, areg);
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        if constexpr (NK == 2) plain_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], c0, c1);
+        if constexpr (NK == 2) plain_product2_asm<kStep>(pa, areg, bq[0], bq[1], bq[2], bq[3], c0, c1);
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }      // measurement: operand reads + products, no inspection
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
+        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && ((A.no_emit >= 1 && A.no_emit <= 3) || A.no_emit == 6)), 0)) {
             // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
             const bool full = park_both(W, R, c0, c1, L, (int) x0 >= 0, (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u,
                                         MEAS && A.no_emit == 5);
@@ -593,6 +633,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }
+    if constexpr (NK == 2) a_reads_drain(areg);
     R.t = back;
 }
 
@@ -670,14 +711,18 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
         bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
         bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
     }
+    [[maybe_unused]] i32x12 areg;
+    if constexpr (NK == 2) a_reads_begin(pa, areg);
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
-        // (reading the NEXT row tile's A operand before this one's inspection was measured again with paired rows: +4 ... 6 % time)
         f32x16 c0, c1;
-        if constexpr (NK == 2) pair_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
+        if constexpr (NK == 2) {
+            if (MEAS && A.no_emit == 6) pair_product2_noreads_asm<kStep>(pa, areg, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
+            else pair_product2_asm<kStep>(pa, areg, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
+        }
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
-        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
+        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && ((A.no_emit >= 1 && A.no_emit <= 3) || A.no_emit == 6)), 0)) {
             // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
             const bool full = park_both(W, R, c0, c1, L, (x0 & kPairMask) != 0u, (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
                                         first_group + 4 * t + 2 * (int32_t) h, 1u, MEAS && A.no_emit == 5);
@@ -685,6 +730,7 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }
+    if constexpr (NK == 2) a_reads_drain(areg);
     R.t = back;
 }
 
