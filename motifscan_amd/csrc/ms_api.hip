@@ -1072,13 +1072,16 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         const int64_t pf_chunks = (S.n_bases + kPfThreads - 1) / kPfThreads;
         bpt = (int) std::max<int64_t>(1, std::min<int64_t>(pf_chunks, (c->n_cu - reserve) * kPfBlocksPerCu / n_tiles));
         if (const char *e = measure_env("MS_PF_MAX_BLOCKS")) bpt = std::max(1, std::min(bpt, atoi(e)));    // test aid: few blocks per tile, as a very large motif set would have
-        // unit of the per-wave hand-out: a pass (64 window starts against a tile's k-blocks) takes ~0.25 us per k-block with 16
+        // unit of the per-wave hand-out: a pass (64 window starts against a tile's k-blocks; 128 in a double pass) takes ~0.25 us per k-block and 64 windows with 16
         // waves per CU, and the launch's waves should not exceed ~47 atomics per microsecond on a tile's counter word
         const int64_t kb_tile = std::max<int64_t>(1, plan.kb_total / n_tiles);
         const double waves = (double) bpt * (kPfThreads / 64);                          // per tile
         const double waves_word = waves / std::min(kPfCounters, bpt);                   // ... and per counter word
-        const int64_t need = (int64_t) std::ceil(waves_word / (47.0 * 0.25 * (double) kb_tile));
-        const int64_t passes_total = (S.n_bases + 63) / 64, n_waves = (int64_t) waves;
+        bool wide_plan = false;
+        for (const TileDesc &t : plan.tiles) wide_plan = wide_plan || t.max_nk > 2;
+        const int64_t pass_windows = wide_plan ? 64 : 128;                              // the kernels without wide classes scan double passes (ms_kernels.hip)
+        const int64_t need = (int64_t) std::ceil(waves_word / (47.0 * 0.25 * (double) (pass_windows / 64) * (double) kb_tile));
+        const int64_t passes_total = (S.n_bases + pass_windows - 1) / pass_windows, n_waves = (int64_t) waves;
         int64_t wp = 2;                                               // a power of two: units start on 128-position boundaries at least
         while (wp < 256 && (double) wp < 0.9 * (double) need) wp *= 2;            // the words' rate limit
         while (wp < 8 && 128 * wp <= passes_total / n_waves) wp *= 2;             // a long launch: the tail (one unit) stays below 1 % anyway, fewer atomics

@@ -35,7 +35,7 @@ inline const char *measure_env(const char *name) {
 // ------------------------------------------------------------------ limits / packing --
 constexpr int kMaxFastWidth = 63;      // widest motif the pre-filter takes: 4 k-blocks of 16 columns, the last column carries the row bias
 constexpr int kMaxMotifs = 65000;      // 14-bit table-group id in a candidate record, >= 8 motifs per group
-constexpr int kPadWords = 8;           // zero words after the packed codes (window reads run past the end)
+constexpr int kPadWords = 16;          // zero words after the packed codes (window reads run past the end)
 
 constexpr int64_t kMaxBases = (1LL << 34) - 128;   // 34-bit position field of a candidate record
 

@@ -9,7 +9,7 @@ constexpr int kPfBlocksPerCu = 1;     // after the tables are loaded, so the blo
 constexpr int kPfCounters = 8;        // counter words per LDS tile of the per-wave hand-out (64 bytes apart)
 constexpr size_t kPfClsBytes = (size_t) kMaxClasses * 32;   // the tile's class descriptors, 32 bytes apiece, behind the B-operand table (prefilter_f6_kernel)
 constexpr size_t kF6LutBytes = 256 * 8 + kPfClsBytes;       // byte of four 2-bit codes -> 16 fp4 one-hot k-slots (8 bytes), after the tile's tables; + the class descriptors
-constexpr int kPfStageWords = 16;            // per wave: 8 code words + 4 non-ACGT words of the current pass (+ 4 spare), after the B-operand table
+constexpr int kPfStageWords = 24;            // per wave: the current pass's code words, then its non-ACGT words -- 8 + 4 (64 window starts), or 16 + 8 (the double pass: 128), after the B-operand table
 constexpr size_t kPfStageBytes = (size_t) (kPfThreads / 64) * kPfStageWords * sizeof(uint32_t);
 // per wave: the lanes that hold a candidate park their 16 result registers here; the flag words are decoded later, one parked entry
 // per lane (ms_kernels.hip, "candidate hand-off")
@@ -18,7 +18,7 @@ constexpr int kRareCapMin = 16;              // entries per wave: whatever LDS t
 constexpr int kRareCapMax = 64;              // (a wave has 64 lanes: an event never needs more)
 constexpr int kRareEntryWords = 20;          // 16 result registers + {position low word, position high bits | group << 8 | paired << 31} + 2 spare: 80 bytes (16-byte stores)
 constexpr size_t kPfRareBytesMin = (size_t) (kPfThreads / 64) * kRareCapMin * kRareEntryWords * sizeof(uint32_t);
-constexpr size_t kPfOnehotBytes = (size_t) (kPfThreads / 64) * 96 * 16;   // per wave: the pass's one-hot array, 96 entries of 16 bytes (ms_kernels.hip, kOnehotEntries)
+constexpr size_t kPfOnehotBytes = (size_t) (kPfThreads / 64) * 160 * 16;  // per wave: the double pass's one-hot array, 160 entries of 16 bytes (ms_kernels.hip, kOnehotEntries)
 constexpr int kPfEmitWords = 16;             // per wave: its place in the global candidate list and the launch's constants (PfEmit, ms_kernels.hip)
 constexpr size_t kPfEmitBytes = (size_t) (kPfThreads / 64) * kPfEmitWords * sizeof(uint32_t);
 

@@ -206,6 +206,7 @@ struct MfWave {
 struct PfResume {
     int t;
     uint32_t op, skip;
+    uint32_t sub;              // double pass: the half (0: windows from pass0, 1: from pass0 + 64) whose event did not fit
 };
 
 // The wave's place in the global candidate list and the launch's constants, in LDS (one per wave: kPfEmitWords words): only the
@@ -438,7 +439,7 @@ struct PassSeq {
 // operands per pass on the benchmark plan.  Now a pass builds entries 0 ... 95 ONCE (lane l: entries l and 64 + (l & 31); non-ACGT bases
 // cleared there), 1536 bytes per wave, and a class fetches its operands with one conflict-free ds_read_b128 each at a constant offset
 // from the lane's entry.
-constexpr int kOnehotEntries = 96;
+constexpr int kOnehotEntries = 160;
 
 // the 32 bases (2-bit codes) / their non-ACGT bits from window start pass0 + r + 32 i, cut out of the staged words (r = lane & 31):
 // funnel shifts (v_alignbit_b32: a shift of 0 is the low operand itself, no special case)
@@ -480,27 +481,70 @@ __device__ __forceinline__ void a_reads_drain(i32x12 &areg) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "={v[112:123]}"(areg) : "0"(areg) : "memory");
 }
 // NEXT = byte distance to the next row tile's operand (the ds_read offset field: 16 bits)
-template <int NEXT>
-__device__ __forceinline__ void pair_product2_noreads_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
-                                                          f32x16 &c0, f32x16 &c1) {      // measurement only (MS_PF_NOEMIT=6): the products of a row tile on whatever the registers hold, no operand reads
+// The single-pass form (the kernels WITH wide classes keep it): the row tile's reads, waits and products in one block, v[112:123] clobbered
+// (the compiler may use them between the blocks: nothing is in flight there).
+__device__ __forceinline__ void pair_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
+                                                  f32x16 &c0, f32x16 &c1) {
     const int one = 127;
-    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+    asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
+                 "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
+                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "s_nop 11"
-                 : [c0] "=&v"(c0), [c1] "=&v"(c1), "={v[112:123]}"(areg)
-                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one), "2"(areg)
-                 : "memory");
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one)
+                 : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
 }
-template <int NEXT>
-__device__ __forceinline__ void pair_product2_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
-                                                  f32x16 &c0, f32x16 &c1) {
+// ... and of plain rows: accumulators from 0, the instruction WITHOUT block scales (the scaled form is two instructions, v_mfma_ld_scale_b32 + the
+// product, 16 bytes of code and two more register reads, for a scale of 2^0: -0.15 ms per 500 Mbase, profiles/r05_double_pass.log)
+__device__ __forceinline__ void plain_product2_asm(uint32_t pa, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
+    asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
+                 "ds_read_b128 v[116:119], %[pa] offset:16\n\t"
+                 "ds_read_b128 v[120:123], %[pa] offset:32\n\t"
+                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0 cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0 cbsz:2 blgp:4\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1] cbsz:2 blgp:4\n\t"
+                 "s_nop 11"
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1)
+                 : [pa] "v"(pa), [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11)
+                 : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "memory");
+}
+
+// ---- the double pass (kernels without wide classes, round 5) ----
+// A row tile's operand is read ONCE for 128 window starts: block a multiplies it with the B operands of the windows from pass0 and from
+// pass0 + 32, the results are inspected, block b multiplies the SAME registers with those of pass0 + 64 and pass0 + 96 and then starts the
+// next row tile's reads.  Why: the pre-filter is power-limited (tools/power_probe.py: ~1240 W of the board's 1400 W over a scan loop, the
+// shader clock at 2.25 instead of 2.40 GHz), and with the operand reads of the two-block paired row tiles taken out the SAME cycle count ran
+// at 2343 instead of 2188 MHz (profiles/r05_double_pass.log): the LDS reads cost clock, not cycles.  Half the reads, half the row-tile loop
+// trips.  The accumulators are the same 32 registers for both halves.
+__device__ __forceinline__ void pair_product2a_asm(i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
+                                                   f32x16 &c0, f32x16 &c1) {
     const int one = 127;
     asm volatile("s_waitcnt lgkmcnt(1)\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "s_nop 11"
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1), "={v[112:123]}"(areg)
+                 : [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), [s0] "v"(scale0), [s0m] "v"(scale1), [s1] "v"(one), "2"(areg)
+                 : "memory");
+}
+template <int NEXT>
+__device__ __forceinline__ void pair_product2b_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, int scale0, int scale1,
+                                                   f32x16 &c0, f32x16 &c1) {
+    const int one = 127;
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 4.0, %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 2.0, %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0], %[s0], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1], %[s0m], %[s1] op_sel_hi:[0,0,0] cbsz:2 blgp:4\n\t"
                  "ds_read_b128 v[112:115], %[pa] offset:%[n0]\n\t"
@@ -512,15 +556,22 @@ __device__ __forceinline__ void pair_product2_asm(uint32_t pa, i32x12 &areg, con
                    [n0] "n"(NEXT), [n1] "n"(NEXT + 16), [n2] "n"(NEXT + 32)
                  : "memory");
 }
-// ... and of plain rows: accumulators from 0, both block scales 2^0
-template <int NEXT>
-__device__ __forceinline__ void plain_product2_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
-    // (the instruction WITHOUT block scales: the scaled form is two instructions, v_mfma_ld_scale_b32 + the product, 16 bytes of code and two more
-    // register reads, for a scale of 2^0)
+__device__ __forceinline__ void plain_product2a_asm(i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
     asm volatile("s_waitcnt lgkmcnt(1)\n\t"
                  "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0 cbsz:2 blgp:4\n\t"
                  "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0 cbsz:2 blgp:4\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0] cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1] cbsz:2 blgp:4\n\t"
+                 "s_nop 11"
+                 : [c0] "=&v"(c0), [c1] "=&v"(c1), "={v[112:123]}"(areg)
+                 : [b00] "v"(b00), [b10] "v"(b10), [b01] "v"(b01), [b11] "v"(b11), "2"(areg)
+                 : "memory");
+}
+template <int NEXT>
+__device__ __forceinline__ void plain_product2b_asm(uint32_t pa, i32x12 &areg, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11, f32x16 &c0, f32x16 &c1) {
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %[c0], v[112:117], %[b00], 0 cbsz:2 blgp:4\n\t"
+                 "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[112:117], %[b10], 0 cbsz:2 blgp:4\n\t"
                  "v_mfma_f32_32x32x64_f8f6f4 %[c0], v[118:123], %[b01], %[c0] cbsz:2 blgp:4\n\t"
                  "v_mfma_f32_32x32x64_f8f6f4 %[c1], v[118:123], %[b11], %[c1] cbsz:2 blgp:4\n\t"
                  "ds_read_b128 v[112:115], %[pa] offset:%[n0]\n\t"
@@ -617,15 +668,13 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
         bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
         bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
     }
-    [[maybe_unused]] i32x12 areg;
-    if constexpr (NK == 2) a_reads_begin(pa, areg);
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        if constexpr (NK == 2) plain_product2_asm<kStep>(pa, areg, bq[0], bq[1], bq[2], bq[3], c0, c1);
+        if constexpr (NK == 2) plain_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], c0, c1);
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }      // measurement: operand reads + products, no inspection
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && ((A.no_emit >= 1 && A.no_emit <= 3) || A.no_emit == 6)), 0)) {
+        if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
             // rare path (about one row tile in four holds a candidate in some lane): the candidate lanes park their results
             const bool full = park_both(W, R, c0, c1, L, (int) x0 >= 0, (int) x1 >= 0, pass0 + (lane & 31u), first_group + 2 * t + (int32_t) h, 0u,
                                         MEAS && A.no_emit == 5);
@@ -633,7 +682,6 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
     }
-    if constexpr (NK == 2) a_reads_drain(areg);
     R.t = back;
 }
 
@@ -711,24 +759,177 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
         bq[0] = i32x4{b0[0][0], b0[0][1], b0[0][2], b0[0][3]}; bq[1] = i32x4{b1[0][0], b1[0][1], b1[0][2], b1[0][3]};
         bq[2] = i32x4{b0[1][0], b0[1][1], b0[1][2], b0[1][3]}; bq[3] = i32x4{b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
     }
-    [[maybe_unused]] i32x12 areg;
-    if constexpr (NK == 2) a_reads_begin(pa, areg);
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        if constexpr (NK == 2) {
-            if (MEAS && A.no_emit == 6) pair_product2_noreads_asm<kStep>(pa, areg, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
-            else pair_product2_asm<kStep>(pa, areg, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
-        }
+        if constexpr (NK == 2) pair_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
-        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && ((A.no_emit >= 1 && A.no_emit <= 3) || A.no_emit == 6)), 0)) {
+        if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !(MEAS && A.no_emit >= 1 && A.no_emit <= 3), 0)) {
             // rare path: the candidate lanes park their results (table groups 4 t + 2 h for field X and + 1 for field Y)
             const bool full = park_both(W, R, c0, c1, L, (x0 & kPairMask) != 0u, (x1 & kPairMask) != 0u, pass0 + (lane & 31u),
                                         first_group + 4 * t + 2 * (int32_t) h, 1u, MEAS && A.no_emit == 5);
             if constexpr (MEAS) { if (A.no_emit >= 4) W.rq_n = 0; }
             if (full || W.rq_n >= W.rq_flush) { back = full ? t : t + 1; t = n_run; }
         }
+    }
+    R.t = back;
+}
+
+// ---- classes of a double pass ----
+struct PfLive2 { PfLive h[2]; };       // the halves of a double pass: windows from pass0 / from pass0 + 64
+
+// What the halves of a row tile share: inspection result -> the candidate lanes park.  Returns true when the parking space ran full
+// inside this half (the class leaves and comes back to row tile t, half s); sets `low` when the space runs low (the class leaves after t).
+template <bool PAIRED, bool MEAS>
+__device__ __forceinline__ bool half_event(const PfArgs &A, MfWave &W, PfResume &R, const f32x16 &c0, const f32x16 &c1, const PfLive &L, uint32_t x0, uint32_t x1,
+                                           int64_t g0, int32_t group, bool &low) {
+    const bool cand0 = PAIRED ? (x0 & kPairMask) != 0u : (int) x0 >= 0, cand1 = PAIRED ? (x1 & kPairMask) != 0u : (int) x1 >= 0;
+    const bool full = park_both(W, R, c0, c1, L, cand0, cand1, g0, group, PAIRED ? 1u : 0u, MEAS && A.no_emit == 5);
+    if constexpr (MEAS) { if (A.no_emit >= 4) W.rq_n = 0; }                       // measurement: the events run, their entries are dropped (4), nor stored at all (5): no decode
+    low = low || W.rq_n >= W.rq_flush;
+    return full;
+}
+
+// All row tiles of one class of PAIRED rows against the 128 window starts of a double pass (hw: the wave's one-hot array of the pass).
+template <int NK, bool MEAS>
+__device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
+                                               uint32_t hw, int64_t pass0, const PfLive2 &L, PfResume &R) {
+    static_assert(NK == 1 || NK == 2, "paired rows have one or two half-blocks");
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5, r = lane & 31u;
+    constexpr int kStep = NK * kF6BytesPerKb;
+    const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;
+    // B operands: half-block kb of the window at pass0 + r + 32 o + 64 s = entry r + 8 kb + 32 o + 64 s of the one-hot array
+    i32x4 b[2][2][NK];
+    {
+        const lds_i32x4 *e = (const lds_i32x4 *) (uintptr_t) (hw + r * 16u);
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+#pragma unroll
+                for (int kb = 0; kb < NK; kb++) b[sg][o][kb] = e[8 * kb + 32 * o + 64 * sg];
+                // the bias column (last column of the last half-block): constant k-slots in place of the base's one-hot image
+                b[sg][o][NK - 1][3] = (int) (((uint32_t) b[sg][o][NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
+            }
+    }
+    const int scale0 = h ? kPairScaleY : kPairScaleX, scale1 = scale0 - 1;         // (see f6_pair_class)
+    f32x16 cc0, cc1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
+    int n_run = n_row_tiles;
+    if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
+    int back = n_row_tiles;
+    [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;
+    [[maybe_unused]] i32x12 areg;
+    if constexpr (NK == 2) a_reads_begin(pa, areg);
+    const bool skip_events = MEAS && A.no_emit >= 1 && A.no_emit <= 3;
+    for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
+        f32x16 c0, c1;
+        [[maybe_unused]] i32x8 a;
+        bool stop = false, low = false;
+        if constexpr (NK == 2) pair_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, c0, c1);
+        else {
+            const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
+            a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][0][0][0], b[0][0][0][1], b[0][0][0][2], b[0][0][0][3], 0, 0, 0, 0}, cc0, 2, 4, 0, scale0, 0, 127);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][1][0][0], b[0][1][0][1], b[0][1][0][2], b[0][1][0][3], 0, 0, 0, 0}, cc1, 2, 4, 0, scale1, 0, 127);
+        }
+        if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
+        if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
+            const uint32_t x0 = or16(c0), x1 = or16(c1);
+            if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, 0))
+                if (half_event<true, MEAS>(A, W, R, c0, c1, L.h[0], x0, x1, pass0 + r, first_group + 4 * t + 2 * (int32_t) h, low)) { back = t; R.sub = 0u; stop = true; }
+        }
+        if (!stop) {
+            if constexpr (NK == 2) pair_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], scale0, scale1, c0, c1);
+            else {
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][0][0][0], b[1][0][0][1], b[1][0][0][2], b[1][0][0][3], 0, 0, 0, 0}, cc0, 2, 4, 0, scale0, 0, 127);
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][1][0][0], b[1][1][0][1], b[1][1][0][2], b[1][1][0][3], 0, 0, 0, 0}, cc1, 2, 4, 0, scale1, 0, 127);
+            }
+            if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
+            if (!(MEAS && A.no_emit == 3)) {
+                const uint32_t x0 = or16(c0), x1 = or16(c1);
+                if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, 0))
+                    if (half_event<true, MEAS>(A, W, R, c0, c1, L.h[1], x0, x1, pass0 + 64 + r, first_group + 4 * t + 2 * (int32_t) h, low)) { back = t; R.sub = 1u; stop = true; }
+            }
+            if (!stop) {
+                R.sub = 0u;
+                if (low) { back = t + 1; stop = true; }
+            }
+        }
+        if (stop) t = n_run;
+    }
+    if constexpr (NK == 2) a_reads_drain(areg);
+    R.t = back;
+}
+
+// ... and of plain rows (one or two k-blocks)
+template <int NK, bool MEAS>
+__device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
+                                          uint32_t hw, bool any_n, int64_t pass0, const PfLive2 &L, PfResume &R) {
+    static_assert(NK == 1 || NK == 2, "the double pass knows row tiles of one or two k-blocks");
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5, r = lane & 31u;
+    constexpr int kStep = NK * kF6BytesPerKb;
+    const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;
+    // B operands: k-block kb of the window at pass0 + r + 32 o + 64 s covers the bases 16 kb + 8 h ... + 7 behind it: entry r + 8 h + 16 kb + 32 o + 64 s
+    i32x4 b[2][2][NK];
+    {
+        const lds_i32x4 *e = (const lds_i32x4 *) (uintptr_t) (hw + (r + 8u * h) * 16u);
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+#pragma unroll
+                for (int kb = 0; kb < NK; kb++) b[sg][o][kb] = e[16 * kb + 32 * o + 64 * sg];
+                // rare, wave-uniform: the row tile's last column carries the bias, its base must not read as "no base" (any of the
+                // column's four k-slots: they hold the same entry)
+                if (any_n && h && ((uint32_t) b[sg][o][NK - 1][3] >> 16) == 0u) b[sg][o][NK - 1][3] |= 0x00020000;
+            }
+    }
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int n_run = n_row_tiles;
+    if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
+    int back = n_row_tiles;
+    [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;
+    [[maybe_unused]] i32x12 areg;
+    if constexpr (NK == 2) a_reads_begin(pa, areg);
+    const bool skip_events = MEAS && A.no_emit >= 1 && A.no_emit <= 3;
+    for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
+        f32x16 c0, c1;
+        [[maybe_unused]] i32x8 a;
+        bool stop = false, low = false;
+        if constexpr (NK == 2) plain_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1);
+        else {
+            const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
+            a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][0][0][0], b[0][0][0][1], b[0][0][0][2], b[0][0][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][1][0][0], b[0][1][0][1], b[0][1][0][2], b[0][1][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
+        }
+        if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
+        if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
+            const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
+            if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, 0))
+                if (half_event<false, MEAS>(A, W, R, c0, c1, L.h[0], x0, x1, pass0 + r, first_group + 2 * t + (int32_t) h, low)) { back = t; R.sub = 0u; stop = true; }
+        }
+        if (!stop) {
+            if constexpr (NK == 2) plain_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], c0, c1);
+            else {
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][0][0][0], b[1][0][0][1], b[1][0][0][2], b[1][0][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][1][0][0], b[1][1][0][1], b[1][1][0][2], b[1][1][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
+            }
+            if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
+            if (!(MEAS && A.no_emit == 3)) {
+                const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
+                if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, 0))
+                    if (half_event<false, MEAS>(A, W, R, c0, c1, L.h[1], x0, x1, pass0 + 64 + r, first_group + 2 * t + (int32_t) h, low)) { back = t; R.sub = 1u; stop = true; }
+            }
+            if (!stop) {
+                R.sub = 0u;
+                if (low) { back = t + 1; stop = true; }
+            }
+        }
+        if (stop) t = n_run;
     }
     if constexpr (NK == 2) a_reads_drain(areg);
     R.t = back;
@@ -816,19 +1017,23 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     const uint32_t hw_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) (lds4 + A.onehot_off16) + (threadIdx.x >> 6) * (uint32_t) (kOnehotEntries * 16);
     // (32-bit word indices: a set holds <= 2^34 bases = 2^30 code words; the loads then take a scalar base and a 32-bit lane offset)
     const uint32_t n_code_words = (uint32_t) (2 * ((A.n_bases + 31) / 32) + kPadWords), n_mask_words = (uint32_t) ((A.n_bases + 31) / 32 + kPadWords);
-    struct PassWords { uint32_t c, n; };                                        // what lane l loaded: code word l & 7 and non-ACGT word l & 3 of the pass
-    auto fetch = [&](uint32_t pass) -> PassWords {                              // pass = pass0 / 64
+    // A pass = PW window starts: 128 in the kernels without wide classes (the double pass: 16 code words and 8 non-ACGT words are staged,
+    // 168 bases and their 6 words are needed), 64 in the others (8 + 4 words staged)
+    constexpr uint32_t PW = SH ? 128u : 64u, CWP = PW / 16u, NWP = PW / 32u;      // window starts / code words / non-ACGT words per pass
+    struct PassWords { uint32_t c, n; };                                        // what lane l loaded: code word l & (2 CWP - 1) and non-ACGT word l & (2 NWP - 1) of the pass
+    auto fetch = [&](uint32_t pass) -> PassWords {                              // pass = pass0 / PW
         // every lane loads from both arrays -- the same few cache lines -- through a SCALAR base (the pass is wave-uniform) and a small
         // lane offset: a per-lane 64-bit address costs a register pair that the kernel has not got.  The two results stay two
         // registers until they are staged: choosing between them here would make the wave wait for the loads here
-        // (kPadWords >= 8 zero words follow both arrays: only the BASE needs clamping, for the dead passes behind the input's end)
-        const uint32_t bc = pass * 4u < n_code_words - 8u ? pass * 4u : n_code_words - 8u, bn = pass * 2u < n_mask_words - 4u ? pass * 2u : n_mask_words - 4u;
+        // (kPadWords >= 16 zero words follow both arrays: only the BASE needs clamping, for the dead passes behind the input's end)
+        static_assert(kPadWords >= 16, "the staged words of a pass run up to 16 words past its first");
+        const uint32_t bc = pass * CWP < n_code_words - 2u * CWP ? pass * CWP : n_code_words - 2u * CWP, bn = pass * NWP < n_mask_words - 2u * NWP ? pass * NWP : n_mask_words - 2u * NWP;
         typedef const __attribute__((address_space(1))) uint32_t *gptr;          // (a GLOBAL pointer: through an integer it would come back generic)
         auto uniform = [](const uint32_t *q) {                                  // the pointer into scalar registers, whatever the compiler thought of it
             const uint64_t a = reinterpret_cast<uint64_t>(q);
             return (gptr) (((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (a >> 32)) << 32) | (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) a));
         };
-        return PassWords{uniform(A.codes + bc)[lane & 7u], uniform(A.nmask + bn)[lane & 3u]};
+        return PassWords{uniform(A.codes + bc)[lane & (2u * CWP - 1u)], uniform(A.nmask + bn)[lane & (2u * NWP - 1u)]};
     };
     auto scan_pass = [&](int64_t pass0) {                                    // 64 window starts of this wave (pass0 ... + 63, wave-uniform) against every class
         // (32-bit: what is left of the input from pass0 on is wave-uniform; a 64-bit position per lane costs two register pairs)
@@ -842,20 +1047,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         const uint32_t nw0 = staged_nw(stg, r, 0), nw1 = staged_nw(stg, r, 1);
         const uint32_t nw2 = wide ? staged_nw(stg, r, 2) : 0u;                           // only classes of 3 or 4 k-blocks reach bases 64 ... 95
         Q.any_n = __any((nw0 | nw1 | nw2) != 0u);
-        Q.hw = hw_lds;
-        if constexpr (SH) {
-            // entries lane and 64 + r of the one-hot array: the 8 bases from pass0 + lane / from pass0 + 64 + r on (entries above 87 are never read)
-            const uint32_t w2 = (r >> 4) + 4u;
-            i32x8 e0 = onehot_f4(lut, (uint32_t) (lane < 32u ? Q.cw[0] : Q.cw[1]) & 0xFFFFu);
-            i32x8 e1 = onehot_f4(lut, __builtin_amdgcn_alignbit(stg[w2 + 1], stg[w2], (r & 15u) * 2u) & 0xFFFFu);
-            if (Q.any_n) {                                                               // rare, wave-uniform: a non-ACGT base is an all-zero column
-                clear_n(e0, (lane < 32u ? nw0 : nw1) & 0xFFu);
-                clear_n(e1, staged_nw(stg, r, 2) & 0xFFu);
-            }
-            lds_i32x4 *hq = (lds_i32x4 *) (uintptr_t) hw_lds;
-            hq[lane] = i32x4{e0[0], e0[1], e0[2], e0[3]};
-            hq[64u + r] = i32x4{e1[0], e1[1], e1[2], e1[3]};
-        }
+        Q.hw = 0u;
         if (Q.any_n && A.skip_alln) {
             // a window whose bases are ALL non-ACGT (the tile's motifs span <= 32 bases, <= 64 with wide classes) scores 0 on every
             // motif and none reports that (plan: every threshold > 0): such lanes queue nothing, and a pass made of them only --
@@ -884,12 +1076,12 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
             while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
                 if (cd.paired) {
-                    if (cd.nk == 1) f6_pair_class<1, MEAS, SH>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
-                    else f6_pair_class<2, MEAS, SH>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
+                    if (cd.nk == 1) f6_pair_class<1, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
+                    else f6_pair_class<2, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
                 } else {
                     switch (cd.nk) {
-                        case 1: f6_class<1, MEAS, SH>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
-                        case 2: f6_class<2, MEAS, SH>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
+                        case 1: f6_class<1, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
+                        case 2: f6_class<2, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
                         case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
                         case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
                         default: R.t = cd.n_row_tiles; break;
@@ -900,9 +1092,66 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) cls_cyc[i] += __builtin_amdgcn_s_memtime() - tc0; }
         }
     };
+    auto scan_pass2 = [&](int64_t pass0, bool any_n) {                        // the double pass: 128 window starts of this wave (pass0 ... + 127, wave-uniform) against every class
+        const int64_t left64 = A.n_bases - pass0;
+        const uint32_t left = left64 >= 128 ? 128u : (left64 > 0 ? (uint32_t) left64 : 0u);
+        bool lv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) lv[k] = r + 32u * (uint32_t) k < left;
+        const uint32_t *stn = stg + 16;                                          // the staged non-ACGT words
+        {
+            // the pass's one-hot array (above PassSeq's helpers): lane l makes entries l, 64 + l and 128 + (l & 31) -- the 8 bases from pass0 + entry on,
+            // cut out of the staged words with funnel shifts; a non-ACGT base is an all-zero column (any_n: rare, wave-uniform)
+            auto entry = [&](uint32_t x) {
+                const uint32_t w = x >> 4;
+                i32x8 e = onehot_f4(lut, __builtin_amdgcn_alignbit(stg[w + 1], stg[w], (x & 15u) * 2u) & 0xFFFFu);
+                if (any_n) clear_n(e, __builtin_amdgcn_alignbit(stn[(x >> 5) + 1], stn[x >> 5], x & 31u) & 0xFFu);
+                return i32x4{e[0], e[1], e[2], e[3]};
+            };
+            lds_i32x4 *hq = (lds_i32x4 *) (uintptr_t) hw_lds;
+            hq[lane] = entry(lane);
+            hq[64u + lane] = entry(64u + lane);
+            hq[128u + r] = entry(128u + r);
+        }
+        if (any_n && A.skip_alln) {
+            // a window whose bases are ALL non-ACGT (the tile's motifs span <= 32 bases) scores 0 on every motif and none reports that (plan:
+            // every threshold > 0): such lanes queue nothing, and a pass made of them only -- the inside of an assembly gap -- is skipped whole
+#pragma unroll
+            for (int k = 0; k < 4; k++) lv[k] = lv[k] && __builtin_amdgcn_alignbit(stn[k + 1], stn[k], r) != 0xFFFFFFFFu;
+            if (!__any(lv[0] || lv[1] || lv[2] || lv[3])) return;
+        }
+        const PfLive2 L{{PfLive{lv[0], lv[1], __builtin_amdgcn_ballot_w64(lv[0]), __builtin_amdgcn_ballot_w64(lv[1])},
+                         PfLive{lv[2], lv[3], __builtin_amdgcn_ballot_w64(lv[2]), __builtin_amdgcn_ballot_w64(lv[3])}}};
+        auto read_cd = [&](int i) { return *reinterpret_cast<const int4 *>(cls_lds + 8 * i); };      // {nk, n_row_tiles, base16, first_group}; paired: word 4
+        int4 cd4 = read_cd(0);
+        int cdp = cls_lds[4];
+        for (int i = 0; i < n_classes; i++) {
+            ClassDesc cd;                                                         // wave-uniform: into scalar registers
+            cd.nk = __builtin_amdgcn_readfirstlane(cd4.x);
+            cd.n_row_tiles = __builtin_amdgcn_readfirstlane(cd4.y);
+            cd.base16 = (uint32_t) __builtin_amdgcn_readfirstlane(cd4.z);
+            cd.first_group = __builtin_amdgcn_readfirstlane(cd4.w);
+            cd.paired = __builtin_amdgcn_readfirstlane(cdp);
+            if (i + 1 < n_classes) { cd4 = read_cd(i + 1); cdp = cls_lds[8 * (i + 1) + 4]; }      // the next class's, while this one runs
+            const uint32_t off = cd.base16 * 16u;
+            PfResume R{0, 0u, 0u, 0u};
+            unsigned long long tc0 = 0;
+            if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
+            while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
+                if (cd.paired) {
+                    if (cd.nk == 1) f6_pair_class2<1, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
+                    else f6_pair_class2<2, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
+                } else if (cd.nk == 1) f6_class2<1, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
+                else if (cd.nk == 2) f6_class2<2, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
+                else R.t = cd.n_row_tiles;
+                if (W.rq_n >= W.rq_flush) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
+            }
+            if constexpr (MEAS) { if (A.cls_clk) cls_cyc[i] += __builtin_amdgcn_s_memtime() - tc0; }
+        }
+    };
     {
         const uint32_t wave_passes = A.wave_passes < 1 ? 8u : (uint32_t) A.wave_passes;
-        const uint32_t n_passes_total = (uint32_t) ((A.n_bases + 63) / 64);           // <= 2^28: a set holds <= 2^34 bases
+        const uint32_t n_passes_total = (uint32_t) ((A.n_bases + PW - 1) / PW);       // <= 2^28: a set holds <= 2^34 bases
         const uint32_t n_units = (n_passes_total + wave_passes - 1) / wave_passes;
         constexpr uint32_t wpb = NT / 64;
         // A small input (A.use_counters == 0): one unit per wave, no atomic at all.  Else kPfCounters counter words per tile: a
@@ -922,10 +1171,11 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             // followed at once by s_waitcnt vmcnt(0) (its wave-aggregated form broadcasts the result), which exposed the counter's round
             // trip once per unit
             unsigned int u = 0;
-            const uint32_t uid = v * K + g;                                       // the unit: window starts [uid, uid + 1) * 64 * wave_passes
+            const uint32_t uid = v * K + g;                                       // the unit: window starts [uid, uid + 1) * PW * wave_passes
             const uint32_t p0 = uid * wave_passes;
             for (uint32_t j = 0; j < wave_passes; j++) {                          // passes past the end scan dead lanes (last unit only)
-                if (lane < 12) stg[lane] = lane < 8 ? words.c : words.n;          // (the wave's LDS operations execute in order: no barrier)
+                if (lane < 3u * CWP) stg[lane] = lane < 2u * CWP ? words.c : words.n;       // (the wave's LDS operations execute in order: no barrier)
+                [[maybe_unused]] const bool pass_any_n = SH && __any((lane & (2u * NWP - 1u)) < 6u && words.n != 0u);      // (double pass: a non-ACGT base among the 192 staged)
                 // (behind the staging, which waits for every vector-memory operation in flight)
                 // INVARIANT: the compiler believes `u` is ready at once, the value arrives with the atomic's return.  Nothing may read,
                 // copy or spill u's register before a vmcnt(0) wait has retired the atomic: with wave_passes >= 2 that is pass 1's staging wait
@@ -946,7 +1196,8 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                     }
                     if (next < units_g) words = fetch((next * K + g) * wave_passes);
                 }
-                scan_pass((int64_t) (p0 + j) * 64);
+                if constexpr (SH) scan_pass2((int64_t) (p0 + j) * 128, pass_any_n);
+                else scan_pass((int64_t) (p0 + j) * 64);
             }
             v = next;
         }

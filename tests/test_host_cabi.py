@@ -557,11 +557,15 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
     """Build-time checks on the gfx950 code object of the pre-filter: what the hand-written
     asm blocks of ms_kernels.hip rest on, read from the disassembly of the object the library was linked from.
       * <= 128 vector registers (four waves per SIMD), no scalar spills, and no scratch traffic between the first and the last
-        matrix instruction (the compiler's three spilled registers live in the unit hand-out around the passes);
+        matrix instruction (the compiler's spilled registers live in the unit hand-out around the passes);
       * the work hand-out's `global_atomic_add vN ... sc0` (issued without a wait): vN is named by no instruction of the pass body
         (first to last matrix instruction) and by nothing in pf_flush, the one real call inside it -- the value arrives while pass 0
         runs and is first read after pass 1's staging wait;
-      * every hand-written two-block product is followed by `s_nop 11` (12 wait states before a vector read of its result)."""
+      * every hand-written two-block product ends in `s_nop 11` (12 wait states before a vector read of its result);
+      * round 5, the double pass: v[112:123] hold a row tile's operand while its reads are IN FLIGHT across compiler-made code, so in
+        the kernels without wide classes NOTHING but the blocks' own ds_read_b128 / matrix instructions may name them (a compiler
+        copy of the tied operand would read registers whose data has not landed), and every run of reads into them is preceded,
+        in the same loop, by the drain or a product block that waited (checked as: the blocks exist in both shapes)."""
     import re, shutil, subprocess
     objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
     obj = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels.o")
@@ -595,8 +599,18 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
         assert len(mf) >= 12
         product = "ILi2ELb0" in k                                  # the kernel every JASPAR-like set runs on (the 3/4-k-block one spills in its rare paths)
         if product:
-            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 4 and num["private_segment_fixed_size"] <= 32, (k, num)
+            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 12 and num["private_segment_fixed_size"] <= 64, (k, num)
             assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("scratch_")], "spill traffic inside the pass body"
+        if "ILi2E" in k:                                            # the double-pass kernels: the operand registers are the blocks' alone
+            areg = re.compile(r"\bv(11[2-9]|12[0-3])\b|\bv\[(\d+):(\d+)\]")
+
+            def touches(line):
+                for m in areg.finditer(line):
+                    if m.group(1) is not None or (int(m.group(2)) <= 123 and int(m.group(3)) >= 112):
+                        return True
+                return False
+            bad = [l for l in body if touches(l) and not (l.startswith("ds_read_b128 v[11") or l.startswith("ds_read_b128 v[12") or l.startswith("v_mfma"))]
+            assert not bad, (k, bad[:4])
         # the hand-out's atomic: the one that is NOT waited for at once
         cand = [i for i, l in enumerate(body) if l.startswith("global_atomic_add") and "sc0" in l
                 and not any(x.startswith("s_waitcnt vmcnt(0)") for x in body[i + 1:i + 4])]
@@ -613,11 +627,26 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
         if product:
             assert not [l for l in body[mf[0]:mf[-1] + 1] if names(l)], f"{reg} is touched while the atomic may be in flight"
             assert not [l for l in funcs[flush[0]] if names(l)], f"pf_flush touches {reg}"
-        # the two-block products by name: three 16-byte reads into v[112:123], four matrix instructions, s_nop 11
+        # the two-block products by name: four matrix instructions on v[112:117] / v[118:123] and `s_nop 11` at the block's end -- with the three
+        # 16-byte reads in front (single pass, wide kernels), or none (block a of a double pass), or the NEXT row tile's behind them (block b)
+        n_blocks = 0
         for i, l in enumerate(body):
-            if l.startswith("ds_read_b128 v[112:115]"):
-                blk = body[i:i + 10]
-                assert sum(x.startswith("v_mfma_scale_f32_32x32x64_f8f6f4") for x in blk) == 4 and blk[9] == "s_nop 11", blk
+            if "ILi2E" not in k:                                    # single pass: reads, four matrix instructions, s_nop 11 (the compiler uses the registers elsewhere too)
+                if l.startswith("ds_read_b128 v[112:115]"):
+                    blk = [x for x in body[i:i + 12] if not x.startswith("s_waitcnt")]
+                    assert sum(x.startswith("v_mfma") for x in blk[3:7]) == 4 and blk[7] == "s_nop 11", blk
+                    n_blocks += 2
+                continue
+            if l.startswith("v_mfma") and "v[112:117]" in l and not (body[i - 1].startswith("v_mfma") and "v[112:117]" in body[i - 1]):
+                blk = [x for x in body[i:i + 10] if not x.startswith("s_waitcnt")]
+                assert sum(x.startswith("v_mfma") for x in blk[:4]) == 4 and "v[118:123]" in blk[2] and "v[118:123]" in blk[3], blk
+                tail = blk[4:]
+                if tail[0].startswith("ds_read_b128 v[112:115]"):
+                    assert tail[1].startswith("ds_read_b128 v[116:119]") and tail[2].startswith("ds_read_b128 v[120:123]") and tail[3] == "s_nop 11", blk
+                else:
+                    assert tail[0] == "s_nop 11", blk
+                n_blocks += 1
+        assert n_blocks >= 4, (k, n_blocks)
 
 
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
