@@ -1,6 +1,6 @@
 # Round evidence on the GPU box: tests, bench lines, profiles.  Usage: bash tools/evidence_round.sh <tag> [quick]
 # Everything lands in gpurun_out/evidence_<tag>/ (scratch); what is to be judged is copied into profiles/ afterwards (profiles/INDEX.md).
-TAG=${1:-r05}
+TAG=${1:-r05d}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
 T="timeout 900"
