@@ -98,7 +98,7 @@ typedef struct ms_scan_stats {
     double  pf_clock_mhz;       /* shader clock held inside the pre-filter kernel; 0 unless MS_PF_CLOCK=1 */
     int64_t mfma_ops;           /* multiply-adds x 2 the pre-filter issues on the matrix cores (one-hot zeros and width padding included) */
     int64_t mfma_ops_algorithmic; /* 2 x windows x strands x W: the adds the reference performs */
-    int32_t pf_engine;          /* always 3: the fp6 x fp4 one-hot product on the matrix cores (the int8 / LDS-lookup engines left the library in round 3) */
+    int32_t pf_engine;          /* 3: the fp6 x fp4 one-hot product on the matrix cores, candidates parked and decoded later; 4: the same with the flags decoded in place (chosen when the previous scan of the PWM set found many hits per row tile: p >= ~5e-4) */
     int32_t reserved;
 } ms_scan_stats;
 

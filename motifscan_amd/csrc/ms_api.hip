@@ -1031,8 +1031,25 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // need, 64 ... 2048 (its first block is its own, without an atomic); the slots a wave leaves unused in its last block are head
     // room on top
     const int64_t pf_waves_max = (int64_t) c->n_cu * kPfBlocksPerCu * (kPfThreads / 64);
+    // what the previous scan of this set at these cutoffs and strands found, per (motif, window): sizes the blocks, and picks the kernel form
+    const bool density_known = pwms->pred_density >= 0 && pwms->pred_strand == strand_mask && pwms->pred_cutoff_version == pwms->cutoff_version &&
+                               pwms->pred_exact_only == exact_only;
+    const double cand_density = density_known ? std::max(1.5e-4, 1.3 * pwms->pred_density) : 1.5e-4;
     uint32_t cand_block = 64;
-    while (cand_block < 2048 && (double) cand_block * 4.0 * (double) pf_waves_max < 1.5e-4 * (double) fast_windows) cand_block *= 2;
+    while (cand_block < 2048 && (double) cand_block * 4.0 * (double) pf_waves_max < cand_density * (double) fast_windows) cand_block *= 2;
+    // the dense-candidate form of the pre-filter (ms_kernels.hip): expected hits per row tile and 64 window starts above kDenseHitsPerHalfTile
+    bool pf_dense = false;
+    {
+        int64_t n_row_tiles = 0;
+        bool wide_plan = false;
+        for (const TileDesc &t : plan.tiles) {
+            wide_plan = wide_plan || t.max_nk > 2;
+            for (int i = 0; i < t.n_classes; i++) n_row_tiles += t.cls[i].n_row_tiles;
+        }
+        if (density_known && !wide_plan && n_row_tiles > 0)
+            pf_dense = pwms->pred_density * 64.0 * (double) plan.fast_motifs.size() / (double) n_row_tiles > kDenseHitsPerHalfTile;
+        if (const char *e = measure_env("MS_PF_DENSE")) pf_dense = !wide_plan && atoi(e) != 0;       // test aid / A-B: either form at any density
+    }
     want_cand += (size_t) 2 * pf_waves_max * cand_block;          // the waves' own first blocks + the unused rest of their last ones
     want_cand = std::max(want_cand, sc.cand_cap);
     want_hits = std::max(want_hits, sc.hit_cap);
@@ -1147,12 +1164,14 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             }
             bool wide = false;
             for (const TileDesc &t : plan.tiles) wide = wide || t.max_nk > 2;
-            const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0);
+            const bool dense = pf_dense && !wide && !pf_meas;
+            const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0) + (dense ? 4 : 0);
             if (lds_bytes > c->lds_set[li]) {
-                if ((rc = prefilter_set_lds(wide, pf_meas, lds_bytes))) return rc;
+                if ((rc = prefilter_set_lds(wide, pf_meas, dense, lds_bytes))) return rc;
                 c->lds_set[li] = lds_bytes;
             }
-            if ((rc = launch_prefilter(A, wide, pf_meas, bpt, n_tiles, lds_bytes, c->stream))) return rc;
+            if ((rc = launch_prefilter(A, wide, pf_meas, dense, bpt, n_tiles, lds_bytes, c->stream))) return rc;
+            stt.pf_engine = dense ? 4 : 3;
         }
         (void) hipEventRecord(ev[1], c->stream);
         if (!plan.fast_motifs.empty())                 // (few blocks for a small scan measured slower: the kernel is a chain of dependent gathers and wants every record in flight at once)

@@ -19,6 +19,8 @@ constexpr int kRareCapMax = 64;              // (a wave has 64 lanes: an event n
 constexpr int kRareEntryWords = 20;          // 16 result registers + {position low word, position high bits | group << 8 | paired << 31} + 2 spare: 80 bytes (16-byte stores)
 constexpr size_t kPfRareBytesMin = (size_t) (kPfThreads / 64) * kRareCapMin * kRareEntryWords * sizeof(uint32_t);
 constexpr size_t kPfOnehotBytes = (size_t) (kPfThreads / 64) * 160 * 16;  // per wave: the double pass's one-hot array, 160 entries of 16 bytes (ms_kernels.hip, kOnehotEntries)
+constexpr double kDenseHitsPerHalfTile = 12.0; // the dense-candidate kernel (ms_kernels.hip) above this many expected hits per row tile and 64 windows: measured 4.4 (p = 1e-3) 34.9 against
+                                               // 31.9 ms parked, 44 (p = 1e-2, 1/8 shard) 5.7 against 9.5 ms (profiles/r05_dense_form.log)
 constexpr int kPfEmitWords = 16;             // per wave: its place in the global candidate list and the launch's constants (PfEmit, ms_kernels.hip)
 constexpr size_t kPfEmitBytes = (size_t) (kPfThreads / 64) * kPfEmitWords * sizeof(uint32_t);
 
@@ -91,8 +93,8 @@ struct PfArgs {
 
 
 int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t *nmask, hipStream_t st);
-int prefilter_set_lds(bool wide, bool meas, size_t bytes);
-int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
+int prefilter_set_lds(bool wide, bool meas, bool dense, size_t bytes);
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool dense, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
                      const HitOut &H, hipStream_t st);
 // the same for long lists: chunks of the list in motif order, the window carried along (rescore_carry_kernel); one 1024-thread block per CU

@@ -776,6 +776,62 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     R.t = back;
 }
 
+// ---- dense candidates (round 5): the kernel for cutoffs at which nearly every row tile holds candidates ----
+// Parking pays while an event is a lane or a few in a row tile (p = 1e-4: 0.4 hits per 64 windows x 32 rows; p = 1e-3: 4.4 -- there the parked
+// form still wins, 31.9 against 34.9 ms per 500 Mbase).  At p = 1e-2 a row tile holds 44: a third of the lanes of both operands park, the
+// space is decoded after every event and the hand-off is most of the kernel.  There the flags are decoded IN PLACE for the whole wave -- the
+// vector work that costs the same for one lane or 64 is well used -- and the records go straight into the wave's block of the list, its
+// place kept in scalar registers (no parking space, no pf_flush): 5.7 against 9.5 ms on the 62.5-Mbase shard (profiles/r05_dense_form.log).
+// scan_locked launches this instantiation when the PREVIOUS scan of the PWM set at these cutoffs and strands found more than
+// kDenseHitsPerHalfTile hits per row tile and 64 windows.
+struct PfOut {
+    unsigned long long base;   // next free slot of this wave's block in the global candidate list
+    uint32_t left;             // slots left in the block
+};
+// bit n of the result = result register 15 - n is non-negative (field n of the lane's table group)
+__device__ __forceinline__ uint32_t nonneg_flags_v(const f32x16 &c) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) m = __builtin_amdgcn_alignbit(m, (uint32_t) __float_as_int(c[j]), 31);   // (m << 1) | sign
+    return ~m & 0xFFFFu;
+}
+// one record per flagged lane into the wave's block (ranks by ballot / mbcnt; a block that cannot take them all is abandoned: its rest becomes
+// empty records, the next one comes from the counter)
+__device__ __forceinline__ void put_recs(const PfArgs &A, PfOut &O, bool flagged, uint64_t rec) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(flagged);
+    if (mask == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_new = (uint32_t) __popcll(mask);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    if (n_new > O.left) {                                           // (cand_block >= 64 >= n_new: the next block always fits them)
+        if (lane < O.left && O.base + lane < A.cand_cap) A.cand[O.base + lane] = 0ULL;
+        unsigned long long b = 0;
+        if (lane == 0) b = A.cand_static + atomicAdd(A.n_cand, (unsigned long long) A.cand_block);
+        O.base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b >> 32)) << 32) |
+                 (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+        O.left = A.cand_block;
+    }
+    if (flagged && O.base + rank < A.cand_cap) A.cand[O.base + rank] = rec;
+    O.base += n_new;
+    O.left -= n_new;
+}
+template <bool PAIRED>
+__device__ __forceinline__ void dense_event(const PfArgs &A, PfOut &O, const f32x16 &c0, const f32x16 &c1, const PfLive &L, int64_t g0, int32_t group) {
+    if constexpr (PAIRED) {
+        uint32_t x0, y0, x1, y1;
+        pair_flags(c0, x0, y0);
+        pair_flags(c1, x1, y1);
+        put_recs(A, O, L.l0 && x0 != 0u, cand_pack((uint64_t) g0, (uint32_t) group, x0));
+        put_recs(A, O, L.l0 && y0 != 0u, cand_pack((uint64_t) g0, (uint32_t) group + 1u, y0));
+        put_recs(A, O, L.l1 && x1 != 0u, cand_pack((uint64_t) g0 + 32u, (uint32_t) group, x1));
+        put_recs(A, O, L.l1 && y1 != 0u, cand_pack((uint64_t) g0 + 32u, (uint32_t) group + 1u, y1));
+    } else {
+        const uint32_t f0 = nonneg_flags_v(c0), f1 = nonneg_flags_v(c1);
+        put_recs(A, O, L.l0 && f0 != 0u, cand_pack((uint64_t) g0, (uint32_t) group, f0));
+        put_recs(A, O, L.l1 && f1 != 0u, cand_pack((uint64_t) g0 + 32u, (uint32_t) group, f1));
+    }
+}
+
 // ---- classes of a double pass ----
 struct PfLive2 { PfLive h[2]; };       // the halves of a double pass: windows from pass0 / from pass0 + 64
 
@@ -792,8 +848,8 @@ __device__ __forceinline__ bool half_event(const PfArgs &A, MfWave &W, PfResume 
 }
 
 // All row tiles of one class of PAIRED rows against the 128 window starts of a double pass (hw: the wave's one-hot array of the pass).
-template <int NK, bool MEAS>
-__device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
+template <int NK, bool MEAS, bool DENSE>
+__device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut &O, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
                                                uint32_t hw, int64_t pass0, const PfLive2 &L, PfResume &R) {
     static_assert(NK == 1 || NK == 2, "paired rows have one or two half-blocks");
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5, r = lane & 31u;
@@ -838,8 +894,10 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, const
         if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
         if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
             const uint32_t x0 = or16(c0), x1 = or16(c1);
-            if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, 0))
-                if (half_event<true, MEAS>(A, W, R, c0, c1, L.h[0], x0, x1, pass0 + r, first_group + 4 * t + 2 * (int32_t) h, low)) { back = t; R.sub = 0u; stop = true; }
+            if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, DENSE ? 1 : 0)) {
+                if constexpr (DENSE) dense_event<true>(A, O, c0, c1, L.h[0], pass0 + r, first_group + 4 * t + 2 * (int32_t) h);
+                else if (half_event<true, MEAS>(A, W, R, c0, c1, L.h[0], x0, x1, pass0 + r, first_group + 4 * t + 2 * (int32_t) h, low)) { back = t; R.sub = 0u; stop = true; }
+            }
         }
         if (!stop) {
             if constexpr (NK == 2) pair_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], scale0, scale1, c0, c1);
@@ -850,8 +908,10 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, const
             if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
             if (!(MEAS && A.no_emit == 3)) {
                 const uint32_t x0 = or16(c0), x1 = or16(c1);
-                if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, 0))
-                    if (half_event<true, MEAS>(A, W, R, c0, c1, L.h[1], x0, x1, pass0 + 64 + r, first_group + 4 * t + 2 * (int32_t) h, low)) { back = t; R.sub = 1u; stop = true; }
+                if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, DENSE ? 1 : 0)) {
+                    if constexpr (DENSE) dense_event<true>(A, O, c0, c1, L.h[1], pass0 + 64 + r, first_group + 4 * t + 2 * (int32_t) h);
+                    else if (half_event<true, MEAS>(A, W, R, c0, c1, L.h[1], x0, x1, pass0 + 64 + r, first_group + 4 * t + 2 * (int32_t) h, low)) { back = t; R.sub = 1u; stop = true; }
+                }
             }
             if (!stop) {
                 R.sub = 0u;
@@ -865,8 +925,8 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, const
 }
 
 // ... and of plain rows (one or two k-blocks)
-template <int NK, bool MEAS>
-__device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
+template <int NK, bool MEAS, bool DENSE>
+__device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
                                           uint32_t hw, bool any_n, int64_t pass0, const PfLive2 &L, PfResume &R) {
     static_assert(NK == 1 || NK == 2, "the double pass knows row tiles of one or two k-blocks");
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5, r = lane & 31u;
@@ -909,8 +969,10 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, const char
         if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
         if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
             const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-            if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, 0))
-                if (half_event<false, MEAS>(A, W, R, c0, c1, L.h[0], x0, x1, pass0 + r, first_group + 2 * t + (int32_t) h, low)) { back = t; R.sub = 0u; stop = true; }
+            if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, DENSE ? 1 : 0)) {
+                if constexpr (DENSE) dense_event<false>(A, O, c0, c1, L.h[0], pass0 + r, first_group + 2 * t + (int32_t) h);
+                else if (half_event<false, MEAS>(A, W, R, c0, c1, L.h[0], x0, x1, pass0 + r, first_group + 2 * t + (int32_t) h, low)) { back = t; R.sub = 0u; stop = true; }
+            }
         }
         if (!stop) {
             if constexpr (NK == 2) plain_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], c0, c1);
@@ -921,8 +983,10 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, const char
             if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
             if (!(MEAS && A.no_emit == 3)) {
                 const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
-                if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, 0))
-                    if (half_event<false, MEAS>(A, W, R, c0, c1, L.h[1], x0, x1, pass0 + 64 + r, first_group + 2 * t + (int32_t) h, low)) { back = t; R.sub = 1u; stop = true; }
+                if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, DENSE ? 1 : 0)) {
+                    if constexpr (DENSE) dense_event<false>(A, O, c0, c1, L.h[1], pass0 + 64 + r, first_group + 2 * t + (int32_t) h);
+                    else if (half_event<false, MEAS>(A, W, R, c0, c1, L.h[1], x0, x1, pass0 + 64 + r, first_group + 2 * t + (int32_t) h, low)) { back = t; R.sub = 1u; stop = true; }
+                }
             }
             if (!stop) {
                 R.sub = 0u;
@@ -953,8 +1017,9 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, const char
 // one-k-block class only, after tools/ubench/insp_probe.hip modes 6 / 7 promised -7 %: +6 % in the kernel), s_setprio around the
 // matrix instructions, 12 / 20 / 24 waves per CU, 128 windows per wave, a block-wide hand-out behind barriers, one branch per pair
 // of row tiles, a real function call for the rare path.)
-template <int MAXNK, bool MEAS>
+template <int MAXNK, bool MEAS, bool DENSE = false>
 __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArgs A) {
+    static_assert(!DENSE || (MAXNK == 2 && !MEAS), "the dense-candidate form exists for the double-pass product kernel");
     extern __shared__ uint4 lds4[];
     constexpr int NT = kPfThreads;
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -1001,6 +1066,12 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         em->base = ((unsigned long long) blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) * A.cand_block + (unsigned long long) (threadIdx.x >> 6) * A.cand_block;
         em->left = A.cand_block;
         em->cand = A.cand; em->n_cand = A.n_cand; em->cand_cap = A.cand_cap; em->cand_static = A.cand_static; em->cand_block = A.cand_block;
+    }
+    PfOut O;                                                                    // DENSE: the wave's place in the candidate list, in scalar registers
+    {
+        const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (((uint32_t) blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t) (NT / 64) + (threadIdx.x >> 6)));
+        O.base = (unsigned long long) wave * A.cand_block;
+        O.left = A.cand_block;
     }
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u;
     unsigned long long t0 = 0, r0 = 0;
@@ -1139,10 +1210,10 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
             while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
                 if (cd.paired) {
-                    if (cd.nk == 1) f6_pair_class2<1, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
-                    else f6_pair_class2<2, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
-                } else if (cd.nk == 1) f6_class2<1, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
-                else if (cd.nk == 2) f6_class2<2, MEAS>(A, W, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
+                    if (cd.nk == 1) f6_pair_class2<1, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
+                    else f6_pair_class2<2, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
+                } else if (cd.nk == 1) f6_class2<1, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
+                else if (cd.nk == 2) f6_class2<2, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
                 else R.t = cd.n_row_tiles;
                 if (W.rq_n >= W.rq_flush) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
             }
@@ -1204,8 +1275,8 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     }
     if (W.rq_n) pf_flush(em_lds, rq_lds, W.rq_n);
     {                                                                             // the unused rest of the last block: empty records
-        const unsigned long long base = em->base;
-        const uint32_t left = em->left;
+        const unsigned long long base = DENSE ? O.base : em->base;
+        const uint32_t left = DENSE ? O.left : em->left;
         for (uint32_t i = 0; i < left; i += 64) {
             const unsigned long long j = base + i + lane;
             if (i + lane < left && j < A.cand_cap) A.cand[j] = 0ULL;
@@ -1837,21 +1908,22 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 }
 
 typedef void (*PfKernel)(const PfArgs);
-static PfKernel pf_kernel(bool wide, bool meas) {
+static PfKernel pf_kernel(bool wide, bool meas, bool dense) {                  // (dense: only without wide classes and outside the measurement instantiation)
     if (wide) return meas ? prefilter_f6_kernel<4, true> : prefilter_f6_kernel<4, false>;
+    if (dense && !meas) return prefilter_f6_kernel<2, false, true>;
     return meas ? prefilter_f6_kernel<2, true> : prefilter_f6_kernel<2, false>;
 }
 
-int prefilter_set_lds(bool wide, bool meas, size_t bytes) {
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+int prefilter_set_lds(bool wide, bool meas, bool dense, size_t bytes) {
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas, dense)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
-// wide: the plan holds row tiles of 3 or 4 k-blocks
-int launch_prefilter(const PfArgs &A, bool wide, bool meas, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+// wide: the plan holds row tiles of 3 or 4 k-blocks; dense: the form that decodes candidates in place (many hits per row tile)
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool dense, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
     const int64_t n_chunks = (A.n_bases + kPfThreads - 1) / kPfThreads;
     if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
-    hipLaunchKernelGGL(pf_kernel(wide, meas), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
+    hipLaunchKernelGGL(pf_kernel(wide, meas, dense), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -451,6 +451,9 @@ def test_low_information_motif_set_vs_oracle(oracle, pkey):
                                  {"MS_RESCORE_SORTED_MIN": "0", "MS_PF_LDS_BUDGET": "24576"},
                                  {"MS_RESCORE_SORTED_MIN": "1e30"},                             # ... and the list-order form throughout
                                  {"MS_BLKINFO_FAR": "1"},                                       # every 64-base block record says "region starts beyond 32 bits": the fp64 stage looks regions up
+                                 {"MS_PF_DENSE": "1"},                                          # the dense-candidate form (flags decoded in place) at a sparse cutoff
+                                 {"MS_PF_DENSE": "1", "MS_PF_LDS_BUDGET": "24576", "MS_PF_MAX_BLOCKS": "5"},
+                                 {"MS_PF_DENSE": "1", "MS_PF_PAIR": "0"},
                                  ])
 def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch, env):
     """Number of LDS tiles, blocks per tile, the hit-key form, the parking space and paired rows are tuning
@@ -466,8 +469,31 @@ def test_kernel_configurations_agree_with_oracle(oracle, jaspar579, monkeypatch,
         res = _lib.scan(_lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets), strand)
         assert_same_hits(res.hits(), want)
         st = res.stats()
-        assert st["pf_engine"] == 3 and st["n_pwms_exact"] == 0
+        assert st["pf_engine"] == (4 if "MS_PF_DENSE" in env else 3) and st["n_pwms_exact"] == 0
         assert (st["n_tiles"] >= 2) == ("MS_PF_LDS_BUDGET" in env)
+
+
+@pytest.mark.parametrize("pkey", ["1e-2", "1e-3"])
+def test_dense_candidate_form_is_chosen_from_the_previous_scan_and_agrees(oracle, jaspar579, pkey):
+    """Round 5: at cutoffs where a row tile holds dozens of candidates (p = 1e-2) the pre-filter decodes the flags in place (pf_engine 4)
+    instead of parking them.  The library picks the form from what the PREVIOUS scan of the PWM set at these cutoffs and strands found: the
+    first scan of a set runs the parked form, the next ones the dense one -- bit for bit the oracle's hits either way, on sequences with
+    non-ACGT bases; other strands start over; p = 1e-3 stays with the parked form (measured faster there)."""
+    vals, widths = jaspar579["pwm_values"], jaspar579["widths"]
+    cutoffs = jaspar579["cutoffs"][pkey]
+    bases, offsets = synth.make_regions(120, 700, seed=23, frac_n=0.03, ragged=True)
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    pw, sq = _lib.PwmSet(vals, widths, cutoffs), _lib.SeqSet(bases, offsets)
+    engines = []
+    for _ in range(3):
+        res = _lib.scan(pw, sq, 3)
+        assert_same_hits(res.hits(), want)
+        engines.append(res.stats()["pf_engine"])
+        res.close()
+    assert engines == ([3, 4, 4] if pkey == "1e-2" else [3, 3, 3]), engines
+    res = _lib.scan(pw, sq, 1)                                 # other strands: no prediction yet
+    assert res.stats()["pf_engine"] == 3
+    assert_same_hits(res.hits(), oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 1, 8))
 
 
 @pytest.mark.parametrize("env", [{}, {"MS_PF_LDS_BUDGET": "16384"}])

@@ -588,7 +588,7 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
     flush = [k for k in funcs if "pf_flush" in k]
     assert len(flush) == 1
     kernels = [k for k in funcs if "prefilter_f6_kernel" in k]
-    assert len(kernels) == 4                                          # <2|4 k-blocks> x <product | measurement>
+    assert len(kernels) == 5                                          # <2|4 k-blocks> x <product | measurement> + the dense-candidate product kernel
     for k in kernels:
         meta = notes[notes.index(".name:           " + k + "\n"):]
         meta = meta[:meta.index(".wavefront_size")]
@@ -614,8 +614,11 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
         # the hand-out's atomic: the one that is NOT waited for at once
         cand = [i for i, l in enumerate(body) if l.startswith("global_atomic_add") and "sc0" in l
                 and not any(x.startswith("s_waitcnt vmcnt(0)") for x in body[i + 1:i + 4])]
-        assert len(cand) == 1, (k, cand)
-        reg = re.match(r"global_atomic_add (v\d+),", body[cand[0]]).group(1)
+        # (one, or two when the compiler's own atomicAdd of the single-pass arm -- same destination register, waited for by the compiler before
+        # its first use -- sits more than three instructions from that wait)
+        regs = {re.match(r"global_atomic_add (v\d+),", body[i]).group(1) for i in cand}
+        assert 1 <= len(cand) <= 2 and len(regs) == 1, (k, cand, regs)
+        reg = regs.pop()
         named = re.compile(rf"\b{reg}\b|\bv\[(\d+):(\d+)\]")
 
         def names(line):
