@@ -601,6 +601,9 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
         if product:
             assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 12 and num["private_segment_fixed_size"] <= 64, (k, num)
             assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("scratch_")], "spill traffic inside the pass body"
+            # the blocks' `s_waitcnt lgkmcnt(1)` counts LDS operations, which finish in order; a scalar load in flight would share the counter and
+            # finish out of order
+            assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("s_load") or l.startswith("s_buffer_load")], "scalar loads inside the pass body"
         if "ILi2E" in k:                                            # the double-pass kernels: the operand registers are the blocks' alone
             areg = re.compile(r"\bv(11[2-9]|12[0-3])\b|\bv\[(\d+):(\d+)\]")
 
