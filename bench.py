@@ -455,7 +455,8 @@ def main():
                     traffic = ent.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
-        # dominant kernel = prefilter_f6_kernel, bound by VALU issue beside the matrix pipe: algorithmic ops =
+        # dominant kernel = prefilter_f6_kernel, on the matrix cores and power-limited (~1240 W of the board's 1400 W over a scan loop, the shader
+        # clock at 2.25 instead of 2.40 GHz: DESIGN.md 4, profiles/r05_double_pass.log): algorithmic ops =
         # SURVEY.md 8(d)'s "one add per (window, column, strand)" counted as a multiply-add (2 ops); what the kernel ISSUES is 4x
         # that (one-hot: 4 k-slots per base) plus the padding of widths to k-blocks of 16 columns.  peak = the dense matrix peak of
         # the operand types the kernel feeds the pipe (fp6 x fp4: MI355X_MICROARCH.md ~10 PF)
@@ -501,6 +502,10 @@ def main():
                                   for k in ("ms_prefilter", "ms_exact", "ms_sort", "ms_finalize", "ms_total")},
             "hits_per_scan": sum(s["n_hits"] for s in all_stats) / n_launch,
             "candidates_per_scan": sum(s["n_candidates"] for s in all_stats) / n_launch,
+            # 3 = candidates parked and decoded later, 4 = decoded in place (the library's choice from the previous scan's density: p >= ~5e-3);
+            # motifs the pre-filter cannot take (a cutoff that lets most windows pass, W > 63) go through exact_all_kernel
+            "prefilter_form_per_scan": sorted({int(s["pf_engine"]) for s in all_stats}),
+            "n_pwms_exact_only": int(all_stats[-1]["n_pwms_exact"]),
             # the path's one collective per step, slowest rank's mean (device events around dist.all_reduce); 0 at N = 1: no collective runs
             "allreduce_ms": max(ranks_report["allreduce_ms_mean_by_rank"]) if ranks_report is not None else 0.0,
         }

@@ -979,7 +979,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     for (int32_t p = 0; p < pwms->P; p++) stt.n_windows += windows_for_width(seqs, pwms->widths[p]);
     for (int32_t p : plan.fast_motifs) fast_windows += windows_for_width(seqs, pwms->widths[p]);
     const int64_t padded = ((seqs->n_bases + 63) / 64) * 64;
-    stt.lds_bytes_read = plan.lds_bytes_per_position * padded;
+    {
+        bool wide_tiles = false;
+        for (const TileDesc &t : plan.tiles) wide_tiles = wide_tiles || t.max_nk > 2;
+        stt.lds_bytes_read = plan.lds_bytes_per_position * padded / (wide_tiles ? 1 : 2);      // (the double pass reads a row tile's operand once for 128 window starts)
+    }
     stt.pf_engine = 3;
     {
         int64_t cells = 0;                                                          // (window, column) pairs of one strand
