@@ -175,10 +175,11 @@ __global__ void __launch_bounds__(256) pack_kernel(const uint8_t *__restrict__ a
 // ---------------------------------------------------------------------- pre-filter --
 //
 // The pre-filter on the matrix cores (operand layout, quantisation and the proof that it never loses a hit: ms_internal.h,
-// ms_plan.cpp).  Per wave and pass: 64 consecutive window starts = two 32-column B operands per k-block (the one-hot image of the
-// lane's bases in fp4, built once per class and reused by every row tile), and per row tile of 32 (motif, strand) rows
-// NK x 3 ds_read_b64 for the A operand (fp6) and 2 NK matrix instructions.  acc >= +0 (sign bit clear) in any of the 16 result
-// registers of a lane marks a candidate.
+// ms_plan.cpp).  Per wave and pass: 128 consecutive window starts (the double pass; 64 in the kernels with wide classes) = four (two)
+// 32-column B operands per k-block -- the one-hot image of the lane's bases in fp4, fetched once per class from the pass's one-hot array and
+// reused by every row tile -- and per row tile of 32 (motif, strand) rows ONE read of the A operand (fp6: 24 bytes per lane and k-block) and
+// 2 NK matrix instructions per 64 window starts.  acc >= +0 (sign bit clear) in any of the 16 result registers of a lane marks a candidate
+// (paired rows: bit 22 / bit 10 of the result, ms_internal.h).
 //
 // ---- candidate hand-off ----
 // Candidates are ~2e-4 of the (window, motif) pairs.  One global atomic per find would put every wave of the chip on ONE address
@@ -1078,10 +1079,10 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     unsigned long long cls_cyc[kMaxClasses] = {0, 0, 0, 0, 0, 0};               // measurement only: this wave's cycles inside each class
     if constexpr (MEAS) { if (A.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); } }
 
-    // The sequence words of a pass, staged per wave in LDS: the wave's 64 window starts and the 32 (wide tiles: 64) bases behind the
-    // last one span 8 code words and 4 non-ACGT words from pass0 on (pass0 is a multiple of 64), which lanes 0 ... 11 fetch -- for
-    // the NEXT pass, before the current one is scanned, so that the global loads' latency hides behind a pass of matrix work --
-    // and every lane then cuts its own windows out of the staged words (rounds 1-2: ten global loads per lane and pass, their
+    // The sequence words of a pass, staged per wave in LDS: the wave's window starts and the 32 (wide tiles: 64) bases behind the
+    // last one span 16 code words and 8 non-ACGT words from pass0 on in a double pass (8 and 4 in a 64-window pass), which lanes
+    // 0 ... 23 (11) fetch -- for the NEXT pass, before the current one is scanned, so that the global loads' latency hides behind a
+    // pass of matrix work -- and every lane then cuts its own windows (double pass: its entries of the one-hot array) out of the staged words (rounds 1-2: ten global loads per lane and pass, their
     // latency exposed once per pass: a third of the kernel's time on inputs with few row tiles per pass, profiles/r03_c2_latency.log).
     uint32_t *stg = reinterpret_cast<uint32_t *>(lds4 + A.stage_off16) + (threadIdx.x >> 6) * kPfStageWords;
     constexpr bool SH = MAXNK == 2;                                             // the pass's one-hot array (above PassSeq's helpers): kernels without wide classes
