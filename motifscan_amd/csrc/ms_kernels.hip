@@ -429,17 +429,16 @@ struct PassSeq {
     uint64_t cw[2];
     const uint32_t *stg; // the wave's staged sequence words of this pass (LDS): 8 code words, then 4 non-ACGT words, from pass0 on
     bool any_n;          // wave-uniform: some lane sees a non-ACGT base in the 96 bases from g0
-    uint32_t hw;         // SH kernels: LDS byte address of the wave's one-hot array of this pass (below)
 };
 
-// ---- the pass's one-hot array (SH = the kernel for row tiles of 1 or 2 k-blocks; round 5) ----
+// ---- the double pass's one-hot array (the kernels for row tiles of 1 or 2 k-blocks; round 5) ----
 // Every B operand of a pass is the fp4 one-hot image of EIGHT consecutive bases, 16 bytes, and the image of the bases from x on is the same
-// whichever class, k-block, lane half or operand asks for it: paired half-block kb of the window at pass0 + r (+ 32) is entry r + 8 kb (+ 32),
-// plain k-block kb entry r + 16 kb + 8 h (+ 32).  Rounds 2-4 built each operand where it was used: two reads of the 256-entry table per
-// operand (random 8-byte reads: the LDS array's only bank conflicts, 14 % of its busy cycles) and half a dozen vector instructions, ten
-// operands per pass on the benchmark plan.  Now a pass builds entries 0 ... 95 ONCE (lane l: entries l and 64 + (l & 31); non-ACGT bases
-// cleared there), 1536 bytes per wave, and a class fetches its operands with one conflict-free ds_read_b128 each at a constant offset
-// from the lane's entry.
+// whichever class, k-block, lane half or operand asks for it: paired half-block kb of the window at pass0 + r + 32 o + 64 s is entry
+// r + 8 kb + 32 o + 64 s, plain k-block kb entry r + 16 kb + 8 h + 32 o + 64 s.  Rounds 2-4 (and the kernels with wide classes still) build each
+// operand where it is used: two reads of the 256-entry table per operand (random 8-byte reads: the LDS array's only bank conflicts, 14 % of its
+// busy cycles) and half a dozen vector instructions, ten operands per 64 windows on the benchmark plan.  A double pass builds entries 0 ... 159
+// ONCE (lane l: entries l, 64 + l and 128 + (l & 31); non-ACGT bases cleared there), 2560 bytes per wave, and a class fetches its operands with
+// one conflict-free ds_read_b128 each at a constant offset from the lane's entry.
 constexpr int kOnehotEntries = 160;
 
 // the 32 bases (2-bit codes) / their non-ACGT bits from window start pass0 + r + 32 i, cut out of the staged words (r = lane & 31):
@@ -586,7 +585,7 @@ __device__ __forceinline__ void plain_product2b_asm(uint32_t pa, i32x12 &areg, c
 }
 
 // All row tiles of one class of plain rows (NK k-blocks each).
-template <int NK, bool MEAS, bool SH>
+template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                          uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
                                          int64_t pass0, const PfLive &L, PfResume &R) {
@@ -600,20 +599,6 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     constexpr int NW = NK > 2 ? 3 : 2;
     // B operands: k-block kb of the window at g0 covers bases 16 kb + 8 h ... + 7 from g0; of the window at g0 + 32 the same from there
     i32x8 b0[NK], b1[NK];
-    if constexpr (SH) {
-        static_assert(!SH || NK <= 2, "the one-hot array covers row tiles of 1 or 2 k-blocks");
-        const lds_i32x4 *e = (const lds_i32x4 *) (uintptr_t) (Q.hw + ((lane & 31u) + 8u * h) * 16u);
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            const i32x4 v0 = e[16 * kb], v1 = e[16 * kb + 32];
-            b0[kb] = i32x8{v0[0], v0[1], v0[2], v0[3], 0, 0, 0, 0};
-            b1[kb] = i32x8{v1[0], v1[1], v1[2], v1[3], 0, 0, 0, 0};
-        }
-        if (Q.any_n && h) {                                                       // rare, wave-uniform: the row tile's last column carries the bias, its base must not read as "no base"
-            if (((uint32_t) b0[NK - 1][3] >> 16) == 0u) b0[NK - 1][3] |= 0x00020000;      // (any of the column's four k-slots: they hold the same entry)
-            if (((uint32_t) b1[NK - 1][3] >> 16) == 0u) b1[NK - 1][3] |= 0x00020000;
-        }
-    } else {
     uint64_t cw[NW];
     cw[0] = Q.cw[0];
     cw[1] = Q.cw[1];
@@ -635,7 +620,6 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
             clear_n(b0[kb], (nw[w] >> (sh + 8 * h)) & keep);
             clear_n(b1[kb], (nw[w + 1] >> (sh + 8 * h)) & keep);
         }
-    }
     }
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto product = [&](const char *q, f32x16 &c0, f32x16 &c1) {
@@ -690,7 +674,7 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
 // scales 2^-6 / 2^-18), both k-halves of the B operand = the same 8 bases, accumulators started at the inline constant 4.0, the bias
 // column's B slots constant.  A row tile answers for 32 motifs x 2 strands with the 32 result registers that answer for 16 in a
 // plain row tile.
-template <int NK, bool MEAS, bool SH>
+template <int NK, bool MEAS>
 __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const char *__restrict__ lds, const char *__restrict__ lut,
                                               uint32_t byte_off, int n_row_tiles, int32_t first_group, const PassSeq &Q,
                                               int64_t pass0, const PfLive &L, PfResume &R) {
@@ -699,15 +683,6 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     const char *p = lds + byte_off + lane * (NK == 2 ? 48u : 8u) + (uint32_t) R.t * (uint32_t) kStep;      // R: see f6_class
     // B operands: half-block kb covers bases 8 kb ... 8 kb + 7 of the window, in both lane halves
     i32x8 b0[NK], b1[NK];
-    if constexpr (SH) {
-        const lds_i32x4 *e = (const lds_i32x4 *) (uintptr_t) (Q.hw + (lane & 31u) * 16u);
-#pragma unroll
-        for (int kb = 0; kb < NK; kb++) {
-            const i32x4 v0 = e[8 * kb], v1 = e[8 * kb + 32];
-            b0[kb] = i32x8{v0[0], v0[1], v0[2], v0[3], 0, 0, 0, 0};
-            b1[kb] = i32x8{v1[0], v1[1], v1[2], v1[3], 0, 0, 0, 0};
-        }
-    } else {
 #pragma unroll
     for (int kb = 0; kb < NK; kb++) {
         b0[kb] = onehot_f4(lut, (uint32_t) (Q.cw[0] >> (16 * kb)) & 0xFFFFu);
@@ -721,7 +696,6 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
             clear_n(b0[kb], (nw0 >> (8 * kb)) & keep);
             clear_n(b1[kb], (nw1 >> (8 * kb)) & keep);
         }
-    }
     }
     // the bias column (last column of the last half-block): constant k-slots in place of the base's one-hot image
     b0[NK - 1][3] = (int) (((uint32_t) b0[NK - 1][3] & 0xFFFFu) | (kPairBiasB << 16));
@@ -1085,7 +1059,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
     // pass of matrix work -- and every lane then cuts its own windows (double pass: its entries of the one-hot array) out of the staged words (rounds 1-2: ten global loads per lane and pass, their
     // latency exposed once per pass: a third of the kernel's time on inputs with few row tiles per pass, profiles/r03_c2_latency.log).
     uint32_t *stg = reinterpret_cast<uint32_t *>(lds4 + A.stage_off16) + (threadIdx.x >> 6) * kPfStageWords;
-    constexpr bool SH = MAXNK == 2;                                             // the pass's one-hot array (above PassSeq's helpers): kernels without wide classes
+    constexpr bool SH = MAXNK == 2;                                             // the double pass with its one-hot array: kernels without wide classes
     const uint32_t hw_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void *) (lds4 + A.onehot_off16) + (threadIdx.x >> 6) * (uint32_t) (kOnehotEntries * 16);
     // (32-bit word indices: a set holds <= 2^34 bases = 2^30 code words; the loads then take a scalar base and a 32-bit lane offset)
     const uint32_t n_code_words = (uint32_t) (2 * ((A.n_bases + 31) / 32) + kPadWords), n_mask_words = (uint32_t) ((A.n_bases + 31) / 32 + kPadWords);
@@ -1119,7 +1093,6 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
         const uint32_t nw0 = staged_nw(stg, r, 0), nw1 = staged_nw(stg, r, 1);
         const uint32_t nw2 = wide ? staged_nw(stg, r, 2) : 0u;                           // only classes of 3 or 4 k-blocks reach bases 64 ... 95
         Q.any_n = __any((nw0 | nw1 | nw2) != 0u);
-        Q.hw = 0u;
         if (Q.any_n && A.skip_alln) {
             // a window whose bases are ALL non-ACGT (the tile's motifs span <= 32 bases, <= 64 with wide classes) scores 0 on every
             // motif and none reports that (plan: every threshold > 0): such lanes queue nothing, and a pass made of them only --
@@ -1148,14 +1121,14 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
             while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
                 if (cd.paired) {
-                    if (cd.nk == 1) f6_pair_class<1, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
-                    else f6_pair_class<2, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
+                    if (cd.nk == 1) f6_pair_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
+                    else f6_pair_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R);
                 } else {
                     switch (cd.nk) {
-                        case 1: f6_class<1, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
-                        case 2: f6_class<2, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
-                        case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
-                        case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS, false>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
+                        case 1: f6_class<1, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
+                        case 2: f6_class<2, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); break;
+                        case 3: if constexpr (MAXNK > 2) f6_class<3, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
+                        case 4: if constexpr (MAXNK > 2) f6_class<4, MEAS>(A, W, lds, lut, off, cd.n_row_tiles, cd.first_group, Q, pass0, L, R); else R.t = cd.n_row_tiles; break;
                         default: R.t = cd.n_row_tiles; break;
                     }
                 }
