@@ -16,7 +16,7 @@ constexpr size_t kPfStageBytes = (size_t) (kPfThreads / 64) * kPfStageWords * si
 constexpr int kPfClkWords = 2 + kMaxClasses;
 constexpr int kRareCapMin = 16;              // entries per wave: whatever LDS the tile's tables leave, between these two (PfArgs::rare_cap)
 constexpr int kRareCapMax = 64;              // (a wave has 64 lanes: an event never needs more)
-constexpr int kRareEntryWords = 20;          // 16 result registers + {position low word, position high bits | group << 8 | paired << 31} + 2 spare: 80 bytes (16-byte stores)
+constexpr int kRareEntryWords = 12;          // the flag bytes of the 16 result registers (8 words for paired rows, 4 for plain ones) + {position low word, position high bits | group << 8 | paired << 31} at byte 32 + 2 spare: 48 bytes (ms_kernels.hip, park_store)
 constexpr size_t kPfRareBytesMin = (size_t) (kPfThreads / 64) * kRareCapMin * kRareEntryWords * sizeof(uint32_t);
 constexpr size_t kPfOnehotBytes = (size_t) (kPfThreads / 64) * 160 * 16;  // per wave: the double pass's one-hot array, 160 entries of 16 bytes (ms_kernels.hip, kOnehotEntries)
 constexpr double kDenseHitsPerHalfTile = 12.0; // the dense-candidate kernel (ms_kernels.hip) above this many expected hits per row tile and 64 windows: measured 4.4 (p = 1e-3) 34.9 against

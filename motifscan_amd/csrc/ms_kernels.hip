@@ -291,18 +291,48 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+// What a parked entry holds (round 5, second half): not the 16 result registers but the BYTES of them that carry the flags -- paired rows:
+// bytes 1 and 2 of every register (bit 10 = field Y's flag, bit 22 = field X's): two registers per word, 8 words; plain rows: byte 3 (the sign),
+// four registers per word, 4 words -- put together with v_perm_b32 (8 / 12 vector instructions per event and operand), then two (one) 16-byte
+// stores and the 8-byte header instead of four and the header.  A parking store costs the wave ~55-65 cycles whatever its exec mask
+// (profiles/r05d_pf_account.log: 2.6 k cycles per pass for 47 store instructions at p = 1e-4, 14.7 k for 220 at p = 1e-3), and a 48-byte
+// entry instead of an 80-byte one gives the space 64 entries again beside the one-hot arrays.
+__device__ __forceinline__ void park_pack(const f32x16 &c, uint32_t paired, u32x4 &p0, u32x4 &p1) {
+    auto u = [&](int j) { return (uint32_t) __float_as_int(c[j]); };
+    if (paired) {
+        // word j = bytes {1, 2} of register j | bytes {1, 2} of register j + 8  (v_perm_b32: selector bytes 0-3 = the second source's, 4-7 = the first's)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { p0[j] = __builtin_amdgcn_perm(u(j + 8), u(j), 0x06050201u); p1[j] = __builtin_amdgcn_perm(u(j + 12), u(j + 4), 0x06050201u); }
+    } else {
+        // word w = byte 3 of registers 4 w ... 4 w + 3
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t lo = __builtin_amdgcn_perm(u(4 * w + 1), u(4 * w), 0x0C0C0703u), hi = __builtin_amdgcn_perm(u(4 * w + 3), u(4 * w + 2), 0x0C0C0703u);
+            p0[w] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        p1 = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+__device__ __forceinline__ void park_put(uint32_t entry_lds, const u32x4 &p0, const u32x4 &p1, uint32_t paired, uint32_t hd0, uint32_t hd1) {
+    lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) entry_lds;
+    e[0] = p0;
+    if (paired) e[1] = p1;
+    *(lds_u32x2 *) (e + 2) = u32x2{hd0, hd1};                                   // the header: always at byte 32
+}
+__device__ __forceinline__ void park_store(uint32_t entry_lds, const f32x16 &c, uint32_t paired, uint32_t hd0, uint32_t hd1) {
+    u32x4 p0, p1;
+    park_pack(c, paired, p0, p1);
+    park_put(entry_lds, p0, p1, paired, hd0, hd1);
+}
+
 // Parks the event's candidate lanes number skip, skip + 1, ... while entries are free.  True: all parked (skip is 0 again).
 __device__ __forceinline__ bool rare_park(MfWave &W, const f32x16 &c, bool hit, int64_t g, int32_t group, uint32_t paired, uint32_t &skip) {
     const unsigned long long mask = __ballot(hit);
     const uint32_t n_new = (uint32_t) __popcll(mask) - skip, n_free = W.rq_cap - W.rq_n;
     const uint32_t n_take = n_new < n_free ? n_new : n_free;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u)) - skip;   // (wraps for the lanes already parked)
-    if (hit && rank < n_take) {
-        lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) (W.rq + __umul24(W.rq_n + rank, (uint32_t) (kRareEntryWords * 4)));      // 80-byte entries: four 16-byte stores + one of 8
-#pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = u32x4{__float_as_uint(c[4 * j]), __float_as_uint(c[4 * j + 1]), __float_as_uint(c[4 * j + 2]), __float_as_uint(c[4 * j + 3])};
-        *(lds_u32x2 *) (e + 4) = u32x2{(uint32_t) g, (uint32_t) ((uint64_t) g >> 32) | ((uint32_t) group << 8) | (paired << 31)};
-    }
+    if (hit && rank < n_take)
+        park_store(W.rq + __umul24(W.rq_n + rank, (uint32_t) (kRareEntryWords * 4)), c, paired, (uint32_t) g, (uint32_t) ((uint64_t) g >> 32) | ((uint32_t) group << 8) | (paired << 31));
     W.rq_n += n_take;
     if (n_take < n_new) { skip += n_take; return false; }
     skip = 0;
@@ -341,18 +371,8 @@ __device__ __forceinline__ bool park_both(MfWave &W, PfResume &R, const f32x16 &
     const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m0, 0u));
     const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m1, n0));
     const uint32_t hi = (uint32_t) ((uint64_t) g0 >> 32) | ((uint32_t) group << 8) | (paired << 31);     // (g0 + 32 never carries into bit 32: g0 < 2^34 is a multiple-of-64 base plus lane & 31)
-    if (hit0 && !no_stores) {
-        lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) (W.rq + __umul24(W.rq_n + rank0, (uint32_t) (kRareEntryWords * 4)));      // 80-byte entries: four 16-byte stores + one of 8
-#pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = u32x4{__float_as_uint(c0[4 * j]), __float_as_uint(c0[4 * j + 1]), __float_as_uint(c0[4 * j + 2]), __float_as_uint(c0[4 * j + 3])};
-        *(lds_u32x2 *) (e + 4) = u32x2{(uint32_t) g0, hi};
-    }
-    if (hit1 && !no_stores) {
-        lds_u32x4 *e = (lds_u32x4 *) (uintptr_t) (W.rq + __umul24(W.rq_n + rank1, (uint32_t) (kRareEntryWords * 4)));      // 80-byte entries: four 16-byte stores + one of 8
-#pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = u32x4{__float_as_uint(c1[4 * j]), __float_as_uint(c1[4 * j + 1]), __float_as_uint(c1[4 * j + 2]), __float_as_uint(c1[4 * j + 3])};
-        *(lds_u32x2 *) (e + 4) = u32x2{(uint32_t) g0 + 32u, hi};
-    }
+    if (hit0 && !no_stores) park_store(W.rq + __umul24(W.rq_n + rank0, (uint32_t) (kRareEntryWords * 4)), c0, paired, (uint32_t) g0, hi);
+    if (hit1 && !no_stores) park_store(W.rq + __umul24(W.rq_n + rank1, (uint32_t) (kRareEntryWords * 4)), c1, paired, (uint32_t) g0 + 32u, hi);
     W.rq_n += n0 + n1;
     return false;
 }
@@ -375,25 +395,37 @@ __device__ __attribute__((noinline)) void pf_flush(uint32_t em_lds, uint32_t rq_
         E.cand_static = ((unsigned long long) w5.y << 32) | w5.x;
         E.cand_block = w6.x;
     }
-    f32x16 c;
-    u32x2 hd = {0u, 0u};
-#pragma unroll
-    for (int j = 0; j < 16; j++) c[j] = 0.0f;
+    // the entry: 8 words of flag bytes (paired rows) or 4 (plain rows), then the header (park_store)
+    u32x2 q[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}}, hd = {0u, 0u};
     if (mine) {
         lds_u32x2 *e = (lds_u32x2 *) (uintptr_t) (rq_lds + lane * (uint32_t) (kRareEntryWords * 4));
-        const u32x2 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5], q6 = e[6], q7 = e[7];
-        hd = e[8];
-        c = f32x16{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q1.x), __uint_as_float(q1.y),
-                   __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q3.x), __uint_as_float(q3.y),
-                   __uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q5.x), __uint_as_float(q5.y),
-                   __uint_as_float(q6.x), __uint_as_float(q6.y), __uint_as_float(q7.x), __uint_as_float(q7.y)};
+        q[0] = e[0]; q[1] = e[1]; q[2] = e[2]; q[3] = e[3];
+        hd = e[4];
     }
     const bool paired = (hd.y >> 31) != 0u;
     const int64_t g = (int64_t) (((uint64_t) (hd.y & 0xFFu) << 32) | hd.x);
     const int32_t group = (int32_t) ((hd.y >> 8) & 0x3FFFu);
-    uint32_t fx, fy;
-    pair_flags(c, fx, fy);
-    const uint32_t fs = nonneg_flags(c);
+    // paired: word j = bits 8 ... 23 of result register j (low half) and of register j + 8 (high half): X's flag (bit 22) is bit 14 of its
+    // half, Y's (bit 10) bit 2.  fx / fy: bit n = result register 15 - n.  Two accumulators walk the bits upwards one position per word.
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t w = (j & 1) ? q[j >> 1].y : q[j >> 1].x;
+        lo = (lo + lo) | (w & 0x4004u);
+        hi = (hi + hi) | ((w >> 16) & 0x4004u);
+    }
+    // register j <= 7: X at bit 21 - j, Y at bit 9 - j of lo; register 8 + j: the same of hi
+    const uint32_t fx = ((lo >> 6) & 0xFF00u) | ((hi >> 14) & 0xFFu);
+    const uint32_t fy = ((lo << 6) & 0xFF00u) | ((hi >> 2) & 0xFFu);
+    // plain: word w = the top bytes of result registers 4 w ... 4 w + 3; bit n of the flags = register 15 - n is non-negative.  The four sign
+    // bits of a word into a nibble (register 4 w first) by one multiplication: bits 0 / 8 / 16 / 24 x (2^27 + 2^18 + 2^9 + 1) meet at bits 27 ... 24
+    uint32_t ms_ = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t t = (((w & 1) ? q[w >> 1].y : q[w >> 1].x) >> 7) & 0x01010101u;
+        ms_ = (ms_ << 4) | ((t * 0x08040201u) >> 24 & 0xFu);
+    }
+    const uint32_t fs = ~ms_ & 0xFFFFu;
     emit_rec(E, mine, g, paired ? fx : fs, group);
     emit_rec(E, mine && paired, g, fy, group + 1);
     if (lane == 0) { em2[0] = u32x2{(uint32_t) E.base, (uint32_t) (E.base >> 32)}; ((lds_u32 *) (uintptr_t) em_lds)[2] = E.left; }
@@ -763,13 +795,6 @@ struct PfOut {
     unsigned long long base;   // next free slot of this wave's block in the global candidate list
     uint32_t left;             // slots left in the block
 };
-// bit n of the result = result register 15 - n is non-negative (field n of the lane's table group)
-__device__ __forceinline__ uint32_t nonneg_flags_v(const f32x16 &c) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) m = __builtin_amdgcn_alignbit(m, (uint32_t) __float_as_int(c[j]), 31);   // (m << 1) | sign
-    return ~m & 0xFFFFu;
-}
 // one record per flagged lane into the wave's block (ranks by ballot / mbcnt; a block that cannot take them all is abandoned: its rest becomes
 // empty records, the next one comes from the counter)
 __device__ __forceinline__ void put_recs(const PfArgs &A, PfOut &O, bool flagged, uint64_t rec) {
@@ -801,7 +826,7 @@ __device__ __forceinline__ void dense_event(const PfArgs &A, PfOut &O, const f32
         put_recs(A, O, L.l1 && x1 != 0u, cand_pack((uint64_t) g0 + 32u, (uint32_t) group, x1));
         put_recs(A, O, L.l1 && y1 != 0u, cand_pack((uint64_t) g0 + 32u, (uint32_t) group + 1u, y1));
     } else {
-        const uint32_t f0 = nonneg_flags_v(c0), f1 = nonneg_flags_v(c1);
+        const uint32_t f0 = nonneg_flags(c0), f1 = nonneg_flags(c1);
         put_recs(A, O, L.l0 && f0 != 0u, cand_pack((uint64_t) g0, (uint32_t) group, f0));
         put_recs(A, O, L.l1 && f1 != 0u, cand_pack((uint64_t) g0 + 32u, (uint32_t) group, f1));
     }

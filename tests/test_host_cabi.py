@@ -599,7 +599,7 @@ def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
         assert len(mf) >= 12
         product = "ILi2ELb0" in k                                  # the kernel every JASPAR-like set runs on (the 3/4-k-block one spills in its rare paths)
         if product:
-            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 12 and num["private_segment_fixed_size"] <= 64, (k, num)
+            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 16 and num["private_segment_fixed_size"] <= 64, (k, num)
             assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("scratch_")], "spill traffic inside the pass body"
             # the blocks' `s_waitcnt lgkmcnt(1)` counts LDS operations, which finish in order; a scalar load in flight would share the counter and
             # finish out of order
