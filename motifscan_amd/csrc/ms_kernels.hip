@@ -281,9 +281,9 @@ __device__ __forceinline__ void pair_flags(const f32x16 &c, uint32_t &fx, uint32
 // A row tile holds a candidate in about one lane of its 64 windows x 32 rows, but decoding WHICH fields (one or two VALU operations
 // per result register) and queueing the record costs the wave the same whether one lane needs it or all 64: in round 3's first
 // paired kernel that was 28 % of the pre-filter (profiles/r03b_pf_pair.log), and -- inlined into every class -- the reason the
-// kernel spilled registers it reloaded once per class and pass.  So the lanes that hold a candidate only PARK their 16 result
-// registers and a two-word header (position, table group, kind) in the wave's LDS space -- four ds_write_b128 and one ds_write_b64
-// under the lanes' exec mask -- and when the space runs low the class returns to the one place that calls pf_flush, an ordinary
+// kernel spilled registers it reloaded once per class and pass.  So the lanes that hold a candidate only PARK the flag bytes of their
+// 16 result registers (park_store below; rounds 3-4: the registers themselves) and a two-word header (position, table group, kind) in
+// the wave's LDS space -- two or three stores under the lanes' exec mask -- and when the space runs low the class returns to the one place that calls pf_flush, an ordinary
 // (not inlined) function: it decodes the parked entries one per lane and queues the records.  An event with more candidate lanes
 // than free entries parks what fits; the class comes back to the same row tile after the flush (PfResume).
 
