@@ -1,6 +1,6 @@
 # Short refresh of the evidence a kernel-source change invalidates (the traffic record is stamped with the source hash): GPU suite, the
 # driver-style line, rocprofv3 kernel stats and the two HBM-traffic PMC passes.  Usage: bash tools/evidence_refresh.sh <tag>
-TAG=${1:-r05e}
+TAG=${1:-r05h}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
 T="timeout 900"
