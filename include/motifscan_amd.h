@@ -104,6 +104,9 @@ typedef struct ms_scan_stats {
 
 const char *ms_last_error(void);
 int ms_version(void);
+/* Bit 0: the library's pre-filter was built without its hand-written gfx950 asm blocks (csrc/Makefile PF_NO_ASM=1, or the build's mandatory
+ * ISA check failed and it fell back): identical results, slower.  No reference counterpart. */
+int ms_build_flags(void);
 
 /* Device selection is per calling thread (like hipSetDevice).  Handles remember their device. */
 int ms_device_count(int *count);
@@ -200,7 +203,9 @@ void ms_host_free(void *p);
 #define MS_STREAM_DEDUP       1u   /* de-duplicate every batch on the device (scanner.py:156-193) before the copy-out      */
 #define MS_STREAM_NO_HITS     2u   /* counts only: hit arrays stay on the device (control regions: stats.py:29-31); a sweep span then
                                       makes ONLY the per-motif window counts and the number of sites (no site is handed out: the hit
-                                      accessors of such a result fail with MS_ERR_INVALID)                                     */
+                                      accessors of such a result fail with MS_ERR_INVALID; ms_result_motif_offsets then gives the running
+                                      per-motif site numbers, consistent with n_hits; with MS_STREAM_DEDUP such a span is NOT de-duplicated --
+                                      de-duplication never empties a window, the counts are the same)                           */
 #define MS_STREAM_EXACT_ONLY  4u   /* MS_SCAN_EXACT_ONLY for every batch (validation)                                      */
 #define MS_STREAM_PACKED      8u   /* copy the hits out in the compact form of ms_result_hits_packed_host                  */
 typedef struct ms_stream ms_stream;

@@ -13,7 +13,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmotifscan_amd.so")
+# MS_LIB_VARIANT=noasm loads the intrinsic-only build of the pre-filter (csrc/Makefile: the safety net the build falls back to when the
+# ISA check of the hand-written blocks fails; the GPU suite runs the goldens on both).  Same C-ABI, same results.
+LIB_VARIANT = os.environ.get("MS_LIB_VARIANT", "")
+if LIB_VARIANT not in ("", "noasm"):
+    raise RuntimeError(f"MS_LIB_VARIANT={LIB_VARIANT!r}: known variants are '' (default) and 'noasm'")
+LIB_PATH = os.path.join(_HERE, "libmotifscan_amd_noasm.so" if LIB_VARIANT == "noasm" else "libmotifscan_amd.so")
 
 MS_OK, MS_ERR_INVALID, MS_ERR_NOMEM, MS_ERR_RUNTIME = 0, 1, 2, 3
 MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY = 0, 1
@@ -87,6 +92,7 @@ def lib():
     sig = {
         "ms_last_error": (ctypes.c_char_p, []),
         "ms_version": (c_int, []),
+        "ms_build_flags": (c_int, []),
         "ms_device_count": (c_int, [ctypes.POINTER(c_int)]),
         "ms_set_device": (c_int, [c_int]),
         "ms_device_name": (c_int, [ctypes.c_char_p, c_int]),
@@ -143,6 +149,10 @@ def lib():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     _lib = L
+    if (L.ms_build_flags() & 1) and LIB_VARIANT != "noasm":
+        import warnings
+        warnings.warn("libmotifscan_amd.so was built WITHOUT the hand-written pre-filter blocks (the build's ISA check failed and it fell "
+                      "back to -DMS_PF_NO_ASM, or PF_NO_ASM=1 was asked for): results are identical, the pre-filter is slower", RuntimeWarning)
     return L
 
 

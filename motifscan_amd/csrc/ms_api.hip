@@ -954,13 +954,34 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
 int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand_mask, uint32_t flags, ms_result **out, PendingScan *pend) {
     int rc;
     const bool exact_only = (flags & MS_SCAN_EXACT_ONLY) != 0;
-    const size_t lds_fixed = kF6LutBytes + kPfStageBytes + kPfEmitBytes + kPfOnehotBytes + kPfRareBytesMin;   // the B-operand table, the waves' sequence staging, their PfEmit, their one-hot arrays and (at least) kRareCapMin parking entries follow the tables
-    // TWO 512-thread blocks per CU (each with its own copy of a <= 70 KB tile) whose waves take their work one by one
-    // (profiles/r02_wave_occupancy_ab.log)
-    size_t lds_budget = c->lds_max / (size_t) kPfBlocksPerCu - lds_fixed;
-    if (const char *e = measure_env("MS_PF_LDS_BUDGET")) lds_budget = std::min(lds_budget, (size_t) std::max(1, atoi(e)));   // test aid: several LDS tiles, as a very large motif set would have
+    // the B-operand table, the waves' sequence staging, their PfEmit and (at least) kRareCapMin parking entries follow the tables -- and the
+    // waves' one-hot arrays (40 KB) in the double-pass kernels ONLY: a plan with a wide tile (a motif of 32 ... 63 columns on the pre-filter)
+    // runs the single-pass kernels, which never touch that array, and keeps the room for its tables
+    const size_t lds_fixed_wide = kF6LutBytes + kPfStageBytes + kPfEmitBytes + kPfRareBytesMin;
+    const size_t lds_fixed_narrow = lds_fixed_wide + kPfOnehotBytes;
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
-    if ((rc = pwmset_plan(pwms, strand_mask, lds_budget, exact_only, true, c->device))) return rc;
+    auto plan_is_wide = [&]() { for (const TileDesc &t : pwms->plan.tiles) if (t.max_nk > 2) return true; return false; };
+    bool wide_layout = false;
+    {
+        auto budget_of = [&](size_t fixed) {
+            size_t b = c->lds_max / (size_t) kPfBlocksPerCu - fixed;
+            if (const char *e = measure_env("MS_PF_LDS_BUDGET")) b = std::min(b, (size_t) std::max(1, atoi(e)));   // test aid: several LDS tiles, as a very large motif set would have
+            return b;
+        };
+        // only a motif of 32 ... kMaxFastWidth columns can make a wide tile; whether one does (it may fall to the all-fp64 path) the plan says.
+        // The outcome is remembered per (strand, cutoffs, exact-only): a set whose wide motifs all left the pre-filter plans once, not twice per scan
+        bool may_be_wide = false;
+        for (int32_t w : pwms->widths) may_be_wide = may_be_wide || (w >= 2 * kF6Cols && w <= kMaxFastWidth);
+        const bool known_narrow = pwms->narrow_strand == strand_mask && pwms->narrow_cutoff_version == pwms->cutoff_version && pwms->narrow_exact_only == exact_only;
+        if (may_be_wide && !exact_only && !known_narrow) {
+            if ((rc = pwmset_plan(pwms, strand_mask, budget_of(lds_fixed_wide), exact_only, false, c->device))) return rc;
+            wide_layout = plan_is_wide();
+            if (!wide_layout) { pwms->narrow_strand = strand_mask; pwms->narrow_cutoff_version = pwms->cutoff_version; pwms->narrow_exact_only = exact_only; }
+        }
+        if ((rc = pwmset_plan(pwms, strand_mask, budget_of(wide_layout ? lds_fixed_wide : lds_fixed_narrow), exact_only, true, c->device))) return rc;
+        if (wide_layout != plan_is_wide()) { set_error("internal: the pre-filter plan changed its kernel family between two builds"); return MS_ERR_RUNTIME; }
+    }
+    const size_t lds_fixed = wide_layout ? lds_fixed_wide : lds_fixed_narrow;
     const PrefilterPlan &plan = pwms->plan;
 
     std::unique_ptr<ms_result> res(new (std::nothrow) ms_result());
@@ -1136,7 +1157,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             A.tables = pwms->d_tables; A.tiles = pwms->d_tiles; A.lut_off16 = lut_off16; A.stage_off16 = lut_off16 + (uint32_t) (kF6LutBytes / 16);
             A.emit_off16 = A.stage_off16 + (uint32_t) (kPfStageBytes / 16);
             A.onehot_off16 = A.emit_off16 + (uint32_t) (kPfEmitBytes / 16);
-            A.rare_off16 = A.onehot_off16 + (uint32_t) (kPfOnehotBytes / 16);
+            A.rare_off16 = A.onehot_off16 + (uint32_t) ((wide_layout ? 0 : kPfOnehotBytes) / 16);      // (a wide plan's kernels have no one-hot array)
             A.rare_cap = rare_cap;
             A.cand = sc.cand; A.n_cand = sc.counters; A.cand_cap = sc.cand_cap; A.cand_block = cand_block;
             const size_t counter_words = (size_t) n_tiles * kPfCounters * 16;            // kPfCounters words per tile, 64 bytes apart
@@ -1761,7 +1782,10 @@ int sweep_handout_locked(DeviceCtx *c, ms_pwmset *pwms, ms_result *r1, int64_t s
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { set_error("sweep count failed: %s", hipGetErrorString(he)); return fail2(MS_ERR_RUNTIME); }
         unsigned long long n_sites = 0;
-        for (unsigned long long v : per_motif) n_sites += v;
+        for (size_t p = 0; p < per_motif.size(); p++) {      // the offsets a caller slices by: consistent with n_hits although no site array exists
+            n_sites += per_motif[p];
+            raw->motif_offsets[p + 1] = (int64_t) n_sites;
+        }
         total = n_sites;
         raw->n_hits = (int64_t) total;
         float ms01 = 0;

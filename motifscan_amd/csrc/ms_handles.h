@@ -150,6 +150,10 @@ struct ms_pwmset {
     bool plan_exact_only = false;
     bool plan_pair = true;                        // paired rows in the plan (always, but for MS_MEASURE=1 MS_PF_PAIR=0)
     int plan_device = -1;
+    // (strand, cutoffs, exact-only) for which a set WITH motifs of >= 32 columns is known to plan without a wide tile (scan_locked)
+    int narrow_strand = -1;
+    uint64_t narrow_cutoff_version = 0;
+    bool narrow_exact_only = false;
     uint4 *d_tables = nullptr;
     ms::TileDesc *d_tiles = nullptr;
     int32_t *d_group_fields = nullptr;            // [table groups][kGroupFields] motif of the field, -1 = empty

@@ -502,6 +502,44 @@ __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, i
 // (`areg`, tied to v[112:123]), not a clobber: the compiler must keep them free between the blocks while the reads are in flight, and
 // nothing but these blocks may touch them -- a_reads_begin starts the first row tile's reads, a_reads_drain waits for the last (unused)
 // ones before the class returns and the registers go back to the compiler.  tests/test_host_cabi.py checks the built code for both.
+// ---- the safety net: `make PF_NO_ASM=1` (-DMS_PF_NO_ASM) builds the pre-filter WITHOUT the hand-written blocks ----
+// The blocks above and below pin v[112:123] across compiler-made code and issue the hand-out's atomic behind the compiler's back; what
+// guards them is csrc/check_isa.py, a mandatory step of the build that reads the code object back.  Should a compiler update trip it, the
+// Makefile falls back -- loudly -- to this form: row tiles of two blocks go through the same builtins the one-block tiles use (the A operand
+// read per half with three ds_read_b128 by the compiler, its own waits, its own register allocation) and the hand-out uses the compiler's
+// atomicAdd.  Same tables, same results bit for bit (tests/test_gpu_parity.py runs the goldens and configs[1] on both builds); slower
+// (DESIGN.md section 7 has the number).  ms_build_flags() bit 0 tells which one a library holds.
+#ifdef MS_PF_NO_ASM
+constexpr bool kPfAsm = false;
+#else
+constexpr bool kPfAsm = true;
+#endif
+extern "C" int ms_build_flags(void) { return kPfAsm ? 0 : 1; }
+
+// a two-block row tile's operands (lane-major, 48 bytes per lane: ms_internal.h) through ordinary LDS reads
+__device__ __forceinline__ void load_a2(uint32_t pa, i32x8 &a0, i32x8 &a1) {
+    const lds_i32x4 *q = (const lds_i32x4 *) (uintptr_t) pa;
+    const i32x4 w0 = q[0], w1 = q[1], w2 = q[2];
+    a0 = i32x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], 0, 0};
+    a1 = i32x8{w1[2], w1[3], w2[0], w2[1], w2[2], w2[3], 0, 0};
+}
+__device__ __forceinline__ i32x8 b_of(const i32x4 &b) { return i32x8{b[0], b[1], b[2], b[3], 0, 0, 0, 0}; }
+__device__ __forceinline__ void pair_product2_intr(const i32x8 &a0, const i32x8 &a1, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11,
+                                                   int scale0, int scale1, const f32x16 &cc0, const f32x16 &cc1, f32x16 &c0, f32x16 &c1) {
+    c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b_of(b00), cc0, 2, 4, 0, scale0, 0, 127);
+    c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b_of(b10), cc1, 2, 4, 0, scale1, 0, 127);
+    c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b_of(b01), c0, 2, 4, 0, scale0, 0, 127);
+    c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b_of(b11), c1, 2, 4, 0, scale1, 0, 127);
+}
+__device__ __forceinline__ void plain_product2_intr(const i32x8 &a0, const i32x8 &a1, const i32x4 &b00, const i32x4 &b10, const i32x4 &b01, const i32x4 &b11,
+                                                    f32x16 &c0, f32x16 &c1) {
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b_of(b00), z, 2, 4, 0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b_of(b10), z, 2, 4, 0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b_of(b01), c0, 2, 4, 0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b_of(b11), c1, 2, 4, 0, 0, 0, 0);
+}
+
 typedef int i32x12 __attribute__((ext_vector_type(12)));
 __device__ __forceinline__ void a_reads_begin(uint32_t pa, i32x12 &areg) {
     asm volatile("ds_read_b128 v[112:115], %[pa]\n\t"
@@ -687,7 +725,8 @@ __device__ __forceinline__ void f6_class(const PfArgs &A, MfWave &W, const char 
     }
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        if constexpr (NK == 2) plain_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], c0, c1);
+        if constexpr (NK == 2 && kPfAsm) plain_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], c0, c1);
+        else if constexpr (NK == 2) { i32x8 a0, a1; load_a2(pa, a0, a1); plain_product2_intr(a0, a1, bq[0], bq[1], bq[2], bq[3], c0, c1); }
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }      // measurement: operand reads + products, no inspection
         const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
@@ -768,7 +807,8 @@ __device__ __forceinline__ void f6_pair_class(const PfArgs &A, MfWave &W, const 
     }
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        if constexpr (NK == 2) pair_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
+        if constexpr (NK == 2 && kPfAsm) pair_product2_asm(pa, bq[0], bq[1], bq[2], bq[3], scale0, scale1, c0, c1);
+        else if constexpr (NK == 2) { i32x8 a0, a1; load_a2(pa, a0, a1); pair_product2_intr(a0, a1, bq[0], bq[1], bq[2], bq[3], scale0, scale1, cc0, cc1, c0, c1); }
         else product(p, c0, c1);
         if constexpr (MEAS) { if (A.no_emit == 3) { asm volatile("" : : "v"(c0), "v"(c1)); continue; } }
         const uint32_t x0 = or16(c0), x1 = or16(c1);
@@ -878,13 +918,14 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut
     int back = n_row_tiles;
     [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;
     [[maybe_unused]] i32x12 areg;
-    if constexpr (NK == 2) a_reads_begin(pa, areg);
+    if constexpr (NK == 2 && kPfAsm) a_reads_begin(pa, areg);
     const bool skip_events = MEAS && A.no_emit >= 1 && A.no_emit <= 3;
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        [[maybe_unused]] i32x8 a;
+        [[maybe_unused]] i32x8 a, a1;
         bool stop = false, low = false;
-        if constexpr (NK == 2) pair_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, c0, c1);
+        if constexpr (NK == 2 && kPfAsm) pair_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, c0, c1);
+        else if constexpr (NK == 2) { load_a2(pa, a, a1); pair_product2_intr(a, a1, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, cc0, cc1, c0, c1); }
         else {
             const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
             a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
@@ -900,7 +941,8 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut
             }
         }
         if (!stop) {
-            if constexpr (NK == 2) pair_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], scale0, scale1, c0, c1);
+            if constexpr (NK == 2 && kPfAsm) pair_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], scale0, scale1, c0, c1);
+            else if constexpr (NK == 2) pair_product2_intr(a, a1, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], scale0, scale1, cc0, cc1, c0, c1);
             else {
                 c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][0][0][0], b[1][0][0][1], b[1][0][0][2], b[1][0][0][3], 0, 0, 0, 0}, cc0, 2, 4, 0, scale0, 0, 127);
                 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][1][0][0], b[1][1][0][1], b[1][1][0][2], b[1][1][0][3], 0, 0, 0, 0}, cc1, 2, 4, 0, scale1, 0, 127);
@@ -920,7 +962,7 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut
         }
         if (stop) t = n_run;
     }
-    if constexpr (NK == 2) a_reads_drain(areg);
+    if constexpr (NK == 2 && kPfAsm) a_reads_drain(areg);
     R.t = back;
 }
 
@@ -953,13 +995,14 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, 
     int back = n_row_tiles;
     [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;
     [[maybe_unused]] i32x12 areg;
-    if constexpr (NK == 2) a_reads_begin(pa, areg);
+    if constexpr (NK == 2 && kPfAsm) a_reads_begin(pa, areg);
     const bool skip_events = MEAS && A.no_emit >= 1 && A.no_emit <= 3;
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
-        [[maybe_unused]] i32x8 a;
+        [[maybe_unused]] i32x8 a, a1;
         bool stop = false, low = false;
-        if constexpr (NK == 2) plain_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1);
+        if constexpr (NK == 2 && kPfAsm) plain_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1);
+        else if constexpr (NK == 2) { load_a2(pa, a, a1); plain_product2_intr(a, a1, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1); }
         else {
             const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
             a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
@@ -975,7 +1018,8 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, 
             }
         }
         if (!stop) {
-            if constexpr (NK == 2) plain_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], c0, c1);
+            if constexpr (NK == 2 && kPfAsm) plain_product2b_asm<kStep>(pa, areg, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], c0, c1);
+            else if constexpr (NK == 2) plain_product2_intr(a, a1, b[1][0][0], b[1][1][0], b[1][0][1], b[1][1][1], c0, c1);
             else {
                 c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][0][0][0], b[1][0][0][1], b[1][0][0][2], b[1][0][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][1][0][0], b[1][1][0][1], b[1][1][0][2], b[1][1][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
@@ -995,7 +1039,7 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, 
         }
         if (stop) t = n_run;
     }
-    if constexpr (NK == 2) a_reads_drain(areg);
+    if constexpr (NK == 2 && kPfAsm) a_reads_drain(areg);
     R.t = back;
 }
 
@@ -1253,15 +1297,15 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                 // tests/test_host_cabi.py::test_prefilter_isa_resources_and_the_atomic_register.  The host never launches wave_passes == 1 with
                 // the counters on (scan_locked refuses it); if it ever did, the compiler's own atomicAdd (waited for at once) takes over.
                 if (j == 0 && dyn && lane == 0) {
-                    if (wave_passes >= 2) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(u) : "v"(word), "v"(1u) : "memory");
-                    else u = atomicAdd(word, 1u);
+                    if (kPfAsm && wave_passes >= 2) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(u) : "v"(word), "v"(1u) : "memory");
+                    else u = atomicAdd(word, 1u);                                  // (also the whole of the PF_NO_ASM build: waited for at once)
                 }
                 // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
                 // flight while this pass is scanned
                 if (j + 1 < wave_passes) words = fetch(p0 + j + 1);
                 else {
                     if (dyn) {
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(u) : : "memory");     // (the compiler does not know the atomic is in flight)
+                        if constexpr (kPfAsm) asm volatile("s_waitcnt vmcnt(0)" : "+v"(u) : : "memory");     // (the compiler does not know the atomic is in flight)
                         next = waves_g + (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
                     }
                     if (next < units_g) words = fetch((next * K + g) * wave_passes);

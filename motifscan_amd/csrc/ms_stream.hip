@@ -98,7 +98,8 @@ struct ms_stream {
                 rc = sweep_handout_locked(c, pwms, r1, j->seqs->n_bases, j->window, j->stride, j->n_windows, &j->res, (flags & MS_STREAM_NO_HITS) != 0);
             }
         }
-        if (!rc && !pending && (flags & MS_STREAM_DEDUP)) rc = ms_result_dedup(j->res, pwms);
+        // (a counts-only span holds no site arrays to de-duplicate, and de-duplication never empties a window: its counts stand as they are)
+        if (!rc && !pending && (flags & MS_STREAM_DEDUP) && !(j->res && j->res->counts_only)) rc = ms_result_dedup(j->res, pwms);
         if (rc) fail_job(j, rc);
         if (!pending && j->seqs) { ms_seqset_free(j->seqs); j->seqs = nullptr; }
         return pending;

@@ -7,6 +7,7 @@ de-duplication equals the reference's.  No compute entry point is called (no GPU
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -553,106 +554,49 @@ def test_bench_refuses_more_ranks_than_gpus_before_spawning():
     assert out.returncode != 0 and "nothing was started" in out.stderr and not out.stdout.strip()
 
 
-def test_prefilter_isa_resources_and_the_atomic_register(tmp_path):
-    """Build-time checks on the gfx950 code object of the pre-filter: what the hand-written
-    asm blocks of ms_kernels.hip rest on, read from the disassembly of the object the library was linked from.
-      * <= 128 vector registers (four waves per SIMD), no scalar spills, and no scratch traffic between the first and the last
-        matrix instruction (the compiler's spilled registers live in the unit hand-out around the passes);
-      * the work hand-out's `global_atomic_add vN ... sc0` (issued without a wait): vN is named by no instruction of the pass body
-        (first to last matrix instruction) and by nothing in pf_flush, the one real call inside it -- the value arrives while pass 0
-        runs and is first read after pass 1's staging wait;
-      * every hand-written two-block product ends in `s_nop 11` (12 wait states before a vector read of its result);
-      * round 5, the double pass: v[112:123] hold a row tile's operand while its reads are IN FLIGHT across compiler-made code, so in
-        the kernels without wide classes NOTHING but the blocks' own ds_read_b128 / matrix instructions may name them (a compiler
-        copy of the tied operand would read registers whose data has not landed), and every run of reads into them is preceded,
-        in the same loop, by the drain or a product block that waited (checked as: the blocks exist in both shapes)."""
-    import re, shutil, subprocess
-    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+def _check_isa():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "motifscan_amd", "csrc", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_prefilter_isa_resources_and_the_atomic_register():
+    """The build-time checks on the gfx950 code object of the pre-filter -- what the hand-written asm
+    blocks of ms_kernels.hip rest on -- are a MANDATORY step of the build since round 6 (csrc/check_isa.py, run by the Makefile right after
+    ms_kernels.o is compiled: an object that fails is never linked; the rules are listed in that file's docstring).  This test re-runs the
+    same check on the objects the two shipped libraries were linked from, and pins the build's behaviour: which variant the default
+    library is, and that the checker does refuse an object of the other kind."""
+    ci = _check_isa()
     obj = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels.o")
-    if not (os.path.exists(objdump) and os.path.exists(obj)):
-        pytest.skip("no ROCm llvm tools / object file here (the build container has both)")
-    shutil.copy(obj, tmp_path / "k.o")
-    subprocess.run([objdump, "--offloading", "k.o"], cwd=tmp_path, check=True, capture_output=True)
-    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
-    assert len(co) == 1
-    asm = subprocess.run([objdump, "-d", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
-    notes = subprocess.run([readelf, "--notes", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
-    funcs, name = {}, None
-    for line in asm.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
-        if m:
-            name = m.group(1)
-            funcs[name] = []
-        elif name and line.startswith("\t"):
-            funcs[name].append(line.split("//")[0].strip())
-    flush = [k for k in funcs if "pf_flush" in k]
-    assert len(flush) == 1
-    kernels = [k for k in funcs if "prefilter_f6_kernel" in k]
-    assert len(kernels) == 5                                          # <2|4 k-blocks> x <product | measurement> + the dense-candidate product kernel
-    for k in kernels:
-        meta = notes[notes.index(".name:           " + k + "\n"):]
-        meta = meta[:meta.index(".wavefront_size")]
-        num = {f: int(re.search(rf"\.{f}:\s+(\d+)", meta).group(1)) for f in ("vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size")}
-        assert num["vgpr_count"] <= 128, (k, num)
-        body = funcs[k]
-        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
-        assert len(mf) >= 12
-        product = "ILi2ELb0" in k                                  # the kernel every JASPAR-like set runs on (the 3/4-k-block one spills in its rare paths)
-        if product:
-            assert num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 16 and num["private_segment_fixed_size"] <= 64, (k, num)
-            assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("scratch_")], "spill traffic inside the pass body"
-            # the blocks' `s_waitcnt lgkmcnt(1)` counts LDS operations, which finish in order; a scalar load in flight would share the counter and
-            # finish out of order
-            assert not [l for l in body[mf[0]:mf[-1] + 1] if l.startswith("s_load") or l.startswith("s_buffer_load")], "scalar loads inside the pass body"
-        if "ILi2E" in k:                                            # the double-pass kernels: the operand registers are the blocks' alone
-            areg = re.compile(r"\bv(11[2-9]|12[0-3])\b|\bv\[(\d+):(\d+)\]")
+    obj_na = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels_noasm.o")
+    assert os.path.exists(obj) and os.path.exists(obj_na), "the build leaves both objects in csrc/ (they travel to the GPU box with the libraries)"
+    if not ci.tools_present():
+        pytest.skip("no ROCm llvm tools here: the build itself would have refused to link (check_isa.main)")
+    default_is_noasm = bool(_lib.lib().ms_build_flags() & 1) and _lib.LIB_VARIANT != "noasm"
+    print(ci.check(obj, no_asm=default_is_noasm))
+    print(ci.check(obj_na, no_asm=True))
+    assert not default_is_noasm, "the default library fell back to the intrinsic-only pre-filter: the ISA check of the asm form failed in this build"
+    with pytest.raises(ci.IsaCheckError):                                  # the rules bite: the intrinsic-only object has none of the blocks
+        ci.check(obj_na, no_asm=False)
 
-            def touches(line):
-                for m in areg.finditer(line):
-                    if m.group(1) is not None or (int(m.group(2)) <= 123 and int(m.group(3)) >= 112):
-                        return True
-                return False
-            bad = [l for l in body if touches(l) and not (l.startswith("ds_read_b128 v[11") or l.startswith("ds_read_b128 v[12") or l.startswith("v_mfma"))]
-            assert not bad, (k, bad[:4])
-        # the hand-out's atomic: the one that is NOT waited for at once
-        cand = [i for i, l in enumerate(body) if l.startswith("global_atomic_add") and "sc0" in l
-                and not any(x.startswith("s_waitcnt vmcnt(0)") for x in body[i + 1:i + 4])]
-        # (one, or two when the compiler's own atomicAdd of the single-pass arm -- same destination register, waited for by the compiler before
-        # its first use -- sits more than three instructions from that wait)
-        regs = {re.match(r"global_atomic_add (v\d+),", body[i]).group(1) for i in cand}
-        assert 1 <= len(cand) <= 2 and len(regs) == 1, (k, cand, regs)
-        reg = regs.pop()
-        named = re.compile(rf"\b{reg}\b|\bv\[(\d+):(\d+)\]")
 
-        def names(line):
-            for m in named.finditer(line):
-                if m.group(1) is None or int(m.group(1)) <= int(reg[1:]) <= int(m.group(2)):
-                    return True
-            return False
-        assert cand[0] < mf[0], "the atomic is issued before the pass body"
-        if product:
-            assert not [l for l in body[mf[0]:mf[-1] + 1] if names(l)], f"{reg} is touched while the atomic may be in flight"
-            assert not [l for l in funcs[flush[0]] if names(l)], f"pf_flush touches {reg}"
-        # the two-block products by name: four matrix instructions on v[112:117] / v[118:123] and `s_nop 11` at the block's end -- with the three
-        # 16-byte reads in front (single pass, wide kernels), or none (block a of a double pass), or the NEXT row tile's behind them (block b)
-        n_blocks = 0
-        for i, l in enumerate(body):
-            if "ILi2E" not in k:                                    # single pass: reads, four matrix instructions, s_nop 11 (the compiler uses the registers elsewhere too)
-                if l.startswith("ds_read_b128 v[112:115]"):
-                    blk = [x for x in body[i:i + 12] if not x.startswith("s_waitcnt")]
-                    assert sum(x.startswith("v_mfma") for x in blk[3:7]) == 4 and blk[7] == "s_nop 11", blk
-                    n_blocks += 2
-                continue
-            if l.startswith("v_mfma") and "v[112:117]" in l and not (body[i - 1].startswith("v_mfma") and "v[112:117]" in body[i - 1]):
-                blk = [x for x in body[i:i + 10] if not x.startswith("s_waitcnt")]
-                assert sum(x.startswith("v_mfma") for x in blk[:4]) == 4 and "v[118:123]" in blk[2] and "v[118:123]" in blk[3], blk
-                tail = blk[4:]
-                if tail[0].startswith("ds_read_b128 v[112:115]"):
-                    assert tail[1].startswith("ds_read_b128 v[116:119]") and tail[2].startswith("ds_read_b128 v[120:123]") and tail[3] == "s_nop 11", blk
-                else:
-                    assert tail[0] == "s_nop 11", blk
-                n_blocks += 1
-        assert n_blocks >= 4, (k, n_blocks)
+def test_both_library_variants_export_the_same_cabi():
+    """libmotifscan_amd_noasm.so (the safety net, csrc/Makefile) is the same library but for the pre-filter's object."""
+    import subprocess
+    import shutil
+    nm = shutil.which("nm")
+    if not nm:
+        pytest.skip("no nm")
+    sets = []
+    for name in ("libmotifscan_amd.so", "libmotifscan_amd_noasm.so"):
+        out = subprocess.run([nm, "-D", "--defined-only", os.path.join(ROOT, "motifscan_amd", name)], capture_output=True, text=True, check=True).stdout
+        sets.append({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("ms_")})
+    assert sets[0] == sets[1] and "ms_build_flags" in sets[0]
+    out = subprocess.run([sys.executable, "-c", "from motifscan_amd import _lib; print(_lib.lib().ms_build_flags(), _lib.LIB_PATH)"],
+                         env=dict(os.environ, MS_LIB_VARIANT="noasm", PYTHONPATH=ROOT), capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == "1" and out[1].endswith("libmotifscan_amd_noasm.so")
 
 
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
