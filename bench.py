@@ -607,7 +607,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     def pipelined(packed):
         def run():
             n = 0
-            st = stages.setdefault("pipelined" if packed else "pipelined_25B", {})
+            st = stages.setdefault({12: "pipelined", 16: "pipelined_16B"}.get(packed, "pipelined_25B"), {})
             dev_ms = {"prefilter": 0.0, "fp64_stage": 0.0, "sort": 0.0, "finalize": 0.0, "scan_total": 0.0, "clock_mhz_sum": 0.0}
             for res in _lib.scan_stream(pw, iter(batches), strand_mask, 0, depth=2, packed=packed, stage_stats=st):
                 n += res.n_hits                         # the arrays are already in pinned host memory at this point
@@ -639,7 +639,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
 
         def run():
             n = 0
-            for res in _lib.scan_stream(pw, iter(bl), strand_mask, 0, depth=2, packed=True):
+            for res in _lib.scan_stream(pw, iter(bl), strand_mask, 0, depth=2, packed=12):
                 n += res.n_hits
                 res.close()
             return n
@@ -652,7 +652,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     def pipelined_cli():
         n = 0
         st = stages.setdefault("pipelined_cli", {})
-        for res, (_, _, counts_only) in zip(_lib.scan_stream(pw, iter(cli_batches), strand_mask, 0, depth=2, packed=True, stage_stats=st), cli_batches):
+        for res, (_, _, counts_only) in zip(_lib.scan_stream(pw, iter(cli_batches), strand_mask, 0, depth=2, packed=12, stage_stats=st), cli_batches):
             if not counts_only:
                 n += res.n_hits                         # in pinned host memory
             res.region_counts()
@@ -670,8 +670,9 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
         return n
 
     passes = max(1, min(a.steps, 4))
-    v_p16, ms_p16, hits = timed(pipelined(True), passes)
+    v_p12, ms_p12, hits = timed(pipelined(12), passes)
     v_cli, ms_cli, hits_cli = timed(pipelined_cli, passes)
+    v_p16, ms_p16, hits16 = timed(pipelined(16), passes)
     v_p25, ms_p25, _ = timed(pipelined(False), passes)
     v_s, ms_s, _ = timed(serial, passes)
     reps = 4
@@ -679,16 +680,17 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     v_su, ms_su = v_su * reps, ms_su / reps                     # timed() counts one call as one pass; the call holds `reps` of them
     for pin in pins:
         pin.close()
-    return {"pipelined": v_p16, "pipelined_cli": v_cli, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
-            "ms_per_pass": {"pipelined": ms_p16, "pipelined_cli": ms_cli, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
+    return {"pipelined": v_p12, "pipelined_cli": v_cli, "pipelined_16B": v_p16, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
+            "ms_per_pass": {"pipelined": ms_p12, "pipelined_cli": ms_cli, "pipelined_16B": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
+            "hits_check_12B_vs_16B": bool(hits == hits16), "bytes_per_hit_on_the_link": {"pipelined": 12, "pipelined_cli": 12, "pipelined_16B": 16, "pipelined_25B": 25},
             "hits_out_per_pass_cli": int(hits_cli),
             "sustained_passes_per_stream": reps, "sustained_hits_check": bool(hits_su == hits * reps),
             "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "max_batch_regions": a.max_batch_regions, "batch_sizes": [int(len(o) - 1) for _, o in batches], "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
             "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
             "cu_partition": "off: the copy / pack kernels share the device with the scan (CU masks -- 1 CU of every 32 for the copy streams -- exist behind MS_MEASURE=1 MS_CU_PARTITION=1 and measured slower end to end, profiles/r02_cu_partition_ab.log)",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "
-                          "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 16 bytes per hit "
-                          "(coord word + fp64 score), 'pipelined_cli' is the reference CLI's own job (cli/scan.py:81-89: the input set's sites out, the control "
+                          "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 12 bytes per hit "
+                          "(32-bit coord word region << shift | pos << 1 | strand + fp64 score: MS_STREAM_PACKED12, every batch of this workload fits it; 'pipelined_16B' = round 5's 64-bit coord word), 'pipelined_cli' is the reference CLI's own job (cli/scan.py:81-89: the input set's sites out, the control "
                           "set counted only -- stats.py:29-31 is all that reads it), 'pipelined_25B' the four plain arrays, 'serial' runs the stages of one batch after another; "
                           "'pipelined' opens and drains a stream for every pass (one pass = the job), 'pipelined_sustained' keeps ONE stream full over "
                           "several consecutive passes and divides by their number (a sweep over many region sets: the per-pass rate once the first "

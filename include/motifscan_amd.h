@@ -23,6 +23,9 @@
  *   ms_seqset_from_device same, for ASCII that is already resident in device memory
  *   ms_genome_create /    Scanner._extract_seq -> Genome.fetch_sequence (pysam)   scanner.py:71-87,
  *   ms_seqset_from_genome   genome/__init__.py:117-135: packed genome resident in HBM, regions cut on device
+ *   ms_genome_create_packed / ms_genome_packed_host / ms_pack_bases_host
+ *                         Genome.__init__ -> pysam.FastaFile (genome/__init__.py:61-83): the FASTA is packed ONCE into a genome
+ *                         file (motifscan_amd/genome.py) whose planes are uploaded as they are
  *   ms_scan_sweep         the same extraction + scan for the windows of a fixed-stride sweep of one chromosome
  *                         (BASELINE configs[4]); every base is scored once instead of window / stride times
  *   ms_scan_regions_once  the same extraction + scan for region lists that overlap (peaks +- window/2, random controls:
@@ -134,6 +137,10 @@ void ms_pwmset_free(ms_pwmset *pwms);
  * re-run the extraction/packing kernel (bench.py times it inside the step). */
 int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, int keep_ascii,
                      ms_seqset **out);
+/* The same set with convert_seq done by n_threads HOST threads: the 2-bit codes, the non-ACGT mask and the region hints are made in pinned
+ * staging memory and copied over -- no kernel runs, so building the set never waits for CUs a running scan holds (what the batch stream's
+ * upload stage does under MS_STREAM_HOST_PACK).  bases is borrowed for the duration of the call. */
+int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, ms_seqset **out);
 /* d_bases: device pointer to the concatenated ASCII (borrowed for the call); offsets on host. */
 int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n_seqs,
                           ms_seqset **out);
@@ -147,6 +154,17 @@ void ms_seqset_free(ms_seqset *seqs);
  * non-ACGT plane), and a region list (chromosome index, 0-based half-open [start, end) already
  * clipped to the chromosome as scanner.py:81-83 does) is cut into a sequence set on the device. */
 int ms_genome_create(const char *bases, const int64_t *chrom_offsets, int32_t n_chroms, ms_genome **out);
+/* The genome from its packed form -- the two planes of the HBM layout: codes[2 * ceil(n / 32)] (2 bits per base, base i of a 32-base unit at
+ * bits [2i, 2i + 2) of the unit's two words; a/A 0, c/C 1, g/G 2, t/T 3, anything else 0) and nmask[ceil(n / 32)] (bit i: base i is none of
+ * those), the chromosomes back to back.  "Pack the FASTA once" (SURVEY.md N3): a genome file made by motifscan_amd/genome.py is uploaded as it
+ * is, 0.375 B per base, with no ASCII and no pack kernel -- what replaces Genome.__init__ / pysam.FastaFile (genome/__init__.py:61-83) on the
+ * measured path.  The planes are validated (MS_ERR_INVALID for a non-ACGT base with a non-zero code, or bits past the last base). */
+int ms_genome_create_packed(const uint32_t *codes, const uint32_t *nmask, const int64_t *chrom_offsets, int32_t n_chroms, ms_genome **out);
+/* The two planes of a resident genome copied back to host buffers of those sizes (to write the genome file). */
+int ms_genome_packed_host(const ms_genome *genome, uint32_t *codes, uint32_t *nmask);
+/* convert_seq (cscore.c:81-114) into the same two planes on n_threads HOST threads -- no device is touched: the genome-file builder.
+ * (Marshalling only: there is still no CPU scan path.) */
+int ms_pack_bases_host(const char *bases, int64_t n_bases, int n_threads, uint32_t *codes, uint32_t *nmask);
 int ms_genome_size(const ms_genome *genome, int32_t *n_chroms, int64_t *n_bases);
 void ms_genome_free(ms_genome *genome);
 int ms_seqset_from_genome(const ms_genome *genome, const int32_t *chrom, const int64_t *start,
@@ -193,6 +211,12 @@ void ms_result_free(ms_result *res);
  * score[i] -- 16 bytes per hit on the host link instead of 25.  Needs seq_idx < 2^32 and pos < 2^31 (MS_ERR_INVALID
  * otherwise).  Valid until the result is freed or de-duplicated. */
 int ms_result_hits_packed_host(ms_result *res, const uint64_t **coord, const double **score);
+/* ... and in 12 bytes per hit: coord32[i] = seq_idx << *shift | pos << 1 | (strand - 1), score[i] -- for results whose region indices and
+ * positions fit 31 bits together (a batch of 250 000 regions of 500 bp: 18 + 9), i.e. every batch of a batch stream; MS_ERR_INVALID (and the
+ * 16-byte form stays available) when they do not.  Same list building (cscore.c:443-471), a quarter less on the host link. */
+int ms_result_hits_packed12_host(ms_result *res, const uint32_t **coord, const double **score, int32_t *shift);
+/* Which compact form a result holds after a batch stream's copy-out: *bytes_per_hit = 12, 16, or 0 (the plain arrays). */
+int ms_result_packed_form(const ms_result *res, int32_t *bytes_per_hit);
 
 /* ---- pinned host memory -------------------------------------------------------------------- */
 /* Page-locked host memory for sequence input: uploads from it run at the full link rate and overlap with scans. */
@@ -208,6 +232,9 @@ void ms_host_free(void *p);
                                       de-duplication never empties a window, the counts are the same)                           */
 #define MS_STREAM_EXACT_ONLY  4u   /* MS_SCAN_EXACT_ONLY for every batch (validation)                                      */
 #define MS_STREAM_PACKED      8u   /* copy the hits out in the compact form of ms_result_hits_packed_host                  */
+#define MS_STREAM_PACKED12   32u   /* ... in the 12-byte form of ms_result_hits_packed12_host for every batch that fits it, the 16-byte form for
+                                      the others (ms_result_packed_form tells which)                                        */
+#define MS_STREAM_HOST_PACK  16u   /* the upload stage packs on host threads (ms_seqset_create_hostpacked): no kernel beside the scan */
 typedef struct ms_stream ms_stream;
 /* depth: batches that may wait between two stages (>= 1; 2 overlaps all three stages).  The stream is bound to the
  * calling thread's device (ms_set_device).  The PWM set must outlive the stream. */

@@ -30,6 +30,10 @@ int ms_debug_plan_dims(const ms_pwmset *pwms, int strand_mask, int64_t lds_budge
 int ms_debug_plan_rows(const ms_pwmset *pwms, int32_t *group_fields, int16_t *rows, int32_t *bias, int32_t *group_kb,
                        int32_t *exact_motifs, int32_t *tile_first_group);
 
+/* The host packer of ms_seqset_create_hostpacked alone (no device): codes [2 x ceil(n / 32)], nmask [ceil(n / 32)], blk2reg [(n + 63) / 64 + 1],
+ * blkinfo [4 x that], n = offsets[n_seqs] -- the layout pack_kernel / blk2reg_kernel write on the device. */
+int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo);
+
 /* Free the current device's grow-only work buffers (candidate list, hit list, sort space), so a
  * test can force the "buffer too small -> grow -> run the pass again" path.  Needs a GPU. */
 int ms_debug_release_scratch(void);

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libmotifscan_amd_noasm.so" if LIB_VARIANT == "no
 
 MS_OK, MS_ERR_INVALID, MS_ERR_NOMEM, MS_ERR_RUNTIME = 0, 1, 2, 3
 MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY = 0, 1
-MS_STREAM_DEDUP, MS_STREAM_NO_HITS, MS_STREAM_EXACT_ONLY, MS_STREAM_PACKED = 1, 2, 4, 8
+MS_STREAM_DEDUP, MS_STREAM_NO_HITS, MS_STREAM_EXACT_ONLY, MS_STREAM_PACKED, MS_STREAM_HOST_PACK, MS_STREAM_PACKED12 = 1, 2, 4, 8, 16, 32
 
 
 class ScanStats(ctypes.Structure):
@@ -102,12 +102,17 @@ def lib():
         "ms_pwmset_max_raw": (c_int, [vp, pd]),
         "ms_pwmset_free": (None, [vp]),
         "ms_seqset_create": (c_int, [ctypes.c_char_p, pi64, c_i64, c_int, pvp]),
+        "ms_seqset_create_hostpacked": (c_int, [ctypes.c_char_p, pi64, c_i64, c_int, pvp]),
+        "ms_debug_host_pack": (c_int, [ctypes.c_char_p, pi64, c_i64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), pi32, pi32]),
         "ms_seqset_from_device": (c_int, [vp, pi64, c_i64, pvp]),
         "ms_seqset_repack": (c_int, [vp]),
         "ms_seqset_size": (c_int, [vp, pi64, pi64]),
         "ms_seqset_free": (None, [vp]),
         "ms_genome_create": (c_int, [ctypes.c_char_p, pi64, c_i32, pvp]),
         "ms_genome_size": (c_int, [vp, pi32, pi64]),
+        "ms_genome_create_packed": (c_int, [pu32, pu32, pi64, c_i32, pvp]),
+        "ms_genome_packed_host": (c_int, [vp, pu32, pu32]),
+        "ms_pack_bases_host": (c_int, [ctypes.c_char_p, c_i64, c_int, pu32, pu32]),
         "ms_genome_free": (None, [vp]),
         "ms_seqset_from_genome": (c_int, [vp, pi32, pi64, pi64, c_i64, pvp]),
         "ms_scan": (c_int, [vp, vp, c_int, c_u32, pvp]),
@@ -118,6 +123,8 @@ def lib():
         "ms_result_hits": (c_int, [vp, pi64, pi64, pd, pi8]),
         "ms_result_hits_host": (c_int, [vp, ctypes.POINTER(pi64), ctypes.POINTER(pi64), ctypes.POINTER(pd), ctypes.POINTER(pi8)]),
         "ms_result_hits_packed_host": (c_int, [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64)), ctypes.POINTER(pd)]),
+        "ms_result_hits_packed12_host": (c_int, [vp, ctypes.POINTER(pu32), ctypes.POINTER(pd), pi32]),
+        "ms_result_packed_form": (c_int, [vp, pi32]),
         "ms_host_alloc": (c_int, [ctypes.c_size_t, pvp]),
         "ms_device_pool_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64)]),
         "ms_host_free": (None, [vp]),
@@ -269,7 +276,8 @@ class PwmSet:
 class SeqSet:
     """Device-side packed sequence set (convert_seq, cscore.c:81-114)."""
 
-    def __init__(self, bases, offsets, keep_ascii=False):
+    def __init__(self, bases, offsets, keep_ascii=False, host_pack_threads=0):
+        """host_pack_threads > 0: convert_seq on that many host threads (ms_seqset_create_hostpacked: no kernel is launched) -- the same set."""
         if isinstance(bases, np.ndarray):
             bases = np.ascontiguousarray(bases, dtype=np.uint8)
             buf = bases.ctypes.data_as(ctypes.c_char_p)
@@ -286,8 +294,11 @@ class SeqSet:
         self.n_seqs = self.offsets.size - 1
         self.n_bases = nbytes
         h = ctypes.c_void_p()
-        check(lib().ms_seqset_create(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(bool(keep_ascii)),
-                                     ctypes.byref(h)))
+        if host_pack_threads and not keep_ascii:
+            check(lib().ms_seqset_create_hostpacked(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(host_pack_threads), ctypes.byref(h)))
+        else:
+            check(lib().ms_seqset_create(buf, ptr(self.offsets, ctypes.c_int64), self.n_seqs, int(bool(keep_ascii)),
+                                         ctypes.byref(h)))
         self.h = h
 
     @classmethod
@@ -358,10 +369,65 @@ class ResidentGenome:
         check(lib().ms_genome_create(b"".join(raws), ptr(self.offsets, ctypes.c_int64), len(raws), ctypes.byref(h)))
         self.h = h
 
+    # ---- FASTA -> packed genome file -> resident genome (motifscan_amd/genome.py has the file format) ----
+    @classmethod
+    def from_packed(cls, packed):
+        """The planes of a genome.PackedGenome (arrays or a memory-mapped genome file) uploaded as they are: 0.375 B per base over the
+        link, no ASCII, no pack kernel (ms_genome_create_packed).  fetch_sequence is served by the packed host side."""
+        g = cls.__new__(cls)
+        g.names = list(packed.names)
+        g.index = dict(packed.index)
+        g.chrom_sizes = dict(packed.chrom_sizes)
+        g.offsets = np.ascontiguousarray(packed.offsets, dtype=np.int64)
+        g._host = None
+        g._packed = packed
+        codes = np.ascontiguousarray(packed.codes, dtype=np.uint32)          # (a memory map: read sequentially here, once)
+        nmask = np.ascontiguousarray(packed.nmask, dtype=np.uint32)
+        h = ctypes.c_void_p()
+        check(lib().ms_genome_create_packed(ptr(codes, ctypes.c_uint32), ptr(nmask, ctypes.c_uint32), ptr(g.offsets, ctypes.c_int64),
+                                            len(g.names), ctypes.byref(h)))
+        g.h = h
+        return g
+
+    @classmethod
+    def from_fasta(cls, path, n_threads=None):
+        """Read a FASTA (plain reader, optional .fai check), pack it on host threads, upload the planes.  To pay the read + pack once
+        per genome instead of once per process: ResidentGenome.from_fasta(fa).save(path) -- then ResidentGenome.load(path)."""
+        from . import genome as _genome
+        return cls.from_packed(_genome.PackedGenome.from_fasta(path, n_threads=n_threads))
+
+    @classmethod
+    def load(cls, path, verify=True):
+        from . import genome as _genome
+        return cls.from_packed(_genome.PackedGenome.load(path, verify=verify))
+
+    def packed(self):
+        """The genome as a genome.PackedGenome: the one it was made from, or -- for a genome packed on the device from strings -- its planes
+        copied back (ms_genome_packed_host; case and IUPAC letters come from the host copy if one was kept, else they are lost: N / upper case)."""
+        if getattr(self, "_packed", None) is not None:
+            return self._packed
+        from . import genome as _genome
+        if self._host is not None:
+            return _genome.PackedGenome.from_arrays(self.names, [self._host[n] for n in self.names])
+        n = int(self.offsets[-1])
+        units = (n + 31) // 32
+        codes, nmask = np.zeros(2 * units, dtype=np.uint32), np.zeros(units, dtype=np.uint32)
+        check(lib().ms_genome_packed_host(self.h, ptr(codes, ctypes.c_uint32), ptr(nmask, ctypes.c_uint32)))
+        return _genome.PackedGenome(self.names, self.offsets, codes, nmask)
+
+    def save(self, path):
+        return self.packed().save(path)
+
+    @property
+    def chroms(self):
+        return sorted(self.names)                        # genome/__init__.py:88-99
+
     def fetch_sequence(self, chrom, start, end):
-        if self._host is None:
-            raise RuntimeError("ResidentGenome was created without keep_host: sequences live on the device only")
-        return self._host[chrom][start:end].decode()
+        if self._host is not None:
+            return self._host[chrom][start:end].decode()
+        if getattr(self, "_packed", None) is not None:
+            return self._packed.fetch_sequence(chrom, start, end)
+        raise RuntimeError("ResidentGenome was created without keep_host: sequences live on the device only")
 
     def extract(self, chrom_idx, starts, ends):
         """SeqSet of the regions (chromosome indices, 0-based half-open, already clipped)."""
@@ -421,7 +487,7 @@ class ScanResult:
         invalidated by an explicit close() or dedup()).  packed=True moves 16 instead of 25 bytes per hit over the host
         link (ms_result_hits_packed_host) and unpacks on the host -- the arrays are then always fresh copies."""
         if packed:
-            return self._hits_packed()
+            return self._hits_packed(None if packed is True else int(packed))
         if self._hits is None or (copy and not self._hits_owned):
             n = self.n_hits
             ps, pp = ctypes.POINTER(ctypes.c_int64)(), ctypes.POINTER(ctypes.c_int64)()
@@ -444,8 +510,30 @@ class ScanResult:
             self._hits = None                            # the views reference this object: caching them here would be a cycle
         return out
 
-    def _hits_packed(self):
+    def packed_form(self):
+        """12, 16 or 0: the compact form a batch stream's copy-out left in this result (ms_result_packed_form)."""
+        b = ctypes.c_int32()
+        check(lib().ms_result_packed_form(self.h, ctypes.byref(b)))
+        return b.value
+
+    def _hits_packed(self, form=None):
+        """form: None = whatever the result holds already (a stream's copy-out), else 12 / 16."""
         n = self.n_hits
+        if form is None:
+            form = self.packed_form() or 16
+        if form == 12:
+            pc, pv, sh = ctypes.POINTER(ctypes.c_uint32)(), ctypes.POINTER(ctypes.c_double)(), ctypes.c_int32()
+            check(lib().ms_result_hits_packed12_host(self.h, ctypes.byref(pc), ctypes.byref(pv), ctypes.byref(sh)))
+            if n:
+                coord = np.ctypeslib.as_array(pc, shape=(n,))
+                score_ = np.ctypeslib.as_array(pv, shape=(n,)).copy()
+                seq_idx = (coord >> np.uint32(sh.value)).astype(np.int64)
+                pos = ((coord & np.uint32((1 << sh.value) - 1)) >> np.uint32(1)).astype(np.int64)
+                strand = ((coord & np.uint32(1)) + np.uint32(1)).astype(np.int8)
+            else:
+                seq_idx, pos, score_, strand = (np.zeros(0, dtype=t) for t in (np.int64, np.int64, np.float64, np.int8))
+            motif = np.repeat(np.arange(self.n_pwms, dtype=np.int32), np.diff(self.motif_offsets))
+            return {"seq_idx": seq_idx, "pos": pos, "score": score_, "strand": strand, "motif": motif, "motif_offsets": self.motif_offsets}
         pc, pv = ctypes.POINTER(ctypes.c_uint64)(), ctypes.POINTER(ctypes.c_double)()
         check(lib().ms_result_hits_packed_host(self.h, ctypes.byref(pc), ctypes.byref(pv)))
         if n:
@@ -498,6 +586,20 @@ class ScanResult:
             self.h = None
 
     __del__ = close
+
+
+def host_pack(bases, offsets):
+    """The host packer alone (ms_debug_host_pack; no device): (codes uint32 [2 x units], nmask uint32 [units], blk2reg int32 [blocks],
+    blkinfo int32 [blocks][4]) of a sequence set -- the layout the device's pack / hint kernels write."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = int(offsets[-1])
+    units, blocks = (n + 31) // 32, (n + 63) // 64 + 1
+    codes, nmask = np.zeros(2 * units, dtype=np.uint32), np.zeros(units, dtype=np.uint32)
+    blk, info = np.zeros(blocks, dtype=np.int32), np.zeros((blocks, 4), dtype=np.int32)
+    check(lib().ms_debug_host_pack(bases.ctypes.data_as(ctypes.c_char_p), ptr(offsets, ctypes.c_int64), offsets.size - 1,
+                                   ptr(codes, ctypes.c_uint32), ptr(nmask, ctypes.c_uint32), ptr(blk, ctypes.c_int32), ptr(info, ctypes.c_int32)))
+    return codes, nmask, blk, info
 
 
 def pool_stats():
@@ -651,12 +753,14 @@ def merge_hits(parts, n_pwms):
     return out
 
 
-def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None):
+def scan_stream(pwms, batches, strand_mask=3, flags=0, depth=2, packed=False, stage_stats=None, host_pack=False):
     """Generator: push (bases, offsets) batches -- or (ResidentGenome, chrom_idx, starts, ends) batches of a genome that sits in
     HBM -- through a Stream, yield each batch's ScanResult in order (the caller closes them).  Keeps the stream as full as its capacity allows.  stage_stats: a dict that receives Stream.stats() at the end.
     A (bases, offsets, True) batch is COUNTS ONLY (ms_stream_submit_counts_only): its hits stay on the device, only the per-motif
-    region counts are read -- what the reference does with the control regions (cli/scan.py:81-89 -> stats.py:29-31)."""
-    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
+    region counts are read -- what the reference does with the control regions (cli/scan.py:81-89 -> stats.py:29-31).
+    host_pack: the upload stage packs the batches on host threads (MS_STREAM_HOST_PACK: no kernel beside the scan).
+    packed: True / 16 = the 16-byte compact copy-out, 12 = the 12-byte form for every batch that fits it (MS_STREAM_PACKED12)."""
+    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED12 if packed == 12 else (MS_STREAM_PACKED if packed else 0)) | (MS_STREAM_HOST_PACK if host_pack else 0), depth)
     try:
         for batch in batches:                             # (bases, offsets), or (ResidentGenome, chrom_idx, starts, ends)
             while st.in_flight >= st.capacity:
@@ -683,7 +787,7 @@ def sweep_stream(pwms, chroms, window, stride, max_span_bases, strand_mask=3, fl
     the sweep to a subset (a rank's share)."""
     if spans is None:
         spans = sweep_spans([len(c) for c in chroms], window, stride, max_span_bases)
-    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED if packed else 0), depth)
+    st = Stream(pwms, strand_mask, flags | (MS_STREAM_PACKED12 if packed == 12 else (MS_STREAM_PACKED if packed else 0)), depth)
     try:
         pending = []
         for sp in spans:

@@ -642,7 +642,7 @@ static int seqset_common(const int64_t *offsets, int64_t n_seqs, std::unique_ptr
     return MS_OK;
 }
 
-static int seqset_alloc_packed(ms_seqset *s) {
+static int seqset_alloc_packed(ms_seqset *s, bool pads_by_copy = false, bool defer_pads = false) {
     const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
     const size_t b_codes = (2 * n_units + kPadWords) * sizeof(uint32_t);
     const size_t b_nmask = (n_units + kPadWords) * sizeof(uint32_t);
@@ -663,9 +663,11 @@ static int seqset_alloc_packed(ms_seqset *s) {
     // only the pad words behind the packed data need clearing: the kernels write everything else
     // sequence sets are built on the upload stream: a batch can be packed while the previous one is being scanned
     s->up = c->stream_up;                                 // read once: every step of building this set stays on one stream
-    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
-    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
-    MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));
+    if (!pads_by_copy && !defer_pads) {                   // (a memset is a KERNEL: the host-packed form copies zero pad words along instead, the upload-only form clears them when it packs)
+        MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+        MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
+    }
+    if (!pads_by_copy) MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));      // (host-packed: the offsets travel in the one copy of the whole block)
     return MS_OK;
 }
 
@@ -699,6 +701,151 @@ int ms_seqset_create(const char *bases, const int64_t *offsets, int64_t n_seqs, 
     *out = raw;
     return MS_OK;
 }
+
+// convert_seq on HOST threads (ms_hostpack.cpp): the packed codes, the mask and the region hints are made in pinned staging memory by
+// n_threads threads and cross the link on the copy engines -- no kernel is launched, so nothing of the set's construction waits for CUs
+// a running scan holds (the batch stream's upload stage, MS_STREAM_HOST_PACK).  The set is identical to ms_seqset_create's.
+int ms_seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, ms_seqset **out) {
+    return seqset_create_hostpacked(bases, offsets, n_seqs, n_threads, nullptr, nullptr, out);
+}
+
+}  // extern "C"  (an internal C++ entry follows: the stream's uploader calls it with its own staging block)
+
+// stage / stage_bytes: the caller's grow-only pinned staging block (a batch stream's uploader keeps ONE for its life: page-locking ~90 MB
+// per batch costs tens of milliseconds); nullptr: a block of the call's own.
+int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(offsets, n_seqs, s);
+    if (rc) return rc;
+    if (s->n_bases > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    DeviceCtx *c;
+    if ((rc = get_ctx(s->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw, true))) return fail(rc);
+    const int64_t n_units = (raw->n_bases + 31) / 32, n_blocks = (raw->n_bases + 63) / 64 + 1;
+    // The staging block MIRRORS the set's device block (seqset_alloc_packed: codes + pad | mask + pad | offsets | region of every 64th
+    // position | block records, 256-byte aligned), so that ONE copy moves everything -- no kernel (a memset is one) and no second copy is
+    // queued on the upload stream.
+    auto up256 = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+    const size_t o_nmask = (size_t) (reinterpret_cast<char *>(raw->d_nmask) - static_cast<char *>(raw->block));
+    const size_t o_off = (size_t) (reinterpret_cast<char *>(raw->d_offsets) - static_cast<char *>(raw->block));
+    const size_t o_blk = (size_t) (reinterpret_cast<char *>(raw->d_blk2reg) - static_cast<char *>(raw->block));
+    const size_t o_info = (size_t) (reinterpret_cast<char *>(raw->d_blkinfo) - static_cast<char *>(raw->block));
+    const size_t need = up256(o_info + (size_t) n_blocks * 16) + 256;
+    size_t got = 0;
+    char *stage = nullptr;
+    if (stage_io) {
+        if (*stage_bytes_io < need) {
+            if (*stage_io) (void) hipHostFree(*stage_io);
+            *stage_io = nullptr; *stage_bytes_io = 0;
+            void *p = nullptr;
+            if (hipHostMalloc(&p, need + need / 8) != hipSuccess) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+            *stage_io = p; *stage_bytes_io = need + need / 8;
+        }
+        stage = static_cast<char *>(*stage_io);
+    } else {
+        stage = static_cast<char *>(pinned_alloc(need, &got));
+        if (!stage) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+    }
+    auto release = [&]() { if (!stage_io) pinned_free(stage, got); };
+    uint32_t *h_codes = reinterpret_cast<uint32_t *>(stage), *h_nmask = reinterpret_cast<uint32_t *>(stage + o_nmask);
+    int32_t *h_blk = reinterpret_cast<int32_t *>(stage + o_blk);
+    int32_t *h_info = reinterpret_cast<int32_t *>(stage + o_info);
+    {
+        const bool all_far = measure_env("MS_BLKINFO_FAR") != nullptr;
+        const int64_t *off = raw->offsets.data();
+        const int64_t R = raw->R, nb = raw->n_bases;
+        const int T = (int) std::min<int64_t>(n_threads, std::max<int64_t>(1, n_units / 4096));
+        auto work = [&](int t) {
+            host_pack_units(reinterpret_cast<const uint8_t *>(bases), nb, n_units * t / T, n_units * (t + 1) / T, h_codes, h_nmask);
+            host_region_hints(off, R, n_blocks * t / T, n_blocks * (t + 1) / T, h_blk, h_info, all_far);
+        };
+        std::vector<std::thread> th;
+        try { for (int t = 1; t < T; t++) th.emplace_back(work, t); }
+        catch (const std::exception &) { for (auto &x : th) x.join(); release(); set_error("could not start packing threads"); return fail(MS_ERR_RUNTIME); }
+        work(0);
+        for (auto &x : th) x.join();
+        std::memset(h_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t));
+        std::memset(h_nmask + n_units, 0, kPadWords * sizeof(uint32_t));
+        std::memcpy(stage + o_off, off, ((size_t) R + 1) * sizeof(int64_t));
+    }
+    hipError_t e = hipMemcpyAsync(raw->block, stage, o_info + (size_t) n_blocks * 16, hipMemcpyHostToDevice, raw->up);
+    if (e == hipSuccess) e = hipStreamSynchronize(raw->up);
+    release();
+    if (e != hipSuccess) { set_error("upload of the packed set failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    raw->built = true;
+    *out = raw;
+    return MS_OK;
+}
+
+extern "C" {
+
+// the host packer alone, for CPU tests (no device): codes [2 * ceil(n / 32)], nmask [ceil(n / 32)], blk2reg [(n + 63) / 64 + 1], blkinfo [4 x that]
+int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo) {
+    if (!offsets || n_seqs < 0 || !codes || !nmask || !blk2reg || !blkinfo) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const int64_t n = offsets[n_seqs];
+    if (n > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    host_pack_units(reinterpret_cast<const uint8_t *>(bases), n, 0, (n + 31) / 32, codes, nmask);
+    host_region_hints(offsets, n_seqs, 0, (n + 63) / 64 + 1, blk2reg, blkinfo, false);
+    return MS_OK;
+}
+
+}  // extern "C"
+
+// The batch stream's upload stage (round 6): ONLY the copies -- ASCII and offsets cross the link on the DMA engines, nothing here needs a CU.
+// convert_seq (pack_kernel) and the region hints are made by the SCAN stage, on the scan stream, in front of the batch's pre-filter
+// (seqset_pack_pending, called by scan_locked).  Why: every kernel launched on the upload stream beside a scan waits for the pre-filter's
+// persistent blocks to retire -- a full CU stalls the dispatcher's in-order hand-out (ms_handles.h, StreamSel) -- so the upload stage used
+// to end when the PREVIOUS batch's pre-filter did (53 ms of "work" per configs[3] pass for 18 ms of copies and 0.6 ms of kernels,
+// profiles/r05d_e2e_bounds.log) and the scan stage could not queue the next batch's scan behind the running one.  On the scan stream the
+// two kernels cost what they cost in the resident step (0.3 ms per 500 Mbase) and wait for nothing.
+int ms::seqset_create_upload_only(const char *bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(offsets, n_seqs, s);
+    if (rc) return rc;
+    if (s->n_bases > 0 && !bases) { set_error("bases is NULL"); return MS_ERR_INVALID; }
+    DeviceCtx *c;
+    if ((rc = get_ctx(s->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw, false, true))) return fail(rc);
+    {
+        void *blk = nullptr;
+        if ((rc = pool_alloc(c, (size_t) raw->n_bases + 64, &blk, &raw->ascii_bytes))) return fail(rc);
+        raw->d_ascii = static_cast<uint8_t *>(blk);
+    }
+    hipError_t e = hipSuccess;
+    if (raw->n_bases > 0) e = hipMemcpyAsync(raw->d_ascii, bases, (size_t) raw->n_bases, hipMemcpyHostToDevice, raw->up);
+    if (e == hipSuccess) e = hipStreamSynchronize(raw->up);
+    if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    raw->built = true;
+    raw->pack_pending = true;
+    *out = raw;
+    return MS_OK;
+}
+
+// ... and the rest of the set's construction, queued on `st` (the scan stream; the caller holds the device's lock)
+int ms::seqset_pack_pending(const ms_seqset *s_c, hipStream_t st) {
+    ms_seqset *s = const_cast<ms_seqset *>(s_c);
+    if (!s->pack_pending) return MS_OK;
+    const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
+    MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), st));
+    MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), st));
+    int rc;
+    if ((rc = launch_pack(s->d_ascii, s->n_bases, s->d_codes, s->d_nmask, st))) return rc;
+    if ((rc = launch_blk2reg(s->d_offsets, s->R, s->n_bases, s->d_blk2reg, s->d_blkinfo, st))) return rc;
+    s->pack_pending = false;                       // (queued: everything that reads the set follows on the same stream, or waits for it)
+    return MS_OK;
+}
+
+extern "C" {
 
 int ms_seqset_from_device(const void *d_bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out) {
     if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
@@ -768,6 +915,82 @@ int ms_genome_create(const char *bases, const int64_t *chrom_offsets, int32_t n_
     int rc = ms_seqset_create(bases, chrom_offsets, n_chroms, 0, &s);
     if (rc) return rc;
     *out = reinterpret_cast<ms_genome *>(s);
+    return MS_OK;
+}
+
+// convert_seq (cscore.c:81-114) into the packed layout on HOST threads, no device: what the genome-file builder runs (ms_hostpack.cpp)
+int ms_pack_bases_host(const char *bases, int64_t n_bases, int n_threads, uint32_t *codes, uint32_t *nmask) {
+    if (n_bases < 0 || (n_bases > 0 && (!bases || !codes || !nmask))) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const int64_t n_units = (n_bases + 31) / 32;
+    const int T = (int) std::max<int64_t>(1, std::min<int64_t>(std::min(n_threads < 1 ? 1 : n_threads, 64), n_units / 4096));
+    auto work = [&](int t) { host_pack_units(reinterpret_cast<const uint8_t *>(bases), n_bases, n_units * t / T, n_units * (t + 1) / T, codes, nmask); };
+    std::vector<std::thread> th;
+    try { for (int t = 1; t < T; t++) th.emplace_back(work, t); }
+    catch (const std::exception &) { for (auto &x : th) x.join(); set_error("could not start packing threads"); return MS_ERR_RUNTIME; }
+    work(0);
+    for (auto &x : th) x.join();
+    return MS_OK;
+}
+
+// A genome from its PACKED form (a genome file made once: motifscan_amd/genome.py): the two planes cross the link as they are -- 0.375 B per
+// base, no ASCII, no pack kernel; only the region hints are made on the device.  The planes are validated first (a file is outside input):
+// a non-ACGT base must hold code 0 and nothing may be set past the last base -- the invariants pack_kernel guarantees and the scan kernels rely on.
+int ms_genome_create_packed(const uint32_t *codes, const uint32_t *nmask, const int64_t *chrom_offsets, int32_t n_chroms, ms_genome **out) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<ms_seqset> s;
+    int rc = seqset_common(chrom_offsets, n_chroms, s);
+    if (rc) return rc;
+    const int64_t n_bases = s->n_bases, n_units = (n_bases + 31) / 32;
+    if (n_bases > 0 && (!codes || !nmask)) { set_error("codes / nmask is NULL"); return MS_ERR_INVALID; }
+    {
+        int64_t cbad[kMaxChunks];
+        for (int t = 0; t < kMaxChunks; t++) cbad[t] = -1;
+        parallel_chunks(n_units, [&](int t, int64_t b, int64_t e) {
+            for (int64_t u = b; u < e; u++) {
+                const uint64_t cw = (uint64_t) codes[2 * u] | ((uint64_t) codes[2 * u + 1] << 32);
+                uint64_t nw = nmask[u], spread = 0;                      // bit i of the mask -> bits 2i, 2i + 1
+                for (int i = 0; nw; i++, nw >>= 1) if (nw & 1u) spread |= 3ULL << (2 * i);
+                uint64_t tail_c = 0;
+                uint32_t tail_n = 0;
+                if (32 * (u + 1) > n_bases) {
+                    const int valid = (int) (n_bases - 32 * u);
+                    tail_c = valid >= 32 ? 0 : ~0ULL << (2 * valid);
+                    tail_n = valid >= 32 ? 0 : ~0u << valid;
+                }
+                if ((cw & spread) || (cw & tail_c) || (nmask[u] & tail_n)) { cbad[t] = u; return; }
+            }
+        });
+        for (int t = 0; t < kMaxChunks; t++)
+            if (cbad[t] >= 0) { set_error("packed genome is corrupt at bases %lld..%lld: a non-ACGT base with a non-zero code, or bits past the end", (long long) (32 * cbad[t]), (long long) (32 * cbad[t] + 31)); return MS_ERR_INVALID; }
+    }
+    DeviceCtx *c;
+    if ((rc = get_ctx(s->device, &c))) return rc;
+    ms_seqset *raw = s.release();
+    auto fail = [&](int code) { ms_seqset_free(raw); return code; };
+    if ((rc = seqset_alloc_packed(raw))) return fail(rc);
+    if (n_units > 0) {
+        hipError_t e = hipMemcpyAsync(raw->d_codes, codes, (size_t) n_units * 8, hipMemcpyHostToDevice, raw->up);
+        if (e == hipSuccess) e = hipMemcpyAsync(raw->d_nmask, nmask, (size_t) n_units * 4, hipMemcpyHostToDevice, raw->up);
+        if (e != hipSuccess) { set_error("H2D copy of the packed genome failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    }
+    if ((rc = launch_blk2reg(raw->d_offsets, raw->R, raw->n_bases, raw->d_blk2reg, raw->d_blkinfo, raw->up))) return fail(rc);
+    hipError_t e = hipStreamSynchronize(raw->up);
+    if (e != hipSuccess) { set_error("upload of the packed genome failed: %s", hipGetErrorString(e)); return fail(MS_ERR_RUNTIME); }
+    raw->built = true;
+    *out = reinterpret_cast<ms_genome *>(raw);
+    return MS_OK;
+}
+
+// ... and back: the two planes of a resident genome on the host (to write the genome file after a genome was packed on the device)
+int ms_genome_packed_host(const ms_genome *g, uint32_t *codes, uint32_t *nmask) {
+    if (!g || !codes || !nmask) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const ms_seqset *s = reinterpret_cast<const ms_seqset *>(g);
+    const size_t n_units = (size_t) ((s->n_bases + 31) / 32);
+    if (n_units == 0) return MS_OK;
+    MS_HIP(hipSetDevice(s->device));
+    MS_HIP(hipMemcpy(codes, s->d_codes, n_units * 8, hipMemcpyDeviceToHost));
+    MS_HIP(hipMemcpy(nmask, s->d_nmask, n_units * 4, hipMemcpyDeviceToHost));
     return MS_OK;
 }
 
@@ -957,6 +1180,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // the B-operand table, the waves' sequence staging, their PfEmit and (at least) kRareCapMin parking entries follow the tables -- and the
     // waves' one-hot arrays (40 KB) in the double-pass kernels ONLY: a plan with a wide tile (a motif of 32 ... 63 columns on the pre-filter)
     // runs the single-pass kernels, which never touch that array, and keeps the room for its tables
+    if ((rc = seqset_pack_pending(seqs, c->stream))) return rc;       // a batch stream's set: its pack / hint kernels run here, in front of its pre-filter
     const size_t lds_fixed_wide = kF6LutBytes + kPfStageBytes + kPfEmitBytes + kPfRareBytesMin;
     const size_t lds_fixed_narrow = lds_fixed_wide + kPfOnehotBytes;
     if ((rc = pwmset_upload(pwms, c->device, c->stream))) return rc;
@@ -1246,14 +1470,23 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         (void) hipEventRecord(ev[4], c->stream);
         if ((rc = launch_finalize(sc.keys_sorted, (int64_t) n_sort, n_dev, gbits, rbits, pbits, pwms->P, S, raw->d_seq_idx, raw->d_pos,
                                   raw->d_strand, raw->d_motif_first, raw->d_region_counts, c->stream))) return rc;
-        if ((flags & MS_SCAN_PACK_INTERNAL) && n_sort > 0) {
+        if ((flags & (MS_SCAN_PACK_INTERNAL | MS_SCAN_PACK12_INTERNAL)) && n_sort > 0) {
             const size_t n_round = (n_sort + 65535) & ~(size_t) 65535;
             if ((rc = pool_alloc(c, 8 * n_round + 256, &raw->coord_blk, &raw->coord_bytes))) return rc;
             raw->d_coord = static_cast<uint64_t *>(raw->coord_blk);
             raw->d_coord_bad = reinterpret_cast<unsigned int *>(raw->d_coord + n_round);
             he = hipMemsetAsync(raw->d_coord_bad, 0, sizeof(unsigned int), c->stream);
             if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
-            if ((rc = launch_pack_hits((int64_t) n_sort, n_dev, raw->d_seq_idx, raw->d_pos, raw->d_strand, raw->d_coord, raw->d_coord_bad, c->stream))) return rc;
+            // the 4-byte form when asked for and the set's largest region index and position fit 31 bits beside the strand bit
+            raw->coord_shift = 0;
+            if (flags & MS_SCAN_PACK12_INTERNAL) {
+                const int64_t max_len = seqs->len_sorted.empty() ? 0 : seqs->len_sorted.back();
+                int pb = 1, rb = 1;
+                while ((1LL << pb) < std::max<int64_t>(max_len, 1)) pb++;
+                while ((1LL << rb) < std::max<int64_t>(seqs->R, 1)) rb++;
+                if (rb + pb + 1 <= 32) raw->coord_shift = pb + 1;
+            }
+            if ((rc = launch_pack_hits((int64_t) n_sort, n_dev, raw->d_seq_idx, raw->d_pos, raw->d_strand, raw->d_coord, raw->d_coord_bad, c->stream, raw->coord_shift))) return rc;
         }
         (void) hipEventRecord(ev[5], c->stream);
         // the complete per-motif offsets are on the device; one copy brings them to the host.  (Not for a scan that is only being
@@ -1506,10 +1739,11 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
     if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->d_coord && r->coord_shift) { set_error("this result holds the 12-byte compact form (MS_STREAM_PACKED12): read it with ms_result_hits_packed12_host"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
     const size_t bytes = 16 * n_round + 64;
-    if (r->h_pinned_hits != r->n_hits || !r->h_pinned || !r->h_packed) {
+    if (r->h_pinned_hits != r->n_hits || !r->h_pinned || !r->h_packed || r->h_coord_shift) {
         if (r->h_pinned && r->h_pinned_bytes < bytes) { pinned_free(r->h_pinned, r->h_pinned_bytes); r->h_pinned = nullptr; }
         if (!r->h_pinned) {
             r->h_pinned = pinned_alloc(bytes, &r->h_pinned_bytes);
@@ -1553,10 +1787,84 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
         }
         r->h_pinned_hits = r->n_hits;
         r->h_packed = true;
+        r->h_coord_shift = 0;
     }
     char *b = static_cast<char *>(r->h_pinned);
     if (coord) *coord = reinterpret_cast<const uint64_t *>(b);
     if (score) *score = reinterpret_cast<const double *>(b + 8 * n_round);
+    return MS_OK;
+}
+
+// The 12-byte form: coord32[i] = seq_idx << shift | pos << 1 | (strand - 1) and score[i].  A batch stream made with MS_STREAM_PACKED12 has
+// produced the words during the scan when the batch fits (copies only here); a result that holds none is packed now if it fits.
+int ms_result_hits_packed12_host(ms_result *r, const uint32_t **coord, const double **score, int32_t *shift_out) {
+    if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->d_coord && !r->coord_shift) { set_error("this result holds the 16-byte compact form (its batch did not fit 31 bits of region index and position): read it with ms_result_hits_packed_host"); return MS_ERR_INVALID; }
+    const size_t n = (size_t) r->n_hits;
+    const size_t n_round = (n + 65535) & ~(size_t) 65535;
+    const size_t bytes = 12 * n_round + 64;
+    if (r->h_pinned_hits != r->n_hits || !r->h_pinned || !r->h_packed || !r->h_coord_shift) {
+        if (r->h_pinned && r->h_pinned_bytes < bytes) { pinned_free(r->h_pinned, r->h_pinned_bytes); r->h_pinned = nullptr; }
+        if (!r->h_pinned) {
+            r->h_pinned = pinned_alloc(bytes, &r->h_pinned_bytes);
+            if (!r->h_pinned) { set_error("pinned host allocation of %zu bytes failed", bytes); return MS_ERR_NOMEM; }
+        }
+        int shift = r->coord_shift;
+        DeviceCtx *c = nullptr;
+        int rc = n > 0 ? get_ctx(r->device, &c) : MS_OK;
+        if (rc) return rc;
+        void *blk = nullptr;
+        size_t got = 0;
+        const uint64_t *d_words = r->d_coord;
+        const unsigned int *d_bad = r->d_coord_bad;
+        if (n > 0 && !r->d_coord) {                     // no words yet: the shift from the hits themselves (largest region index / position)
+            const hipStream_t down = c->stream_down;
+            int64_t last_seq = 0;
+            // the hits of a motif are ordered by region: the largest region index is the maximum over the motifs' last hits -- P small
+            // copies would do; R is known to the result, so the bound is R - 1 whatever the hits are
+            last_seq = std::max<int64_t>(r->R - 1, 0);
+            int rb = 1;
+            while ((1LL << rb) <= last_seq) rb++;
+            if (rb >= 31) { set_error("the result's region indices need %d bits: the 12-byte compact form does not fit (use ms_result_hits_packed_host)", rb); return MS_ERR_INVALID; }
+            shift = 32 - rb;                            // positions get every remaining bit; the kernel flags a position that does not fit
+            if ((rc = pool_alloc(c, 4 * n_round + 256, &blk, &got))) return rc;
+            unsigned int *bad_w = reinterpret_cast<unsigned int *>(static_cast<char *>(blk) + 4 * n_round);
+            hipError_t he = hipMemsetAsync(bad_w, 0, sizeof(unsigned int), down);
+            if (he == hipSuccess) rc = launch_pack_hits((int64_t) n, nullptr, r->d_seq_idx, r->d_pos, r->d_strand, static_cast<uint64_t *>(blk), bad_w, down, shift);
+            if (he != hipSuccess || rc) { pool_free(c, blk, got); if (!rc) { set_error("memset failed: %s", hipGetErrorString(he)); rc = MS_ERR_RUNTIME; } return rc; }
+            d_words = static_cast<const uint64_t *>(blk);
+            d_bad = bad_w;
+        }
+        if (n > 0) {
+            unsigned int bad = 0;
+            const hipStream_t down = c->stream_down;
+            char *hb = static_cast<char *>(r->h_pinned);
+            hipError_t he = hipMemcpyAsync(hb, d_words, 4 * n, hipMemcpyDeviceToHost, down);
+            if (he == hipSuccess) he = hipMemcpyAsync(hb + 4 * n_round, r->d_score, 8 * n, hipMemcpyDeviceToHost, down);
+            if (he == hipSuccess) he = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, down);
+            const hipError_t hs = hipStreamSynchronize(down);
+            if (blk) pool_free(c, blk, got);
+            if (he != hipSuccess || hs != hipSuccess) { set_error("compact copy-out failed: %s", hipGetErrorString(he != hipSuccess ? he : hs)); return MS_ERR_RUNTIME; }
+            if (bad) { set_error("a hit does not fit the 12-byte compact form (region index and position beside the strand bit need more than 32 bits): use ms_result_hits_packed_host"); return MS_ERR_INVALID; }
+        }
+        if (n == 0 && shift == 0) shift = 1;
+        r->h_pinned_hits = r->n_hits;
+        r->h_packed = true;
+        r->h_coord_shift = shift;
+    }
+    char *b = static_cast<char *>(r->h_pinned);
+    if (coord) *coord = reinterpret_cast<const uint32_t *>(b);
+    if (score) *score = reinterpret_cast<const double *>(b + 4 * n_round);
+    if (shift_out) *shift_out = r->h_coord_shift;
+    return MS_OK;
+}
+
+// which compact form a batch stream left in a result: 16 (coord64 | score), 12 (coord32 | score), 0 (none: the plain arrays)
+int ms_result_packed_form(const ms_result *r, int32_t *bytes_per_hit) {
+    if (!r || !bytes_per_hit) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    *bytes_per_hit = r->h_packed && r->h_pinned_hits == r->n_hits ? (r->h_coord_shift ? 12 : 16) : (r->d_coord ? (r->coord_shift ? 12 : 16) : 0);
     return MS_OK;
 }
 
@@ -1618,7 +1926,7 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     if (r->coord_blk) {                                  // coordinate words of the hits before de-duplication: void
         DeviceCtx *c0;
         if (get_ctx(r->device, &c0) == MS_OK) pool_free(c0, r->coord_blk, r->coord_bytes); else (void) hipFree(r->coord_blk);
-        r->coord_blk = nullptr; r->d_coord = nullptr; r->d_coord_bad = nullptr;
+        r->coord_blk = nullptr; r->d_coord = nullptr; r->d_coord_bad = nullptr; r->coord_shift = 0;
     }
     DeviceCtx *c;
     int rc = get_ctx(r->device, &c);

@@ -81,6 +81,12 @@ void set_current_device(int device);  // thread-local only; no HIP call
 
 // Give every cached block of the calling thread's device back to the driver (ms_api.hip); returns the bytes released.
 size_t pool_trim_current_device();
+// ms_hostpack.cpp: convert_seq and the region hints on host threads (units of 32 bases / blocks of 64 positions [u0, u1) / [b0, b1))
+void host_pack_units(const uint8_t *bases, int64_t n_bases, int64_t u0, int64_t u1, uint32_t *codes, uint32_t *nmask);
+void host_region_hints(const int64_t *offsets, int64_t R, int64_t b0, int64_t b1, int32_t *blk2reg, int32_t *info, bool all_far);
+int seqset_create_upload_only(const char *bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out);
+int seqset_pack_pending(const ms_seqset *s, hipStream_t st);
+int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out);
 
 template <typename T>
 inline int dev_alloc(T **p, size_t n) {
@@ -180,6 +186,7 @@ struct ms_seqset {
     int4 *d_blkinfo = nullptr;            // ... with the region's and the next two regions' starts relative to 64*b (DevSeq::blkinfo)
     hipStream_t up = nullptr;             // the upload stream this set is being built on (DeviceCtx::stream_up, read once)
     bool built = false;                   // construction finished (its work on `up` is done)
+    bool pack_pending = false;            // a batch stream's upload-only set: ASCII and offsets are in HBM, pack_kernel / blk2reg_kernel still to run (seqset_pack_pending, on the scan stream)
 };
 
 struct ms_result {
@@ -204,6 +211,8 @@ struct ms_result {
     size_t coord_bytes = 0;
     uint64_t *d_coord = nullptr;                      // ... [n slots] + a "does not fit" flag word behind them
     unsigned int *d_coord_bad = nullptr;
+    int coord_shift = 0;                              // 0: 8-byte words; > 0: 4-byte words seq_idx << coord_shift | pos << 1 | strand bit (MS_SCAN_PACK12_INTERNAL, when the set fits)
+    int h_coord_shift = 0;                            // ... the form of the host copy
     void *h_pinned = nullptr;                         // host copy of the hit arrays (pinned), made on demand
     bool h_packed = false;                            // ... in the compact form (coord | score)
     size_t h_pinned_bytes = 0;
@@ -223,6 +232,8 @@ namespace ms {
 // stream -- a batch stream's copy-out then consists of copies only (a pack kernel launched on the copy-out stream would wait for
 // the next batch's pre-filter, whose persistent blocks fill every CU).
 #define MS_SCAN_PACK_INTERNAL 0x20000000u
+// ... in the 4-byte form (ms_result_hits_packed12_host) when every (region, position) of the set fits 31 bits; the 8-byte form otherwise.
+#define MS_SCAN_PACK12_INTERNAL 0x10000000u
 // Internal scan flag: never use the predicted-size form (the exactly-sized re-run after a failed prediction).
 #define MS_SCAN_NO_PREDICT_INTERNAL 0x40000000u
 

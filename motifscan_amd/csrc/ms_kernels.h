@@ -131,7 +131,7 @@ int launch_compact_hits(int64_t n, const uint32_t *keep, const uint64_t *dst, co
 int launch_site_tables(int64_t n, const int64_t *motif_off, int32_t P, int64_t R, const int64_t *seq_idx,
                        const double *score, int32_t *n_sites, double *max_score, hipStream_t st);
 int launch_pack_hits(int64_t n, const unsigned long long *n_dev, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord,
-                     unsigned int *bad, hipStream_t st);
+                     unsigned int *bad, hipStream_t st, int shift = 0);
 int launch_gather_ranks(const double *sorted, int64_t n, const int64_t *ranks, int32_t n_ranks, double *out, hipStream_t st);
 
 }  // namespace ms

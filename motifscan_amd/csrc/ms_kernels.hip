@@ -1898,22 +1898,28 @@ __global__ void __launch_bounds__(256) blk2reg_kernel(const int64_t *__restrict_
 // ---------------------------------------------------------------- compact copy-out --
 
 // coord = seq_idx << 32 | pos << 1 | (strand - 1): 8 bytes per hit on the host link instead of 17 (ms_result_hits_packed_host).
-// bad[0] is set if a hit does not fit the format.
+// shift > 0: the 4-byte form, coord32 = seq_idx << shift | pos << 1 | (strand - 1) (ms_result_hits_packed12_host: the caller has
+// checked that every region index and position of the set fits).  bad[0] is set if a hit does not fit the format.
 __global__ void __launch_bounds__(256) pack_hits_kernel(int64_t n, const unsigned long long *__restrict__ n_dev, const int64_t *__restrict__ seq_idx,
                                                         const int64_t *__restrict__ pos, const int8_t *__restrict__ strand,
-                                                        uint64_t *__restrict__ coord, unsigned int *__restrict__ bad) {
+                                                        uint64_t *__restrict__ coord, unsigned int *__restrict__ bad, int shift) {
     if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }     // (finalize_kernel: a predicted-size scan)
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t sq = (uint64_t) seq_idx[i], ps = (uint64_t) pos[i];
+    if (shift > 0) {
+        if ((ps >> (shift - 1)) != 0 || (sq >> (32 - shift)) != 0) *bad = 1u;
+        reinterpret_cast<uint32_t *>(coord)[i] = (uint32_t) ((sq << shift) | (ps << 1) | (uint64_t) (strand[i] == 2 ? 1 : 0));
+        return;
+    }
     if ((sq >> 32) != 0 || (ps >> 31) != 0) *bad = 1u;
     coord[i] = (sq << 32) | ((ps & 0x7FFFFFFFull) << 1) | (uint64_t) (strand[i] == 2 ? 1 : 0);
 }
 
 int launch_pack_hits(int64_t n, const unsigned long long *n_dev, const int64_t *seq_idx, const int64_t *pos, const int8_t *strand, uint64_t *coord,
-                     unsigned int *bad, hipStream_t st) {
+                     unsigned int *bad, hipStream_t st, int shift) {
     if (n == 0) return MS_OK;
-    hipLaunchKernelGGL(pack_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, n_dev, seq_idx, pos, strand, coord, bad);
+    hipLaunchKernelGGL(pack_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, n, n_dev, seq_idx, pos, strand, coord, bad, shift);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }

@@ -48,6 +48,10 @@ struct ms_stream {
     uint32_t flags = 0;
     int device = 0;
     int depth = 2;
+    int pack_threads = 8;             // MS_STREAM_HOST_PACK: host threads of the upload stage (MS_PACK_THREADS overrides)
+    void *pack_stage = nullptr;       // ... and the uploader's pinned staging block (grow-only, freed with the stream)
+    size_t pack_stage_bytes = 0;
+    bool upload_only = true;          // the upload stage copies, the scan stage packs (seqset_create_upload_only; MS_MEASURE=1 MS_STREAM_PACK_IN_UPLOAD=1: round 5's form, for A/B runs)
     std::unique_ptr<StagePipeline<Job, ms_stream>> pipe;
 
     void bind_thread() {
@@ -59,7 +63,9 @@ struct ms_stream {
         if (j->rc != MS_OK) return;
         // (kind 2: the "upload" is the cut of the regions out of the resident 2-bit genome, on the set's own stream like a copy)
         const int rc = j->kind == 2 ? ms_seqset_from_genome(j->genome, j->chrom.data(), j->offsets.data(), j->ends.data(), j->n_seqs, &j->seqs)
-                                    : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
+                       : (flags & MS_STREAM_HOST_PACK) ? seqset_create_hostpacked(j->bases, j->offsets.data(), j->n_seqs, pack_threads, &pack_stage, &pack_stage_bytes, &j->seqs)
+                       : upload_only ? seqset_create_upload_only(j->bases, j->offsets.data(), j->n_seqs, &j->seqs)
+                                                       : ms_seqset_create(j->bases, j->offsets.data(), j->n_seqs, 0, &j->seqs);
         if (rc) fail_job(j, rc);
     }
 
@@ -88,7 +94,7 @@ struct ms_stream {
             std::lock_guard<std::mutex> lk_pwm(pwms->mu);
             const bool simple = j->kind != 1 && !(flags & MS_STREAM_DEDUP);
             const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) |
-                                ((simple && (flags & MS_STREAM_PACKED) && !(flags & MS_STREAM_NO_HITS)) ? MS_SCAN_PACK_INTERNAL : 0u);
+                                ((simple && (flags & (MS_STREAM_PACKED | MS_STREAM_PACKED12)) && !(flags & MS_STREAM_NO_HITS)) ? ((flags & MS_STREAM_PACKED12) ? MS_SCAN_PACK12_INTERNAL : MS_SCAN_PACK_INTERNAL) : 0u);
             const bool plain = simple && slot >= 0;
             rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? &pend_slot[slot] : nullptr);
             if (rc == MS_SCAN_PENDING) { rc = MS_OK; pending = true; }
@@ -118,7 +124,7 @@ struct ms_stream {
                 std::lock_guard<std::mutex> lk_dev(c->mu);
                 std::lock_guard<std::mutex> lk_pwm(pwms->mu);
                 const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) | MS_SCAN_NO_PREDICT_INTERNAL |
-                                    (((flags & MS_STREAM_PACKED) && !(flags & MS_STREAM_NO_HITS)) ? MS_SCAN_PACK_INTERNAL : 0u);
+                                    (((flags & (MS_STREAM_PACKED | MS_STREAM_PACKED12)) && !(flags & MS_STREAM_NO_HITS)) ? ((flags & MS_STREAM_PACKED12) ? MS_SCAN_PACK12_INTERNAL : MS_SCAN_PACK_INTERNAL) : 0u);
                 rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res);
             }
         }
@@ -129,8 +135,15 @@ struct ms_stream {
     void download(Job *j) {
         const uint32_t flags = j->flags;
         if (j->rc != MS_OK || (flags & MS_STREAM_NO_HITS)) return;
-        const int rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
-                                                  : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
+        // MS_STREAM_PACKED12: the 12-byte form where the scan could make it (the batch's region indices and positions fit 31 bits), and for
+        // results the scan left without words (sweep spans, de-duplicated batches) if it fits them; the 16-byte form otherwise
+        int rc;
+        if (flags & MS_STREAM_PACKED12) {
+            rc = (j->res->d_coord && !j->res->coord_shift) ? MS_ERR_INVALID : ms_result_hits_packed12_host(j->res, nullptr, nullptr, nullptr);
+            if (rc == MS_ERR_INVALID) rc = ms_result_hits_packed_host(j->res, nullptr, nullptr);
+        } else
+            rc = (flags & MS_STREAM_PACKED) ? ms_result_hits_packed_host(j->res, nullptr, nullptr)
+                                            : ms_result_hits_host(j->res, nullptr, nullptr, nullptr, nullptr);
         if (rc) fail_job(j, rc);
     }
 };
@@ -149,7 +162,7 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     if (!pwms) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
     if (depth < 1 || depth > 16) { set_error("depth must be in [1, 16]"); return MS_ERR_INVALID; }
-    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
+    if (flags & ~(MS_STREAM_DEDUP | MS_STREAM_NO_HITS | MS_STREAM_EXACT_ONLY | MS_STREAM_PACKED | MS_STREAM_HOST_PACK | MS_STREAM_PACKED12)) { set_error("unknown stream flags 0x%x", flags); return MS_ERR_INVALID; }
     DeviceCtx *c;
     int rc = get_ctx(current_device(), &c);             // no device: fail here, loudly, not in a worker
     if (rc) return rc;
@@ -160,6 +173,8 @@ int ms_stream_create(const ms_pwmset *pwms, int strand_mask, uint32_t flags, int
     st->flags = flags;
     st->device = c->device;
     st->depth = depth;
+    if (const char *e = getenv("MS_PACK_THREADS")) st->pack_threads = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = measure_env("MS_STREAM_PACK_IN_UPLOAD")) st->upload_only = !(e[0] == '1');
     try {
         st->pipe.reset(new StagePipeline<Job, ms_stream>(st.get(), depth));
         st->pipe->start();
@@ -282,6 +297,7 @@ int ms_stream_capacity(const ms_stream *st, int *n) {
 void ms_stream_free(ms_stream *st) {
     if (!st) return;
     st->pipe->shutdown(drop_job);
+    if (st->pack_stage) (void) hipHostFree(st->pack_stage);
     DeviceCtx *c = nullptr;
     if (get_ctx(st->device, &c) == MS_OK) {
         std::lock_guard<std::mutex> lk_dev(c->mu);

@@ -63,6 +63,8 @@ def lib():
         L.oracle_max_raw_score.argtypes = [pd, ctypes.c_int32]
         L.oracle_free.restype = None
         L.oracle_free.argtypes = [ctypes.c_void_p]
+        L.oracle_encode.restype = None
+        L.oracle_encode.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int8)]
         _LIB = L
     return _LIB
 
@@ -91,6 +93,14 @@ def flatten_seqs(seqs):
 
 def _p(a, ct):
     return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def convert_seq(bases):
+    """cscore.c:81-114 (convert_seq): bytes -> int8 codes, A/a 0, C/c 1, G/g 2, T/t 3, anything else -1 ("no contribution")."""
+    raw = bytes(bases)
+    out = np.zeros(len(raw), dtype=np.int8)
+    lib().oracle_encode(raw, len(raw), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)))
+    return out
 
 
 def max_raw_score(matrix):

@@ -19,6 +19,7 @@ How the reference is reached (no reference source enters this repo):
 Outputs (all under tests/golden/):
   ref_small.json        G1/G2/G6/G7: known answers of the reference's tests re-run, toy-genome
                         Scanner results, edge cases, matrix numerics, de-dup cases
+  ref_genome.json       N3 (round 6): the toy genome's FASTA / .fai as data, the reference tests' fetch literals, every slice
   ref_random.npz        G3/G4/G5: seeded random PWMs built by the reference's PFM->PPM->PWM,
                         cutoffs from c_score + get_score_cutoffs, sequences with N / soft-mask /
                         IUPAC / short and empty entries; full hit lists for strands 1,2,3;
@@ -533,14 +534,46 @@ def make_579_realistic(R, n_kmers):
           f"{int((np.array(infos) < 6).sum())} motifs under 6 bits)")
 
 
+def make_genome():
+    """ref_genome.json (round 6, N3): the reference tests' toy genome as DATA -- tests/data/genomes/test/test.fa and its .fai, byte for
+    byte -- with the answers the reference's own tests pin for it (tests/test_genome_class.py:14-23: sorted chromosome names, sizes, whole-
+    chromosome fetches; tests/test_scanner.py:17,22: chr1[2:5] = 'TtC', chr1[1:5] = 'aTtC'), every (start, end) slice of every chromosome
+    (pysam's fetch of an in-range request is the 0-based half-open slice, which those literals pin), and two re-wrapped copies of the same
+    records (7 bases per line; CRLF line ends with a description behind the name) that must read back the same."""
+    d = os.path.join(REF, "tests/data/genomes/test")
+    fa = open(os.path.join(d, "test.fa")).read()
+    fai = open(os.path.join(d, "test.fa.fai")).read()
+    chroms = read_fasta(os.path.join(d, "test.fa"))
+    # the literals of tests/test_genome_class.py:14-23
+    assert sorted(chroms) == ["chr1", "chr2", "chrM", "chrX"]
+    assert {k: len(v) for k, v in chroms.items()} == {"chr1": 10, "chr2": 17, "chrM": 15, "chrX": 16}
+    assert chroms["chr1"] == "AaTtCcGgNn" and chroms["chr2"] == "AAAaCCccTTtGNNNNN" and chroms["chrM"] == "AaaaaAAAAAAAnnn" and chroms["chrX"] == "AAACCTACNNTnggAC"
+    assert chroms["chr1"][2:5] == "TtC" and chroms["chr1"][1:5] == "aTtC"        # tests/test_scanner.py:17,22
+    wrapped = "".join(f">{k}\n" + "".join(v[i:i + 7] + "\n" for i in range(0, len(v), 7)) for k, v in chroms.items())
+    crlf = "".join(f">{k} some description\r\n" + "".join(v[i:i + 5] + "\r\n" for i in range(0, len(v), 5)) + "\r\n" for k, v in chroms.items())
+    out = {"files": {"test.fa": fa, "test.fa.fai": fai, "wrapped7.fa": wrapped, "crlf5.fa": crlf},
+           "order": list(chroms), "chroms_sorted": sorted(chroms), "chrom_sizes": {k: len(v) for k, v in chroms.items()},
+           "whole": dict(chroms),
+           "reference_test_fetches": [["chr1", 0, 10, "AaTtCcGgNn"], ["chr2", 0, 17, "AAAaCCccTTtGNNNNN"], ["chrM", 0, 15, "AaaaaAAAAAAAnnn"],
+                                      ["chrX", 0, 16, "AAACCTACNNTnggAC"], ["chr1", 2, 5, "TtC"], ["chr1", 1, 5, "aTtC"]],
+           "all_slices": {k: [[a, b, v[a:b]] for a in range(len(v) + 1) for b in range(a, len(v) + 1)] for k, v in chroms.items()}}
+    with open(os.path.join(HERE, "ref_genome.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+    print("wrote ref_genome.json")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-genome", action="store_true", help="only ref_genome.json (the toy genome's data files and the reference tests' answers for them)")
     ap.add_argument("--skip-579", action="store_true")
     ap.add_argument("--only-579", action="store_true")
     ap.add_argument("--only-lowinfo", action="store_true", help="only the JASPAR-like-information 579-motif side set")
     ap.add_argument("--only-dedup", action="store_true", help="refresh only the de-dup cases of ref_small.json (everything else stays byte for byte)")
     ap.add_argument("--n-kmers", type=int, default=1000000)
     a = ap.parse_args()
+    if a.only_genome:
+        make_genome()
+        sys.exit(0)
     R = import_reference()
     if a.only_lowinfo:
         make_579_realistic(R, a.n_kmers)
@@ -557,5 +590,6 @@ if __name__ == "__main__":
     if not a.only_579:
         make_small(R)
         make_random(R)
+        make_genome()
     if not a.skip_579:
         make_579(R, a.n_kmers)

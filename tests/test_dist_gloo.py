@@ -157,3 +157,138 @@ def test_rank_shard_generation_fits_the_box(monkeypatch):
     # rank 5's share is exactly block 5 of both sets: what the 1-GPU run scans at regions [625 000, 750 000)
     again = synth.make_regions(125_000, 500, seed=1000 * 5 + 1)[0]
     assert np.array_equal(sh["sets"][0][0], again)
+
+
+# ---- the reference-side edits beyond the import swap, extracted and executed ----
+
+def _cli_stub(tmp_dir):
+    """The `motifscan/cli/scan_amd.py` block of INTEGRATION.md section 4, written out and imported."""
+    import importlib.util
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"`motifscan/cli/scan_amd.py`:\s*```python\n(.*?)```", text, re.S).group(1)
+    path = os.path.join(tmp_dir, "scan_amd_stub.py")
+    if not os.path.exists(path):
+        with open(path, "w") as fh:
+            fh.write(code)
+    spec = importlib.util.spec_from_file_location("scan_amd_stub", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _Genome:
+    def __init__(self, chroms):
+        self._c = chroms
+        self.chrom_sizes = {k: len(v) for k, v in chroms.items()}
+
+    def fetch_sequence(self, chrom, start, end):
+        return self._c[chrom][start:end]
+
+
+class _Region:
+    def __init__(self, chrom, start, end):
+        self.chrom, self.start, self.end, self.summit = chrom, start, end, (start + end) // 2
+
+
+class _Pwm:
+    def __init__(self, i, m, cut):
+        self.matrix, self.cutoffs, self.length = m, {"1e-4": cut}, m.shape[1]
+        self.matrix_id, self.name = f"MA{i:04d}.1", f"motif{i}"
+
+
+def cli_job(n_pwms=20):
+    """A toy `motifscan scan` job: a 3-chromosome genome, 90 input regions, 130 control regions, windows of 200 bp, n_pwms motifs."""
+    from motifscan_amd import synth
+    vals, widths, cutoffs = synth.load_motif_set(n_pwms)
+    mats = synth.matrices_of(vals, widths)
+    bases, off = synth.make_regions(3, 6000, seed=9, frac_n=0.03)
+    raw = bases.tobytes().decode()
+    chroms = {f"chr{k + 1}": raw[int(off[k]):int(off[k + 1])] for k in range(3)}
+    rng = np.random.default_rng(17)
+
+    def regions(n):
+        out = []
+        for _ in range(n):
+            c = f"chr{int(rng.integers(1, 4))}"
+            a = int(rng.integers(0, 5600))
+            out.append(_Region(c, a, a + int(rng.integers(50, 400))))
+        return out
+    return _Genome(chroms), [_Pwm(i, m, c) for i, (m, c) in enumerate(zip(mats, cutoffs))], regions(90), regions(130)
+
+
+def expected_enrichment(pwms, sites_in, sites_ctl):
+    """stats.py:18-45 as the reference runs it, on nested lists (the checker's own copy of the arithmetic; scipy's Fisher test)."""
+    from scipy.stats import fisher_exact
+    rows, n_motifs = [], len(sites_in)
+    for pwm, a_l, c_l in zip(pwms, sites_in, sites_ctl):
+        nt, ct = len(a_l), len(c_l)
+        a, c = sum(len(x) > 0 for x in a_l), sum(len(x) > 0 for x in c_l)
+        fold = a * ct / c / nt if nt > 0 and c > 0 else np.nan
+        table = [[a, nt - a], [c, ct - c]]
+        pe, pd_ = fisher_exact(table, "greater")[1], fisher_exact(table, "less")[1]
+        rows.append((pwm.matrix_id + "," + pwm.name, a, c, fold, pe, pd_, min(min(pe, pd_) * n_motifs, 1)))
+    return rows
+
+
+def oracle_nested(pwms, scanner, strand=3):
+    from oracle import oracle
+    flat = oracle.c_scan_motif([p.matrix.tolist() for p in pwms], [p.cutoffs["1e-4"] for p in pwms], list(scanner.sequences), strand, 2)
+    return oracle.make_motif_sites(flat, list(scanner.seq_starts))
+
+
+def same_results(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert tuple(g)[:3] == w[:3]
+        for x, y in zip(tuple(g)[3:], w[3:]):
+            assert (np.isnan(x) and np.isnan(y)) or x == y
+
+
+def _cli_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import pickle
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stub = _cli_stub(out_dir if rank == 0 else os.path.join(out_dir, "r1"))
+        genome, pwms, regions, control = cli_job()
+        sites, results = stub.run_sharded(genome, pwms, regions, control, 200, "both", "1e-4", rank, world, scan_fn=oracle_scan)
+        with open(os.path.join(out_dir, f"cli_rank{rank}.pkl"), "wb") as fh:
+            pickle.dump({"sites": {k: np.asarray(v) for k, v in sites.items()}, "results": [tuple(r) for r in results]}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_integration_stub_of_the_sharded_cli_run(tmp_path):
+    """the rank-sharded `run()` a maintainer would write, extracted from the document and run as two ranks
+    over gloo (the local scan injected: the oracle).  Every rank ends with the enrichment results of the WHOLE job -- equal to
+    stats.py:18-45 run on the nested lists of a single-process scan -- and the ranks' input sites, in rank order, are the
+    single-process sites with global region indices and genome coordinates."""
+    import pickle
+    import torch.multiprocessing as mp
+    from motifscan_amd.scanner import Scanner
+    os.makedirs(tmp_path / "r1", exist_ok=True)
+    world, port = 2, _free_port()
+    mp.spawn(_cli_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [pickle.load(open(tmp_path / f"cli_rank{k}.pkl", "rb")) for k in range(world)]
+    genome, pwms, regions, control = cli_job()
+    sc_in, sc_ctl = Scanner(genome, regions, window_size=200), Scanner(genome, control, window_size=200)
+    nested_in, nested_ctl = oracle_nested(pwms, sc_in), oracle_nested(pwms, sc_ctl)
+    want = expected_enrichment(pwms, nested_in, nested_ctl)
+    same_results(r[0]["results"], want)
+    same_results(r[1]["results"], want)
+    assert sum(w[1] for w in want) > 20 and sum(w[2] for w in want) > 20
+    assert r[0]["sites"]["rows"][1] == r[1]["sites"]["rows"][0] and r[1]["sites"]["rows"][1] == len(regions)
+    for m in range(len(pwms)):
+        got = []
+        for k in range(world):
+            s = r[k]["sites"]
+            a, b = int(s["motif_offsets"][m]), int(s["motif_offsets"][m + 1])
+            got += list(zip(s["region"][a:b].tolist(), s["start"][a:b].tolist(), s["score"][a:b].tolist(), ["+" if x == 1 else "-" for x in s["strand"][a:b].tolist()]))
+        flat = [(ri, st.start, st.score, st.strand) for ri, per in enumerate(nested_in[m]) for st in per]
+        assert got == flat
+

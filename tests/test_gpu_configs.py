@@ -424,6 +424,134 @@ def test_stream_counts_only_errors_and_pinned_input(oracle):
         _lib.Stream(pw, 3, 0, depth=0)
 
 
+def test_twelve_byte_copy_out_where_it_fits_sixteen_where_not(oracle):
+    """MS_STREAM_PACKED12 / ms_result_hits_packed12_host (VERDICT r5 #2a): coord32 = region << shift | pos << 1 | strand + the fp64 score --
+    12 bytes per hit on the host link -- for every batch whose region indices and positions fit 31 bits; a batch that does not fit comes
+    out in the 16-byte form by itself (ms_result_packed_form says which).  Both forms decode to the oracle's hits; a result that holds
+    one form refuses the other's accessor; a single scan (no stream) can be read in either."""
+    vals, widths, cutoffs = synth.load_motif_set(60)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    b1, o1 = synth.make_regions(900, 400, seed=5, frac_n=0.04, ragged=True)             # 10 + 9 + 1 bits: fits
+    b2, o2 = synth.make_regions(3, 70000, seed=6, frac_n=0.01)                           # fits (2 + 17 + 1)
+    lens = np.r_[np.full(70000, 1), [40000]]                                             # 17 bits of region index + 16 of position: does not fit
+    rng = np.random.default_rng(8)
+    b3 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(lens.sum()))]
+    o3 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    batches = [(b1, o1), (b2, o2), (b3, o3)]
+    forms = []
+    for (b_, o_), res in zip(batches, _lib.scan_stream(pw, iter(batches), 3, packed=12)):
+        forms.append(res.packed_form())
+        got = res.hits(packed=True)
+        want = oracle.scan_arrays(vals, widths, cutoffs, b_.tobytes(), o_, 3, 8)
+        for k in ("motif_offsets", "seq_idx", "pos", "score"):
+            assert np.array_equal(got[k], want[k]), (forms, k)
+        assert np.array_equal(got["strand"].astype(np.int32), want["strand"])
+        with pytest.raises(ValueError):
+            res.hits(packed=16 if forms[-1] == 12 else 12)                               # the form the stream did not make for this batch
+        res.close()
+    assert forms == [12, 12, 16]
+    # the 16-byte stream is unchanged
+    for (b_, o_), res in zip(batches[:1], _lib.scan_stream(pw, iter(batches[:1]), 3, packed=True)):
+        assert res.packed_form() == 16 and res.hits(packed=True)["pos"].size == res.n_hits
+        res.close()
+    # a plain scan: either form on demand, and back to the plain arrays
+    sq = _lib.SeqSet(b1, o1)
+    res = _lib.scan(pw, sq, 3)
+    want = oracle.scan_arrays(vals, widths, cutoffs, b1.tobytes(), o1, 3, 8)
+    for form in (12, 16, 12):
+        got = res.hits(packed=form)
+        assert res.packed_form() == form
+        assert all(np.array_equal(got[k], want[k]) for k in ("seq_idx", "pos", "score"))
+    assert np.array_equal(res.hits()["pos"], want["pos"])
+    res.dedup(pw)
+    got = res.hits(packed=12)
+    assert got["pos"].size == res.n_hits and np.array_equal(got["pos"], res.hits()["pos"])
+    res.close(); sq.close(); pw.close()
+
+
+def test_stream_packs_on_the_scan_stage_and_the_old_form_agrees(oracle, monkeypatch):
+    """Round 6: a batch stream's upload stage only copies (ASCII + offsets on the DMA engines); pack_kernel / blk2reg_kernel run on the scan
+    stream in front of the batch's pre-filter (seqset_create_upload_only / seqset_pack_pending).  Same results as round 5's form (packing on
+    the upload stream, MS_MEASURE=1 MS_STREAM_PACK_IN_UPLOAD=1) and as the oracle, for plain batches, counts-only batches and sweep spans."""
+    vals, widths, cutoffs = synth.load_motif_set(80)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    bases, offsets = synth.make_regions(2400, 300, seed=12, frac_n=0.05, ragged=True)
+    cuts = [0, 300, 301, 1500, 2400]
+    batches = [(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a], k == 2) for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    outs = {}
+    for mode in ("scan_stage", "upload_stage"):
+        if mode == "upload_stage":
+            monkeypatch.setenv("MS_MEASURE", "1")
+            monkeypatch.setenv("MS_STREAM_PACK_IN_UPLOAD", "1")
+        parts, counts = [], np.zeros(len(widths), dtype=np.int64)
+        for (b_, o_, co), (a, _), res in zip(batches, zip(cuts[:-1], cuts[1:]), _lib.scan_stream(pw, iter(batches), 3, packed=12)):
+            counts += res.region_counts()
+            if not co:
+                parts.append((res.hits(packed=True), a))
+            res.close()
+        outs[mode] = (_lib.merge_hits(parts, len(widths)), counts)
+    monkeypatch.undo()
+    sel = (want["seq_idx"] < 301) | (want["seq_idx"] >= 1500)
+    for mode, (merged, counts) in outs.items():
+        for k in ("seq_idx", "pos", "score"):
+            assert np.array_equal(merged[k], want[k][sel]), (mode, k)
+        pair = np.unique((np.repeat(np.arange(len(widths)), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
+        assert np.array_equal(counts, np.bincount(pair >> 32, minlength=len(widths)))
+    # a sweep span through the stream (kind 1) takes the same upload-only path
+    g, _ = synth.make_regions(1, 50000, seed=3, frac_n=0.02)
+    spans = list(_lib.sweep_stream(pw, [g], 200, 50, 20000, 3))
+    n_sites = sum(r.n_hits for _, r in spans)
+    rg = _lib.ResidentGenome({"c": g})
+    ref = _lib.scan_sweep(pw, rg, 0, 0, 50000, 200, 50, 3)
+    assert n_sites == ref.n_hits and n_sites > 100
+    for _, r in spans:
+        r.close()
+    ref.close(); rg.close(); pw.close()
+
+
+def test_host_packed_sets_and_streams_equal_device_packed_ones(oracle):
+    """ms_seqset_create_hostpacked / MS_STREAM_HOST_PACK: convert_seq and the region hints made by host threads, no kernel in the upload
+    stage.  The set scans to the same hits as the device-packed one (ragged regions incl. empty ones, runs of N, lower case, IUPAC letters,
+    an unaligned tail), and a stream of host-packed batches -- hits out and counts-only mixed -- equals the oracle."""
+    vals, widths, cutoffs = synth.load_motif_set(120)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    rng = np.random.default_rng(77)
+    bases, offsets = synth.make_regions(3001, 333, seed=31, frac_n=0.08, ragged=True)
+    bases = bases.copy()
+    for ch in b"RYKMSWryn-*":                                         # letters that "add nothing" (cscore.c:92-111)
+        bases[rng.integers(0, bases.size, 40)] = ch
+    lens = np.diff(offsets)
+    lens[[5, 6, 900]] = 0                                             # empty regions
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bases = bases[:int(offsets[-1])]
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, 3, 8)
+    for threads in (1, 5):
+        sq = _lib.SeqSet(bases, offsets, host_pack_threads=threads)
+        res = _lib.scan(pw, sq, 3)
+        assert_same_hits(res.hits(), want)
+        res.close(); sq.close()
+    cuts = [0, 1, 700, 700, 2200, 3001]
+    batches = [(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a], k == 3) for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+    parts, st = [], {}
+    results = list(_lib.scan_stream(pw, iter(batches), 3, packed=True, host_pack=True, stage_stats=st))
+    for (b_, o_, counts_only), (a, _), res in zip(batches, zip(cuts[:-1], cuts[1:]), results):
+        ref = _lib.scan(pw, _lib.SeqSet(b_, o_), 3)
+        assert res.n_hits == ref.n_hits and np.array_equal(res.region_counts(), ref.region_counts())
+        if not counts_only:
+            parts.append((res.hits(packed=True), a))
+        res.close(); ref.close()
+    merged = _lib.merge_hits(parts, len(widths))
+    # (the counts-only batch is regions [700, 2200): its hits stay on the device)
+    sel = (want["seq_idx"] < 700) | (want["seq_idx"] >= 2200)
+    wm = np.repeat(np.arange(len(widths)), np.diff(want["motif_offsets"]))
+    for k in ("seq_idx", "pos", "score"):
+        assert np.array_equal(merged[k], want[k][sel])
+    assert np.array_equal(np.repeat(np.arange(len(widths)), np.diff(merged["motif_offsets"])), wm[sel])
+    assert st["upload"]["batches"] == len(batches)
+    pw.close()
+
+
 def test_stream_stage_clocks_and_block_pool_statistics():
     """ms_stream_stats counts every batch once per stage and its clocks are sane; ms_device_pool_stats: a second pass over the
     same batches is served from the block cache (size classes), not by the driver."""
@@ -881,3 +1009,45 @@ def test_overlapping_regions_are_scanned_once_with_identical_result(oracle, jasp
     a = sc.scan_motifs_arrays([P(mats[i], c, w) for i, c, w in zip(sel, cutoffs, widths)])
     assert np.array_equal(a["region"], want["seq_idx"]) and np.array_equal(a["start"], st[want["seq_idx"]] + want["pos"])
     assert np.array_equal(a["score"], want["score"])
+
+
+def test_integration_stub_of_the_cli_edits_on_the_gpu(oracle, tmp_path):
+    """INTEGRATION.md section 4, executed on the GPU: (a) `scan_and_enrich` -- input sites through Scanner.scan_motifs, the control set
+    through Scanner.count_regions_with_sites (no site leaves the device) -- gives the enrichment rows stats.py:18-45 computes from the
+    oracle's nested lists; (b) `run_sharded` with the library's own local scan (dist.gpu_scan: the shard through an ms_stream) as one
+    rank, and as the two ranks of a 2-GPU job run one after the other (no process group: each call returns its LOCAL counts, which must
+    add up to the whole job's)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dist_gloo_helpers", os.path.join(ROOT, "tests", "test_dist_gloo.py"))
+    hlp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hlp)
+    stub = hlp._cli_stub(str(tmp_path))
+    genome, pwms, regions, control = hlp.cli_job(n_pwms=40)
+    sc_in, sc_ctl = scanner.Scanner(genome, regions, window_size=200), scanner.Scanner(genome, control, window_size=200)
+    nested_in = oracle.deduplicate_motif_sites(hlp.oracle_nested(pwms, sc_in), [p.length for p in pwms])
+    nested_ctl = hlp.oracle_nested(pwms, sc_ctl)
+    want = hlp.expected_enrichment(pwms, nested_in, nested_ctl)
+    motif_sites, results = stub.scan_and_enrich(genome, pwms, regions, control, 200, "both", "1e-4")
+    hlp.same_results(results, want)
+    assert motif_sites == [[[tuple(s) for s in per] for per in m] for m in nested_in]        # (a)'s sites are the reference's, de-duplicated
+    assert sum(w[1] for w in want) > 40
+    sites1, results1 = stub.run_sharded(genome, pwms, regions, control, 200, "both", "1e-4", 0, 1)
+    hlp.same_results(results1, want)
+    parts = [stub.run_sharded(genome, pwms, regions, control, 200, "both", "1e-4", k, 2) for k in range(2)]
+    assert [sum(x) for x in zip(*[[r.n_input for r in res] for _, res in parts])] == [w[1] for w in want]
+    assert [sum(x) for x in zip(*[[r.n_control for r in res] for _, res in parts])] == [w[2] for w in want]
+    assert parts[0][0]["rows"][1] == parts[1][0]["rows"][0]
+    raw_in = hlp.oracle_nested(pwms, sc_in)                                                     # the sharded scan leaves de-duplication to the writer
+    for m in range(len(pwms)):
+        flat = [(ri, st.start, st.score, 1 if st.strand == "+" else 2) for ri, per in enumerate(raw_in[m]) for st in per]
+        got = []
+        for s, _ in [(sites1, None)]:
+            a, b = int(s["motif_offsets"][m]), int(s["motif_offsets"][m + 1])
+            got += list(zip(s["region"][a:b].tolist(), s["start"][a:b].tolist(), s["score"][a:b].tolist(), s["strand"][a:b].tolist()))
+        assert got == flat
+        got2 = []
+        for s, _ in parts:
+            a, b = int(s["motif_offsets"][m]), int(s["motif_offsets"][m + 1])
+            got2 += list(zip(s["region"][a:b].tolist(), s["start"][a:b].tolist(), s["score"][a:b].tolist(), s["strand"][a:b].tolist()))
+        assert got2 == flat
+

@@ -252,6 +252,85 @@ def test_resident_genome_extraction_equals_host_strings(rnd):
         rg.extract([7], [0], [10])
 
 
+def test_genome_file_fasta_to_packed_to_resident(rnd, small, tmp_path):
+    """N3 finished: FASTA -> PackedGenome (host packer) -> genome file -> ResidentGenome.load (planes uploaded as they
+    are, ms_genome_create_packed) -- regions cut from the LOADED file scan to exactly the reference-made G4 hits, equal the regions cut
+    from a genome packed on the device from the same strings, and `sequences` come back with the FASTA's own case; the toy genome of
+    the reference's tests gives its G2 answers through the same path; a damaged plane is refused by the library."""
+    import ctypes
+    from motifscan_amd import genome
+    names = [str(x) for x in rnd["g4_chrom_names"]]
+    raw = rnd["g4_chrom_bytes"].tobytes().decode()
+    n = len(raw) // len(names)
+    chroms = {nm: raw[i * n:(i + 1) * n] for i, nm in enumerate(names)}
+    fa = tmp_path / "g4.fa"
+    with open(fa, "w") as fh:
+        for nm, s in chroms.items():
+            fh.write(f">{nm} synthetic\n" + "".join(s[i:i + 61] + "\n" for i in range(0, len(s), 61)))
+    path = str(tmp_path / "g4.msg")
+    rg0 = _lib.ResidentGenome.from_fasta(str(fa))
+    rg0.save(path)
+    rg = _lib.ResidentGenome.load(path)
+    assert rg.chrom_sizes == {k: len(v) for k, v in chroms.items()} and rg.names == names
+
+    class Reg:
+        def __init__(self, row):
+            self.chrom, self.start, self.end, self.summit = names[int(row[0])], int(row[1]), int(row[2]), int(row[3])
+
+    class P:
+        def __init__(self, m, c):
+            self.matrix, self.cutoffs, self.length = m, {"1e-3": c}, m.shape[1]
+
+    pw = [P(m, c) for m, c in zip(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])]
+    regs = [Reg(r) for r in rnd["g4_regions"]]
+    for wsize, dup in ((0, True), (201, True)):
+        tag = f"g4_w{wsize}_dup{int(dup)}_both"
+        sc = scanner.Scanner(rg, regs, window_size=wsize, p_value="1e-3", remove_dup=dup)
+        a = sc.scan_motifs_arrays(pw)
+        for k, g in (("motif", "_motif"), ("region", "_region"), ("start", "_start"), ("strand", "_strand"), ("score", "_score")):
+            assert np.array_equal(a[k], rnd[tag + g]), (tag, k)
+        assert sc.sequences[5] == chroms[regs[5].chrom][sc.seq_starts[5]:sc.seq_ends[5]]      # case and N as in the FASTA
+    # the planes on the device: loaded file == packed on the device from the strings (pack_kernel) == host packer
+    rd = _lib.ResidentGenome(chroms)
+    pa, pb = rd.packed(), rg.packed()
+    assert np.array_equal(np.asarray(pa.codes), np.asarray(pb.codes)) and np.array_equal(np.asarray(pa.nmask), np.asarray(pb.nmask))
+    rng = np.random.default_rng(11)
+    ci = rng.integers(0, len(names), size=400)
+    st = rng.integers(0, n - 90, size=400)
+    en = st + rng.integers(0, 90, size=400)
+    pws = _lib.PwmSet.from_matrices(rnd["mats"], rnd["cutoff_by_key"]["1e-3"])
+    h1 = _lib.scan(pws, rg.extract(ci, st, en), 3).hits()
+    h2 = _lib.scan(pws, _lib.SeqSet.from_strings([chroms[names[c]][a:b] for c, a, b in zip(ci, st, en)]), 3).hits()
+    assert len(h1["pos"]) > 100 and all(np.array_equal(h1[k], h2[k]) for k in ("seq_idx", "pos", "score", "strand", "motif_offsets"))
+    # the reference tests' toy genome (G2) through FASTA -> file -> resident genome
+    g2 = small["G2"]
+    toy = tmp_path / "test.fa"
+    with open(toy, "w") as fh:
+        for nm, s in g2["chroms"].items():
+            fh.write(f">{nm}\n{s}\n")
+    _lib.ResidentGenome.from_fasta(str(toy)).save(str(tmp_path / "test.msg"))
+    tg = _lib.ResidentGenome.load(str(tmp_path / "test.msg"))
+
+    class R1:
+        chrom, start, end, summit = g2["region"][0], g2["region"][1], g2["region"][2], (g2["region"][1] + g2["region"][2]) // 2
+    s0 = scanner.Scanner(tg, [R1], window_size=0)
+    s4 = scanner.Scanner(tg, [R1], window_size=4, strand="+")
+    assert [list(s0.sequences), list(s0.seq_starts), list(s0.seq_ends)] == g2["extract"]["w0"]
+    assert [list(s4.sequences), list(s4.seq_starts), list(s4.seq_ends)] == g2["extract"]["w4"]
+    pwm = matrix.PositionWeightMatrix(g2["pwm"], cutoffs=g2["cutoffs"])
+    for case in g2["cases"]:
+        sc = scanner.Scanner(tg, [R1], window_size=case["window_size"], p_value=case["p_value"], remove_dup=case["remove_dup"])
+        got = [[0, 0, int(s.start), float(s.score), s.strand] for s in sc.scan_motifs([pwm])[0][0]]
+        assert got == case["sites"]
+    # a plane that breaks the layout's invariants never reaches the device
+    bad = genome.PackedGenome(pb.names, pb.offsets, np.array(pb.codes, dtype=np.uint32), np.array(pb.nmask, dtype=np.uint32))
+    k = int(np.flatnonzero(bad.nmask)[0])
+    bad.codes[2 * k] = 0xFFFFFFFF
+    bad.codes[2 * k + 1] = 0xFFFFFFFF
+    with pytest.raises(ValueError):
+        _lib.ResidentGenome.from_packed(bad)
+
+
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("dup", [False, True])
 def test_scanner_batches_equal_the_single_call(rnd, resident, dup):

@@ -599,6 +599,36 @@ def test_both_library_variants_export_the_same_cabi():
     assert out[0] == "1" and out[1].endswith("libmotifscan_amd_noasm.so")
 
 
+def test_host_packer_is_convert_seq_word_for_word():
+    """ms_seqset_create_hostpacked's packer (ms_hostpack.cpp: AVX2 + BMI2 with a scalar tail) against a numpy restatement of convert_seq
+    (cscore.c:81-114: case folded, anything but ACGT "adds nothing") in the device layout: 2-bit codes 16 per word (non-ACGT -> 0), one
+    mask bit per base, positions past the end neither N nor coded; and the region hints against a direct search."""
+    rng = np.random.default_rng(41)
+    alphabet = np.frombuffer(b"ACGTacgtNnRYKMSWBDHVU-*. \x00\xff@`", dtype=np.uint8)
+    for n_seqs, lo, hi in ((1, 0, 1), (1, 31, 34), (7, 0, 70), (300, 1, 400), (3, 5000, 9000), (50, 64, 65)):
+        lens = rng.integers(lo, hi, size=n_seqs)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        n = int(offsets[-1])
+        bases = alphabet[rng.choice(len(alphabet), size=n, p=np.r_[np.full(8, 0.11), np.full(len(alphabet) - 8, 0.12 / (len(alphabet) - 8))])]
+        codes, nmask, blk, info = _lib.host_pack(bases, offsets)
+        up = bases | 0x20
+        code = np.select([up == ord("a"), up == ord("c"), up == ord("g"), up == ord("t")], [0, 1, 2, 3], default=0).astype(np.uint64)
+        isn = ~np.isin(up, np.frombuffer(b"acgt", dtype=np.uint8))
+        units = (n + 31) // 32
+        pad_c, pad_n = np.zeros(32 * units, dtype=np.uint64), np.zeros(32 * units, dtype=np.uint64)
+        pad_c[:n], pad_n[:n] = code, isn
+        want_cw = (pad_c.reshape(units, 32) << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+        want_nw = (pad_n.reshape(units, 32) << np.arange(32, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+        assert np.array_equal(codes.reshape(units, 2)[:, 0].astype(np.uint64) | (codes.reshape(units, 2)[:, 1].astype(np.uint64) << np.uint64(32)), want_cw)
+        assert np.array_equal(nmask.astype(np.uint64), want_nw)
+        R = n_seqs
+        for b in range(len(blk)):
+            r = max(int(np.searchsorted(offsets[:R], 64 * b, side="right")) - 1, 0)      # the last region that starts at or before the block
+            assert blk[b] == r
+            o = [int(offsets[min(r + k, R)]) - 64 * b for k in range(3)]
+            assert info[b].tolist() == [r] + o
+
+
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
     """measurement variables alone must not change what the library does; the retired engine / variant / tail switches
     of rounds 1-2 change nothing at all (host-visible part: the plan)."""
@@ -614,3 +644,20 @@ def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
             monkeypatch.setenv("MS_MEASURE", measure)
         other = _lib.PwmSet(vals[:4 * int(widths[:n].sum())], widths[:n], cutoffs[:n, 2]).plan(3)
         assert all(np.array_equal(base[k], other[k]) for k in ("group_fields", "rows", "bias", "group_kb"))
+
+
+def test_integration_c_stub_of_the_collective_compiles(tmp_path):
+    """how a compiled host runs the one collective on ms_result_region_counts_device's vector (RCCL ncclAllReduce,
+    int64, 2 x n_pwms).  The block is extracted and compiled as plain C against include/ and the image's HIP / RCCL headers (no multi-GPU
+    node here to run it on)."""
+    import shutil, subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"A compiled host\*\* does \(b\).*?```c\n(.*?)```", text, re.S).group(1)
+    if not (shutil.which("gcc") and os.path.exists("/opt/rocm/include/rccl/rccl.h")):
+        pytest.skip("no gcc / RCCL headers")
+    (tmp_path / "stub.c").write_text(code)
+    out = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                          "-I" + os.path.join(ROOT, "include"), str(tmp_path / "stub.c")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "ncclAllReduce" in code and "ncclInt64" in code and "ms_result_region_counts_device" in code
+
