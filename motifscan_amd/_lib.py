@@ -610,10 +610,30 @@ def pool_stats():
             "cached_bytes": int(out[4]), "cached_blocks": int(out[5])}
 
 
+_warned_exact_only = set()
+
+
+def _fence_exact_only(res, pwms, flags=0):
+    """motifs the pre-filter cannot take -- wider than 63 columns, max_raw <= 0, non-finite entries, a cutoff under the
+    quantiser's floor -- are scored in fp64 at EVERY window (exact_all_kernel: correct, the reference's arithmetic, but with no performance
+    floor: ~1000 x the cost per motif of the matrix-core path; the reference itself has no width limit, cscore.c:50-51).  Never silent:
+    one warning per PWM set with the number of such motifs (MS_SCAN_EXACT_ONLY scans -- validation -- are the caller's own choice)."""
+    if (flags & MS_SCAN_EXACT_ONLY) or id(pwms) in _warned_exact_only:
+        return res
+    st = res.stats()
+    if st["n_pwms_exact"] > 0:
+        _warned_exact_only.add(id(pwms))
+        import warnings
+        warnings.warn(f"{st['n_pwms_exact']} of {st['n_pwms']} PWMs cannot take the matrix-core pre-filter (wider than 63 columns, max_raw <= 0, "
+                      f"non-finite entries or a cutoff below the quantiser's floor) and are scored in fp64 at every window: same results, "
+                      f"roughly 1000 x the device time per such motif (fp64 stage of this scan: {st['ms_exact']:.1f} ms of {st['ms_total']:.1f} ms)", RuntimeWarning, stacklevel=3)
+    return res
+
+
 def scan(pwms, seqs, strand_mask=3, flags=MS_SCAN_DEFAULT):
     h = ctypes.c_void_p()
     check(lib().ms_scan(pwms.h, seqs.h, int(strand_mask), int(flags), ctypes.byref(h)))
-    return ScanResult(h, pwms.n)
+    return _fence_exact_only(ScanResult(h, pwms.n), pwms, int(flags))
 
 
 def scan_sweep(pwms, genome, chrom, begin, end, window, stride, strand_mask=3, flags=MS_SCAN_DEFAULT):
@@ -623,7 +643,7 @@ def scan_sweep(pwms, genome, chrom, begin, end, window, stride, strand_mask=3, f
     h = ctypes.c_void_p()
     check(lib().ms_scan_sweep(pwms.h, genome.h, ci, int(begin), int(end), int(window), int(stride), int(strand_mask),
                               int(flags), ctypes.byref(h)))
-    return ScanResult(h, pwms.n)
+    return _fence_exact_only(ScanResult(h, pwms.n), pwms, int(flags))
 
 
 class PinnedBuffer:
@@ -658,6 +678,7 @@ class Stream:
 
     def __init__(self, pwms, strand_mask=3, flags=0, depth=2):
         self.pwms = pwms                               # keep alive
+        self.flags = int(flags)
         h = ctypes.c_void_p()
         check(lib().ms_stream_create(pwms.h, int(strand_mask), int(flags), int(depth), ctypes.byref(h)))
         self.h = h
@@ -708,7 +729,7 @@ class Stream:
         finally:
             if self._keep:
                 self._keep.pop(0)                      # returned or failed: either way the batch no longer borrows its buffer
-        return ScanResult(h, self.pwms.n) if h.value else None
+        return _fence_exact_only(ScanResult(h, self.pwms.n), self.pwms, MS_SCAN_EXACT_ONLY if self.flags & MS_STREAM_EXACT_ONLY else 0) if h.value else None
 
     def stats(self):
         """ms_stream_stats: per stage {batches, ms_work, ms_wait_in, ms_wait_out}; the stage that waits least bounds the stream."""
@@ -827,7 +848,7 @@ def scan_regions_once(pwms, genome, chrom_idx, starts, ends, strand_mask=3, flag
     h = ctypes.c_void_p()
     check(lib().ms_scan_regions_once(pwms.h, genome.h, ptr(ci, ctypes.c_int32), ptr(st, ctypes.c_int64), ptr(en, ctypes.c_int64),
                                      len(ci), int(strand_mask), int(flags), ctypes.byref(h)))
-    return ScanResult(h, pwms.n)
+    return _fence_exact_only(ScanResult(h, pwms.n), pwms, int(flags))
 
 
 def union_bases(chrom_idx, starts, ends):
