@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--strand", default="both", choices=["both", "+", "-"], help="the reference's --strand (cli/main.py:543); default both")
     ap.add_argument("--motif-set", default="benchmark", choices=["benchmark", "lowinfo"],
                     help="lowinfo: the JASPAR-like-information side set (informative core, weak flanks, 10 %% weak motifs); a side workload, the line says so")
+    ap.add_argument("--host-pack", action="store_true", help="end-to-end legs: convert_seq on the stream's host threads (MS_STREAM_HOST_PACK: 0.69 B/base over the link "
+                    "instead of 1, no pack kernel) -- an option for multi-GPU nodes whose host link is the bound; slower at N = 1 (profiles/r05_host_packed_upload.log)")
     ap.add_argument("--extra-widths", default="", help="comma list: append one synthetic motif of each of these widths (side workload: motifs wider than the set holds)")
     a = ap.parse_args()
     strand_mask = {"both": 3, "+": 1, "-": 2}[a.strand]
@@ -571,10 +573,16 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     from motifscan_amd import _lib, dist as msdist
     pins, batches, cuts = [], [], []
     n_sets = len(wl["sets"])
+    # the rank's main thread onto the GPU's NUMA node BEFORE it allocates its pinned input (first touch places the pages): the library's
+    # policy -- multi-GPU nodes with more than one NUMA node, MS_NUMA_BIND=0/1 overrides (ms_numa.cpp); the stream's threads bind themselves
+    numa_node = _lib.numa_bind_thread()
+    t_pin = time.perf_counter()
     for k, (bases, offsets) in enumerate(wl["sets"]):
         pin = _lib.PinnedBuffer(max(bases.size, 1))
         pin.array[:bases.size] = bases
         pins.append(pin)
+    t_pin = time.perf_counter() - t_pin
+    for k, (bases, offsets) in enumerate(wl["sets"]):
         # batches grow from --batch-regions / 4 to --max-batch-regions at the start of a pass and shrink again at its end
         # (dist.batch_bounds): the pass begins with an upload nothing overlaps and ends with a copy-out nothing overlaps
         for r0, r1 in msdist.batch_bounds(len(offsets) - 1, a.batch_regions, ramp=not a.no_batch_ramp, max_batch=a.max_batch_regions,
@@ -586,15 +594,21 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
         batches.append((pins[k].array[lo:hi], np.ascontiguousarray(offsets[r0:r1 + 1] - lo)))
     units = float(wl["units"])
 
-    def timed(fn, passes):
+    own = {}                                            # this rank's own seconds and process CPU seconds per leg (the per-rank report at N > 1)
+
+    def timed(fn, passes, name=None):
         fn()                                            # warm: pools, pinned blocks (they take two passes to reach their steady sizes:
         fn()                                            # tools/e2e_phases.py -- 195, 93, 63, 62, 60 ms for passes 0 ... 4)
         if dist is not None:
             dist.barrier()
+        c0 = os.times()
         t0 = time.perf_counter()
         hits = 0
         for _ in range(passes):
             hits += fn()
+        if name:
+            c1 = os.times()
+            own[name] = ((time.perf_counter() - t0) / passes, (c1.user + c1.system - c0.user - c0.system) / passes)
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         u = torch.tensor([units * passes], dtype=torch.float64, device=dev)
         if dist is not None:
@@ -609,7 +623,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
             n = 0
             st = stages.setdefault({12: "pipelined", 16: "pipelined_16B"}.get(packed, "pipelined_25B"), {})
             dev_ms = {"prefilter": 0.0, "fp64_stage": 0.0, "sort": 0.0, "finalize": 0.0, "scan_total": 0.0, "clock_mhz_sum": 0.0}
-            for res in _lib.scan_stream(pw, iter(batches), strand_mask, 0, depth=2, packed=packed, stage_stats=st):
+            for res in _lib.scan_stream(pw, iter(batches), strand_mask, 0, depth=2, packed=packed, stage_stats=st, host_pack=a.host_pack):
                 n += res.n_hits                         # the arrays are already in pinned host memory at this point
                 s_ = res.stats()
                 for k_, f_ in (("prefilter", "ms_prefilter"), ("fp64_stage", "ms_exact"), ("sort", "ms_sort"), ("finalize", "ms_finalize"),
@@ -639,7 +653,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
 
         def run():
             n = 0
-            for res in _lib.scan_stream(pw, iter(bl), strand_mask, 0, depth=2, packed=12):
+            for res in _lib.scan_stream(pw, iter(bl), strand_mask, 0, depth=2, packed=12, host_pack=a.host_pack):
                 n += res.n_hits
                 res.close()
             return n
@@ -652,7 +666,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     def pipelined_cli():
         n = 0
         st = stages.setdefault("pipelined_cli", {})
-        for res, (_, _, counts_only) in zip(_lib.scan_stream(pw, iter(cli_batches), strand_mask, 0, depth=2, packed=12, stage_stats=st), cli_batches):
+        for res, (_, _, counts_only) in zip(_lib.scan_stream(pw, iter(cli_batches), strand_mask, 0, depth=2, packed=12, stage_stats=st, host_pack=a.host_pack), cli_batches):
             if not counts_only:
                 n += res.n_hits                         # in pinned host memory
             res.region_counts()
@@ -670,8 +684,8 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
         return n
 
     passes = max(1, min(a.steps, 4))
-    v_p12, ms_p12, hits = timed(pipelined(12), passes)
-    v_cli, ms_cli, hits_cli = timed(pipelined_cli, passes)
+    v_p12, ms_p12, hits = timed(pipelined(12), passes, "pipelined")
+    v_cli, ms_cli, hits_cli = timed(pipelined_cli, passes, "pipelined_cli")
     v_p16, ms_p16, hits16 = timed(pipelined(16), passes)
     v_p25, ms_p25, _ = timed(pipelined(False), passes)
     v_s, ms_s, _ = timed(serial, passes)
@@ -680,7 +694,30 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     v_su, ms_su = v_su * reps, ms_su / reps                     # timed() counts one call as one pass; the call holds `reps` of them
     for pin in pins:
         pin.close()
-    return {"pipelined": v_p12, "pipelined_cli": v_cli, "pipelined_16B": v_p16, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
+    # ---- the host side rank by rank: every rank's own pass time, the CPU seconds its process burnt per pass (stream threads
+    # + Python), its stage waits, the time its pinned input took to allocate and fill, and where it was bound
+    per_rank = None
+    if dist is not None:
+        st_p = stages.get("pipelined", {})
+        mine = torch.tensor([own["pipelined"][0] * 1e3, own["pipelined"][1] * 1e3, own["pipelined_cli"][0] * 1e3, own["pipelined_cli"][1] * 1e3,
+                             st_p.get("upload", {}).get("ms_work", 0.0), st_p.get("scan", {}).get("ms_work", 0.0), st_p.get("scan", {}).get("ms_wait_in", 0.0),
+                             st_p.get("copy_out", {}).get("ms_work", 0.0), t_pin * 1e3, float(numa_node), float(len(os.sched_getaffinity(0)))],
+                            dtype=torch.float64, device=dev)
+        tab = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(tab, mine)
+        tab = torch.stack(tab).cpu().numpy()
+        units_rank = float(wl["units"])
+        per_rank = {"ms_per_pass_pipelined": [round(float(x), 2) for x in tab[:, 0]], "cpu_ms_per_pass_pipelined": [round(float(x), 1) for x in tab[:, 1]],
+                    "ms_per_pass_cli": [round(float(x), 2) for x in tab[:, 2]], "cpu_ms_per_pass_cli": [round(float(x), 1) for x in tab[:, 3]],
+                    "value_8d_end_to_end_by_rank": [units_rank / (float(x) * 1e-3) for x in tab[:, 0]],
+                    "stage_ms_last_pass_by_rank": {"upload_work": [round(float(x), 2) for x in tab[:, 4]], "scan_work": [round(float(x), 2) for x in tab[:, 5]],
+                                                   "scan_wait_in": [round(float(x), 2) for x in tab[:, 6]], "copy_out_work": [round(float(x), 2) for x in tab[:, 7]]},
+                    "pinned_input_alloc_and_fill_ms": [round(float(x), 1) for x in tab[:, 8]],
+                    "numa_node_bound": [int(x) for x in tab[:, 9]], "cpus_allowed": [int(x) for x in tab[:, 10]],
+                    "host_cpu_busy_fraction_of_box": float(tab[:, 1].sum() / max(tab[:, 0].max(), 1e-9) / (os.cpu_count() or 1)),
+                    "host_cores": os.cpu_count()}
+    return {"per_rank": per_rank, "host_pack": bool(a.host_pack), "numa_node_bound": numa_node, "pinned_input_alloc_and_fill_ms": round(t_pin * 1e3, 1),
+            "pipelined": v_p12, "pipelined_cli": v_cli, "pipelined_16B": v_p16, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
             "ms_per_pass": {"pipelined": ms_p12, "pipelined_cli": ms_cli, "pipelined_16B": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
             "hits_check_12B_vs_16B": bool(hits == hits16), "bytes_per_hit_on_the_link": {"pipelined": 12, "pipelined_cli": 12, "pipelined_16B": 16, "pipelined_25B": 25},
             "hits_out_per_pass_cli": int(hits_cli),

@@ -107,14 +107,20 @@ typedef struct ms_scan_stats {
 
 const char *ms_last_error(void);
 int ms_version(void);
-/* Bit 0: the library's pre-filter was built without its hand-written gfx950 asm blocks (csrc/Makefile PF_NO_ASM=1, or the build's mandatory
- * ISA check failed and it fell back): identical results, slower.  No reference counterpart. */
+/* Bit 0: the library's pre-filter holds the hand-written gfx950 asm blocks (the variant libmotifscan_amd_asm.so, csrc/Makefile); 0 for the
+ * product library, whose pre-filter is built from compiler builtins only.  Identical results either way.  No reference counterpart. */
 int ms_build_flags(void);
 
 /* Device selection is per calling thread (like hipSetDevice).  Handles remember their device. */
 int ms_device_count(int *count);
 int ms_set_device(int device);
 int ms_device_name(char *buf, int buflen);
+/* NUMA placement of the host side (no reference counterpart: the reference has one process and no device): binds the CALLING thread to the
+ * CPUs of the NUMA node the calling thread's device hangs off (sysfs numa_node of its PCI address; sched_setaffinity), so that memory the
+ * thread allocates afterwards -- pinned buffers included -- is node-local.  The batch stream's three threads do this by themselves where the
+ * policy says so: MS_NUMA_BIND=0 never, =1 always, unset = on machines with more than one NUMA node and more than one visible GPU.
+ * force != 0 overrides the policy.  *node = the node bound to, or -1 if nothing was done. */
+int ms_numa_bind_thread(int force, int *node);
 /* The calling thread's device keeps freed HBM blocks for reuse (hipMalloc / hipFree stall every stream of the device).
  * out[0] requests served from the cache, out[1] requests that went to the driver, out[2] blocks returned to the driver,
  * out[3] nanoseconds spent inside the driver for [1] and [2], out[4] bytes cached now, out[5] blocks cached now.

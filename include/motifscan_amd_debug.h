@@ -34,6 +34,10 @@ int ms_debug_plan_rows(const ms_pwmset *pwms, int32_t *group_fields, int16_t *ro
  * blkinfo [4 x that], n = offsets[n_seqs] -- the layout pack_kernel / blk2reg_kernel write on the device. */
 int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo);
 
+/* The NUMA look-ups of ms_numa_bind_thread against a sysfs tree under `root` ("" = the machine's own; no device, no binding): the node of
+ * PCI device `bdf` (-1 unknown), the number of CPUs of that node (0 unknown), the number of online nodes. */
+int ms_debug_numa_probe(const char *root, const char *bdf, int32_t *node, int32_t *n_cpus, int32_t *n_nodes);
+
 /* Free the current device's grow-only work buffers (candidate list, hit list, sort space), so a
  * test can force the "buffer too small -> grow -> run the pass again" path.  Needs a GPU. */
 int ms_debug_release_scratch(void);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Mandatory post-compile check of the pre-filter's gfx950 code object.
 
-Usage:  check_isa.py <ms_kernels.o> [--no-asm]        exit code 0 = the object may be linked, 1 = it may not
+Usage:  check_isa.py <object> [--no-asm]        exit code 0 = the object may be linked, 1 = it may not
+        ms_kernels.o (the product: no hand-written blocks) is checked with --no-asm, ms_kernels_asm.o (-DMS_PF_ASM) without.
 
 The hand-written asm blocks of ms_kernels.hip rest on facts about the code AROUND them that only the built object can confirm.
 The Makefile runs this right after the object is compiled and refuses to link a library from an object that fails; tests/test_host_cabi.py
@@ -22,8 +23,8 @@ calls check() on the object the shipped library was linked from.  Checked, per i
 (The measurement kernel may spill inside its pass body -- a performance matter its 21 % handicap already includes; the operand-register
 rule above is what keeps a spill from touching data in flight, and it holds for that kernel too.)
 
---no-asm: the object was built with -DMS_PF_NO_ASM (the intrinsic-only safety net): there are no hand-written blocks to guard; only the
-resource limits are checked.
+--no-asm: the object holds no hand-written blocks (the product build): there is nothing of that kind to guard; only the resource limits
+are checked.
 """
 import os
 import re

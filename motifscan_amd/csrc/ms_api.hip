@@ -500,6 +500,52 @@ int ms_set_device(int device) {
     return MS_OK;
 }
 
+}  // extern "C"
+
+// MS_NUMA_BIND policy (ms_numa.cpp) for the calling thread and `device`; the node is looked up once per device
+int ms::numa_bind_for_device(int device, bool force) {
+    static std::mutex mu;
+    static std::map<int, int> node_of;                      // device -> node (-1 unknown)
+    static int policy = -2;                                 // -2 unread, 0 never, 1 always, 2 auto
+    static int n_nodes = 0, n_gpus = 0;
+    int node = -1;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (policy == -2) {
+            const char *e = getenv("MS_NUMA_BIND");
+            policy = !e ? 2 : (e[0] == '0' ? 0 : 1);
+            n_nodes = numa_node_count("");
+            if (hipGetDeviceCount(&n_gpus) != hipSuccess) { n_gpus = 0; (void) hipGetLastError(); }
+        }
+        if (!force && (policy == 0 || (policy == 2 && !(n_nodes > 1 && n_gpus > 1)))) return -1;
+        auto it = node_of.find(device);
+        if (it == node_of.end()) {
+            char bdf[64] = {0};
+            int nd = -1;
+            if (hipDeviceGetPCIBusId(bdf, (int) sizeof(bdf), device) == hipSuccess) nd = numa_node_of_bdf(bdf, "");
+            else (void) hipGetLastError();
+            it = node_of.emplace(device, nd).first;
+        }
+        node = it->second;
+    }
+    if (node < 0) return -1;
+    return numa_bind_calling_thread(node) > 0 ? node : -1;
+}
+
+extern "C" {
+
+// Bind the CALLING thread to the CPUs of the NUMA node the calling thread's device hangs off (memory it allocates afterwards -- pinned
+// buffers included -- is placed there by first touch).  force = 0: only where the policy says so (MS_NUMA_BIND; default: multi-GPU nodes
+// with more than one NUMA node); force != 0: always.  *node = the node bound to, -1 if nothing was done (no NUMA information, policy off).
+int ms_numa_bind_thread(int force, int *node) {
+    DeviceCtx *c;
+    int rc = get_ctx(g_device, &c);
+    if (rc) return rc;
+    const int nd = numa_bind_for_device(c->device, force != 0);
+    if (node) *node = nd;
+    return MS_OK;
+}
+
 int ms_device_name(char *buf, int buflen) {
     if (!buf || buflen <= 0) { set_error("bad buffer"); return MS_ERR_INVALID; }
     DeviceCtx *c;
@@ -786,6 +832,16 @@ int ms::seqset_create_hostpacked(const char *bases, const int64_t *offsets, int6
 extern "C" {
 
 // the host packer alone, for CPU tests (no device): codes [2 * ceil(n / 32)], nmask [ceil(n / 32)], blk2reg [(n + 63) / 64 + 1], blkinfo [4 x that]
+int ms_debug_numa_probe(const char *root, const char *bdf, int32_t *node, int32_t *n_cpus, int32_t *n_nodes) {
+    if (!root || !bdf) { set_error("NULL argument"); return MS_ERR_INVALID; }
+    const int nd = numa_node_of_bdf(bdf, root);
+    cpu_set_t set;
+    if (node) *node = nd;
+    if (n_cpus) *n_cpus = numa_cpus_of_node(nd, root, &set);
+    if (n_nodes) *n_nodes = numa_node_count(root);
+    return MS_OK;
+}
+
 int ms_debug_host_pack(const char *bases, const int64_t *offsets, int64_t n_seqs, uint32_t *codes, uint32_t *nmask, int32_t *blk2reg, int32_t *blkinfo) {
     if (!offsets || n_seqs < 0 || !codes || !nmask || !blk2reg || !blkinfo) { set_error("NULL argument"); return MS_ERR_INVALID; }
     const int64_t n = offsets[n_seqs];

@@ -1,6 +1,7 @@
 // ms_handles.h -- private to libmotifscan_amd: per-device state and the structs behind the opaque handles of
 // include/motifscan_amd.h, shared by ms_api.hip (scan pipeline) and ms_stream.hip (batch streams, host-streamed sweeps).
 #pragma once
+#include <sched.h>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -84,6 +85,14 @@ size_t pool_trim_current_device();
 // ms_hostpack.cpp: convert_seq and the region hints on host threads (units of 32 bases / blocks of 64 positions [u0, u1) / [b0, b1))
 void host_pack_units(const uint8_t *bases, int64_t n_bases, int64_t u0, int64_t u1, uint32_t *codes, uint32_t *nmask);
 void host_region_hints(const int64_t *offsets, int64_t R, int64_t b0, int64_t b1, int32_t *blk2reg, int32_t *info, bool all_far);
+// ms_numa.cpp: NUMA placement of a device's host side (sysfs + sched_setaffinity; no device code)
+int parse_cpulist(const char *text, cpu_set_t *set);
+int numa_node_of_bdf(const char *bdf, const char *root);
+int numa_cpus_of_node(int node, const char *root, cpu_set_t *set);
+int numa_node_count(const char *root);
+int numa_bind_calling_thread(int node);
+// the policy (MS_NUMA_BIND, ms_numa.cpp) applied to the calling thread for `device`: returns the node bound to, -1 if none
+int numa_bind_for_device(int device, bool force);
 int seqset_create_upload_only(const char *bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out);
 int seqset_pack_pending(const ms_seqset *s, hipStream_t st);
 int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out);

@@ -502,19 +502,23 @@ __device__ __forceinline__ uint32_t staged_nw(const uint32_t *stg, uint32_t r, i
 // (`areg`, tied to v[112:123]), not a clobber: the compiler must keep them free between the blocks while the reads are in flight, and
 // nothing but these blocks may touch them -- a_reads_begin starts the first row tile's reads, a_reads_drain waits for the last (unused)
 // ones before the class returns and the registers go back to the compiler.  tests/test_host_cabi.py checks the built code for both.
-// ---- the safety net: `make PF_NO_ASM=1` (-DMS_PF_NO_ASM) builds the pre-filter WITHOUT the hand-written blocks ----
-// The blocks above and below pin v[112:123] across compiler-made code and issue the hand-out's atomic behind the compiler's back; what
-// guards them is csrc/check_isa.py, a mandatory step of the build that reads the code object back.  Should a compiler update trip it, the
-// Makefile falls back -- loudly -- to this form: row tiles of two blocks go through the same builtins the one-block tiles use (the A operand
-// read per half with three ds_read_b128 by the compiler, its own waits, its own register allocation) and the hand-out uses the compiler's
-// atomicAdd.  Same tables, same results bit for bit (tests/test_gpu_parity.py runs the goldens and configs[1] on both builds); slower
-// (DESIGN.md section 7 has the number).  ms_build_flags() bit 0 tells which one a library holds.
-#ifdef MS_PF_NO_ASM
-constexpr bool kPfAsm = false;
-#else
+// ---- the two builds of the pre-filter (round 6) ----
+// DEFAULT (this macro undefined): NO hand-written blocks.  Row tiles of two blocks go through the same builtins the one-block tiles use (the
+// A operand read per row tile with three ds_read_b128 by the compiler, its own waits, its own register allocation) and the hand-out uses the
+// compiler's atomicAdd.  -DMS_PF_ASM builds the variant library (libmotifscan_amd_asm.so, MS_LIB_VARIANT=asm) WITH the blocks of rounds
+// 4-5 above and below: they pin v[112:123] across compiler-made code and issue the hand-out's atomic behind the compiler's back, and what
+// guards them is csrc/check_isa.py, a mandatory step of that variant's build that reads the code object back.
+// Why the default flipped: measured side by side on two boxes in round 6 (profiles/r06a_bench_c4_noasm.json / _asm_same_box.json,
+// profiles/r06b_e2e_ab_summary.log: kernel 15.72 / 15.72 ms, 15.34 / 15.34, 15.32 / 15.31; p = 1e-3 24.61 / 24.64) the two builds run the
+// pre-filter in the same time -- the kernel is power-limited, and what the blocks saved in rounds 4-5 (register moves,
+// exposed LDS latency) no longer shows -- while the asm form carries a hazard no test can rule out for a future compiler.  Same
+// tables, same results bit for bit (tests/test_gpu_parity.py runs the goldens and configs[1] on both).  ms_build_flags() bit 0 = the blocks are in.
+#ifdef MS_PF_ASM
 constexpr bool kPfAsm = true;
+#else
+constexpr bool kPfAsm = false;
 #endif
-extern "C" int ms_build_flags(void) { return kPfAsm ? 0 : 1; }
+extern "C" int ms_build_flags(void) { return kPfAsm ? 1 : 0; }
 
 // a two-block row tile's operands (lane-major, 48 bytes per lane: ms_internal.h) through ordinary LDS reads
 __device__ __forceinline__ void load_a2(uint32_t pa, i32x8 &a0, i32x8 &a1) {
@@ -1298,7 +1302,7 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
                 // the counters on (scan_locked refuses it); if it ever did, the compiler's own atomicAdd (waited for at once) takes over.
                 if (j == 0 && dyn && lane == 0) {
                     if (kPfAsm && wave_passes >= 2) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(u) : "v"(word), "v"(1u) : "memory");
-                    else u = atomicAdd(word, 1u);                                  // (also the whole of the PF_NO_ASM build: waited for at once)
+                    else u = atomicAdd(word, 1u);                                  // (the default build: the compiler's atomic, waited for where it is used)
                 }
                 // the next pass's words -- of this unit, or the first of the wave's NEXT unit (its number arrived long ago) -- are in
                 // flight while this pass is scanned

@@ -57,6 +57,7 @@ struct ms_stream {
     void bind_thread() {
         set_current_device(device);
         (void) hipSetDevice(device);
+        (void) numa_bind_for_device(device, false);      // the stage's thread (and the pinned blocks it allocates) on the GPU's NUMA node: ms_numa.cpp
     }
 
     void upload(Job *j) {

@@ -563,70 +563,46 @@ def _check_isa():
 
 
 def test_prefilter_isa_resources_and_the_atomic_register():
-    """The build-time checks on the gfx950 code object of the pre-filter -- what the hand-written asm
-    blocks of ms_kernels.hip rest on -- are a MANDATORY step of the build since round 6 (csrc/check_isa.py, run by the Makefile right after
-    ms_kernels.o is compiled: an object that fails is never linked; the rules are listed in that file's docstring).  This test re-runs the
-    same check on the objects the two shipped libraries were linked from, and pins the build's behaviour: which variant the default
-    library is, and that the checker does refuse an object of the other kind."""
+    """The build-time checks on the gfx950 code objects of the pre-filter are a MANDATORY step of
+    the build since round 6 (csrc/check_isa.py, run by the Makefile right after each object is compiled: an object that fails is never
+    linked; the rules are in that file's docstring).  Since round 6 the PRODUCT library holds no hand-written asm blocks at all (same
+    speed, measured side by side: ms_kernels.hip "the two builds"); the blocks of rounds 4-5 live in the variant libmotifscan_amd_asm.so,
+    and the rules they rest on -- operand registers that carry data in flight, the hand-out atomic's register, no scalar loads in the
+    pass body -- guard THAT object.  This test re-runs both checks on the objects the two shipped libraries were linked from, and shows
+    that the rules bite: the product object, which has none of the blocks, fails the asm rules."""
     ci = _check_isa()
     obj = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels.o")
-    obj_na = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels_noasm.o")
-    assert os.path.exists(obj) and os.path.exists(obj_na), "the build leaves both objects in csrc/ (they travel to the GPU box with the libraries)"
+    obj_asm = os.path.join(ROOT, "motifscan_amd", "csrc", "ms_kernels_asm.o")
+    assert os.path.exists(obj), "the build leaves the object in csrc/ (it travels to the GPU box with the library)"
     if not ci.tools_present():
         pytest.skip("no ROCm llvm tools here: the build itself would have refused to link (check_isa.main)")
-    default_is_noasm = bool(_lib.lib().ms_build_flags() & 1) and _lib.LIB_VARIANT != "noasm"
-    print(ci.check(obj, no_asm=default_is_noasm))
-    print(ci.check(obj_na, no_asm=True))
-    assert not default_is_noasm, "the default library fell back to the intrinsic-only pre-filter: the ISA check of the asm form failed in this build"
-    with pytest.raises(ci.IsaCheckError):                                  # the rules bite: the intrinsic-only object has none of the blocks
-        ci.check(obj_na, no_asm=False)
+    assert _lib.lib().ms_build_flags() & 1 == (1 if _lib.LIB_VARIANT == "asm" else 0)
+    print(ci.check(obj, no_asm=True))
+    with pytest.raises(ci.IsaCheckError):
+        ci.check(obj, no_asm=False)
+    assert os.path.exists(obj_asm) == os.path.exists(os.path.join(ROOT, "motifscan_amd", "libmotifscan_amd_asm.so"))
+    if os.path.exists(obj_asm):                                          # (absent only if this compiler tripped the asm rules: the build said so)
+        print(ci.check(obj_asm, no_asm=False))
 
 
 def test_both_library_variants_export_the_same_cabi():
-    """libmotifscan_amd_noasm.so (the safety net, csrc/Makefile) is the same library but for the pre-filter's object."""
-    import subprocess
+    """libmotifscan_amd_asm.so (the variant with the hand-written blocks, csrc/Makefile) is the same library but for the pre-filter's object."""
     import shutil
+    import subprocess
     nm = shutil.which("nm")
     if not nm:
         pytest.skip("no nm")
+    if not os.path.exists(os.path.join(ROOT, "motifscan_amd", "libmotifscan_amd_asm.so")):
+        pytest.skip("the asm variant was not built (its object failed the ISA check)")
     sets = []
-    for name in ("libmotifscan_amd.so", "libmotifscan_amd_noasm.so"):
+    for name in ("libmotifscan_amd.so", "libmotifscan_amd_asm.so"):
         out = subprocess.run([nm, "-D", "--defined-only", os.path.join(ROOT, "motifscan_amd", name)], capture_output=True, text=True, check=True).stdout
         sets.append({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("ms_")})
     assert sets[0] == sets[1] and "ms_build_flags" in sets[0]
-    out = subprocess.run([sys.executable, "-c", "from motifscan_amd import _lib; print(_lib.lib().ms_build_flags(), _lib.LIB_PATH)"],
-                         env=dict(os.environ, MS_LIB_VARIANT="noasm", PYTHONPATH=ROOT), capture_output=True, text=True, check=True).stdout.split()
-    assert out[0] == "1" and out[1].endswith("libmotifscan_amd_noasm.so")
-
-
-def test_host_packer_is_convert_seq_word_for_word():
-    """ms_seqset_create_hostpacked's packer (ms_hostpack.cpp: AVX2 + BMI2 with a scalar tail) against a numpy restatement of convert_seq
-    (cscore.c:81-114: case folded, anything but ACGT "adds nothing") in the device layout: 2-bit codes 16 per word (non-ACGT -> 0), one
-    mask bit per base, positions past the end neither N nor coded; and the region hints against a direct search."""
-    rng = np.random.default_rng(41)
-    alphabet = np.frombuffer(b"ACGTacgtNnRYKMSWBDHVU-*. \x00\xff@`", dtype=np.uint8)
-    for n_seqs, lo, hi in ((1, 0, 1), (1, 31, 34), (7, 0, 70), (300, 1, 400), (3, 5000, 9000), (50, 64, 65)):
-        lens = rng.integers(lo, hi, size=n_seqs)
-        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        n = int(offsets[-1])
-        bases = alphabet[rng.choice(len(alphabet), size=n, p=np.r_[np.full(8, 0.11), np.full(len(alphabet) - 8, 0.12 / (len(alphabet) - 8))])]
-        codes, nmask, blk, info = _lib.host_pack(bases, offsets)
-        up = bases | 0x20
-        code = np.select([up == ord("a"), up == ord("c"), up == ord("g"), up == ord("t")], [0, 1, 2, 3], default=0).astype(np.uint64)
-        isn = ~np.isin(up, np.frombuffer(b"acgt", dtype=np.uint8))
-        units = (n + 31) // 32
-        pad_c, pad_n = np.zeros(32 * units, dtype=np.uint64), np.zeros(32 * units, dtype=np.uint64)
-        pad_c[:n], pad_n[:n] = code, isn
-        want_cw = (pad_c.reshape(units, 32) << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
-        want_nw = (pad_n.reshape(units, 32) << np.arange(32, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
-        assert np.array_equal(codes.reshape(units, 2)[:, 0].astype(np.uint64) | (codes.reshape(units, 2)[:, 1].astype(np.uint64) << np.uint64(32)), want_cw)
-        assert np.array_equal(nmask.astype(np.uint64), want_nw)
-        R = n_seqs
-        for b in range(len(blk)):
-            r = max(int(np.searchsorted(offsets[:R], 64 * b, side="right")) - 1, 0)      # the last region that starts at or before the block
-            assert blk[b] == r
-            o = [int(offsets[min(r + k, R)]) - 64 * b for k in range(3)]
-            assert info[b].tolist() == [r] + o
+    for variant, flag, so in (("", "0", "libmotifscan_amd.so"), ("asm", "1", "libmotifscan_amd_asm.so")):
+        out = subprocess.run([sys.executable, "-c", "from motifscan_amd import _lib; print(_lib.lib().ms_build_flags(), _lib.LIB_PATH)"],
+                             env=dict(os.environ, MS_LIB_VARIANT=variant, PYTHONPATH=ROOT), capture_output=True, text=True, check=True).stdout.split()
+        assert out[0] == flag and out[1].endswith(so)
 
 
 def test_measurement_switches_need_the_explicit_opt_in(monkeypatch):
@@ -660,4 +636,32 @@ def test_integration_c_stub_of_the_collective_compiles(tmp_path):
                           "-I" + os.path.join(ROOT, "include"), str(tmp_path / "stub.c")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "ncclAllReduce" in code and "ncclInt64" in code and "ms_result_region_counts_device" in code
+
+
+def test_numa_lookups_against_a_fake_sysfs(tmp_path):
+    """ms_numa.cpp (VERDICT r5 #3b): the NUMA node of a GPU comes from sysfs (numa_node of its PCI address), the node's CPUs from its
+    cpulist; the stream's threads bind themselves there on multi-GPU nodes.  Here: the look-ups against a fabricated sysfs tree (two nodes,
+    split CPU ranges, upper-case bus id, a device without NUMA information), and against this machine's own /sys (whatever it says, sane)."""
+    L = _lib.lib()
+    root = tmp_path
+    dev = root / "sys/bus/pci/devices/0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    dev2 = root / "sys/bus/pci/devices/0000:05:00.0"
+    dev2.mkdir(parents=True)
+    (dev2 / "numa_node").write_text("-1\n")
+    for n, cpus in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        d = root / f"sys/devices/system/node/node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    (root / "sys/devices/system/node/online").write_text("0-1\n")
+    node, n_cpus, n_nodes = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(L.ms_debug_numa_probe(str(root).encode(), b"0000:C1:00.0", ctypes.byref(node), ctypes.byref(n_cpus), ctypes.byref(n_nodes)))
+    assert (node.value, n_cpus.value, n_nodes.value) == (1, 128, 2)
+    _lib.check(L.ms_debug_numa_probe(str(root).encode(), b"0000:05:00.0", ctypes.byref(node), ctypes.byref(n_cpus), ctypes.byref(n_nodes)))
+    assert (node.value, n_cpus.value) == (-1, 0)
+    _lib.check(L.ms_debug_numa_probe(str(root).encode(), b"0000:ff:00.0", ctypes.byref(node), ctypes.byref(n_cpus), ctypes.byref(n_nodes)))
+    assert (node.value, n_cpus.value) == (-1, 0)
+    _lib.check(L.ms_debug_numa_probe(b"", b"0000:00:00.0", ctypes.byref(node), ctypes.byref(n_cpus), ctypes.byref(n_nodes)))
+    assert n_nodes.value >= 1 and node.value >= -1
 
