@@ -76,13 +76,16 @@ def check(obj, no_asm=False):
     flush = [k for k in funcs if "pf_flush" in k]
     _need(len(flush) == 1, "expected one pf_flush, found", flush)
     kernels = [k for k in funcs if "prefilter_f6_kernel" in k]
-    _need(len(kernels) == 5, "expected 5 instantiations of prefilter_f6_kernel (<2|4 k-blocks> x <product | measurement> + dense), found", len(kernels))
+    _need(len(kernels) == 9, "expected 9 instantiations of prefilter_f6_kernel (<2|4 k-blocks> x <product | measurement> + dense + 4 floor cuts), found", len(kernels))
     summary = []
     for k in kernels:
         meta = notes[notes.index(".name:           " + k + "\n"):]
         meta = meta[:meta.index(".wavefront_size")]
         num = {f: int(re.search(rf"\.{f}:\s+(\d+)", meta).group(1)) for f in ("vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size")}
         _need(num["vgpr_count"] <= 128, k, "uses more than 128 vector registers:", num)
+        if re.search(r"ELi[1-4]EEEv", k):                           # the floor cuts (measurement only, results void): the register limit is all they owe
+            summary.append(f"floor cut {re.search(r'ELi([1-4])EEEv', k).group(1)}: {num['vgpr_count']} vgprs")
+            continue
         body = funcs[k]
         mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
         _need(len(mf) >= 12, k, "holds only", len(mf), "matrix instructions")
@@ -92,7 +95,7 @@ def check(obj, no_asm=False):
         if product:
             _need(num["sgpr_spill_count"] == 0 and num["vgpr_spill_count"] <= 16 and num["private_segment_fixed_size"] <= 64, k, "spills:", num)
             _need(not [l for l in pass_body if l.startswith("scratch_")], k, "spill traffic inside the pass body")
-        summary.append(f"{k[k.index('ILi'):].rstrip('Evv')[:16]}: {num['vgpr_count']} vgprs, {num['vgpr_spill_count']} spilled")
+        summary.append(f"{k[k.index('ILi'):][:18]}: {num['vgpr_count']} vgprs, {num['vgpr_spill_count']} spilled")
         if no_asm:                                                  # the compiler's own reads, waits and atomic: nothing hand-written to guard
             continue
         if narrow:

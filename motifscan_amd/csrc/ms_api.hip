@@ -1380,7 +1380,10 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     unsigned long long *d_clk = nullptr;
     int clk_blocks = 0;
     const bool pf_meas = pf_no_emit != 0 || pf_clock;              // the measurement instantiation of the kernel
-    raw->invalid = pf_no_emit != 0;                                // stage times only: the hit accessors refuse such a result
+    int pf_floor = 0;                                              // MS_MEASURE=1 MS_PF_FLOOR=1..4: a compile-time cut of the product kernel (ms_kernels.hip, FLOOR)
+    if (const char *e = measure_env("MS_PF_FLOOR")) pf_floor = std::max(0, std::min(4, atoi(e)));
+    if (pf_meas) pf_floor = 0;
+    raw->invalid = pf_no_emit != 0 || pf_floor != 0;               // stage times only: the hit accessors refuse such a result
 
     // ---- the pre-filter's launch geometry
     const int n_tiles = (int) plan.tiles.size();
@@ -1469,13 +1472,14 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             }
             bool wide = false;
             for (const TileDesc &t : plan.tiles) wide = wide || t.max_nk > 2;
-            const bool dense = pf_dense && !wide && !pf_meas;
-            const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0) + (dense ? 4 : 0);
+            const int floor_ = wide ? 0 : pf_floor;
+            const bool dense = pf_dense && !wide && !pf_meas && !floor_;
+            const int li = (wide ? 2 : 0) + (pf_meas ? 1 : 0) + (dense ? 4 : 0) + 8 * floor_;
             if (lds_bytes > c->lds_set[li]) {
-                if ((rc = prefilter_set_lds(wide, pf_meas, dense, lds_bytes))) return rc;
+                if ((rc = prefilter_set_lds(wide, pf_meas, dense, lds_bytes, floor_))) return rc;
                 c->lds_set[li] = lds_bytes;
             }
-            if ((rc = launch_prefilter(A, wide, pf_meas, dense, bpt, n_tiles, lds_bytes, c->stream))) return rc;
+            if ((rc = launch_prefilter(A, wide, pf_meas, dense, bpt, n_tiles, lds_bytes, c->stream, floor_))) return rc;
             stt.pf_engine = dense ? 4 : 3;
         }
         (void) hipEventRecord(ev[1], c->stream);

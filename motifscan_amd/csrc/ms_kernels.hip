@@ -892,7 +892,7 @@ __device__ __forceinline__ bool half_event(const PfArgs &A, MfWave &W, PfResume 
 }
 
 // All row tiles of one class of PAIRED rows against the 128 window starts of a double pass (hw: the wave's one-hot array of the pass).
-template <int NK, bool MEAS, bool DENSE>
+template <int NK, bool MEAS, bool DENSE, int FLOOR = 0>
 __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut &O, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
                                                uint32_t hw, int64_t pass0, const PfLive2 &L, PfResume &R) {
     static_assert(NK == 1 || NK == 2, "paired rows have one or two half-blocks");
@@ -919,25 +919,33 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut
     for (int j = 0; j < 16; j++) { cc0[j] = kPairC; cc1[j] = 0.5f * kPairC; }
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
+    if constexpr (FLOOR == 4) n_run = 0;                                             // floor instantiation: the per-pass and per-class set-up alone
     int back = n_row_tiles;
     [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;
     [[maybe_unused]] i32x12 areg;
     if constexpr (NK == 2 && kPfAsm) a_reads_begin(pa, areg);
     const bool skip_events = MEAS && A.no_emit >= 1 && A.no_emit <= 3;
+    [[maybe_unused]] i32x8 a_fix, a1_fix;                                            // FLOOR 3: ONE operand read per class, the matrix instructions alone in the loop
+    if constexpr (FLOOR == 3) { if constexpr (NK == 2) load_a2(pa, a_fix, a1_fix); else { const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024); a_fix = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0}; a1_fix = a_fix; } }
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
         [[maybe_unused]] i32x8 a, a1;
         bool stop = false, low = false;
         if constexpr (NK == 2 && kPfAsm) pair_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, c0, c1);
-        else if constexpr (NK == 2) { load_a2(pa, a, a1); pair_product2_intr(a, a1, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, cc0, cc1, c0, c1); }
+        else if constexpr (NK == 2) { if constexpr (FLOOR == 3) { a = a_fix; a1 = a1_fix; } else load_a2(pa, a, a1); pair_product2_intr(a, a1, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], scale0, scale1, cc0, cc1, c0, c1); }
         else {
-            const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
-            a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+            if constexpr (FLOOR == 3) a = a_fix;
+            else {
+                const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
+                a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+            }
             c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][0][0][0], b[0][0][0][1], b[0][0][0][2], b[0][0][0][3], 0, 0, 0, 0}, cc0, 2, 4, 0, scale0, 0, 127);
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][1][0][0], b[0][1][0][1], b[0][1][0][2], b[0][1][0][3], 0, 0, 0, 0}, cc1, 2, 4, 0, scale1, 0, 127);
         }
         if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
-        if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
+        if constexpr (FLOOR >= 2) asm volatile("" : : "v"(c0), "v"(c1));          // floor instantiations (below): no inspection
+        else if constexpr (FLOOR == 1) { const uint32_t x0 = or16(c0), x1 = or16(c1); asm volatile("" : : "s"(__builtin_amdgcn_ballot_w64(((x0 | x1) & kPairMask) != 0u))); }   // inspection, no hand-off
+        else if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
             const uint32_t x0 = or16(c0), x1 = or16(c1);
             if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, DENSE ? 1 : 0)) {
                 if constexpr (DENSE) dense_event<true>(A, O, c0, c1, L.h[0], pass0 + r, first_group + 4 * t + 2 * (int32_t) h);
@@ -952,7 +960,9 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut
                 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][1][0][0], b[1][1][0][1], b[1][1][0][2], b[1][1][0][3], 0, 0, 0, 0}, cc1, 2, 4, 0, scale1, 0, 127);
             }
             if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
-            if (!(MEAS && A.no_emit == 3)) {
+            if constexpr (FLOOR >= 2) asm volatile("" : : "v"(c0), "v"(c1));
+            else if constexpr (FLOOR == 1) { const uint32_t x0 = or16(c0), x1 = or16(c1); asm volatile("" : : "s"(__builtin_amdgcn_ballot_w64(((x0 | x1) & kPairMask) != 0u))); }
+            else if (!(MEAS && A.no_emit == 3)) {
                 const uint32_t x0 = or16(c0), x1 = or16(c1);
                 if (__builtin_expect(__any(((x0 | x1) & kPairMask) != 0u) && !skip_events, DENSE ? 1 : 0)) {
                     if constexpr (DENSE) dense_event<true>(A, O, c0, c1, L.h[1], pass0 + 64 + r, first_group + 4 * t + 2 * (int32_t) h);
@@ -971,7 +981,7 @@ __device__ __forceinline__ void f6_pair_class2(const PfArgs &A, MfWave &W, PfOut
 }
 
 // ... and of plain rows (one or two k-blocks)
-template <int NK, bool MEAS, bool DENSE>
+template <int NK, bool MEAS, bool DENSE, int FLOOR = 0>
 __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, const char *__restrict__ lds, uint32_t byte_off, int n_row_tiles, int32_t first_group,
                                           uint32_t hw, bool any_n, int64_t pass0, const PfLive2 &L, PfResume &R) {
     static_assert(NK == 1 || NK == 2, "the double pass knows row tiles of one or two k-blocks");
@@ -996,25 +1006,33 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, 
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int n_run = n_row_tiles;
     if constexpr (MEAS) { if (A.no_emit == 2) n_run = 0; }
+    if constexpr (FLOOR == 4) n_run = 0;                                             // floor instantiation: the per-pass and per-class set-up alone
     int back = n_row_tiles;
     [[maybe_unused]] uint32_t pa = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const char *) p;
     [[maybe_unused]] i32x12 areg;
     if constexpr (NK == 2 && kPfAsm) a_reads_begin(pa, areg);
     const bool skip_events = MEAS && A.no_emit >= 1 && A.no_emit <= 3;
+    [[maybe_unused]] i32x8 a_fix, a1_fix;                                            // FLOOR 3: ONE operand read per class, the matrix instructions alone in the loop
+    if constexpr (FLOOR == 3) { if constexpr (NK == 2) load_a2(pa, a_fix, a1_fix); else { const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024); a_fix = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0}; a1_fix = a_fix; } }
     for (int t = R.t; t < n_run; t++, p += kStep, pa += (uint32_t) kStep) {
         f32x16 c0, c1;
         [[maybe_unused]] i32x8 a, a1;
         bool stop = false, low = false;
         if constexpr (NK == 2 && kPfAsm) plain_product2a_asm(areg, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1);
-        else if constexpr (NK == 2) { load_a2(pa, a, a1); plain_product2_intr(a, a1, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1); }
+        else if constexpr (NK == 2) { if constexpr (FLOOR == 3) { a = a_fix; a1 = a1_fix; } else load_a2(pa, a, a1); plain_product2_intr(a, a1, b[0][0][0], b[0][1][0], b[0][0][1], b[0][1][1], c0, c1); }
         else {
-            const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
-            a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+            if constexpr (FLOOR == 3) a = a_fix;
+            else {
+                const int2 w0 = *reinterpret_cast<const int2 *>(p), w1 = *reinterpret_cast<const int2 *>(p + 512), w2 = *reinterpret_cast<const int2 *>(p + 1024);
+                a = i32x8{w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, 0, 0};
+            }
             c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][0][0][0], b[0][0][0][1], b[0][0][0][2], b[0][0][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[0][1][0][0], b[0][1][0][1], b[0][1][0][2], b[0][1][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
         }
         if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
-        if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
+        if constexpr (FLOOR >= 2) asm volatile("" : : "v"(c0), "v"(c1));
+        else if constexpr (FLOOR == 1) { const uint32_t x0 = all_negative(c0), x1 = all_negative(c1); asm volatile("" : : "s"(__builtin_amdgcn_ballot_w64((int) (x0 & x1) >= 0))); }
+        else if (R.sub == 0u && !(MEAS && A.no_emit == 3)) {
             const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
             if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, DENSE ? 1 : 0)) {
                 if constexpr (DENSE) dense_event<false>(A, O, c0, c1, L.h[0], pass0 + r, first_group + 2 * t + (int32_t) h);
@@ -1029,7 +1047,9 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, 
                 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, i32x8{b[1][1][0][0], b[1][1][0][1], b[1][1][0][2], b[1][1][0][3], 0, 0, 0, 0}, z, 2, 4, 0, 0, 0, 0);
             }
             if constexpr (MEAS) { if (A.no_emit == 3) asm volatile("" : : "v"(c0), "v"(c1)); }
-            if (!(MEAS && A.no_emit == 3)) {
+            if constexpr (FLOOR >= 2) asm volatile("" : : "v"(c0), "v"(c1));
+            else if constexpr (FLOOR == 1) { const uint32_t x0 = all_negative(c0), x1 = all_negative(c1); asm volatile("" : : "s"(__builtin_amdgcn_ballot_w64((int) (x0 & x1) >= 0))); }
+            else if (!(MEAS && A.no_emit == 3)) {
                 const uint32_t x0 = all_negative(c0), x1 = all_negative(c1);
                 if (__builtin_expect(__any((int) (x0 & x1) >= 0) && !skip_events, DENSE ? 1 : 0)) {
                     if constexpr (DENSE) dense_event<false>(A, O, c0, c1, L.h[1], pass0 + 64 + r, first_group + 2 * t + (int32_t) h);
@@ -1065,9 +1085,14 @@ __device__ __forceinline__ void f6_class2(const PfArgs &A, MfWave &W, PfOut &O, 
 // one-k-block class only, after tools/ubench/insp_probe.hip modes 6 / 7 promised -7 %: +6 % in the kernel), s_setprio around the
 // matrix instructions, 12 / 20 / 24 waves per CU, 128 windows per wave, a block-wide hand-out behind barriers, one branch per pair
 // of row tiles, a real function call for the rare path.)
-template <int MAXNK, bool MEAS, bool DENSE = false>
+// FLOOR (measurement only, MS_MEASURE=1 MS_PF_FLOOR=n; round 6): compile-time cuts of the PRODUCT kernel -- no run-time switch inside, so what is
+// left runs exactly as it does in the product -- for the floor table of DESIGN.md section 7: 1 = inspection but no hand-off (no event is ever
+// parked), 2 = no inspection either (operand reads + matrix instructions), 3 = the matrix instructions alone (one operand read per class),
+// 4 = set-up only (staging, one-hot array, class loop without row tiles).  Their results are void (ms_result::invalid).
+template <int MAXNK, bool MEAS, bool DENSE = false, int FLOOR = 0>
 __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArgs A) {
     static_assert(!DENSE || (MAXNK == 2 && !MEAS), "the dense-candidate form exists for the double-pass product kernel");
+    static_assert(FLOOR == 0 || (MAXNK == 2 && !MEAS && !DENSE), "the floor instantiations are cuts of the double-pass product kernel");
     extern __shared__ uint4 lds4[];
     constexpr int NT = kPfThreads;
     const TileDesc *__restrict__ T = A.tiles + blockIdx.y;
@@ -1257,10 +1282,10 @@ __global__ void __launch_bounds__(kPfThreads, 4) prefilter_f6_kernel(const PfArg
             if constexpr (MEAS) { if (A.cls_clk) tc0 = __builtin_amdgcn_s_memtime(); }
             while (R.t < cd.n_row_tiles) {                                        // a class comes back early when the parking space runs low
                 if (cd.paired) {
-                    if (cd.nk == 1) f6_pair_class2<1, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
-                    else f6_pair_class2<2, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
-                } else if (cd.nk == 1) f6_class2<1, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
-                else if (cd.nk == 2) f6_class2<2, MEAS, DENSE>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
+                    if (cd.nk == 1) f6_pair_class2<1, MEAS, DENSE, FLOOR>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
+                    else f6_pair_class2<2, MEAS, DENSE, FLOOR>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, pass0, L, R);
+                } else if (cd.nk == 1) f6_class2<1, MEAS, DENSE, FLOOR>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
+                else if (cd.nk == 2) f6_class2<2, MEAS, DENSE, FLOOR>(A, W, O, lds, off, cd.n_row_tiles, cd.first_group, hw_lds, any_n, pass0, L, R);
                 else R.t = cd.n_row_tiles;
                 if (W.rq_n >= W.rq_flush) { pf_flush(em_lds, rq_lds, W.rq_n); W.rq_n = 0; }
             }
@@ -1961,22 +1986,26 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 }
 
 typedef void (*PfKernel)(const PfArgs);
-static PfKernel pf_kernel(bool wide, bool meas, bool dense) {                  // (dense: only without wide classes and outside the measurement instantiation)
+static PfKernel pf_kernel(bool wide, bool meas, bool dense, int floor_ = 0) {                  // (dense: only without wide classes and outside the measurement instantiation)
     if (wide) return meas ? prefilter_f6_kernel<4, true> : prefilter_f6_kernel<4, false>;
+    if (floor_ == 1) return prefilter_f6_kernel<2, false, false, 1>;
+    if (floor_ == 2) return prefilter_f6_kernel<2, false, false, 2>;
+    if (floor_ == 3) return prefilter_f6_kernel<2, false, false, 3>;
+    if (floor_ == 4) return prefilter_f6_kernel<2, false, false, 4>;
     if (dense && !meas) return prefilter_f6_kernel<2, false, true>;
     return meas ? prefilter_f6_kernel<2, true> : prefilter_f6_kernel<2, false>;
 }
 
-int prefilter_set_lds(bool wide, bool meas, bool dense, size_t bytes) {
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas, dense)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+int prefilter_set_lds(bool wide, bool meas, bool dense, size_t bytes, int floor_) {
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pf_kernel(wide, meas, dense, floor_)), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
     return MS_OK;
 }
 
 // wide: the plan holds row tiles of 3 or 4 k-blocks; dense: the form that decodes candidates in place (many hits per row tile)
-int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool dense, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st) {
+int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool dense, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st, int floor_) {
     const int64_t n_chunks = (A.n_bases + kPfThreads - 1) / kPfThreads;
     if (blocks_per_tile > n_chunks) blocks_per_tile = (int) n_chunks;
-    hipLaunchKernelGGL(pf_kernel(wide, meas, dense), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
+    hipLaunchKernelGGL(pf_kernel(wide, meas, dense, floor_), dim3((unsigned) blocks_per_tile, (unsigned) n_tiles), dim3(kPfThreads), lds_bytes, st, A);
     MS_HIP(hipGetLastError());
     return MS_OK;
 }
