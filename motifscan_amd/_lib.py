@@ -629,7 +629,7 @@ def _fence_exact_only(res, pwms, flags=0):
     if (flags & MS_SCAN_EXACT_ONLY) or id(pwms) in _warned_exact_only:
         return res
     st = res.stats()
-    if st["n_pwms_exact"] > 0:
+    if st["n_pwms_exact"] > 0 and st["n_pwms_exact"] * st["n_bases"] >= 10_000_000:       # (a handful of short sequences costs nothing either way)
         _warned_exact_only.add(id(pwms))
         import warnings
         warnings.warn(f"{st['n_pwms_exact']} of {st['n_pwms']} PWMs cannot take the matrix-core pre-filter (wider than 63 columns, max_raw <= 0, "

@@ -1170,6 +1170,27 @@ int pending_scan_init(PendingScan *p) {
     return MS_OK;
 }
 
+PendingScan *pending_scan_acquire(DeviceCtx *c) {
+    {
+        std::lock_guard<std::mutex> lk(c->pend_mu);
+        if (!c->pend_cache.empty()) { PendingScan *p = c->pend_cache.back(); c->pend_cache.pop_back(); return p; }
+    }
+    PendingScan *p = new (std::nothrow) PendingScan();
+    if (!p) { set_error("out of host memory"); return nullptr; }
+    if (pending_scan_init(p) != MS_OK) { pending_scan_destroy(p); delete p; return nullptr; }
+    return p;
+}
+
+void pending_scan_release(DeviceCtx *c, PendingScan *p) {
+    if (!p) return;
+    if (p->raw) { ms_result_free(p->raw); p->raw = nullptr; }
+    p->active = false;
+    std::lock_guard<std::mutex> lk(c->pend_mu);
+    if (c->pend_cache.size() < 8) { c->pend_cache.push_back(p); return; }
+    pending_scan_destroy(p);
+    delete p;
+}
+
 void pending_scan_destroy(PendingScan *p) {
     for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
     if (p->done) (void) hipEventDestroy(p->done);

@@ -74,6 +74,11 @@ struct DeviceCtx {
     size_t lds_set[128] = {};               // dynamic-LDS attribute already raised to this, per kernel variant (+64: measurement instantiation)
     Scratch sc;
     std::mutex mu;               // one scan at a time per device (shared scratch)
+    // the pending-scan slots (events + pinned counter words) of batch streams that have ended, for the next stream on this device: a pass that
+    // opens and drains its own stream (bench.py 'pipelined') otherwise pays 14 hipEventCreate + 2 hipHostMalloc at its start and their release --
+    // hipHostFree waits for the whole device -- at its end (round 6)
+    std::mutex pend_mu;
+    std::vector<struct PendingScan *> pend_cache;
 };
 
 int get_ctx(int device, DeviceCtx **out);
@@ -265,6 +270,9 @@ struct PendingScan {
 constexpr int MS_SCAN_PENDING = 1000;        // scan_locked: queued, call scan_complete
 constexpr int MS_SCAN_RETRY = 1001;          // scan_complete: the prediction failed, run scan_locked(..., MS_SCAN_NO_PREDICT_INTERNAL) again
 int pending_scan_init(PendingScan *p);
+// a slot from the device's cache (or a new one), and back (ms_api.hip); a slot that holds an unfinished scan must not be released
+PendingScan *pending_scan_acquire(DeviceCtx *c);
+void pending_scan_release(DeviceCtx *c, PendingScan *p);
 void pending_scan_destroy(PendingScan *p);
 // waits for a pending scan; MS_OK: *out is the result; MS_SCAN_RETRY: nothing was produced.  The caller holds pwms->mu.
 int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out);

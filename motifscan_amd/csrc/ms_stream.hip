@@ -74,13 +74,19 @@ struct ms_stream {
     // (scan_locked with a PendingScan) is only queued; the stage then takes the next batch, queues its scan too, and only then
     // waits for the first -- the device goes from one batch's last kernel straight into the next batch's first.  Sweep spans
     // and de-duplicated batches need their result at once and run to the end as before.
-    PendingScan pend_slot[2];
+    PendingScan *pend_slot[2] = {nullptr, nullptr};      // from the device's cache (pending_scan_acquire): no event / pinned allocation per stream
 
-    bool scanner_begin() { return pending_scan_init(&pend_slot[0]) == MS_OK && pending_scan_init(&pend_slot[1]) == MS_OK; }
+    bool scanner_begin() {
+        DeviceCtx *c = nullptr;
+        if (get_ctx(device, &c) != MS_OK) return false;
+        pend_slot[0] = pending_scan_acquire(c);
+        pend_slot[1] = pending_scan_acquire(c);
+        return pend_slot[0] && pend_slot[1];
+    }
     void scanner_end() {
-        // (a slot whose init failed was left empty by pending_scan_init: destroying it is a no-op)
-        pending_scan_destroy(&pend_slot[0]);
-        pending_scan_destroy(&pend_slot[1]);
+        DeviceCtx *c = nullptr;
+        if (get_ctx(device, &c) != MS_OK) return;
+        for (PendingScan *&p : pend_slot) { pending_scan_release(c, p); p = nullptr; }
     }
 
     // returns true if the job's scan is pending in pend_slot[slot] (finish with scan_finish), false if the job is done (or failed)
@@ -97,7 +103,7 @@ struct ms_stream {
             const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) |
                                 ((simple && (flags & (MS_STREAM_PACKED | MS_STREAM_PACKED12)) && !(flags & MS_STREAM_NO_HITS)) ? ((flags & MS_STREAM_PACKED12) ? MS_SCAN_PACK12_INTERNAL : MS_SCAN_PACK_INTERNAL) : 0u);
             const bool plain = simple && slot >= 0;
-            rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? &pend_slot[slot] : nullptr);
+            rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? pend_slot[slot] : nullptr);
             if (rc == MS_SCAN_PENDING) { rc = MS_OK; pending = true; }
             if (!rc && !pending && j->kind == 1) {
                 ms_result *r1 = j->res;
@@ -119,7 +125,7 @@ struct ms_stream {
         if (!rc) {
             {
                 std::lock_guard<std::mutex> lk_pwm(pwms->mu);
-                rc = scan_complete(c, pwms, &pend_slot[slot], &j->res);
+                rc = scan_complete(c, pwms, pend_slot[slot], &j->res);
             }
             if (rc == MS_SCAN_RETRY) {                       // the predicted sizes were too small: once more, exactly sized
                 std::lock_guard<std::mutex> lk_dev(c->mu);

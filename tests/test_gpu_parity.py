@@ -601,16 +601,20 @@ def test_wide_motif_classes_vs_oracle(oracle, monkeypatch, env):
         got = cscore.c_scan_motif(ml, cuts, seqs, strand, 1)
         assert got == want, (strand, cut)
     pw = _lib.PwmSet.from_matrices(mats, [0.55] * len(mats))
-    with pytest.warns(RuntimeWarning, match="2 of .* PWMs cannot take the matrix-core pre-filter"):      # the fence: never silent
-        res = _lib.scan(pw, _lib.SeqSet.from_strings(seqs), 3)
-    assert res.stats()["n_pwms_exact"] == 2                      # only the 64- and 70-column motifs leave the pre-filter
     import warnings
     with warnings.catch_warnings():
-        warnings.simplefilter("error")                           # ... once per PWM set, and not at all for a validation scan or a set the filter takes whole
-        _lib.scan(pw, _lib.SeqSet.from_strings(seqs[:5]), 3).close()
+        warnings.simplefilter("error")                           # (a few short sequences: nothing worth a warning)
+        res = _lib.scan(pw, _lib.SeqSet.from_strings(seqs), 3)
+    assert res.stats()["n_pwms_exact"] == 2                      # only the 64- and 70-column motifs leave the pre-filter
+    big, boff = synth.make_regions(12000, 500, seed=4)           # 6 Mbase x 2 such motifs: the fence speaks up, once per PWM set
+    with pytest.warns(RuntimeWarning, match="2 of .* PWMs cannot take the matrix-core pre-filter"):
+        _lib.scan(pw, _lib.SeqSet(big, boff), 3).close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                           # ... and not at all for a validation scan or a set the filter takes whole
+        _lib.scan(pw, _lib.SeqSet(big, boff), 3).close()
         pw2 = _lib.PwmSet.from_matrices(mats[:40], [0.55] * 40)
-        _lib.scan(pw2, _lib.SeqSet.from_strings(seqs[:5]), 3).close()
-        _lib.scan(pw2, _lib.SeqSet.from_strings(seqs[:5]), 3, _lib.MS_SCAN_EXACT_ONLY).close()
+        _lib.scan(pw2, _lib.SeqSet(big, boff), 3).close()
+        _lib.scan(pw2, _lib.SeqSet(big[:500 * 2000], boff[:2001]), 3, _lib.MS_SCAN_EXACT_ONLY).close()
 
 
 def test_pwm_with_minus_inf_entries_vs_oracle(oracle):

@@ -23,7 +23,7 @@ python - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$OUT/*.json")):
     try:
-        j = json.load(open(f))
+        j = json.loads([l for l in open(f) if l.startswith('{"metric"')][-1])
     except Exception as e:
         print(os.path.basename(f), "unreadable", e); continue
     e2e = j.get("value_end_to_end")

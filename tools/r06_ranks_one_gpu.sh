@@ -16,7 +16,7 @@ python - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$OUT/e2e_8ranks*.json")):
     try:
-        j = json.load(open(f))
+        j = json.loads([l for l in open(f) if l.startswith('{"metric"')][-1])
     except Exception as e:
         print(os.path.basename(f), "unreadable", e); continue
     e = j["value_end_to_end"]; pr = e["per_rank"]
