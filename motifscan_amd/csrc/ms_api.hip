@@ -1978,10 +1978,31 @@ void ms_host_free(void *p) { if (p) (void) hipHostFree(p); }
 int ms_result_region_counts(const ms_result *r, int64_t *out) {
     if (!r || (!out && r->P > 0)) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->P == 0) return MS_OK;
+    if (r->h_region_counts.size() == (size_t) r->P) { std::memcpy(out, r->h_region_counts.data(), (size_t) r->P * sizeof(int64_t)); return MS_OK; }
     MS_HIP(hipSetDevice(r->device));
     MS_HIP(hipMemcpy(out, r->d_region_counts, (size_t) r->P * sizeof(int64_t), hipMemcpyDeviceToHost));
     return MS_OK;
 }
+
+}  // extern "C"
+
+// The counts onto the host on the copy-out stream (a batch stream's third stage: the consumer's ms_result_region_counts then never issues a
+// blocking device copy of its own -- 14 of those per configs[3] pass, each queued behind the copy engine's hit arrays, cost the reference
+// CLI's job 5-7 ms per pass in round 6's first measurements)
+int ms::result_fetch_region_counts(ms_result *r) {
+    if (!r || r->P == 0) return MS_OK;
+    DeviceCtx *c;
+    int rc = get_ctx(r->device, &c);
+    if (rc) return rc;
+    try { r->h_region_counts.assign((size_t) r->P, 0); } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
+    const hipStream_t down = c->stream_down;
+    hipError_t he = hipMemcpyAsync(r->h_region_counts.data(), r->d_region_counts, (size_t) r->P * sizeof(int64_t), hipMemcpyDeviceToHost, down);
+    if (he == hipSuccess) he = hipStreamSynchronize(down);
+    if (he != hipSuccess) { r->h_region_counts.clear(); set_error("copy of the region counts failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+    return MS_OK;
+}
+
+extern "C" {
 
 int ms_result_region_counts_device(const ms_result *r, void **d_counts) {
     if (!r || !d_counts) { set_error("NULL argument"); return MS_ERR_INVALID; }

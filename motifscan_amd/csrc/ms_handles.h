@@ -98,6 +98,7 @@ int numa_node_count(const char *root);
 int numa_bind_calling_thread(int node);
 // the policy (MS_NUMA_BIND, ms_numa.cpp) applied to the calling thread for `device`: returns the node bound to, -1 if none
 int numa_bind_for_device(int device, bool force);
+int result_fetch_region_counts(ms_result *r);
 int seqset_create_upload_only(const char *bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out);
 int seqset_pack_pending(const ms_seqset *s, hipStream_t st);
 int seqset_create_hostpacked(const char *bases, const int64_t *offsets, int64_t n_seqs, int n_threads, void **stage_io, size_t *stage_bytes_io, ms_seqset **out);
@@ -231,6 +232,7 @@ struct ms_result {
     bool h_packed = false;                            // ... in the compact form (coord | score)
     size_t h_pinned_bytes = 0;
     int64_t h_pinned_hits = -1;
+    std::vector<int64_t> h_region_counts;             // a batch stream's copy-out stage brings the per-motif region counts along (ms_result_region_counts then copies host to host)
     ms_scan_stats stats;
 };
 

@@ -141,7 +141,9 @@ struct ms_stream {
 
     void download(Job *j) {
         const uint32_t flags = j->flags;
-        if (j->rc != MS_OK || (flags & MS_STREAM_NO_HITS)) return;
+        if (j->rc != MS_OK) return;
+        { const int rc0 = result_fetch_region_counts(j->res); if (rc0) { fail_job(j, rc0); return; } }      // every batch, counts-only ones included
+        if (flags & MS_STREAM_NO_HITS) return;
         // MS_STREAM_PACKED12: the 12-byte form where the scan could make it (the batch's region indices and positions fit 31 bits), and for
         // results the scan left without words (sweep spans, de-duplicated batches) if it fits them; the 16-byte form otherwise
         int rc;

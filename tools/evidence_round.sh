@@ -1,6 +1,6 @@
 # Round evidence on the GPU box: tests, bench lines, profiles.  Usage: bash tools/evidence_round.sh <tag> [quick]
 # Everything lands in gpurun_out/evidence_<tag>/ (scratch); what is to be judged is copied into profiles/ afterwards (profiles/INDEX.md).
-TAG=${1:-r05d}
+TAG=${1:-r06}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
 T="timeout 900"
@@ -60,4 +60,14 @@ for q in sq1 sq2 fetch write lds; do python3 tools/pmc_summary.py $P/$q $OUT/pmc
 f=$(ls $P/stats/*/*kernel_stats.csv 2>/dev/null | head -n 1); if [ -n "$f" ]; then cp "$f" $OUT/kernel_stats_c4.csv; fi
 cp $P/bench_under_rocprof.json $OUT/bench_under_rocprof_c4.json
 rm -rf $P
+# the line once more, with the traffic of the passes above (the record is rewritten on the box for this run only; the committed one is
+# rewritten from the copied-back summaries by tools/pmc_traffic_update.py)
+python3 tools/pmc_traffic_update.py c4 $OUT/pmc_fetch.csv $OUT/pmc_write.csv "evidence round $TAG" > /dev/null
+$T python bench.py > $OUT/bench_c4_with_traffic.json 2> /dev/null
+# round 6: the floor table of the pre-filter, the asm variant beside the product, the 8-rank end-to-end leg on this one GPU
+$T python tools/pf_floor.py 1e-4 3 > $OUT/pf_floor.log 2>&1
+for i in 1 2; do
+MS_LIB_VARIANT=asm $T python bench.py --no-cpu-baseline --no-end-to-end --no-api --no-scale-projection > $OUT/bench_c4_asm_variant_$i.json 2> /dev/null
+$T python bench.py --no-cpu-baseline --no-end-to-end --no-api --no-scale-projection > $OUT/bench_c4_product_same_box_$i.json 2> /dev/null
+done
 ls $OUT
