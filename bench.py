@@ -594,6 +594,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
         batches.append((pins[k].array[lo:hi], np.ascontiguousarray(offsets[r0:r1 + 1] - lo)))
     units = float(wl["units"])
 
+    each_pass = {}                                      # every timed pass of a leg by itself (ms): a leg's mean hides a single slow pass
     own = {}                                            # this rank's own seconds and process CPU seconds per leg (the per-rank report at N > 1)
 
     def timed(fn, passes, name=None):
@@ -604,8 +605,13 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
         c0 = os.times()
         t0 = time.perf_counter()
         hits = 0
+        each = []
         for _ in range(passes):
+            t1 = time.perf_counter()
             hits += fn()
+            each.append(round((time.perf_counter() - t1) * 1e3, 2))
+        if name:
+            each_pass[name] = each
         if name:
             c1 = os.times()
             own[name] = ((time.perf_counter() - t0) / passes, (c1.user + c1.system - c0.user - c0.system) / passes)
@@ -686,7 +692,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     passes = max(1, min(a.steps, 4))
     v_p12, ms_p12, hits = timed(pipelined(12), passes, "pipelined")
     v_cli, ms_cli, hits_cli = timed(pipelined_cli, passes, "pipelined_cli")
-    v_p16, ms_p16, hits16 = timed(pipelined(16), passes)
+    v_p16, ms_p16, hits16 = timed(pipelined(16), passes, "pipelined_16B")
     v_p25, ms_p25, _ = timed(pipelined(False), passes)
     v_s, ms_s, _ = timed(serial, passes)
     reps = 4
@@ -716,7 +722,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
                     "numa_node_bound": [int(x) for x in tab[:, 9]], "cpus_allowed": [int(x) for x in tab[:, 10]],
                     "host_cpu_busy_fraction_of_box": float(tab[:, 1].sum() / max(tab[:, 0].max(), 1e-9) / (os.cpu_count() or 1)),
                     "host_cores": os.cpu_count()}
-    return {"per_rank": per_rank, "host_pack": bool(a.host_pack), "numa_node_bound": numa_node, "pinned_input_alloc_and_fill_ms": round(t_pin * 1e3, 1),
+    return {"per_rank": per_rank, "ms_each_pass": each_pass, "host_pack": bool(a.host_pack), "numa_node_bound": numa_node, "pinned_input_alloc_and_fill_ms": round(t_pin * 1e3, 1),
             "pipelined": v_p12, "pipelined_cli": v_cli, "pipelined_16B": v_p16, "pipelined_25B": v_p25, "serial": v_s, "pipelined_sustained": v_su, "unit": "bp*motifs/s",
             "ms_per_pass": {"pipelined": ms_p12, "pipelined_cli": ms_cli, "pipelined_16B": ms_p16, "pipelined_25B": ms_p25, "serial": ms_s, "pipelined_sustained": ms_su},
             "hits_check_12B_vs_16B": bool(hits == hits16), "bytes_per_hit_on_the_link": {"pipelined": 12, "pipelined_cli": 12, "pipelined_16B": 16, "pipelined_25B": 25},
