@@ -227,6 +227,9 @@ int ms_result_packed_form(const ms_result *res, int32_t *bytes_per_hit);
 /* ---- pinned host memory -------------------------------------------------------------------- */
 /* Page-locked host memory for sequence input: uploads from it run at the full link rate and overlap with scans. */
 int ms_host_alloc(size_t bytes, void **out);
+/* The library's cache of pinned result blocks (size classes, like the device block cache): out[0] requests served from it, out[1] requests that
+ * went to the driver, out[2] blocks returned to the driver, out[3] nanoseconds inside the driver.  Steady-state batches show no [1] / [2]. */
+int ms_host_pool_stats(uint64_t out[4]);
 void ms_host_free(void *p);
 
 /* ---- batch streams: upload + pack | scan | copy-out overlapped ------------------------------- */

@@ -129,6 +129,7 @@ def lib():
         "ms_host_alloc": (c_int, [ctypes.c_size_t, pvp]),
         "ms_device_pool_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64)]),
         "ms_host_free": (None, [vp]),
+        "ms_host_pool_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64)]),
         "ms_stream_create": (c_int, [vp, c_int, c_u32, c_int, pvp]),
         "ms_stream_submit": (c_int, [vp, vp, pi64, c_i64]),
         "ms_stream_submit_counts_only": (c_int, [vp, vp, pi64, c_i64]),
@@ -608,6 +609,13 @@ def host_pack(bases, offsets):
     check(lib().ms_debug_host_pack(bases.ctypes.data_as(ctypes.c_char_p), ptr(offsets, ctypes.c_int64), offsets.size - 1,
                                    ptr(codes, ctypes.c_uint32), ptr(nmask, ctypes.c_uint32), ptr(blk, ctypes.c_int32), ptr(info, ctypes.c_int32)))
     return codes, nmask, blk, info
+
+
+def host_pool_stats():
+    """The pinned-block cache (ms_host_pool_stats): dict(hits, misses, driver_frees, ms_in_driver)."""
+    out = (ctypes.c_uint64 * 4)()
+    check(lib().ms_host_pool_stats(out))
+    return {"hits": int(out[0]), "misses": int(out[1]), "driver_frees": int(out[2]), "ms_in_driver": out[3] / 1e6}
 
 
 def pool_stats():

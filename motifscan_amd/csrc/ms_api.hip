@@ -147,38 +147,59 @@ int pool_alloc(DeviceCtx *c, size_t bytes, void **out, size_t *got) {
     return MS_OK;
 }
 
-// Pinned host blocks are even dearer to create than device blocks; keep a few for reuse.
+// Pinned host blocks are even dearer to create than device blocks (page-locking ~0.25 ms per MB, and hipHostFree waits for the whole device):
+// kept for reuse in the device pool's SIZE CLASSES (round 6).  Rounds 2-5 matched a request to any free block of 1 ... 2 x its size, at most 16
+// blocks: the 14 batches of a configs[3] pass ask for 14 different sizes, a small request took the block a larger one needed, the largest
+// went to the driver, the list ran over and a block went back to the driver -- episodes of 80-ms passes among 48-ms ones
+// (profiles/r06f_e2e_cli_probe.log).  With classes a pass's blocks come back to exactly the requests that made them.
 static std::mutex g_pin_mu;
 static std::vector<std::pair<void *, size_t>> g_pin_free;
+static uint64_t g_pin_stats[4] = {0, 0, 0, 0};            // served from the list, went to hipHostMalloc, returned to the driver, ns inside the driver
 
 void *pinned_alloc(size_t bytes, size_t *got) {
+    const size_t want = pool_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
-        size_t best = (size_t) -1;
-        for (size_t i = 0; i < g_pin_free.size(); i++) {
-            const size_t sz = g_pin_free[i].second;
-            if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && (best == (size_t) -1 || sz < g_pin_free[best].second)) best = i;
-        }
-        if (best != (size_t) -1) {
-            void *p = g_pin_free[best].first;
-            *got = g_pin_free[best].second;
-            g_pin_free.erase(g_pin_free.begin() + (long) best);
-            return p;
-        }
+        for (size_t i = g_pin_free.size(); i-- > 0;)
+            if (g_pin_free[i].second == want) {
+                void *p = g_pin_free[i].first;
+                *got = want;
+                g_pin_free.erase(g_pin_free.begin() + (long) i);
+                g_pin_stats[0]++;
+                return p;
+            }
     }
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
-    *got = bytes;
+    const uint64_t t0 = now_ns();
+    const bool ok = hipHostMalloc(&p, want) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        g_pin_stats[1]++;
+        g_pin_stats[3] += now_ns() - t0;
+    }
+    if (!ok) { (void) hipGetLastError(); return nullptr; }
+    *got = want;
     return p;
 }
 
 void pinned_free(void *p, size_t bytes) {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        size_t total = bytes;
+        for (auto &b : g_pin_free) total += b.second;
+        if (g_pin_free.size() < 96 && total <= (24ull << 30)) { g_pin_free.emplace_back(p, bytes); return; }
+    }
+    const uint64_t t0 = now_ns();
+    (void) hipHostFree(p);
     std::lock_guard<std::mutex> lk(g_pin_mu);
-    size_t total = bytes;
-    for (auto &b : g_pin_free) total += b.second;
-    if (g_pin_free.size() >= 16 || total > (16ull << 30)) { (void) hipHostFree(p); return; }
-    g_pin_free.emplace_back(p, bytes);
+    g_pin_stats[2]++;
+    g_pin_stats[3] += now_ns() - t0;
+}
+
+void pinned_pool_stats(uint64_t out[4]) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (int i = 0; i < 4; i++) out[i] = g_pin_stats[i];
 }
 
 size_t pool_trim_current_device() {
@@ -1957,6 +1978,14 @@ int ms_device_pool_stats(uint64_t out[6]) {
     std::lock_guard<std::mutex> lk(c->pool.mu);
     out[0] = c->pool.n_hit; out[1] = c->pool.n_miss; out[2] = c->pool.n_driver_free; out[3] = c->pool.ns_driver;
     out[4] = c->pool.bytes; out[5] = c->pool.free_.size();
+    return MS_OK;
+}
+
+// the pinned-block cache (process-wide): out[0] requests served from the cache, out[1] requests that went to hipHostMalloc, out[2] blocks returned
+// to the driver, out[3] nanoseconds inside the driver for [1] and [2].  Steady-state batches should show no [1] / [2].
+int ms_host_pool_stats(uint64_t out[4]) {
+    if (!out) { set_error("out is NULL"); return MS_ERR_INVALID; }
+    pinned_pool_stats(out);
     return MS_OK;
 }
 

@@ -98,6 +98,7 @@ int numa_node_count(const char *root);
 int numa_bind_calling_thread(int node);
 // the policy (MS_NUMA_BIND, ms_numa.cpp) applied to the calling thread for `device`: returns the node bound to, -1 if none
 int numa_bind_for_device(int device, bool force);
+void pinned_pool_stats(uint64_t out[4]);
 int result_fetch_region_counts(ms_result *r);
 int seqset_create_upload_only(const char *bases, const int64_t *offsets, int64_t n_seqs, ms_seqset **out);
 int seqset_pack_pending(const ms_seqset *s, hipStream_t st);

@@ -25,7 +25,10 @@ def run(cli, read_counts=True):
             res.region_counts()
         res.close()
     return (time.perf_counter() - t0) * 1e3, st
-for name, cli, rc in (("all hits", False, False), ("cli, counts read", True, True), ("cli, counts not read", True, False), ("all hits", False, False), ("cli, counts read", True, True)):
+for name, cli, rc in (("all hits", False, False), ("cli, counts read", True, True), ("cli, counts not read", True, False), ("all hits", False, False), ("cli, counts read", True, True), ("all hits", False, False), ("all hits", False, False)):
+    h0, d0 = _lib.host_pool_stats(), _lib.pool_stats()
     rows = [run(cli, rc) for _ in range(10)]
+    h1, d1 = _lib.host_pool_stats(), _lib.pool_stats()
+    print("   pinned pool: +%d served, +%d hipHostMalloc, +%d hipHostFree, +%.1f ms in the driver | device pool: %s -> %s" % (h1["hits"] - h0["hits"], h1["misses"] - h0["misses"], h1["driver_frees"] - h0["driver_frees"], h1["ms_in_driver"] - h0["ms_in_driver"], d0, d1), flush=True)
     ms = [r[0] for r in rows]
     print(f"{name:24s} passes {' '.join('%.1f' % x for x in ms)}  | median {sorted(ms)[5]:.1f}  | last pass scan work {rows[-1][1]['scan']['ms_work']:.1f} wait_in {rows[-1][1]['scan']['ms_wait_in']:.1f} upload {rows[-1][1]['upload']['ms_work']:.1f} copy_out {rows[-1][1]['copy_out']['ms_work']:.1f}", flush=True)
