@@ -75,6 +75,9 @@ extern "C" {
 /* ms_scan flags */
 #define MS_SCAN_DEFAULT      0u
 #define MS_SCAN_EXACT_ONLY   1u   /* skip the integer pre-filter: score every window in fp64 (validation) */
+#define MS_SCAN_COUNTS_ONLY  2u   /* only what the enrichment statistics read of a region set (stats.py:27-31): n_hits, the per-motif site numbers
+                                     (ms_result_motif_offsets) and the per-motif region counts -- the hits are counted unordered, no site array is
+                                     made (the hit accessors of the result fail with MS_ERR_INVALID).  What cli/scan.py:81-89 needs of the control regions. */
 
 typedef struct ms_pwmset ms_pwmset;
 typedef struct ms_seqset ms_seqset;
@@ -234,8 +237,8 @@ void ms_host_free(void *p);
 
 /* ---- batch streams: upload + pack | scan | copy-out overlapped ------------------------------- */
 #define MS_STREAM_DEDUP       1u   /* de-duplicate every batch on the device (scanner.py:156-193) before the copy-out      */
-#define MS_STREAM_NO_HITS     2u   /* counts only: hit arrays stay on the device (control regions: stats.py:29-31); a sweep span then
-                                      makes ONLY the per-motif window counts and the number of sites (no site is handed out: the hit
+#define MS_STREAM_NO_HITS     2u   /* counts only (control regions: stats.py:29-31): a batch is scanned with MS_SCAN_COUNTS_ONLY, a sweep span
+                                      makes ONLY the per-motif window counts and the number of sites (no site array exists: the hit
                                       accessors of such a result fail with MS_ERR_INVALID; ms_result_motif_offsets then gives the running
                                       per-motif site numbers, consistent with n_hits; with MS_STREAM_DEDUP such a span is NOT de-duplicated --
                                       de-duplication never empties a window, the counts are the same)                           */

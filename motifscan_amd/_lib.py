@@ -21,7 +21,7 @@ if LIB_VARIANT not in ("", "asm"):
 LIB_PATH = os.path.join(_HERE, "libmotifscan_amd_asm.so" if LIB_VARIANT == "asm" else "libmotifscan_amd.so")
 
 MS_OK, MS_ERR_INVALID, MS_ERR_NOMEM, MS_ERR_RUNTIME = 0, 1, 2, 3
-MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY = 0, 1
+MS_SCAN_DEFAULT, MS_SCAN_EXACT_ONLY, MS_SCAN_COUNTS_ONLY = 0, 1, 2
 MS_STREAM_DEDUP, MS_STREAM_NO_HITS, MS_STREAM_EXACT_ONLY, MS_STREAM_PACKED, MS_STREAM_HOST_PACK, MS_STREAM_PACKED12 = 1, 2, 4, 8, 16, 32
 
 

@@ -1547,10 +1547,27 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // a short hit list is ordered by launch latencies, not passes: one kernel fewer matters more there)
     const int sort_begin_large = (end_bit > 2 * kSortLowBits && !measure_env("MS_SORT_FULL")) ? kSortLowBits : 0;
     bool queue_only = false;                     // this back() belongs to a scan that is only queued (scan_complete finishes it)
+    const bool counts_fast = (flags & MS_SCAN_COUNTS_ONLY_INTERNAL) && !(flags & MS_SCAN_RAW_INTERNAL) && count_only_supported(pwms->P, seqs->R, pbits);
     auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
         (void) hipEventRecord(ev[3], c->stream);
+        if (counts_fast) {
+            // the bitmap + the per-motif site counters in one pooled block the result owns (a queued scan's kernels outlive this call)
+            const size_t words = count_only_bitmap_words(pwms->P, seqs->R);
+            if ((rc = pool_alloc(c, words * 4 + 256 + 8 * (size_t) pwms->P, &raw->coord_blk, &raw->coord_bytes))) return rc;
+            uint32_t *bitmap = static_cast<uint32_t *>(raw->coord_blk);
+            unsigned long long *motif_hits = reinterpret_cast<unsigned long long *>(static_cast<char *>(raw->coord_blk) + ((words * 4 + 255) & ~(size_t) 255));
+            if ((rc = launch_count_only(sc.keys, (int64_t) n_sort, n_dev, gbits, pbits, seqs->R, pwms->P, bitmap, raw->d_region_counts, motif_hits, raw->d_motif_first, c->stream))) return rc;
+            raw->counts_only = true;
+            (void) hipEventRecord(ev[4], c->stream);
+            (void) hipEventRecord(ev[5], c->stream);
+            if (!queue_only) {
+                he = hipMemcpyAsync(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+                if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
+            }
+            return MS_OK;
+        }
         size_t fixup_min = (size_t) 1 << 20;
         if (const char *e = measure_env("MS_SORT_FIXUP_MIN")) fixup_min = (size_t) std::max(0, atoi(e));     // test aid: the fix-up form on short lists too
         const int sort_begin = n_sort >= fixup_min ? sort_begin_large : 0;
@@ -1655,7 +1672,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         const size_t n_pred = (size_t) std::min<double>(mu * (1.0 + pwms->pred_margin) + 6.0 * std::sqrt(mu + 1.0) + 256.0, 3.0e9);
         want_hits = std::max(want_hits, n_pred);
         if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
-        if ((rc = result_block(n_pred))) return fail(rc);
+        if ((rc = result_block(counts_fast ? 1 : n_pred))) return fail(rc);
         stt.n_passes = 1;
         HitOut H;
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
@@ -1739,7 +1756,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     }
 
     // one pooled block for everything the result owns
-    if ((rc = result_block((size_t) n_hits))) return fail(rc);
+    if ((rc = result_block(counts_fast ? 1 : (size_t) n_hits))) return fail(rc);
     if ((rc = back((size_t) n_hits, nullptr))) return fail(rc);
     he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) { set_error("finalize failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
@@ -1757,14 +1774,15 @@ int ms_scan(const ms_pwmset *pwms_c, const ms_seqset *seqs, int strand_mask, uin
     *out = nullptr;
     if (!pwms_c || !seqs) { set_error("NULL handle"); return MS_ERR_INVALID; }
     if (strand_mask < 1 || strand_mask > 3) { set_error("invalid strand mask %d (1 '+', 2 '-', 3 both)", strand_mask); return MS_ERR_INVALID; }
-    if (flags & ~(uint32_t) MS_SCAN_EXACT_ONLY) { set_error("unknown scan flags 0x%x", flags); return MS_ERR_INVALID; }
+    if (flags & ~(uint32_t) (MS_SCAN_EXACT_ONLY | MS_SCAN_COUNTS_ONLY)) { set_error("unknown scan flags 0x%x", flags); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);       // lazily cached device copies / plan
     DeviceCtx *c;
     int rc = get_ctx(seqs->device, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk_dev(c->mu);
     std::lock_guard<std::mutex> lk_pwm(pwms->mu);
-    return scan_locked(c, pwms, seqs, strand_mask, flags, out);
+    const uint32_t internal = (flags & MS_SCAN_EXACT_ONLY) | ((flags & MS_SCAN_COUNTS_ONLY) ? MS_SCAN_COUNTS_ONLY_INTERNAL : 0u);
+    return scan_locked(c, pwms, seqs, strand_mask, internal, out);
 }
 
 int ms_result_num_hits(const ms_result *r, int64_t *n_hits) {
@@ -1782,7 +1800,7 @@ int ms_result_motif_offsets(const ms_result *r, int64_t *out) {
 int ms_result_hits(const ms_result *r, int64_t *seq_idx, int64_t *pos, double *score, int8_t *strand) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
-    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only result (MS_SCAN_COUNTS_ONLY, a counts-only batch or sweep span of a stream) holds the per-motif region counts and site numbers, no site arrays"); return MS_ERR_INVALID; }
     if (r->n_hits == 0) return MS_OK;
     MS_HIP(hipSetDevice(r->device));
     const size_t n = (size_t) r->n_hits;
@@ -1800,7 +1818,7 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
                         const int8_t **strand) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
-    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only result (MS_SCAN_COUNTS_ONLY, a counts-only batch or sweep span of a stream) holds the per-motif region counts and site numbers, no site arrays"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
     const size_t bytes = 25 * n_round + 64;
@@ -1840,7 +1858,7 @@ int ms_result_hits_host(ms_result *r, const int64_t **seq_idx, const int64_t **p
 int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const double **score) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
-    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only result (MS_SCAN_COUNTS_ONLY, a counts-only batch or sweep span of a stream) holds the per-motif region counts and site numbers, no site arrays"); return MS_ERR_INVALID; }
     if (r->d_coord && r->coord_shift) { set_error("this result holds the 12-byte compact form (MS_STREAM_PACKED12): read it with ms_result_hits_packed12_host"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
@@ -1902,7 +1920,7 @@ int ms_result_hits_packed_host(ms_result *r, const uint64_t **coord, const doubl
 int ms_result_hits_packed12_host(ms_result *r, const uint32_t **coord, const double **score, int32_t *shift_out) {
     if (!r) { set_error("NULL argument"); return MS_ERR_INVALID; }
     if (r->invalid) { set_error("result of a no-emit measurement run (MS_MEASURE=1 MS_PF_NOEMIT=1) holds no hits"); return MS_ERR_INVALID; }
-    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only result (MS_SCAN_COUNTS_ONLY, a counts-only batch or sweep span of a stream) holds the per-motif region counts and site numbers, no site arrays"); return MS_ERR_INVALID; }
     if (r->d_coord && !r->coord_shift) { set_error("this result holds the 16-byte compact form (its batch did not fit 31 bits of region index and position): read it with ms_result_hits_packed_host"); return MS_ERR_INVALID; }
     const size_t n = (size_t) r->n_hits;
     const size_t n_round = (n + 65535) & ~(size_t) 65535;
@@ -2052,7 +2070,7 @@ int ms_result_dedup(ms_result *r, const ms_pwmset *pwms_c) {
     if (!r || !pwms_c) { set_error("NULL handle"); return MS_ERR_INVALID; }
     ms_pwmset *pwms = const_cast<ms_pwmset *>(pwms_c);
     if (pwms->P != r->P) { set_error("result and PWM set disagree on the number of PWMs"); return MS_ERR_INVALID; }
-    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only result (MS_SCAN_COUNTS_ONLY, a counts-only batch or sweep span of a stream) holds the per-motif region counts and site numbers, no site arrays"); return MS_ERR_INVALID; }
     if (r->deduped || r->n_hits == 0) { r->deduped = true; return MS_OK; }
     if (r->coord_blk) {                                  // coordinate words of the hits before de-duplication: void
         DeviceCtx *c0;
@@ -2123,7 +2141,7 @@ int ms_result_site_tables(const ms_result *r, int32_t *n_sites, double *max_scor
     if (!r) { set_error("NULL handle"); return MS_ERR_INVALID; }
     const size_t cells = (size_t) r->P * (size_t) r->R;
     if (cells == 0) return MS_OK;
-    if (r->counts_only) { set_error("a counts-only sweep span (MS_STREAM_NO_HITS) holds per-motif window counts and the number of sites, no site arrays"); return MS_ERR_INVALID; }
+    if (r->counts_only) { set_error("a counts-only result (MS_SCAN_COUNTS_ONLY, a counts-only batch or sweep span of a stream) holds the per-motif region counts and site numbers, no site arrays"); return MS_ERR_INVALID; }
     if (!n_sites || !max_score) { set_error("NULL output"); return MS_ERR_INVALID; }
     DeviceCtx *c;
     int rc = get_ctx(r->device, &c);

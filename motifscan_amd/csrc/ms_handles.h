@@ -251,6 +251,11 @@ namespace ms {
 #define MS_SCAN_PACK_INTERNAL 0x20000000u
 // ... in the 4-byte form (ms_result_hits_packed12_host) when every (region, position) of the set fits 31 bits; the 8-byte form otherwise.
 #define MS_SCAN_PACK12_INTERNAL 0x10000000u
+// Internal scan flag: COUNTS ONLY -- the result holds n_hits, the per-motif site numbers (motif_offsets) and the per-motif region counts, NO site
+// arrays (ms_result::counts_only: the hit accessors refuse it): the hits are counted where the fp64 stage left them, unordered
+// (count_only_kernel), and the radix sort + finalize are skipped.  Falls back to the ordered path by itself where the bitmap form does not
+// apply (global-position keys, more than 4096 motifs, an absurd P x R).
+#define MS_SCAN_COUNTS_ONLY_INTERNAL 0x08000000u
 // Internal scan flag: never use the predicted-size form (the exactly-sized re-run after a failed prediction).
 #define MS_SCAN_NO_PREDICT_INTERNAL 0x40000000u
 

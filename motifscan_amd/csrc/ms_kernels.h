@@ -116,6 +116,11 @@ int launch_blk2reg(const int64_t *offsets, int64_t R, int64_t n_bases, int32_t *
 int launch_score(const DevSeq &S, const DevPwm &Pw, int strand_mask, double *out, hipStream_t st);
 int launch_sweep_count(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                        int32_t window, int32_t stride, int64_t n_windows, uint32_t *cnt, hipStream_t st);
+// counts only, from the unordered hit keys (ms_regions.hip)
+bool count_only_supported(int32_t P, int64_t R, int pbits);
+size_t count_only_bitmap_words(int32_t P, int64_t R);
+int launch_count_only(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int pbits, int64_t R, int32_t P, uint32_t *bitmap,
+                      unsigned long long *region_counts, unsigned long long *motif_hits, int64_t *motif_first, hipStream_t st);
 int launch_sweep_countonly(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,
                            int32_t window, int32_t stride, int64_t n_windows, unsigned long long *region_counts, unsigned long long *n_sites, hipStream_t st);
 int launch_sweep_scatter(int64_t n, const int64_t *motif_off, int32_t P, const int32_t *width, const int64_t *pos,

@@ -101,6 +101,7 @@ struct ms_stream {
             std::lock_guard<std::mutex> lk_pwm(pwms->mu);
             const bool simple = j->kind != 1 && !(flags & MS_STREAM_DEDUP);
             const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) |
+                                ((simple && (flags & MS_STREAM_NO_HITS)) ? MS_SCAN_COUNTS_ONLY_INTERNAL : 0u) |      // nothing but the counts will be read: no ordering
                                 ((simple && (flags & (MS_STREAM_PACKED | MS_STREAM_PACKED12)) && !(flags & MS_STREAM_NO_HITS)) ? ((flags & MS_STREAM_PACKED12) ? MS_SCAN_PACK12_INTERNAL : MS_SCAN_PACK_INTERNAL) : 0u);
             const bool plain = simple && slot >= 0;
             rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res, plain ? pend_slot[slot] : nullptr);
@@ -131,6 +132,7 @@ struct ms_stream {
                 std::lock_guard<std::mutex> lk_dev(c->mu);
                 std::lock_guard<std::mutex> lk_pwm(pwms->mu);
                 const uint32_t sf = ((flags & MS_STREAM_EXACT_ONLY) ? MS_SCAN_EXACT_ONLY : MS_SCAN_DEFAULT) | MS_SCAN_NO_PREDICT_INTERNAL |
+                                    ((flags & MS_STREAM_NO_HITS) ? MS_SCAN_COUNTS_ONLY_INTERNAL : 0u) |
                                     (((flags & (MS_STREAM_PACKED | MS_STREAM_PACKED12)) && !(flags & MS_STREAM_NO_HITS)) ? ((flags & MS_STREAM_PACKED12) ? MS_SCAN_PACK12_INTERNAL : MS_SCAN_PACK_INTERNAL) : 0u);
                 rc = scan_locked(c, pwms, j->seqs, strand, sf, &j->res);
             }

@@ -275,7 +275,8 @@ class Scanner:
                 g, idx = overlapping
                 res = _lib.scan_regions_once(pw, g, idx, self.seq_starts, self.seq_ends, _STRAND_FLAG[self.strand])
             else:
-                res = _lib.scan(pw, self._seqset(), _STRAND_FLAG[self.strand])
+                # nothing but the counts is read: the hits are counted where the fp64 stage left them -- no ordering, no site arrays
+                res = _lib.scan(pw, self._seqset(), _STRAND_FLAG[self.strand], _lib.MS_SCAN_COUNTS_ONLY)
             try:
                 return res.region_counts()
             finally:

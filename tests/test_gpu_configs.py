@@ -401,6 +401,10 @@ def test_stream_counts_only_errors_and_pinned_input(oracle):
     wb = _lib.scan(pw, _lib.SeqSet(bases[half:], offsets[1500:] - half), 3)
     for r, w, counts_only in zip(got, (wa, wb, wa, wb), (False, True, True, False)):
         assert r.n_hits == w.n_hits and np.array_equal(r.region_counts(), w.region_counts())
+        assert np.array_equal(r.motif_offsets, w.motif_offsets)                    # a counts-only batch still knows every motif's number of sites
+        if counts_only:
+            with pytest.raises(ValueError):                                        # ... but holds no site arrays (counted unordered: MS_SCAN_COUNTS_ONLY)
+                r.hits()
         if not counts_only:
             hp, hw = r.hits(packed=True), w.hits()
             for k in ("motif_offsets", "seq_idx", "pos", "score"):
@@ -422,6 +426,47 @@ def test_stream_counts_only_errors_and_pinned_input(oracle):
     st.close(); pin.close()
     with pytest.raises(ValueError):
         _lib.Stream(pw, 3, 0, depth=0)
+
+
+@pytest.mark.parametrize("shape", ["ragged", "one_long_region", "single_strand", "empty_and_tiny"])
+def test_counts_only_scan_equals_the_ordered_scan(oracle, shape):
+    """MS_SCAN_COUNTS_ONLY (round 6): n_hits, per-motif site numbers and per-motif region counts from the UNORDERED hits (a bit per
+    (motif, region), no radix sort, no finalize) == the same three from the ordered scan and from the oracle's nested result
+    (stats.py:29-31: sum(len(sites_by_region) > 0 ...)).  Where the bitmap form does not apply (a region so long that the hit keys carry
+    global positions) the scan falls back to the ordered path by itself: same numbers."""
+    vals, widths, cutoffs = synth.load_motif_set(90)
+    pw = _lib.PwmSet(vals, widths, cutoffs)
+    strand = 3
+    if shape == "ragged":
+        bases, offsets = synth.make_regions(4000, 260, seed=41, frac_n=0.06, ragged=True)
+    elif shape == "one_long_region":
+        b1, o1 = synth.make_regions(300, 120, seed=42)
+        b2, _ = synth.make_regions(1, 900_000, seed=43)
+        bases = np.concatenate([b1, b2, b1])
+        offsets = np.concatenate([o1, o1[-1] + np.array([b2.size]), o1[-1] + b2.size + o1[1:]]).astype(np.int64)
+    elif shape == "single_strand":
+        bases, offsets = synth.make_regions(2500, 500, seed=44, frac_n=0.02)
+        strand = 2
+    else:
+        lens = np.array([0, 3, 0, 500, 1, 499, 0, 0, 64, 63, 65, 0])
+        rng = np.random.default_rng(45)
+        bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(lens.sum()))]
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    sq = _lib.SeqSet(bases, offsets)
+    full = _lib.scan(pw, sq, strand)
+    want = oracle.scan_arrays(vals, widths, cutoffs, bases.tobytes(), offsets, strand, 8)
+    pair = np.unique((np.repeat(np.arange(len(widths)), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
+    want_regions = np.bincount(pair >> 32, minlength=len(widths))
+    for rep in range(2):                                     # (the second scan takes the predicted-size, one-sync form)
+        res = _lib.scan(pw, sq, strand, _lib.MS_SCAN_COUNTS_ONLY)
+        assert res.n_hits == full.n_hits == len(want["pos"])
+        assert np.array_equal(res.motif_offsets, want["motif_offsets"])
+        assert np.array_equal(res.region_counts(), want_regions) and np.array_equal(full.region_counts(), want_regions)
+        if shape != "one_long_region":
+            with pytest.raises(ValueError):
+                res.hits()
+        res.close()
+    full.close(); sq.close(); pw.close()
 
 
 def test_twelve_byte_copy_out_where_it_fits_sixteen_where_not(oracle):
