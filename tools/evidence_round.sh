@@ -29,6 +29,8 @@ $T python bench.py --no-cpu-baseline --no-end-to-end --no-api --motif-set lowinf
 $T python bench.py --no-cpu-baseline --no-api --no-scale-projection --batch-regions 250000 --max-batch-regions 250000 --no-batch-ramp --steps 4 > $OUT/bench_c4_e2e_8_equal_batches.json 2> /dev/null
 $T python bench.py --no-cpu-baseline --no-api --no-scale-projection --batch-regions 62500 --max-batch-regions 125000 --steps 4 > $OUT/bench_c4_e2e_small_batches.json 2> /dev/null
 $T python bench.py --no-cpu-baseline --no-end-to-end --extra-widths 33,40 > $OUT/bench_c4_plus_w33_w40.json 2> /dev/null
+# what the all-fp64 kernel costs (the fence of VERDICT r5 #8): two motifs the pre-filter cannot take, on one GPU's shard of an 8-GPU run
+$T python bench.py --no-cpu-baseline --no-end-to-end --no-api --extra-widths 70,90 --regions-per-set 125000 --steps 3 > $OUT/bench_c4shard_plus_w70_w90.json 2> $OUT/bench_c4shard_plus_w70_w90.err
 $T python tools/pf_account.py 1e-4 full 2>&1 | grep -v amdgpu.ids > $OUT/pf_account.log
 $T python tools/pf_account.py 1e-3 2>&1 | grep -v amdgpu.ids >> $OUT/pf_account.log
 $T python tools/pf_class_clock.py 3 1e-4 2>&1 | grep -v amdgpu.ids > $OUT/class_clock.log
@@ -70,4 +72,7 @@ for i in 1 2; do
 MS_LIB_VARIANT=asm $T python bench.py --no-cpu-baseline --no-end-to-end --no-api --no-scale-projection > $OUT/bench_c4_asm_variant_$i.json 2> /dev/null
 $T python bench.py --no-cpu-baseline --no-end-to-end --no-api --no-scale-projection > $OUT/bench_c4_product_same_box_$i.json 2> /dev/null
 done
+timeout 300 ./tools/ubench/shape_probe16.bin > $OUT/shape_probe16.log 2>&1
+$T python tools/e2e_cli_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/e2e_cli_probe.log
+bash tools/r06_ranks_one_gpu.sh evidence_$TAG/ranks > $OUT/ranks_one_gpu_summary.log 2>&1
 ls $OUT

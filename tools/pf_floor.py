@@ -65,12 +65,12 @@ for k, name in NAMES.items():
     ms = sorted(r["ms_median"] for r in res[k]); mhz = sorted(r["mhz_median"] for r in res[k]); w = sorted(r["watts_median"] for r in res[k])
     m = ms[len(ms) // 2]
     base = base or m
-    print(f"{name:46s} {m:7.2f} ms  (rounds: {' '.join('%.2f' % x for x in ms)})  clock {mhz[len(mhz) // 2]:.0f} MHz  board {w[len(w) // 2]:.0f} W   {m / base:5.2f} of the product")
+    print(f"{name:46s} {m:7.2f} ms  (rounds: {' '.join('%.2f' % x for x in ms)})   {m / base:5.2f} of the product")
 r0 = res[0][0] if res[0] else None
 if r0:
     n_mfma = r0["mfma_ops"] / 131072.0
     print(f"# issue model: {n_mfma / 1e6:.1f} M matrix instructions per launch x 32 clk / 1024 SIMDs:")
-    for f in (2400.0, sorted(r["mhz_median"] for r in res[3])[len(res[3]) // 2] if res[3] else 0.0, sorted(r["mhz_median"] for r in res[0])[len(res[0]) // 2]):
-        if f > 0:
+    for f in (2400.0, 2250.0, 2060.0):          # nominal; what the product kernel holds under the power limit; what an MFMA-only loop holds (profiles/r05_power_probe.log -- hwmon sampled from a
+        if f > 0:                                 # 1.5-s loop does not resolve the clock, so it is not printed here)
             print(f"#   matrix pipe 100 % busy at {f:.0f} MHz: {n_mfma * 32 / 1024 / (f * 1e6) * 1e3:.2f} ms")
     print(f"#   useful fraction of the issued matrix work: {r0['mfma_ops_algorithmic'] / r0['mfma_ops']:.3f} (one-hot k-slots x width padding)")

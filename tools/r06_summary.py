@@ -12,7 +12,9 @@ def show(f, extra=()):
     j = line(f)
     if not j:
         print(f, "-- missing"); return
-    r = j["roofline"]; s = j.get("stage_ms_per_scan", {})
+    r = j.get("roofline") or {}; s = j.get("stage_ms_per_scan", {})
+    if not r:
+        print(f"{f:44s} value {j['value']:.4e}  step {j['ms_per_step']:.2f} ms  " + json.dumps({k: j[k] for k in j if k.startswith('value_') or k in ('config',)})[:700]); return
     out = f"{f:44s} value {j['value']:.4e}  step {j['ms_per_step']:.2f} ms  kernel_ms {r['kernel_ms']:.2f} frac {r['frac']:.4f} traffic {r.get('traffic')}  stages " + " ".join(f"{k[3:]}={v:.2f}" for k, v in s.items())
     if "value_8d_end_to_end" in j:
         e = j["value_end_to_end"]
