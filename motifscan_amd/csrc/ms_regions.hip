@@ -113,16 +113,34 @@ __global__ void __launch_bounds__(256) count_only_kernel(const uint64_t *__restr
     __syncthreads();
     if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }
     const uint64_t cmask = (1ULL << gbits) - 1ULL;
-    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) {
-        const uint64_t key = keys[i];
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t n_round = ((n + stride - 1) / stride) * stride;          // whole waves take every trip: the aggregation below is wave-wide
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const uint64_t key = i < n ? keys[i] : ~0ULL;
         const uint32_t motif = (uint32_t) (key >> (gbits + 1));
-        if (motif >= (uint32_t) P) continue;                 // (an all-ones padding key of a predicted-size list: never below n, but harmless)
-        const uint64_t region = ((key >> 1) & cmask) >> pbits;
-        atomicAdd(&h_hits[motif], 1u);
-        const uint64_t bit = (uint64_t) motif * (uint64_t) R + region;
-        const uint32_t m = 1u << (bit & 31u);
-        const uint32_t old = atomicOr(&bitmap[bit >> 5], m);
-        if (!(old & m)) atomicAdd(&h_regs[motif], 1u);
+        const bool live = i < n && motif < (uint32_t) P;     // (an all-ones padding key of a predicted-size list: never below n, but harmless)
+        bool first = false;
+        if (live) {
+            const uint64_t region = ((key >> 1) & cmask) >> pbits;
+            const uint64_t bit = (uint64_t) motif * (uint64_t) R + region;
+            const uint32_t m = 1u << (bit & 31u);
+            const uint32_t old = atomicOr(&bitmap[bit >> 5], m);
+            first = !(old & m);
+        }
+        // the fp64 stage emits its hits in motif-ordered chunks: a wave's 64 keys hold one or two motifs, and 64 LDS atomics on one address
+        // serialise.  So the wave counts per DISTINCT motif: one leader lane per motif adds the two popcounts.
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t m0 = (uint32_t) __builtin_amdgcn_readlane((int) motif, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(live && motif == m0);
+            const unsigned long long firsts = __builtin_amdgcn_ballot_w64(live && motif == m0 && first);
+            if ((int) (threadIdx.x & 63u) == leader) {
+                atomicAdd(&h_hits[m0], (unsigned int) __popcll(same));
+                if (firsts) atomicAdd(&h_regs[m0], (unsigned int) __popcll(firsts));
+            }
+            todo &= ~same;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
