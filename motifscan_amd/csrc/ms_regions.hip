@@ -100,16 +100,15 @@ __global__ void __launch_bounds__(256) once_expand_kernel(int64_t n, const RawKe
 // ---- counts only, without ordering the hits (round 6) ----
 // What the enrichment statistics read of a region set -- per motif the number of regions with >= 1 site (stats.py:29-31) and the number of
 // sites -- from the UNORDERED hit keys the fp64 stage leaves (key = motif << (gbits + 1) | (region << pbits | position) << 1 | strand bit):
-// one pass, a bit per (motif, region) set with a returning atomic (the lane that finds it clear counts the region), per-motif counts
-// aggregated in LDS.  No radix sort, no finalize, no hit arrays: a counts-only batch of a stream (the control regions of cli/scan.py:81-89)
-// and Scanner.count_regions_with_sites skip 1.2 ms of every 250 000-region batch's 3.3.
-constexpr int kCountBins = 4096;                              // motifs the LDS histograms hold (more: the ordered path)
+// one pass sets a bit per (motif, region) with a NON-returning atomic (a returning one runs at ~22 G/s chip-wide: 0.71 ms for the 15 M hits
+// of a 250 000-region batch, as long as the radix sort it was meant to save -- tools/counts_only_time.py), per-motif site numbers aggregated
+// per wave and block in LDS; a second pass counts every motif's bits.  No radix sort, no finalize, no hit arrays.
+constexpr int kCountBins = 4096;                              // motifs the LDS histogram holds (more: the ordered path)
 
 __global__ void __launch_bounds__(256) count_only_kernel(const uint64_t *__restrict__ keys, int64_t n, const unsigned long long *__restrict__ n_dev, int gbits, int pbits,
-                                                         int64_t R, int32_t P, uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ region_counts,
-                                                         unsigned long long *__restrict__ motif_hits) {
-    __shared__ unsigned int h_hits[kCountBins], h_regs[kCountBins];
-    for (int i = threadIdx.x; i < P; i += blockDim.x) { h_hits[i] = 0; h_regs[i] = 0; }
+                                                         int64_t row_words, int32_t P, uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ motif_hits) {
+    __shared__ unsigned int h_hits[kCountBins];
+    for (int i = threadIdx.x; i < P; i += blockDim.x) h_hits[i] = 0;
     __syncthreads();
     if (n_dev) { const unsigned long long nd = *n_dev; if ((unsigned long long) n > nd) n = (int64_t) nd; }
     const uint64_t cmask = (1ULL << gbits) - 1ULL;
@@ -119,34 +118,36 @@ __global__ void __launch_bounds__(256) count_only_kernel(const uint64_t *__restr
         const uint64_t key = i < n ? keys[i] : ~0ULL;
         const uint32_t motif = (uint32_t) (key >> (gbits + 1));
         const bool live = i < n && motif < (uint32_t) P;     // (an all-ones padding key of a predicted-size list: never below n, but harmless)
-        bool first = false;
         if (live) {
             const uint64_t region = ((key >> 1) & cmask) >> pbits;
-            const uint64_t bit = (uint64_t) motif * (uint64_t) R + region;
-            const uint32_t m = 1u << (bit & 31u);
-            const uint32_t old = atomicOr(&bitmap[bit >> 5], m);
-            first = !(old & m);
+            (void) atomicOr(&bitmap[(uint64_t) motif * (uint64_t) row_words + (region >> 5)], 1u << (region & 31u));      // result unused: the non-returning form
         }
         // the fp64 stage emits its hits in motif-ordered chunks: a wave's 64 keys hold one or two motifs, and 64 LDS atomics on one address
-        // serialise.  So the wave counts per DISTINCT motif: one leader lane per motif adds the two popcounts.
+        // serialise.  So the wave counts per DISTINCT motif: one leader lane per motif adds the popcount.
         unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
         while (todo) {
             const int leader = __builtin_ctzll(todo);
             const uint32_t m0 = (uint32_t) __builtin_amdgcn_readlane((int) motif, leader);
             const unsigned long long same = __builtin_amdgcn_ballot_w64(live && motif == m0);
-            const unsigned long long firsts = __builtin_amdgcn_ballot_w64(live && motif == m0 && first);
-            if ((int) (threadIdx.x & 63u) == leader) {
-                atomicAdd(&h_hits[m0], (unsigned int) __popcll(same));
-                if (firsts) atomicAdd(&h_regs[m0], (unsigned int) __popcll(firsts));
-            }
+            if ((int) (threadIdx.x & 63u) == leader) atomicAdd(&h_hits[m0], (unsigned int) __popcll(same));
             todo &= ~same;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
         if (h_hits[i]) atomicAdd(&motif_hits[i], (unsigned long long) h_hits[i]);
-        if (h_regs[i]) atomicAdd(&region_counts[i], (unsigned long long) h_regs[i]);
-    }
+}
+
+// one block per motif: the regions with a site = the set bits of the motif's row
+__global__ void __launch_bounds__(256) count_rows_kernel(const uint32_t *__restrict__ bitmap, int64_t row_words, unsigned long long *__restrict__ region_counts) {
+    __shared__ unsigned long long part[256];
+    const uint32_t *row = bitmap + (uint64_t) blockIdx.x * (uint64_t) row_words;
+    unsigned long long c = 0;
+    for (int64_t w = threadIdx.x; w < row_words; w += blockDim.x) c += (unsigned long long) __popc(row[w]);
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int) threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) region_counts[blockIdx.x] = part[0];
 }
 
 // motif_first[0 .. P] = exclusive prefix of the per-motif site numbers (one block; P <= kCountBins)
@@ -163,18 +164,21 @@ __global__ void __launch_bounds__(256) motif_prefix_kernel(const unsigned long l
     if (threadIdx.x == 255) motif_first[P] = (int64_t) run;     // (the last thread's range ends at P, or is empty and `run` is the total)
 }
 
-bool count_only_supported(int32_t P, int64_t R, int pbits) { return pbits > 0 && P > 0 && P <= kCountBins && (double) P * (double) R <= 8.0e9; }
-size_t count_only_bitmap_words(int32_t P, int64_t R) { return (size_t) (((uint64_t) P * (uint64_t) R + 31) / 32); }
+bool count_only_supported(int32_t P, int64_t R, int pbits) { return pbits > 0 && P > 0 && P <= kCountBins && (double) P * (double) (R + 32) <= 8.0e9; }
+size_t count_only_bitmap_words(int32_t P, int64_t R) { return (size_t) P * (size_t) ((R + 31) / 32); }
 
 int launch_count_only(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int pbits, int64_t R, int32_t P, uint32_t *bitmap,
                       unsigned long long *region_counts, unsigned long long *motif_hits, int64_t *motif_first, hipStream_t st) {
+    const int64_t row_words = (R + 31) / 32;
     MS_HIP(hipMemsetAsync(bitmap, 0, count_only_bitmap_words(P, R) * sizeof(uint32_t), st));
     MS_HIP(hipMemsetAsync(motif_hits, 0, (size_t) P * sizeof(unsigned long long), st));
     if (n > 0) {
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(2048, (n + 4095) / 4096));
-        hipLaunchKernelGGL(count_only_kernel, dim3((unsigned) blocks), dim3(256), 0, st, keys, n, n_dev, gbits, pbits, R, P, bitmap, region_counts, motif_hits);
+        hipLaunchKernelGGL(count_only_kernel, dim3((unsigned) blocks), dim3(256), 0, st, keys, n, n_dev, gbits, pbits, row_words, P, bitmap, motif_hits);
         MS_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(count_rows_kernel, dim3((unsigned) P), dim3(256), 0, st, bitmap, row_words, region_counts);
+    MS_HIP(hipGetLastError());
     hipLaunchKernelGGL(motif_prefix_kernel, dim3(1), dim3(256), 0, st, motif_hits, P, motif_first);
     MS_HIP(hipGetLastError());
     return MS_OK;
