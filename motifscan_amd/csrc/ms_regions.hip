@@ -100,9 +100,10 @@ __global__ void __launch_bounds__(256) once_expand_kernel(int64_t n, const RawKe
 // ---- counts only, without ordering the hits (round 6) ----
 // What the enrichment statistics read of a region set -- per motif the number of regions with >= 1 site (stats.py:29-31) and the number of
 // sites -- from the UNORDERED hit keys the fp64 stage leaves (key = motif << (gbits + 1) | (region << pbits | position) << 1 | strand bit):
-// one pass sets a bit per (motif, region) with a NON-returning atomic (a returning one runs at ~22 G/s chip-wide: 0.71 ms for the 15 M hits
-// of a 250 000-region batch, as long as the radix sort it was meant to save -- tools/counts_only_time.py), per-motif site numbers aggregated
-// per wave and block in LDS; a second pass counts every motif's bits.  No radix sort, no finalize, no hit arrays.
+// one pass sets a flag BYTE per (motif, region) with a plain store (a bit map needs an atomic per hit, and scattered global atomics run at
+// ~22 G/s chip-wide, returning or not: 0.7 ms for the 15 M hits of a 250 000-region batch -- as long as the radix sort they were meant to
+// save; tools/counts_only_time.py), per-motif site numbers aggregated per wave and block in LDS; a second pass counts every motif's flags.
+// No radix sort, no finalize, no hit arrays.
 constexpr int kCountBins = 4096;                              // motifs the LDS histogram holds (more: the ordered path)
 
 __global__ void __launch_bounds__(256) count_only_kernel(const uint64_t *__restrict__ keys, int64_t n, const unsigned long long *__restrict__ n_dev, int gbits, int pbits,
@@ -120,7 +121,8 @@ __global__ void __launch_bounds__(256) count_only_kernel(const uint64_t *__restr
         const bool live = i < n && motif < (uint32_t) P;     // (an all-ones padding key of a predicted-size list: never below n, but harmless)
         if (live) {
             const uint64_t region = ((key >> 1) & cmask) >> pbits;
-            (void) atomicOr(&bitmap[(uint64_t) motif * (uint64_t) row_words + (region >> 5)], 1u << (region & 31u));      // result unused: the non-returning form
+            // a plain one-byte store, no atomic (every writer stores the same 1; the L2s merge partial lines by byte mask)
+            reinterpret_cast<volatile uint8_t *>(bitmap)[(uint64_t) motif * (uint64_t) row_words * 4ULL + region] = (uint8_t) 1;
         }
         // the fp64 stage emits its hits in motif-ordered chunks: a wave's 64 keys hold one or two motifs, and 64 LDS atomics on one address
         // serialise.  So the wave counts per DISTINCT motif: one leader lane per motif adds the popcount.
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256) count_rows_kernel(const uint32_t *__restr
     __shared__ unsigned long long part[256];
     const uint32_t *row = bitmap + (uint64_t) blockIdx.x * (uint64_t) row_words;
     unsigned long long c = 0;
-    for (int64_t w = threadIdx.x; w < row_words; w += blockDim.x) c += (unsigned long long) __popc(row[w]);
+    for (int64_t w = threadIdx.x; w < row_words; w += blockDim.x) c += (unsigned long long) __popc(row[w] & 0x01010101u);      // four flag bytes per word
     part[threadIdx.x] = c;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if ((int) threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
@@ -164,12 +166,12 @@ __global__ void __launch_bounds__(256) motif_prefix_kernel(const unsigned long l
     if (threadIdx.x == 255) motif_first[P] = (int64_t) run;     // (the last thread's range ends at P, or is empty and `run` is the total)
 }
 
-bool count_only_supported(int32_t P, int64_t R, int pbits) { return pbits > 0 && P > 0 && P <= kCountBins && (double) P * (double) (R + 32) <= 8.0e9; }
-size_t count_only_bitmap_words(int32_t P, int64_t R) { return (size_t) P * (size_t) ((R + 31) / 32); }
+bool count_only_supported(int32_t P, int64_t R, int pbits) { return pbits > 0 && P > 0 && P <= kCountBins && (double) P * (double) (R + 16) <= 6.0e9; }
+size_t count_only_bitmap_words(int32_t P, int64_t R) { return (size_t) P * (size_t) ((R + 3) / 4); }      // (a byte per (motif, region), rows of whole words)
 
 int launch_count_only(const uint64_t *keys, int64_t n, const unsigned long long *n_dev, int gbits, int pbits, int64_t R, int32_t P, uint32_t *bitmap,
                       unsigned long long *region_counts, unsigned long long *motif_hits, int64_t *motif_first, hipStream_t st) {
-    const int64_t row_words = (R + 31) / 32;
+    const int64_t row_words = (R + 3) / 4;
     MS_HIP(hipMemsetAsync(bitmap, 0, count_only_bitmap_words(P, R) * sizeof(uint32_t), st));
     MS_HIP(hipMemsetAsync(motif_hits, 0, (size_t) P * sizeof(unsigned long long), st));
     if (n > 0) {
