@@ -96,9 +96,10 @@ def gpu_scan(pwm_values, widths, cutoffs, bases, offsets, strand, batch_regions=
     counts = np.zeros(len(widths), dtype=np.int64)
     parts = []
     try:
-        gen = _lib.scan_stream(pw, (take_shard(bases, offsets, r0, r1) for r0, r1 in bounds), strand)
+        # (the 12-byte compact copy-out: every batch of at most 2 x batch_regions regions fits it; a batch that does not leaves in the 16-byte form)
+        gen = _lib.scan_stream(pw, (take_shard(bases, offsets, r0, r1) for r0, r1 in bounds), strand, packed=12)
         for (r0, _), res in zip(bounds, gen):
-            parts.append((res.hits(), r0))
+            parts.append((res.hits(packed=True), r0))
             counts += res.region_counts()
             res.close()
         return _lib.merge_hits(parts, len(widths)), counts
