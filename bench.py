@@ -598,8 +598,8 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     own = {}                                            # this rank's own seconds and process CPU seconds per leg (the per-rank report at N > 1)
 
     def timed(fn, passes, name=None):
-        fn()                                            # warm: pools, pinned blocks (they take two passes to reach their steady sizes:
-        fn()                                            # tools/e2e_phases.py -- 195, 93, 63, 62, 60 ms for passes 0 ... 4)
+        for _ in range(4):                              # warm: the device and pinned block caches take three passes to hold every size class a pass
+            fn()                                        # asks for (tools/e2e_slow_pass_probe.py: 130, 65, 54, then 49 ms per pass; two warm passes left 54-58 ms passes in the timed four)
         if dist is not None:
             dist.barrier()
         c0 = os.times()
