@@ -1547,7 +1547,12 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     // a short hit list is ordered by launch latencies, not passes: one kernel fewer matters more there)
     const int sort_begin_large = (end_bit > 2 * kSortLowBits && !measure_env("MS_SORT_FULL")) ? kSortLowBits : 0;
     bool queue_only = false;                     // this back() belongs to a scan that is only queued (scan_complete finishes it)
-    const bool counts_fast = (flags & MS_SCAN_COUNTS_ONLY_INTERNAL) && !(flags & MS_SCAN_RAW_INTERNAL) && count_only_supported(pwms->P, seqs->R, pbits);
+    // counts only: the flag map costs ~2 x P x R bytes of traffic (clear + count), the ordering it replaces ~200 bytes per hit -- so the map is
+    // taken where the set holds at least one hit per ~50 (motif, region) cells (configs[3]: one per 9; a million 50-bp regions: one per 100,
+    // where the sort is the cheaper way to the same counts).  Decided once per scan, before the result block is sized.
+    const bool counts_ok = (flags & MS_SCAN_COUNTS_ONLY_INTERNAL) && !(flags & MS_SCAN_RAW_INTERNAL) && count_only_supported(pwms->P, seqs->R, pbits);
+    bool counts_fast = false;
+    auto decide_counts = [&](size_t n_expected) { counts_fast = counts_ok && (double) pwms->P * (double) seqs->R <= 50.0 * (double) std::max<size_t>(n_expected, 1); };
     auto back = [&](size_t n_sort, const unsigned long long *n_dev) -> int {
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
@@ -1672,6 +1677,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         const size_t n_pred = (size_t) std::min<double>(mu * (1.0 + pwms->pred_margin) + 6.0 * std::sqrt(mu + 1.0) + 256.0, 3.0e9);
         want_hits = std::max(want_hits, n_pred);
         if ((rc = scratch_reserve(sc, want_cand, want_hits))) return fail(rc);
+        decide_counts(n_pred);
         if ((rc = result_block(counts_fast ? 1 : n_pred))) return fail(rc);
         stt.n_passes = 1;
         HitOut H;
@@ -1756,6 +1762,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
     }
 
     // one pooled block for everything the result owns
+    decide_counts((size_t) n_hits);
     if ((rc = result_block(counts_fast ? 1 : (size_t) n_hits))) return fail(rc);
     if ((rc = back((size_t) n_hits, nullptr))) return fail(rc);
     he = hipStreamSynchronize(c->stream);

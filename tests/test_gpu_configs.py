@@ -462,9 +462,13 @@ def test_counts_only_scan_equals_the_ordered_scan(oracle, shape):
         assert res.n_hits == full.n_hits == len(want["pos"])
         assert np.array_equal(res.motif_offsets, want["motif_offsets"])
         assert np.array_equal(res.region_counts(), want_regions) and np.array_equal(full.region_counts(), want_regions)
-        if shape != "one_long_region":
+        # the flag map is taken where the set holds a hit per ~50 (motif, region) cells or more, and region-local keys exist; else the ordered path
+        # gives the same three numbers (and its result still holds the site arrays)
+        if shape in ("ragged", "single_strand"):
             with pytest.raises(ValueError):
                 res.hits()
+        elif shape == "one_long_region":
+            assert res.hits()["pos"].size == res.n_hits
         res.close()
     full.close(); sq.close(); pw.close()
 

@@ -6,7 +6,8 @@ globals (cscore.c:26-34); this library runs three host threads per device with q
   * motifscan_amd/csrc/ms_pipeline.h -- the header ms_stream.hip's threads, queues and one-scan-ahead loop are built from --
     under TSan with stub stage functions (tests/sanitize/stream_tsan.cpp);
   * motifscan_amd/csrc/ms_plan.cpp -- thresholds, quantiser, paired rows, row-tile DP, operand image -- under ASan + UBSan
-    (tests/sanitize/plan_asan.cpp), on random / degenerate motif sets and on the benchmark set at every cutoff column.
+    (tests/sanitize/plan_asan.cpp), on random / degenerate motif sets and on the benchmark set at every cutoff column;
+  * motifscan_amd/csrc/ms_hostpack.cpp + ms_numa.cpp -- the host packer and the NUMA look-ups -- under ASan + UBSan (tests/sanitize/host_asan.cpp).
 """
 import os
 import shutil
@@ -58,6 +59,15 @@ def test_prefilter_planner_under_address_and_ub_sanitizers(sanitize_binaries, tm
     assert out.returncode == 0 and "plan_asan: ok" in out.stdout, (out.stdout + out.stderr)[-4000:]
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
     assert int(out.stdout.split("(")[1].split()[0]) > 300
+
+
+def test_host_packer_and_numa_lookups_under_address_and_ub_sanitizers(sanitize_binaries):
+    """Round 6's host-only sources from the library's own files (ms_hostpack.cpp: the packer behind the genome file and MS_STREAM_HOST_PACK,
+    AVX2 and scalar paths on exact-size buffers; ms_numa.cpp: the cpulist parser and sysfs reads on malformed and missing inputs)."""
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([os.path.join(SAN, "host_asan.bin")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "host_asan: ok" in out.stdout, (out.stdout + out.stderr)[-4000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
 
 
 def test_oracle_restatement_under_address_and_ub_sanitizers():
