@@ -7,7 +7,8 @@ to sit ON the decision boundary of cscore.c:360-389 (`score / max_raw - cutoff >
     1e-10 either side (the reference's own slack);
   * widths 1..66 (every k-block class of the pre-filter, and the all-fp64 kernel past 63 columns), all-negative matrices (max_raw == 0),
     huge / tiny magnitudes, cutoffs <= 0 (everything hits) and > 1 (nothing can);
-  * sequences with N runs, lower case, other IUPAC letters, empty and shorter-than-W regions.
+  * sequences with N runs, lower case, other IUPAC letters, empty and shorter-than-W regions;
+  * (round 6) every case also through MS_SCAN_COUNTS_ONLY and through a two-batch stream with the 12-byte copy-out.
 
 It lives under tests/ because it uses the oracle (test infrastructure).  Run on the GPU box:
     python tests/fuzz_parity.py --cases 200 --seed 0
@@ -154,6 +155,44 @@ def check_dedup_and_score(seed, oracle, _lib, mats, widths, seqs, strand, want, 
     return None
 
 
+def check_round6_paths(seed, _lib, raw, offsets, strand, want, pw, sq):
+    """Round 6's paths on the same case: MS_SCAN_COUNTS_ONLY (n_hits, per-motif site numbers, per-motif region counts from the UNORDERED hits,
+    or from the ordered path where the flag map does not apply) and the batch stream with the 12-byte copy-out (two batches cut at a random
+    region; packing on the scan stage; the second batch counts-only every other seed)."""
+    n_motifs = len(want["motif_offsets"]) - 1
+    pair = np.unique((np.repeat(np.arange(n_motifs), np.diff(want["motif_offsets"])).astype(np.int64) << 32) | want["seq_idx"])
+    want_regions = np.bincount(pair >> 32, minlength=n_motifs)
+    co = _lib.scan(pw, sq, strand, _lib.MS_SCAN_COUNTS_ONLY)
+    try:
+        if co.n_hits != len(want["pos"]) or not np.array_equal(co.motif_offsets, want["motif_offsets"]) or not np.array_equal(co.region_counts(), want_regions):
+            return f"seed {seed}: counts-only scan differs"
+    finally:
+        co.close()
+    R = len(offsets) - 1
+    if R < 2:
+        return None
+    cut = 1 + seed % (R - 1)
+    second_counts_only = seed % 2 == 1
+    b = np.frombuffer(raw, dtype=np.uint8)
+    batches = [(b[:int(offsets[cut])], offsets[:cut + 1].copy(), False), (b[int(offsets[cut]):], offsets[cut:] - offsets[cut], second_counts_only)]
+    parts, counts = [], np.zeros(n_motifs, dtype=np.int64)
+    for (bb, oo, co_), start, res in zip(batches, (0, cut), _lib.scan_stream(pw, iter(batches), strand, packed=12)):
+        counts += res.region_counts()
+        if not co_:
+            parts.append((res.hits(packed=True), start))
+        res.close()
+    if not np.array_equal(counts, want_regions):
+        return f"seed {seed}: the stream's region counts differ"
+    merged = _lib.merge_hits(parts, n_motifs)
+    sel = np.ones(len(want["pos"]), dtype=bool) if not second_counts_only else want["seq_idx"] < cut
+    for k in ("seq_idx", "pos", "score"):
+        if not np.array_equal(merged[k], want[k][sel]):
+            return f"seed {seed}: the 12-byte stream's {k} differ"
+    if not np.array_equal(merged["strand"].astype(np.int32), want["strand"].astype(np.int32)[sel]):
+        return f"seed {seed}: the 12-byte stream's strands differ"
+    return None
+
+
 def run_case(seed, oracle, _lib):
     mats, cutoffs, seqs, strand = make_case(seed)
     vals = np.concatenate([m.ravel() for m in mats])
@@ -166,7 +205,8 @@ def run_case(seed, oracle, _lib):
     try:
         got = {k: v.copy() for k, v in res.hits().items()}
         st = res.stats()
-        extra = check_dedup_and_score(seed, oracle, _lib, mats, widths, seqs, strand, want, pw, res)
+        extra = check_round6_paths(seed, _lib, raw, offsets, strand, want, pw, sq)
+        extra = extra or check_dedup_and_score(seed, oracle, _lib, mats, widths, seqs, strand, want, pw, res)
     finally:
         res.close()
         sq.close()
