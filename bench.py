@@ -602,6 +602,12 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
             fn()                                        # asks for (tools/e2e_slow_pass_probe.py: 130, 65, 54, then 49 ms per pass; two warm passes left 54-58 ms passes in the timed four)
         if dist is not None:
             dist.barrier()
+        # (the cycle collector off inside the timed passes, as timeit does: this process has held tens of millions of Python objects -- the api leg's
+        # sites -- and a full collection on the consumer's thread is a 30-ms hole in a 45-ms pass: the single slow passes of profiles/r06r_*.json)
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         c0 = os.times()
         t0 = time.perf_counter()
         hits = 0
@@ -610,6 +616,8 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
             t1 = time.perf_counter()
             hits += fn()
             each.append(round((time.perf_counter() - t1) * 1e3, 2))
+        if gc_was_on:
+            gc.enable()
         if name:
             each_pass[name] = each
         if name:
