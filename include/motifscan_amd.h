@@ -47,7 +47,7 @@
  *   ms_dedup_hits         _deduplicate_sites / deduplicate_motif_sites  scanner.py:156-193
  *                         (host-side, on the sparse hit arrays)
  *   ms_stream_*           the same scan_motifs path (scanner.py:89-132) for region lists handed over in batches: host ASCII
- *                         in -> hit arrays in pinned host memory out, with the upload + packing of batch i+2, the scan of
+ *                         in -> hit arrays in pinned host memory out, with the upload of batch i+2, the packing + scan of
  *                         batch i+1 and the copy-out of batch i overlapped per device (SURVEY.md 8(d) "pack + H2D + kernel +
  *                         D2H", 8(e) "double-buffered chunks"); ms_stream_submit_span does the same for the spans of a
  *                         host-streamed window sweep (BASELINE configs[4]: cli/scan.py:43-48 over a whole genome)
@@ -235,7 +235,7 @@ int ms_host_alloc(size_t bytes, void **out);
 int ms_host_pool_stats(uint64_t out[4]);
 void ms_host_free(void *p);
 
-/* ---- batch streams: upload + pack | scan | copy-out overlapped ------------------------------- */
+/* ---- batch streams: upload | pack + scan | copy-out overlapped ------------------------------- */
 #define MS_STREAM_DEDUP       1u   /* de-duplicate every batch on the device (scanner.py:156-193) before the copy-out      */
 #define MS_STREAM_NO_HITS     2u   /* counts only (control regions: stats.py:29-31): a batch is scanned with MS_SCAN_COUNTS_ONLY, a sweep span
                                       makes ONLY the per-motif window counts and the number of sites (no site array exists: the hit
