@@ -1536,7 +1536,11 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             } else if ((rc = launch_rescore(S, Pw, sc.cand, sc.counters, cand_static, sc.cand_cap, pwms->d_field_meta, strand_mask, H, c->n_cu * 8, c->stream))) return rc;
         }
         if (!plan.exact_motifs.empty())
-            if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream))) return rc;
+            {
+                int max_w = 0;
+                for (int32_t m : plan.exact_motifs) max_w = std::max(max_w, (int) pwms->widths[m]);
+                if ((rc = launch_exact_all(S, Pw, pwms->d_exact_motifs, (int32_t) plan.exact_motifs.size(), strand_mask, H, c->stream, max_w))) return rc;
+            }
         (void) hipEventRecord(ev[2], c->stream);
         return MS_OK;
     };

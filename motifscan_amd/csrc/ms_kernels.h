@@ -96,7 +96,7 @@ int launch_pack(const uint8_t *ascii, int64_t n_bases, uint32_t *codes, uint32_t
 int prefilter_set_lds(bool wide, bool meas, bool dense, size_t bytes, int floor_ = 0);
 int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool dense, int blocks_per_tile, int n_tiles, size_t lds_bytes, hipStream_t st, int floor_ = 0);
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
-                     const HitOut &H, hipStream_t st);
+                     const HitOut &H, hipStream_t st, int max_width);
 // the same for long lists: chunks of the list in motif order, the window carried along (rescore_carry_kernel); one 1024-thread block per CU
 int rescore_carry_set_lds();
 int launch_rescore_carry(const DevSeq &S, const DevPwm &Pw, const uint64_t *cand, const unsigned long long *n_cand, uint64_t n_static,

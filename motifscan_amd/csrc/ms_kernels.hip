@@ -1382,6 +1382,52 @@ __global__ void __launch_bounds__(256) exact_all_kernel(const DevSeq S, const De
     test_and_emit(H, Pw, (uint32_t) p, hit_coord(H, S, r, g), fwd, rev, strand_mask);
 }
 
+// The same with the motif's table in LDS (round 6): exact_all_kernel reads a table entry per (window, column) through the
+// texture addressers -- the unit the fp64 stage is bound by (profiles/r03t_rescore_ta.log) -- although a wave's 64 lanes want at most four
+// different entries of a column.  Here a block stages its motif's W x 4 entries (+ an all-zero entry for the columns that add nothing) once,
+// scans kExactIter strips of 256 window starts against them, and a column is one 16-byte LDS read (a broadcast: <= 5 distinct addresses per
+// wave) + the two fp64 adds, in the reference's column order; a column that adds nothing ADDS the zero entry (score_window32's argument: a
+// running sum that started at +0.0 is never -0.0, so x + (+0.0) = x bit for bit).  Motifs wider than kExactTileMaxW keep exact_all_kernel.
+constexpr int kExactTileMaxW = 1024;       // 64 KB of LDS for the table
+constexpr int kExactIter = 8;
+
+__global__ void __launch_bounds__(256) exact_tiled_kernel(const DevSeq S, const DevPwm Pw, const int32_t *__restrict__ motifs, int strand_mask, const HitOut H) {
+    extern __shared__ double2 tab_lds[];                       // [W * 4 + 1]
+    const int32_t p = motifs[blockIdx.y];
+    const int W = Pw.width[p];
+    {
+        const double2 *__restrict__ tab = Pw.tab2 + Pw.tab_off[p];
+        for (int i = threadIdx.x; i < W * 4; i += 256) tab_lds[i] = tab[i];
+        if (threadIdx.x == 0) tab_lds[W * 4] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const uint32_t zero = (uint32_t) W * 4u;
+    for (int it = 0; it < kExactIter; it++) {
+        const int64_t g = ((int64_t) blockIdx.x * kExactIter + it) * 256 + threadIdx.x;
+        if (g >= S.n_bases) break;
+        const int64_t r = find_region(S, g);
+        if (g + W > S.offsets[r + 1]) continue;
+        double fwd = 0.0, rev = 0.0;
+        for (int c0 = 0; c0 < W; c0 += 32) {
+            const uint64_t cw = code_window(S.codes, g + c0);
+            const int n = (W - c0) < 32 ? (W - c0) : 32;
+            const uint32_t skip = n_window(S.nmask, g + c0) | ~low_mask(n);           // bit c: column c0 + c adds nothing
+            for (int c1 = 0; c1 < n; c1 += 8) {
+                double2 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int c = c1 + k;
+                    const uint32_t idx = (uint32_t) (c0 + c) * 4u + ((uint32_t) (cw >> (2 * c)) & 3u);
+                    t[k] = tab_lds[((skip >> c) & 1u) ? zero : idx];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) { fwd += t[k].x; rev += t[k].y; }
+            }
+        }
+        test_and_emit(H, Pw, (uint32_t) p, hit_coord(H, S, r, g), fwd, rev, strand_mask);
+    }
+}
+
 // U candidate records per thread and round, their loads issued side by side: the kernel is a chain of dependent gathers
 // (record -> region hint / sequence words / motif id -> offsets / width / table offset -> table entries), so the records in
 // flight per thread -- not the arithmetic -- set its speed; one barrier pair per round of U records instead of per record.
@@ -2011,12 +2057,21 @@ int launch_prefilter(const PfArgs &A, bool wide, bool meas, bool dense, int bloc
 }
 
 int launch_exact_all(const DevSeq &S, const DevPwm &Pw, const int32_t *motifs, int32_t n_motifs, int strand_mask,
-                     const HitOut &H, hipStream_t st) {
+                     const HitOut &H, hipStream_t st, int max_width) {
     if (S.n_bases == 0 || n_motifs == 0) return MS_OK;
+    const bool tiled = max_width >= 1 && max_width <= kExactTileMaxW && !measure_env("MS_EXACT_UNTILED");      // (A/B and test aid: the round-1 kernel)
+    const size_t lds = tiled ? ((size_t) max_width * 4 + 1) * sizeof(double2) : 0;
+    if (tiled && lds > 48 * 1024)                                    // (motifs of more than 767 columns: rare enough to ask the driver every time, on whatever device is current)
+        MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     for (int32_t m0 = 0; m0 < n_motifs; m0 += 32768) {               // grid.y limit
         const int32_t n = n_motifs - m0 < 32768 ? n_motifs - m0 : 32768;
-        dim3 grid((unsigned) ((S.n_bases + 255) / 256), (unsigned) n);
-        hipLaunchKernelGGL(exact_all_kernel, grid, dim3(256), 0, st, S, Pw, motifs + m0, strand_mask, H);
+        if (tiled) {
+            dim3 grid((unsigned) ((S.n_bases + 256 * kExactIter - 1) / (256 * kExactIter)), (unsigned) n);
+            hipLaunchKernelGGL(exact_tiled_kernel, grid, dim3(256), lds, st, S, Pw, motifs + m0, strand_mask, H);
+        } else {
+            dim3 grid((unsigned) ((S.n_bases + 255) / 256), (unsigned) n);
+            hipLaunchKernelGGL(exact_all_kernel, grid, dim3(256), 0, st, S, Pw, motifs + m0, strand_mask, H);
+        }
         MS_HIP(hipGetLastError());
     }
     return MS_OK;

@@ -617,6 +617,40 @@ def test_wide_motif_classes_vs_oracle(oracle, monkeypatch, env):
         _lib.scan(pw2, _lib.SeqSet(big[:500 * 2000], boff[:2001]), 3, _lib.MS_SCAN_EXACT_ONLY).close()
 
 
+@pytest.mark.parametrize("strand", [1, 3])
+def test_tiled_all_fp64_kernel_equals_the_round1_kernel_and_the_oracle(oracle, monkeypatch, strand):
+    """exact_tiled_kernel (round 6: the motif's table in LDS, eight strips of 256 windows per block, columns that add nothing add a +0.0 entry)
+    against exact_all_kernel (MS_MEASURE=1 MS_EXACT_UNTILED=1) and the oracle: motifs of 64 ... 900 columns (the all-fp64 path: cscore.c:50-51
+    has no width limit), one with -inf entries, one narrow motif forced there by a cutoff under the quantiser's floor; runs of N, regions
+    shorter than the motifs, a region end inside the last strip; and the whole G3 motif set under MS_SCAN_EXACT_ONLY."""
+    rng = np.random.default_rng(123)
+    mats = []
+    for w in (64, 65, 70, 96, 127, 128, 129, 200, 333, 900, 12):
+        p = rng.dirichlet(np.full(4, 0.6), size=w).T
+        mats.append(np.round(np.log(np.maximum(p, 1e-3) / 0.25), 5))
+    mats[3][2, 40] = -np.inf
+    cuts = [0.42, 0.42, 0.4, 0.4, 0.38, 0.38, 0.38, 0.33, 0.3, 0.27, -5.0]
+    bases, offsets = synth.make_regions(40, 2600, seed=19, frac_n=0.25, ragged=True)
+    raw = bases.tobytes()
+    seqs = [raw[offsets[i]:offsets[i + 1]].decode() for i in range(len(offsets) - 1)] + ["ACGT" * 20, "N" * 1000 + "ACGTTGCA" * 150, "", "A" * 899, "C" * 901]
+    ml = [m.tolist() for m in mats]
+    want = oracle.c_scan_motif(ml, cuts, seqs, strand, 8)
+    got = cscore.c_scan_motif(ml, cuts, seqs, strand, 1)
+    assert got == want and sum(len(x) for x in want) > 200
+    pw = _lib.PwmSet.from_matrices(mats, cuts)
+    sq = _lib.SeqSet.from_strings(seqs)
+    a = _lib.scan(pw, sq, strand)
+    assert a.stats()["n_pwms_exact"] == len(mats)
+    ha = a.hits()
+    monkeypatch.setenv("MS_MEASURE", "1")
+    monkeypatch.setenv("MS_EXACT_UNTILED", "1")
+    b = _lib.scan(pw, sq, strand)
+    hb = b.hits()
+    for k in ("motif_offsets", "seq_idx", "pos", "score", "strand"):
+        assert np.array_equal(ha[k], hb[k]), k
+    a.close(); b.close(); sq.close(); pw.close()
+
+
 def test_pwm_with_minus_inf_entries_vs_oracle(oracle):
     """An un-normalised PPM through to_pwm gives log(0) = -inf entries (matrix.py:149-171); the reference adds them like any
     other double (cscore.c:345-353): a window touching one scores -inf and is no hit, the others are scored as usual.  Such a
