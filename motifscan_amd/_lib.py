@@ -631,8 +631,8 @@ _warned_exact_only = set()
 
 def _fence_exact_only(res, pwms, flags=0):
     """motifs the pre-filter cannot take -- wider than 63 columns, max_raw <= 0, non-finite entries, a cutoff under the
-    quantiser's floor -- are scored in fp64 at EVERY window (exact_all_kernel: correct, the reference's arithmetic, but with no performance
-    floor: ~1000 x the cost per motif of the matrix-core path; the reference itself has no width limit, cscore.c:50-51).  Never silent:
+    quantiser's floor -- are scored in fp64 at EVERY window (exact_tiled_kernel: correct, the reference's arithmetic, the motif's table in LDS --
+    and still ~400 x the cost per motif of the matrix-core path; the reference itself has no width limit, cscore.c:50-51).  Never silent:
     one warning per PWM set with the number of such motifs (MS_SCAN_EXACT_ONLY scans -- validation -- are the caller's own choice)."""
     if (flags & MS_SCAN_EXACT_ONLY) or id(pwms) in _warned_exact_only:
         return res
@@ -642,7 +642,7 @@ def _fence_exact_only(res, pwms, flags=0):
         import warnings
         warnings.warn(f"{st['n_pwms_exact']} of {st['n_pwms']} PWMs cannot take the matrix-core pre-filter (wider than 63 columns, max_raw <= 0, "
                       f"non-finite entries or a cutoff below the quantiser's floor) and are scored in fp64 at every window: same results, "
-                      f"roughly 1000 x the device time per such motif (fp64 stage of this scan: {st['ms_exact']:.1f} ms of {st['ms_total']:.1f} ms)", RuntimeWarning, stacklevel=3)
+                      f"roughly 400 x the device time per such motif (fp64 stage of this scan: {st['ms_exact']:.1f} ms of {st['ms_total']:.1f} ms)", RuntimeWarning, stacklevel=3)
     return res
 
 

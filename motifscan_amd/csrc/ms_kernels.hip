@@ -13,7 +13,7 @@
 //   pack_kernel       ASCII -> codes + nmask                     (cscore.c:81-114)
 //   prefilter_f6_kernel  rigorous upper bound of both strand scores for EVERY window (with or without non-ACGT bases) as an
 //                     fp6 x fp4 one-hot product on the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4); emits candidates
-//   exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take
+//   exact_tiled_kernel / exact_all_kernel  fp64 scoring of every window for motifs the pre-filter cannot take (the motif's table in LDS / in HBM)
 //   rescore_kernel    fp64 scoring of the candidates, in the reference's order of operations,
 //                     and the reference's hit test (cscore.c:356-358, 373-375); short candidate lists
 //   rescore_carry_kernel   the same for long lists: chunks of the list in motif order, the windows read in list order and
