@@ -287,12 +287,20 @@ def main():
     # than ranks (ranks then share devices; RCCL itself refuses two ranks on one GPU)
     backend = os.environ.get("MS_BENCH_BACKEND", "nccl")
     share = os.environ.get("MS_BENCH_SHARE_GPU") == "1"
+    # MS_BENCH_FORCE_PG=1 (test aid only): a ONE-rank run opens the process group too and takes every N > 1 branch below -- on a one-GPU box
+    # that is the only way the RCCL calls of this file (init with device_id, the int64 all-reduce on the library's vector, all_gather, barrier) ever execute
+    use_pg = world > 1 or os.environ.get("MS_BENCH_FORCE_PG") == "1"
     dev_index = local_rank % _lib.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)               # before the process group: RCCL binds to the current device
     _lib.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:         # (only a forced one-rank group is ever started without a launcher)
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -318,7 +326,7 @@ def main():
             torch.cuda.current_stream().synchronize()          # the result block returns to the pool on close()
             res.close()
         local_counts.copy_(counts)
-        if world > 1:
+        if use_pg:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -329,7 +337,7 @@ def main():
         return stats
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -339,7 +347,7 @@ def main():
         step()
         n_warm += 1
         more = n_warm < a.warmup or time.perf_counter() - t_warm < a.min_warm_seconds
-        if world > 1:                              # the ranks agree on when to stop (every step holds a collective)
+        if use_pg:                                 # the ranks agree on when to stop (every step holds a collective)
             flag = torch.tensor([1 if more else 0], dtype=torch.int64, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             more = bool(flag.item())
@@ -356,7 +364,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     units = torch.tensor([float(wl["units"])], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
@@ -365,7 +373,7 @@ def main():
     # the collective, checked: all-reduced vector == sum over ranks of the vectors each rank's library handed over
     counts_check = None
     ranks_report = None
-    if world > 1:
+    if use_pg:
         gathered = [torch.zeros_like(local_counts) for _ in range(world)]
         dist.all_gather(gathered, local_counts)
         counts_check = {"allreduce_equals_sum_of_rank_counts": bool(torch.equal(torch.stack(gathered).sum(0), counts)),
@@ -439,7 +447,7 @@ def main():
     # ---- SURVEY.md 8(d) end-to-end: host ASCII (pinned) -> hit arrays in pinned host memory, through the batch stream ----
     e2e = None
     if not a.no_end_to_end:
-        e2e = end_to_end(a, wl, pw, world, dev, torch, dist if world > 1 else None, strand_mask)
+        e2e = end_to_end(a, wl, pw, world, dev, torch, dist if use_pg else None, strand_mask)
 
     if rank == 0:
         n_launch = len(all_stats)
@@ -536,7 +544,7 @@ def main():
         if api is not None:
             line["value_api"] = api
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -976,6 +976,28 @@ def test_bench_sweep_world_of_eight_on_one_gpu():
     assert line["modes"]["hits_packed"]["sites_per_step_per_gpu"] > 0
 
 
+def test_bench_collectives_over_rccl_on_a_one_rank_communicator():
+    """The only RCCL run a one-GPU box allows: MS_BENCH_FORCE_PG=1 makes a single rank open the process group (backend "nccl" = RCCL,
+    bound to its device) and take every N > 1 branch of bench.py -- the int64 all-reduce on the vector the library hands over, the
+    all_gathers of the rank report and of the end-to-end block, the barriers, the per-rank oracle sample.  What is NOT covered: more
+    than one device (xGMI, one rank per GPU); the gloo tests above cover the sharding across ranks."""
+    env = dict(os.environ, MS_BENCH_FORCE_PG="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MS_BENCH_SHARE_GPU", "MS_BENCH_BACKEND", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--regions-per-set", "40000", "--steps", "3", "--warmup", "1", "--min-warm-seconds", "0",
+                          "--no-cpu-baseline", "--no-api", "--no-scale-projection"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["rccl"]["backend"] == "nccl" and line["rccl"]["world"] == 1 and line["rccl"]["one_rank_per_device"] is True and line["rccl"]["nccl_version"]
+    assert line["counts_check"]["allreduce_equals_sum_of_rank_counts"] is True and line["counts_check"]["max_regions_with_site"] > 0
+    rk = line["ranks"]
+    assert rk["shards_tile_every_set"] is True and rk["parity_sample"]["ranks_identical_to_oracle"] == 1 and rk["parity_sample"]["hits_checked"] > 10_000
+    assert line["allreduce_ms"] > 0                                  # a device-side collective really ran inside the timed steps
+    pr = line["value_end_to_end"]["per_rank"]
+    assert pr is not None and len(pr["ms_per_pass_pipelined"]) == 1 and pr["ms_per_pass_pipelined"][0] > 0
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """--gpus N with N > visible devices: one line, non-zero exit, nothing spawned (and nothing generated)."""
     import time

@@ -8,6 +8,7 @@ $T python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -n 2 $OUT/p
 if [ "$2" = "quick" ]; then QUICK=1; fi
 $T python bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 MS_BENCH_BACKEND=gloo MS_BENCH_SHARE_GPU=1 $T python bench.py --gpus 2 --steps 5 --no-cpu-baseline > $OUT/bench_c4_2ranks_one_gpu_gloo.json 2> $OUT/bench_c4_2ranks_one_gpu_gloo.log
+MS_BENCH_FORCE_PG=1 $T python bench.py --steps 5 --no-cpu-baseline --no-api --no-scale-projection > $OUT/bench_c4_rccl_one_rank.json 2> $OUT/bench_c4_rccl_one_rank.log      # the N > 1 branches over a ONE-rank RCCL communicator
 # the shape of the driver's 8-GPU SCALE run on this box's one GPU (gloo: RCCL refuses several ranks per device)
 MS_BENCH_BACKEND=gloo MS_BENCH_SHARE_GPU=1 $T python bench.py --gpus 8 --regions-per-set 160000 --steps 3 > $OUT/bench_c4_8ranks_one_gpu_gloo.json 2> $OUT/bench_c4_8ranks_one_gpu_gloo.log
 MS_BENCH_BACKEND=gloo MS_BENCH_SHARE_GPU=1 $T python bench.py --gpus 8 --workload c5 --genome-mbp 800 --steps 2 --warmup 1 --min-warm-seconds 0 > $OUT/bench_c5_8ranks_one_gpu_gloo.json 2> $OUT/bench_c5_8ranks_one_gpu_gloo.log
