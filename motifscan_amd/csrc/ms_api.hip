@@ -1561,6 +1561,7 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         he = hipMemsetAsync(raw->d_region_counts, 0, 8 * ((size_t) pwms->P + 1), c->stream);
         if (he != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(he)); return MS_ERR_RUNTIME; }
         (void) hipEventRecord(ev[3], c->stream);
+        raw->counts_only = false;                // (a second, exactly-sized run after a failed prediction decides again)
         if (counts_fast) {
             // the bitmap + the per-motif site counters in one pooled block the result owns (a queued scan's kernels outlive this call)
             const size_t words = count_only_bitmap_words(pwms->P, seqs->R);
