@@ -557,7 +557,7 @@ def api_leg():
     import api_time
     out = {"unit": "bp*motifs/s", "definition": "region_bp x n_motifs / wall time of Scanner.scan_motifs(pwms) (host strings in, lazy "
            "MotifSites view out, de-dup on); writer = io/__init__.py:23-33's len(sites[idx]) / max(site.score) double loop, stats = stats.py:27-31, both run verbatim over the whole result",
-           "reference_in_build_container": "profiles/r04_api_time_reference.json (real Scanner.scan_motifs, configs[1], 8 threads)"}
+           "reference_in_build_container": "profiles/archive/r04_api_time_reference.json (real Scanner.scan_motifs, configs[1], 8 threads)"}
     for key, name in (("configs1", "c2"), ("configs2", "c3")):
         m = api_time.measure(name)
         out[key] = {"value": m["value_api"], "scan_motifs_s": m["scan_motifs_s"], "scan_motifs_again_s": m["scan_motifs_again_s"],
@@ -746,7 +746,7 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
             "sustained_passes_per_stream": reps, "sustained_hits_check": bool(hits_su == hits * reps),
             "batches_per_pass_per_gpu": len(batches), "batch_regions": a.batch_regions, "max_batch_regions": a.max_batch_regions, "batch_sizes": [int(len(o) - 1) for _, o in batches], "batch_ramp": not a.no_batch_ramp, "hits_per_pass_per_gpu": int(hits),
             "stage_ms_last_pass": {k: {sk: {f: round(x, 2) for f, x in sv.items()} for sk, sv in v.items()} for k, v in stages.items()},
-            "cu_partition": "off: the copy / pack kernels share the device with the scan (CU masks -- 1 CU of every 32 for the copy streams -- exist behind MS_MEASURE=1 MS_CU_PARTITION=1 and measured slower end to end, profiles/r02_cu_partition_ab.log)",
+            "cu_partition": "off: the copy / pack kernels share the device with the scan (CU masks -- 1 CU of every 32 for the copy streams -- exist behind MS_MEASURE=1 MS_CU_PARTITION=1 and measured slower end to end, profiles/archive/r02_cu_partition_ab.log)",
             "definition": "SURVEY.md 8(d): host ASCII in pinned memory -> H2D + pack -> scan -> hit arrays (seq_idx, pos, score, strand) in pinned "
                           "host memory; 'pipelined' overlaps the three stages of consecutive batches (ms_stream) and moves 12 bytes per hit "
                           "(32-bit coord word region << shift | pos << 1 | strand + fp64 score: MS_STREAM_PACKED12, every batch of this workload fits it; 'pipelined_16B' = round 5's 64-bit coord word), 'pipelined_cli' is the reference CLI's own job (cli/scan.py:81-89: the input set's sites out, the control "

@@ -45,7 +45,7 @@ def batch_bounds(n, batch_regions, ramp=True, max_batch=None, ramp_up=True, ramp
     doubling up to max_batch (default 2 x batch_regions) at the start of a pass, stay there, and shrink the same way at its end
     (ramp_up / ramp_down: whether this set begins / ends the pass).  ramp=False: equal batches of batch_regions.
     Round 2 cut only the first and last batch (1/4 + 1/4 + 1/2): 20 batches per configs[3] pass against 14 now, 62.5 against
-    65.5 ms (profiles/r03j_bench_m250000.json; batches of 500k regions make the copy-out stage the bottleneck: 67.8 ms)."""
+    65.5 ms (profiles/archive/r03j_bench_m250000.json; batches of 500k regions make the copy-out stage the bottleneck: 67.8 ms)."""
     step = max(1, int(batch_regions))
     if not ramp or n < 4 * step:
         bounds = [(r0, min(n, r0 + step)) for r0 in range(0, max(n, 1), step)]

@@ -150,7 +150,7 @@ class Scanner:
         """(genome, chromosome indices) if the regions lie on a ResidentGenome and overlap enough (their union is under half of
         their summed length: peaks +- window/2 much closer than the window, dense random controls, cli/scan.py:43-48, 76-86) for
         ms_scan_regions_once to pay: it scores the union once and hands every site to each region that holds it -- the identical
-        result.  At half it breaks even with the per-region scan (profiles/r02_scan_once_overlap.log): the hand-out re-keys and
+        result.  At half it breaks even with the per-region scan (profiles/archive/r02_scan_once_overlap.log): the hand-out re-keys and
         re-orders every site."""
         if self._resident is None or len(self.seq_starts) < 2:
             return None

@@ -6,7 +6,7 @@ BASELINE configs[1] (10k x 500 bp x 50 PWMs), with its consumers' access pattern
 figures stand beside.  configs[2] is out of its reach in this container (57.9M region lists: SURVEY.md H4), so only the cost of
 its empty result shape is extrapolated from 8 motifs.
 
-    python tools/api_time_reference.py [--threads 8] > profiles/r04_api_time_reference.json
+    python tools/api_time_reference.py [--threads 8] > profiles/archive/r04_api_time_reference.json
 """
 import argparse
 import json

@@ -73,7 +73,7 @@ for g in range(gf.shape[0]):
         a[0] += 1; a[1] += full; a[2] += tr
         n_rows += 1
 
-# hits per window and row on the benchmark (measured: 61.7 M hits per 500 Mbase scan of 579 motifs x 2 strands, profiles/r04a bench line)
+# hits per window and row on the benchmark (measured: 61.7 M hits per 500 Mbase scan of 579 motifs x 2 strands, profiles/archive/r04a bench line)
 hit_rate = {"1e-4": 61_748_087 / 500e6, "1e-3": 3.8e8 / 500e6}.get(pkey)
 print(f"p = {pkey}: {n_rows} (motif, strand) rows; candidates per window, all rows: shipped rows {tot['full']:.4f}, truncated rows {tot['trunc']:.4f}")
 if hit_rate:
