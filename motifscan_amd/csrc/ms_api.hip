@@ -1216,6 +1216,7 @@ void pending_scan_destroy(PendingScan *p) {
     for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
     if (p->done) (void) hipEventDestroy(p->done);
     if (p->h_counters) (void) hipHostFree(p->h_counters);
+    if (p->h_offsets) (void) hipHostFree(p->h_offsets);
     *p = PendingScan();
 }
 
@@ -1240,6 +1241,8 @@ static void finish_scan(ms_result *raw, hipEvent_t *ev, ms_pwmset *pwms, int64_t
         (void) hipEventElapsedTime(&ms05, ev[0], ev[5]);
         stt.ms_sort = ms34; stt.ms_finalize = ms45; stt.ms_total = ms05;
     }
+    if (measure_env("MS_TRACE_BLOCKS"))                  // measurement: which device blocks a scan worked on, beside its stage times (tools/e2e_block_probe.py)
+        fprintf(stderr, "MSBLK done res=%p bases=%lld pf=%.3f fp64=%.3f sort=%.3f fin=%.3f\n", raw->block, (long long) n_bases, ms01, ms12, ms34, ms45);
     if (stt.n_windows > 0 && !raw->invalid) {            // what the next scan of this set of PWMs may expect (scan_locked)
         pwms->pred_density = (double) n_hits / (double) stt.n_windows;
         pwms->pred_strand = strand_mask;
@@ -1258,8 +1261,7 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
     if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
     const unsigned long long n_cand = p->cand_static + p->h_counters[0], n_hits = p->h_counters[1];
     if (n_cand <= p->cand_cap && n_hits <= p->hit_cap && n_hits <= p->n_pred) {
-        he = hipMemcpy(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
-        if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
+        std::memcpy(raw->motif_offsets.data(), p->h_offsets, raw->motif_offsets.size() * sizeof(int64_t));       // (copied in stream order, in front of `done`: scan_locked)
         pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
         finish_scan(raw, p->ev, pwms, p->n_bases, p->R, p->strand_mask, p->exact_only, n_cand, n_hits, true);
         *out = raw;
@@ -1687,6 +1689,9 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
         stt.n_passes = 1;
         HitOut H;
         H.keys = sc.keys; H.vals = sc.vals; H.n_hits = sc.counters + 1; H.cap = sc.hit_cap; H.gbits = gbits; H.pbits = pbits;
+        if (measure_env("MS_TRACE_BLOCKS"))
+            fprintf(stderr, "MSBLK launch res=%p (%zu bytes) codes=%p nmask=%p blkinfo=%p offsets=%p cand=%p keys=%p\n", raw->block, raw->block_bytes, (const void *) S.codes, (const void *) S.nmask,
+                    (const void *) S.blkinfo, (const void *) S.offsets, (void *) sc.cand, (void *) sc.keys);
         if ((rc = front(H))) return fail(rc);
         if ((rc = launch_fill_tail(sc.keys, sc.counters + 1, n_pred, c->stream))) return fail(rc);
         queue_only = pend != nullptr;
@@ -1697,7 +1702,19 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             // queued, not waited for: the owner queues its next scan behind this one first (everything is in order on one stream:
             // the next scan's kernels only touch the shared scratch after this scan's are done; a scratch buffer that has to grow
             // is freed by hipFree, which waits for the device)
-            he = hipMemcpyAsync(pend->h_counters, sc.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+            // the per-motif offsets too, into the slot's own pinned words: scan_complete used to fetch them with a blocking hipMemcpy into pageable
+            // memory once the scan was done -- a copy of 5 KB that queued up behind whatever 100-MB copy-out held the engine it was given, for 3-4 ms per
+            // batch: the 80-ms passes of profiles/r06z_e2e_stage_clock.log
+            const size_t n_off = raw->motif_offsets.size();
+            if (pend->h_offsets_cap < n_off) {
+                if (pend->h_offsets) (void) hipHostFree(pend->h_offsets);
+                pend->h_offsets = nullptr; pend->h_offsets_cap = 0;
+                he = hipHostMalloc(&pend->h_offsets, (n_off + 64) * sizeof(int64_t));
+                if (he != hipSuccess) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
+                pend->h_offsets_cap = n_off + 64;
+            }
+            he = hipMemcpyAsync(pend->h_offsets, raw->d_motif_first, n_off * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(pend->h_counters, sc.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
             if (he == hipSuccess) he = hipEventRecord(pend->done, c->stream);
             if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
             pend->cand_cap = sc.cand_cap;

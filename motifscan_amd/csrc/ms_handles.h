@@ -266,6 +266,8 @@ struct PendingScan {
     hipEvent_t ev[6] = {};                   // around the stages, as DeviceCtx::ev
     hipEvent_t done = nullptr;
     unsigned long long *h_counters = nullptr;   // pinned, 8 words
+    int64_t *h_offsets = nullptr;               // pinned: the queued scan's per-motif offsets land here, in stream order, in front of `done`
+    size_t h_offsets_cap = 0;                   // (words; grown to P + 1)
     size_t cand_cap = 0, hit_cap = 0;           // the scratch capacities at queue time
     bool active = false;
     ms_result *raw = nullptr;
