@@ -606,16 +606,19 @@ def end_to_end(a, wl, pw, world, dev, torch, dist, strand_mask=3):
     own = {}                                            # this rank's own seconds and process CPU seconds per leg (the per-rank report at N > 1)
 
     def timed(fn, passes, name=None):
-        for _ in range(4):                              # warm: the device and pinned block caches take three passes to hold every size class a pass
-            fn()                                        # asks for (tools/e2e_slow_pass_probe.py: 130, 65, 54, then 49 ms per pass; two warm passes left 54-58 ms passes in the timed four)
-        if dist is not None:
-            dist.barrier()
         # (the cycle collector off inside the timed passes, as timeit does: this process has held tens of millions of Python objects -- the api leg's
-        # sites -- and a full collection on the consumer's thread is a 30-ms hole in a 45-ms pass: the single slow passes of profiles/r06r_*.json)
+        # sites -- and a full collection on the consumer's thread is a 30-ms hole in a 45-ms pass: the single slow passes of profiles/r06r_*.json.
+        # Collected BEFORE the warm passes, not between them and the timed ones: what a collection frees -- results of the previous leg still held by
+        # cycles -- goes back to the block caches and changes which blocks the next pass is handed; with the collection in between, the first timed
+        # pass took 70-90 ms in half of the runs, profiles/r06z_offsets_ab.log)
         import gc
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
+        for _ in range(4):                              # warm: the device and pinned block caches take three passes to hold every size class a pass
+            fn()                                        # asks for (tools/e2e_slow_pass_probe.py: 130, 65, 54, then 49 ms per pass; two warm passes left 54-58 ms passes in the timed four)
+        if dist is not None:
+            dist.barrier()
         c0 = os.times()
         t0 = time.perf_counter()
         hits = 0

@@ -1261,7 +1261,11 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
     if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
     const unsigned long long n_cand = p->cand_static + p->h_counters[0], n_hits = p->h_counters[1];
     if (n_cand <= p->cand_cap && n_hits <= p->hit_cap && n_hits <= p->n_pred) {
-        std::memcpy(raw->motif_offsets.data(), p->h_offsets, raw->motif_offsets.size() * sizeof(int64_t));       // (copied in stream order, in front of `done`: scan_locked)
+        if (p->offsets_queued) std::memcpy(raw->motif_offsets.data(), p->h_offsets, raw->motif_offsets.size() * sizeof(int64_t));       // (copied in stream order, in front of `done`: scan_locked)
+        else {
+            he = hipMemcpy(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
+        }
         pwms->pred_margin = std::max(0.04, pwms->pred_margin * 0.9);
         finish_scan(raw, p->ev, pwms, p->n_bases, p->R, p->strand_mask, p->exact_only, n_cand, n_hits, true);
         *out = raw;
@@ -1706,14 +1710,15 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             // memory once the scan was done -- a copy of 5 KB that queued up behind whatever 100-MB copy-out held the engine it was given, for 3-4 ms per
             // batch: the 80-ms passes of profiles/r06z_e2e_stage_clock.log
             const size_t n_off = raw->motif_offsets.size();
-            if (pend->h_offsets_cap < n_off) {
+            pend->offsets_queued = !measure_env("MS_OFFSETS_BLOCKING");
+            if (pend->offsets_queued && pend->h_offsets_cap < n_off) {
                 if (pend->h_offsets) (void) hipHostFree(pend->h_offsets);
                 pend->h_offsets = nullptr; pend->h_offsets_cap = 0;
                 he = hipHostMalloc(&pend->h_offsets, (n_off + 64) * sizeof(int64_t));
                 if (he != hipSuccess) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
                 pend->h_offsets_cap = n_off + 64;
             }
-            he = hipMemcpyAsync(pend->h_offsets, raw->d_motif_first, n_off * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+            he = pend->offsets_queued ? hipMemcpyAsync(pend->h_offsets, raw->d_motif_first, n_off * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) : hipSuccess;
             if (he == hipSuccess) he = hipMemcpyAsync(pend->h_counters, sc.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
             if (he == hipSuccess) he = hipEventRecord(pend->done, c->stream);
             if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }

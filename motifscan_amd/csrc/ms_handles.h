@@ -268,6 +268,7 @@ struct PendingScan {
     unsigned long long *h_counters = nullptr;   // pinned, 8 words
     int64_t *h_offsets = nullptr;               // pinned: the queued scan's per-motif offsets land here, in stream order, in front of `done`
     size_t h_offsets_cap = 0;                   // (words; grown to P + 1)
+    bool offsets_queued = false;                // (false only under MS_MEASURE=1 MS_OFFSETS_BLOCKING=1: round 5's blocking fetch in scan_complete, for A/B runs)
     size_t cand_cap = 0, hit_cap = 0;           // the scratch capacities at queue time
     bool active = false;
     ms_result *raw = nullptr;
