@@ -18,7 +18,7 @@ for p in range(12):
     st = {}
     h0, d0 = _lib.host_pool_stats(), _lib.pool_stats()
     t0 = time.perf_counter()
-    for res in _lib.scan_stream(pw, iter(batches), 3, 0, depth=2, packed=12, stage_stats=st):
+    for res in _lib.scan_stream(pw, iter(batches), 3, 0, depth=2, packed=int(os.environ.get("E2E_PACKED", "12")), stage_stats=st):
         res.close()
     ms = (time.perf_counter() - t0) * 1e3
     h1, d1 = _lib.host_pool_stats(), _lib.pool_stats()
