@@ -734,7 +734,17 @@ static int seqset_alloc_packed(ms_seqset *s, bool pads_by_copy = false, bool def
         MS_HIP(hipMemsetAsync(s->d_codes + 2 * n_units, 0, kPadWords * sizeof(uint32_t), s->up));
         MS_HIP(hipMemsetAsync(s->d_nmask + n_units, 0, kPadWords * sizeof(uint32_t), s->up));
     }
-    if (!pads_by_copy) MS_HIP(hipMemcpyAsync(s->d_offsets, s->offsets.data(), b_off, hipMemcpyHostToDevice, s->up));      // (host-packed: the offsets travel in the one copy of the whole block)
+    if (!pads_by_copy) {                                  // (host-packed: the offsets travel in the one copy of the whole block)
+        // through pinned words, so that the copy runs on the SDMA engines like the sequence's: from the pageable vector the runtime copies with a one-workgroup
+        // KERNEL, which in a batch stream waits for a CU while the previous batch's pre-filter holds them all (profiles/r06z_trace_e2e_gaps_sdma.log: 3.5 ms
+        // per batch on the upload stream).  MS_MEASURE=1 MS_OFFSETS_PAGEABLE=1: the old way, for A/B runs.
+        const void *src = s->offsets.data();
+        if (!measure_env("MS_OFFSETS_PAGEABLE") && (s->h_off_pin = pinned_alloc(b_off, &s->h_off_pin_bytes))) {
+            std::memcpy(s->h_off_pin, s->offsets.data(), b_off);
+            src = s->h_off_pin;
+        }
+        MS_HIP(hipMemcpyAsync(s->d_offsets, src, b_off, hipMemcpyHostToDevice, s->up));
+    }
     return MS_OK;
 }
 
@@ -978,6 +988,7 @@ void ms_seqset_free(ms_seqset *s) {
     const bool have = get_ctx(s->device, &c) == MS_OK;
     if (s->d_ascii) { if (have) pool_free(c, s->d_ascii, s->ascii_bytes); else (void) hipFree(s->d_ascii); }
     if (s->block) { if (have) pool_free(c, s->block, s->block_bytes); else (void) hipFree(s->block); }
+    if (s->h_off_pin) pinned_free(s->h_off_pin, s->h_off_pin_bytes);
     delete s;
 }
 

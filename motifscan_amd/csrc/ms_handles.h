@@ -201,6 +201,8 @@ struct ms_seqset {
     int32_t *d_blk2reg = nullptr;         // region of position 64*b
     int4 *d_blkinfo = nullptr;            // ... with the region's and the next two regions' starts relative to 64*b (DevSeq::blkinfo)
     hipStream_t up = nullptr;             // the upload stream this set is being built on (DeviceCtx::stream_up, read once)
+    void *h_off_pin = nullptr;            // the offsets' way to the device: a pinned copy (from pageable memory the runtime copies with a KERNEL, which waits for a CU the pre-filter holds)
+    size_t h_off_pin_bytes = 0;
     bool built = false;                   // construction finished (its work on `up` is done)
     bool pack_pending = false;            // a batch stream's upload-only set: ASCII and offsets are in HBM, pack_kernel / blk2reg_kernel still to run (seqset_pack_pending, on the scan stream)
 };
