@@ -63,8 +63,19 @@ int get_ctx(int device, DeviceCtx **out) {
     if (c->lds_max < 65536) c->lds_max = 65536;
     if (c->lds_max > 163840) c->lds_max = 163840;
     MS_HIP(hipStreamCreateWithFlags(&c->stream.whole, hipStreamNonBlocking));
-    MS_HIP(hipStreamCreateWithFlags(&c->stream_up.whole, hipStreamNonBlocking));
-    MS_HIP(hipStreamCreateWithFlags(&c->stream_down.whole, hipStreamNonBlocking));
+    {
+        // MS_MEASURE=1 MS_COPY_PRIORITY=1 (A/B): the copy streams at the device's highest priority -- a copy-out that runs as a blit kernel then wins freed CUs
+        // over the pre-filter's pending blocks
+        int lo = 0, hi = 0;
+        const bool prio = measure_env("MS_COPY_PRIORITY") && atoi(measure_env("MS_COPY_PRIORITY")) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
+        if (prio) {
+            MS_HIP(hipStreamCreateWithPriority(&c->stream_up.whole, hipStreamNonBlocking, hi));
+            MS_HIP(hipStreamCreateWithPriority(&c->stream_down.whole, hipStreamNonBlocking, hi));
+        } else {
+            MS_HIP(hipStreamCreateWithFlags(&c->stream_up.whole, hipStreamNonBlocking));
+            MS_HIP(hipStreamCreateWithFlags(&c->stream_down.whole, hipStreamNonBlocking));
+        }
+    }
     for (StreamSel *s : {&c->stream, &c->stream_up, &c->stream_down}) s->n_streams = &c->n_streams;
     if (measure_env("MS_CU_PARTITION")) {
         // A/B switch (MS_MEASURE=1 MS_CU_PARTITION=1); off by default, see StreamSel.
