@@ -1283,8 +1283,11 @@ int scan_complete(DeviceCtx *c, ms_pwmset *pwms, PendingScan *p, ms_result **out
     if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
     const unsigned long long n_cand = p->cand_static + p->h_counters[0], n_hits = p->h_counters[1];
     if (n_cand <= p->cand_cap && n_hits <= p->hit_cap && n_hits <= p->n_pred) {
-        if (p->offsets_queued) std::memcpy(raw->motif_offsets.data(), p->h_offsets, raw->motif_offsets.size() * sizeof(int64_t));       // (copied in stream order, in front of `done`: scan_locked)
-        else {
+        if (p->offsets_queued) {                       // (copied in stream order, in front of `done`: scan_locked)
+            const size_t n_off = raw->motif_offsets.size();
+            std::memcpy(raw->motif_offsets.data(), p->h_offsets, n_off * sizeof(int64_t));
+            try { raw->h_region_counts.assign(p->h_offsets + n_off, p->h_offsets + n_off + raw->P); } catch (const std::bad_alloc &) { raw->h_region_counts.clear(); }
+        } else {
             he = hipMemcpy(raw->motif_offsets.data(), raw->d_motif_first, raw->motif_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
             if (he != hipSuccess) { set_error("copy failed: %s", hipGetErrorString(he)); ms_result_free(raw); return MS_ERR_RUNTIME; }
         }
@@ -1728,19 +1731,23 @@ int scan_locked(DeviceCtx *c, ms_pwmset *pwms, const ms_seqset *seqs, int strand
             // queued, not waited for: the owner queues its next scan behind this one first (everything is in order on one stream:
             // the next scan's kernels only touch the shared scratch after this scan's are done; a scratch buffer that has to grow
             // is freed by hipFree, which waits for the device)
-            // the per-motif offsets too, into the slot's own pinned words: scan_complete used to fetch them with a blocking hipMemcpy into pageable
-            // memory once the scan was done -- a copy of 5 KB that queued up behind whatever 100-MB copy-out held the engine it was given, for 3-4 ms per
-            // batch: the 80-ms passes of profiles/r06z_e2e_stage_clock.log
-            const size_t n_off = raw->motif_offsets.size();
+            // the per-motif offsets too, in stream order, into the slot's own pinned words: scan_complete used to fetch them with a blocking hipMemcpy
+            // into pageable memory once the scan was done -- one more synchronous driver call per batch on the scan stage's thread (same pass time
+            // either way, profiles/r06z_offsets_ab.log; kept because nothing on that thread should block that need not).  The per-motif region counts
+            // ride along: the stream's copy-out stage brings them to the host with every batch, and its own small copy is one more blit kernel that
+            // has to find a CU beside the running pre-filter
+            const size_t n_off = raw->motif_offsets.size(), n_words = n_off + (size_t) pwms->P;
             pend->offsets_queued = !measure_env("MS_OFFSETS_BLOCKING");
-            if (pend->offsets_queued && pend->h_offsets_cap < n_off) {
+            if (pend->offsets_queued && pend->h_offsets_cap < n_words) {
                 if (pend->h_offsets) (void) hipHostFree(pend->h_offsets);
                 pend->h_offsets = nullptr; pend->h_offsets_cap = 0;
-                he = hipHostMalloc(&pend->h_offsets, (n_off + 64) * sizeof(int64_t));
+                he = hipHostMalloc(&pend->h_offsets, (n_words + 64) * sizeof(int64_t));
                 if (he != hipSuccess) { set_error("out of pinned host memory"); return fail(MS_ERR_NOMEM); }
-                pend->h_offsets_cap = n_off + 64;
+                pend->h_offsets_cap = n_words + 64;
             }
             he = pend->offsets_queued ? hipMemcpyAsync(pend->h_offsets, raw->d_motif_first, n_off * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+            if (he == hipSuccess && pend->offsets_queued && pwms->P > 0)
+                he = hipMemcpyAsync(pend->h_offsets + n_off, raw->d_region_counts, (size_t) pwms->P * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(pend->h_counters, sc.counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
             if (he == hipSuccess) he = hipEventRecord(pend->done, c->stream);
             if (he != hipSuccess) { set_error("scan kernels failed: %s", hipGetErrorString(he)); return fail(MS_ERR_RUNTIME); }
@@ -2097,6 +2104,7 @@ int ms::result_fetch_region_counts(ms_result *r) {
     DeviceCtx *c;
     int rc = get_ctx(r->device, &c);
     if (rc) return rc;
+    if (r->h_region_counts.size() == (size_t) r->P) return MS_OK;      // (a queued scan brought them along: scan_complete)
     try { r->h_region_counts.assign((size_t) r->P, 0); } catch (const std::bad_alloc &) { set_error("out of host memory"); return MS_ERR_NOMEM; }
     const hipStream_t down = c->stream_down;
     hipError_t he = hipMemcpyAsync(r->h_region_counts.data(), r->d_region_counts, (size_t) r->P * sizeof(int64_t), hipMemcpyDeviceToHost, down);
